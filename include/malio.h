@@ -1,0 +1,205 @@
+/*
+ * malio.h — C ABI of libmalio_hip.so: the MI355X (gfx950) replacement for MA-LIO's per-scan
+ * measurement-update hot path. The reference has no FFI layer; the path is reached
+ * through ONE function-pointer hook and ONE class API, and every entry point below names the
+ * reference interface it replaces (paths relative to /root/reference/MA_LIO):
+ *
+ *   hook : void h_share_model(state_ikfom&, esekfom::dyn_share_datastruct<double>&)
+ *          src/laserMapping.cpp:552, registered at :852, invoked at
+ *          include/IKFoM_toolkit/esekfom/esekfom.hpp:512
+ *   class: KD_TREE<PointType> ikdtree   src/laserMapping.cpp:95, include/ikd-Tree/ikd_Tree.h:308-340
+ *
+ * Conventions: extern "C", opaque handle, plain pointers + sizes, caller-owned HOST buffers unless a
+ * parameter is named d_* (device pointer). Every function returns an int status: 0 = MALIO_OK,
+ * > 0 = soft condition (e.g. MALIO_NO_EFFECTIVE_POINTS), < 0 = hard error; no exceptions cross the
+ * boundary. One handle = one GPU + one HIP stream; calls on a handle are not re-entrant (the
+ * reference calls from its single main thread). There is NO CPU fallback: if no gfx950 device is
+ * present malio_create fails with MALIO_ERR_NO_DEVICE.
+ *
+ * INTEGRATION.md shows the shim a MA-LIO maintainer adds around these calls.
+ */
+#ifndef MALIO_H_
+#define MALIO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MALIO_ABI_VERSION 1
+#define MALIO_MAX_LIDAR 4       /* reference ships lid_num in {1,2,3} (src/use-ikfom.hpp:12-41) */
+#define MALIO_NUM_MATCH_POINTS 5 /* include/common_lib.h:22 */
+
+enum {
+  MALIO_OK = 0,
+  MALIO_NO_EFFECTIVE_POINTS = 1, /* ekfom_data.valid = false, src/laserMapping.cpp:635-639 */
+  MALIO_SMALL_M_FALLBACK = 2,    /* M < n: caller must use the rows path (esekfom.hpp:574-582) */
+  MALIO_ERR_NO_DEVICE = -1,
+  MALIO_ERR_HIP = -2,
+  MALIO_ERR_BAD_ARG = -3,
+  MALIO_ERR_NO_MAP = -4,
+  MALIO_ERR_NO_SCAN = -5,
+  MALIO_ERR_ALLOC = -6
+};
+
+typedef struct malio_ctx *malio_handle_t;
+
+/* == pcl::PointXYZINormal, 48 bytes (typedef PointType, include/common_lib.h:31). Field overloading
+ * along the pipeline is tabulated in SURVEY.md §2.2: after the voxel filter `intensity` = LiDAR slot,
+ * `normal_x` = mean uncertainty-interval index, `normal_y` = trace(Sigma_p) / map-point uncertainty,
+ * `curvature` = time offset [ms]. A PointCloudXYZI's points.data() can be passed as is. */
+typedef struct malio_point {
+  float x, y, z, _pad0;
+  float normal_x, normal_y, normal_z, _pad1;
+  float intensity, curvature, _pad2, _pad3;
+} malio_point_t;
+
+/* == struct Pose, include/common_lib.h:57-63 (q_ as x,y,z,w; T_ and cov_ row-major). */
+typedef struct malio_pose {
+  double q[4];
+  double t[3];
+  double T[16];
+  double cov[36];
+} malio_pose_t;
+
+/* == BoxPointType, include/ikd-Tree/ikd_Tree.h:25-29 */
+typedef struct malio_box {
+  float vertex_min[3];
+  float vertex_max[3];
+} malio_box_t;
+
+/* The globals readParameters fills (src/parameters.cpp:17-65; values SURVEY.md §5.1). */
+typedef struct malio_params {
+  int32_t lid_num;          /* common/lid_num */
+  int32_t max_iteration;    /* NUM_MAX_ITERATIONS */
+  int32_t extrinsic_est_en; /* mapping/extrinsic_est_en */
+  float plane_th;           /* plane_th */
+  double cov_threshold;
+  double range_min, range_max;
+  double point_cov_max, point_cov_min;
+  double plane_cov_max, plane_cov_min;
+  double localize_cov_max, localize_cov_min;
+  double localize_thresh_max, localize_thresh_min;
+  double filter_size_map; /* filter_size_map_min: ikdtree.set_downsample_param, laserMapping.cpp:999 */
+  float cell_size;        /* spatial-hash cell edge [m]; 0 = default (2.25 m >= sqrt(5)) */
+  int32_t reserved[3];
+} malio_params_t;
+
+/* == the parts of state_ikfom (src/use-ikfom.hpp:14-27) h_share_model reads, plus the rest of the
+ * manifold for malio_update_iterated. Quaternions are (x,y,z,w). offset_R/offset_T are the ITERATED
+ * extrinsics (extrinsic_update() aliases the filter's live state, laserMapping.cpp:291-308). */
+typedef struct malio_state {
+  double pos[3];
+  double rot[4];
+  double offset_R[MALIO_MAX_LIDAR][4];
+  double offset_T[MALIO_MAX_LIDAR][3];
+  double vel[3], bg[3], ba[3];
+  double grav[3]; /* S2<double,98090,10000,1>: |grav| = 9.809 */
+} malio_state_t;
+
+/* Result of one fused pass. With C = 6(1+lid_num):
+ *   HtRinvH[C*C] (row-major, full symmetric) = H^T diag(1/R) H   (esekfom.hpp:622-629, R clamp :624-626)
+ *   HtRinvh[C]                               = H^T diag(1/R) h   (the HT * dyn_share.h factor of :635)
+ * both already include the localization weight w_loc (laserMapping.cpp:758-759 scales H and h by w,
+ * hence w^2 here). Optional row outputs reproduce ekfom_data.h_x / h / R exactly as the reference fills
+ * them (laserMapping.cpp:642-644,679-722,758-759), M rows in ascending scan index. */
+typedef struct malio_measure_out {
+  int32_t valid;         /* ekfom_data.valid */
+  int32_t M;             /* effct_feat_num */
+  double w_loc;          /* localization weight applied (laserMapping.cpp:749-756) */
+  double unit_cov_minmax[2]; /* min/max_unit_cov (:615-616,625-628) */
+  double R_minmax[2];        /* min_cov / max_cov (:646-647,700-703) */
+  double HtRinvH[36 * (1 + MALIO_MAX_LIDAR) * (1 + MALIO_MAX_LIDAR)];
+  double HtRinvh[6 * (1 + MALIO_MAX_LIDAR)];
+  double *h_x; /* optional, capacity N*C, row-major M x C */
+  double *h;   /* optional, capacity N */
+  double *R;   /* optional, capacity N */
+} malio_measure_out_t;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* replaces: the file-scope globals + KD_TREE ctor (laserMapping.cpp:55-115). device = HIP ordinal. */
+int malio_create(const malio_params_t *params, int device, malio_handle_t *out);
+int malio_destroy(malio_handle_t h);
+const char *malio_version(void);
+const char *malio_last_error(malio_handle_t h);
+/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own one. */
+int malio_set_stream(malio_handle_t h, void *hip_stream);
+
+/* ---- map: KD_TREE<PointType> call sites ------------------------------------------------------ */
+/* ikdtree.Build(feats_down_world->points)            laserMapping.cpp:1007 / ikd_Tree.cpp:369-397 */
+int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n);
+/* ikdtree.size()                                     laserMapping.cpp:824 */
+int malio_map_size(malio_handle_t h, int *out_size);
+/* ikdtree.Nearest_Search(point, k, near, d2), batched laserMapping.cpp:586 / ikd_Tree.cpp:426-461.
+ * Exact k-NN (k <= 5) inside radius cell_size (>= sqrt(5) m, the reference's own acceptance gate
+ * laserMapping.cpp:587); float32 squared distances computed as ikd_Tree.cpp:1697; ascending.
+ * out_pts [n*k], out_d2 [n*k] (INFINITY-padded), out_count [n]. */
+int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,
+                         float *out_d2, int *out_count);
+/* ikdtree.Add_Points(PointToAdd, downsample_on)      laserMapping.cpp:443-444 / ikd_Tree.cpp:478-584 */
+int malio_map_add(malio_handle_t h, const malio_point_t *pts, int n, int downsample_on, int *out_added);
+/* ikdtree.Delete_Point_Boxes(cub_needrm)             laserMapping.cpp:223 / ikd_Tree.cpp:643-669 */
+int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, int *out_deleted);
+
+/* ---- per scan ------------------------------------------------------------------------------- */
+/* replaces the per-scan globals h_share_model reads: feats_down_body (laserMapping.cpp:86,982),
+ * pose_unc[lid][k] (:1028-1048), kf.temporal_comp[lid-1] (IMU_Processing.hpp:510-522). Uploads the
+ * scan to HBM once; resets Nearest_Points / point_selected_surf (:1024-1025). */
+int malio_scan_set(malio_handle_t h, const malio_point_t *feats_down_body, int n,
+                   const malio_pose_t *const *pose_unc, const int *pose_unc_len,
+                   const malio_pose_t *temporal_comp);
+
+/* ONE h_share_model pass (laserMapping.cpp:552-760) fused with the H^T R^-1 H / H^T R^-1 h
+ * accumulation of esekfom.hpp:621-635. converge = ekfom_data.converge (search vs neighbour reuse,
+ * :583-591). Returns MALIO_OK or MALIO_NO_EFFECTIVE_POINTS. */
+int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_measure_out_t *out);
+
+/* Side effects later reference code relies on, in original scan order; any pointer
+ * may be NULL: feats_down_body[i].normal_y (:699,730,741) | Nearest_Points[i] (:582, read by
+ * map_incremental :411-435) + sizes | point_selected_surf[i] | res_last[i] (:609) |
+ * feats_down_world xyz (:576-578) | normvec (n, pd2) (:604-607). */
+int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, int *nearest_count,
+                   uint8_t *selected, float *res_last, float *world_xyz, float *normvec4);
+
+/* kf.update_iterated_dyn_share_modified(R, solve_time) (esekfom.hpp:495-721) with the fused measure
+ * pass as h_dyn_share: state x (in/out), covariance P (n x n row-major, n = 17+6 lid_num, in/out).
+ * stats (optional, int[4]) = {passes, searches, last M, converged-count t}. */
+int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats,
+                          double *solve_time);
+
+/* ---- undistortion (IMU_Processing.hpp:475-507 + BsplineSE3.cpp:84-118) --------------------- */
+/* Per-raw-point SE(3) cubic B-spline pose + rigid compensation into the LiDAR's own scan-end frame.
+ * pts (in/out, sorted by curvature as :229-233): x,y,z rewritten, intensity <- uncertainty-interval
+ * index; the first point is left untouched like the reference's loop bounds (:475-476).
+ * knot_times[n_knots] / knot_poses[n_knots*16]: the spline's control poses (BsplineSE3.cpp:59-77),
+ * absolute seconds. imu_stamps[n_imu]: imu_cov[k].first.first; cov_pointer0: value after :453-467.
+ * out_cross_index[n] (optional): idx after each point, for building the uncertainty tables on host. */
+int malio_undistort(malio_handle_t h, malio_point_t *pts, int n, double lidar_beg_time, const double *knot_times,
+                    const double *knot_poses, int n_knots, const double ext_q[4], const double ext_t[3],
+                    const double end_q[4], const double end_t[3], const double *imu_stamps, int n_imu,
+                    int cov_pointer0, int *out_entry_point, int *out_n_entries);
+
+/* ---- multi-GPU staging: scan points sharded, map replicated -------------------- */
+/* Stage 1: search/plane/gates + local [max_unit_cov, -min_unit_cov, max_R, -min_R] into d_minmax4
+ * (device, 4 doubles) -> caller all-reduces with MAX. Stage 2: rows + local sums into d_sums (device,
+ * malio_sums_len() doubles: HtRinvH upper triangle, HtRinvh, sum c^2 n n^T (6), M) -> all-reduce SUM.
+ * Finish: host-side weight/valid logic on the reduced sums, fills `out` like malio_measure. */
+int malio_sums_len(malio_handle_t h);
+int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax4);
+int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_sums);
+int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax4_host,
+                         malio_measure_out_t *out);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded
+ * on the handle's stream. names: up to cap pointers to static strings. Returns count via *out_n. */
+int malio_last_kernel_times(malio_handle_t h, const char **names, float *ms, int cap, int *out_n);
+/* Enable/disable per-kernel event timing (off by default: events add launch latency). */
+int malio_set_profiling(malio_handle_t h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MALIO_H_ */

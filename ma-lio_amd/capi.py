@@ -1,0 +1,260 @@
+"""ctypes view of the C ABI in include/malio.h (libmalio_hip.so).
+
+This is plumbing for tests and bench.py: the product is the shared library. Loading fails loudly
+when the library has not been built (`__graft_entry__.build()` / `make -C ma-lio_amd`); creating a
+handle fails with MALIO_ERR_NO_DEVICE when no gfx950 GPU is visible - there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmalio_hip.so")
+
+MAX_LIDAR = 4
+OK, NO_EFFECTIVE_POINTS, SMALL_M_FALLBACK = 0, 1, 2
+ERR_NO_DEVICE = -1
+
+EXPORTS = [
+    "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_scan_set",
+    "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
+    "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
+    "malio_set_profiling",
+]
+
+
+class Point(C.Structure):  # malio_point_t == pcl::PointXYZINormal
+    _fields_ = [(n, C.c_float) for n in ("x", "y", "z", "_pad0", "normal_x", "normal_y", "normal_z", "_pad1",
+                                         "intensity", "curvature", "_pad2", "_pad3")]
+
+
+class Pose(C.Structure):  # malio_pose_t
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("T", C.c_double * 16), ("cov", C.c_double * 36)]
+
+
+class Params(C.Structure):  # malio_params_t
+    _fields_ = [("lid_num", C.c_int32), ("max_iteration", C.c_int32), ("extrinsic_est_en", C.c_int32),
+                ("plane_th", C.c_float), ("cov_threshold", C.c_double), ("range_min", C.c_double),
+                ("range_max", C.c_double), ("point_cov_max", C.c_double), ("point_cov_min", C.c_double),
+                ("plane_cov_max", C.c_double), ("plane_cov_min", C.c_double), ("localize_cov_max", C.c_double),
+                ("localize_cov_min", C.c_double), ("localize_thresh_max", C.c_double),
+                ("localize_thresh_min", C.c_double), ("filter_size_map", C.c_double), ("cell_size", C.c_float),
+                ("reserved", C.c_int32 * 3)]
+
+
+class State(C.Structure):  # malio_state_t
+    _fields_ = [("pos", C.c_double * 3), ("rot", C.c_double * 4), ("offset_R", (C.c_double * 4) * MAX_LIDAR),
+                ("offset_T", (C.c_double * 3) * MAX_LIDAR), ("vel", C.c_double * 3), ("bg", C.c_double * 3),
+                ("ba", C.c_double * 3), ("grav", C.c_double * 3)]
+
+
+class MeasureOut(C.Structure):  # malio_measure_out_t
+    _fields_ = [("valid", C.c_int32), ("M", C.c_int32), ("w_loc", C.c_double), ("unit_cov_minmax", C.c_double * 2),
+                ("R_minmax", C.c_double * 2), ("HtRinvH", C.c_double * (36 * (1 + MAX_LIDAR) ** 2)),
+                ("HtRinvh", C.c_double * (6 * (1 + MAX_LIDAR))), ("h_x", C.POINTER(C.c_double)),
+                ("h", C.POINTER(C.c_double)), ("R", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.malio_version.restype = C.c_char_p
+        _lib.malio_last_error.restype = C.c_char_p
+        _lib.malio_last_error.argtypes = [C.c_void_p]
+        for name in EXPORTS:
+            getattr(_lib, name)  # AttributeError if an include/malio.h symbol is not exported
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def state_from_flat(flat, L):
+    """[19+7L] flat state (scenes.pack_state layout) -> malio_state_t."""
+    flat = np.asarray(flat, np.float64)
+    s = State()
+    o = 0
+    s.pos[:] = flat[o:o + 3]; o += 3
+    s.rot[:] = flat[o:o + 4]; o += 4
+    for l in range(MAX_LIDAR):
+        s.offset_R[l][:] = [0, 0, 0, 1]
+    for l in range(L):
+        s.offset_R[l][:] = flat[o:o + 4]; o += 4
+    for l in range(L):
+        s.offset_T[l][:] = flat[o:o + 3]; o += 3
+    s.vel[:] = flat[o:o + 3]; o += 3
+    s.bg[:] = flat[o:o + 3]; o += 3
+    s.ba[:] = flat[o:o + 3]; o += 3
+    s.grav[:] = flat[o:o + 3]
+    return s
+
+
+def state_to_flat(s, L):
+    out = list(s.pos) + list(s.rot)
+    for l in range(L):
+        out += list(s.offset_R[l])
+    for l in range(L):
+        out += list(s.offset_T[l])
+    out += list(s.vel) + list(s.bg) + list(s.ba) + list(s.grav)
+    return np.array(out, np.float64)
+
+
+def make_params(p: dict, cell_size=0.0):
+    prm = Params()
+    for k, _ in Params._fields_:
+        if k in p:
+            setattr(prm, k, p[k])
+    prm.cell_size = cell_size
+    return prm
+
+
+class MalioError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One libmalio_hip handle (one GPU, one stream)."""
+
+    def __init__(self, params: dict, device=0, cell_size=0.0):
+        self.L = int(params["lid_num"])
+        self.C = 6 * (1 + self.L)
+        self.n = 17 + 6 * self.L
+        self.params = dict(params)
+        self._prm = make_params(params, cell_size)
+        self.h = C.c_void_p()
+        rc = lib().malio_create(C.byref(self._prm), int(device), C.byref(self.h))
+        if rc != OK:
+            raise MalioError(f"malio_create failed rc={rc} (no gfx950 device? there is no CPU fallback)")
+        self.N = 0
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise MalioError(f"{what} rc={rc}: {lib().malio_last_error(self.h).decode()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().malio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().malio_set_stream(self.h, C.c_void_p(stream_ptr)), "malio_set_stream")
+
+    def set_profiling(self, on=True):
+        self._chk(lib().malio_set_profiling(self.h, int(on)), "malio_set_profiling")
+
+    def last_kernel_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = C.c_int(0)
+        lib().malio_last_kernel_times(self.h, names, ms, 16, C.byref(n))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def map_build(self, pts12):
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        self._chk(lib().malio_map_build(self.h, _p(pts12, Point), pts12.shape[0]), "malio_map_build")
+
+    def map_size(self):
+        n = C.c_int(0)
+        self._chk(lib().malio_map_size(self.h, C.byref(n)), "malio_map_size")
+        return n.value
+
+    def nearest_search(self, q12, k=5):
+        q12 = np.ascontiguousarray(q12, np.float32)
+        n = q12.shape[0]
+        out = np.zeros((n, k, 12), np.float32)
+        d2 = np.zeros((n, k), np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(lib().malio_nearest_search(self.h, _p(q12, Point), n, k, _p(out, Point), _p(d2, C.c_float),
+                                             _p(cnt, C.c_int)), "malio_nearest_search")
+        return out, d2, cnt
+
+    def scan_set(self, pts12, pose_tables, temporal_comp):
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        self.N = pts12.shape[0]
+        tabs = [np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1, 59)) for t in pose_tables]
+        ptrs = (C.POINTER(Pose) * self.L)(*[_p(t, Pose) for t in tabs])
+        lens = (C.c_int * self.L)(*[t.shape[0] for t in tabs])
+        tc = np.ascontiguousarray(np.asarray(temporal_comp, np.float64).reshape(-1, 59))
+        tcp = _p(tc, Pose) if self.L > 1 else None
+        self._keep = (tabs, tc)
+        self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
+
+    def measure(self, state_flat, converge=True, want_rows=False):
+        s = state_from_flat(state_flat, self.L)
+        out = MeasureOut()
+        if want_rows:
+            hx = np.zeros((self.N, self.C), np.float64)
+            hv = np.zeros(self.N, np.float64)
+            Rv = np.zeros(self.N, np.float64)
+            out.h_x, out.h, out.R = _p(hx, C.c_double), _p(hv, C.c_double), _p(Rv, C.c_double)
+        rc = self._chk(lib().malio_measure(self.h, C.byref(s), int(bool(converge)), C.byref(out)), "malio_measure")
+        Cc = self.C
+        res = dict(rc=rc, valid=bool(out.valid), M=int(out.M), w_loc=float(out.w_loc),
+                   HtRinvH=np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), HtRinvh=np.array(out.HtRinvh[:Cc]),
+                   unit_cov_minmax=tuple(out.unit_cov_minmax), R_minmax=tuple(out.R_minmax))
+        if want_rows:
+            M = res["M"] if res["valid"] else 0
+            res.update(h_x=hx[:M].copy(), h=hv[:M].copy(), R=Rv[:M].copy())
+        return res
+
+    def scan_get(self):
+        n = self.N
+        out = dict(normal_y=np.zeros(n, np.float32), nearest=np.zeros((n, 5, 12), np.float32),
+                   nearest_cnt=np.zeros(n, np.int32), selected=np.zeros(n, np.uint8),
+                   res_last=np.zeros(n, np.float32), world=np.zeros((n, 3), np.float32),
+                   normvec=np.zeros((n, 4), np.float32))
+        self._chk(lib().malio_scan_get(self.h, _p(out["normal_y"], C.c_float), _p(out["nearest"], Point),
+                                       _p(out["nearest_cnt"], C.c_int), _p(out["selected"], C.c_uint8),
+                                       _p(out["res_last"], C.c_float), _p(out["world"], C.c_float),
+                                       _p(out["normvec"], C.c_float)), "malio_scan_get")
+        return out
+
+    def update_iterated(self, state_flat, P, R=0.001):
+        s = state_from_flat(state_flat, self.L)
+        P = np.ascontiguousarray(P, np.float64).copy()
+        stats = (C.c_int * 4)()
+        st = C.c_double(0)
+        self._chk(lib().malio_update_iterated(self.h, C.byref(s), _p(P, C.c_double), C.c_double(R), stats,
+                                              C.byref(st)), "malio_update_iterated")
+        return dict(state=state_to_flat(s, self.L), P=P, passes=stats[0], searches=stats[1], M=stats[2],
+                    t=stats[3], solve_time=st.value)
+
+    # ---- multi-GPU staging (device pointers are plain ints, e.g. torch.Tensor.data_ptr()) ----
+    def sums_len(self):
+        return lib().malio_sums_len(self.h)
+
+    def stage1(self, state_flat, converge, d_minmax_ptr):
+        s = state_from_flat(state_flat, self.L)
+        self._chk(lib().malio_measure_stage1(self.h, C.byref(s), int(bool(converge)), C.c_void_p(d_minmax_ptr)),
+                  "malio_measure_stage1")
+
+    def stage2(self, d_minmax_ptr, d_sums_ptr):
+        self._chk(lib().malio_measure_stage2(self.h, C.c_void_p(d_minmax_ptr), C.c_void_p(d_sums_ptr)),
+                  "malio_measure_stage2")
+
+    def finish(self, sums_host, minmax_host):
+        sums_host = np.ascontiguousarray(sums_host, np.float64)
+        minmax_host = np.ascontiguousarray(minmax_host, np.float64)
+        out = MeasureOut()
+        rc = self._chk(lib().malio_measure_finish(self.h, _p(sums_host, C.c_double), _p(minmax_host, C.c_double),
+                                                  C.byref(out)), "malio_measure_finish")
+        Cc = self.C
+        return dict(rc=rc, valid=bool(out.valid), M=int(out.M), w_loc=float(out.w_loc),
+                    HtRinvH=np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), HtRinvh=np.array(out.HtRinvh[:Cc]))

@@ -1,0 +1,459 @@
+// C ABI of libmalio_hip.so (include/malio.h). Thin: argument checks, host<->HBM staging, kernel
+// orchestration on the handle's stream. No CPU fallback: without a gfx950 device malio_create fails.
+#include <algorithm>
+#include <cmath>
+#include "malio_internal.hpp"
+
+using namespace malio;
+
+namespace malio {
+
+void prof_begin(Ctx *c) {
+  c->ev_used = 0;
+  c->ev_names.clear();
+  if (!c->profiling) return;
+  if (c->ev.empty()) {
+    c->ev.resize(16);
+    for (auto &e : c->ev) (void)hipEventCreate(&e);
+  }
+  (void)hipEventRecord(c->ev[0], c->stream);
+  c->ev_used = 1;
+}
+void prof_mark(Ctx *c, const char *name) {
+  if (!c->profiling || c->ev_used == 0 || c->ev_used >= (int)c->ev.size()) return;
+  (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+  c->ev_names.push_back(name);
+  c->ev_used++;
+}
+void prof_end(Ctx *c) {
+  if (!c->profiling || c->ev_used < 2) return;
+  (void)hipEventSynchronize(c->ev[c->ev_used - 1]);
+  c->last_ms.clear();
+  c->last_names.clear();
+  for (int k = 1; k < c->ev_used; k++) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[k - 1], c->ev[k]);
+    c->last_ms.push_back(ms);
+    c->last_names.push_back(c->ev_names[k - 1]);
+  }
+}
+
+// Fold one pose_unc entry so that trace(Sigma_p) is a quadratic form in p' = T (0.05 p, 1):
+// G = [I | -[p']x | R],  Sigma = blkdiag(1e4 cov, 0.1 I)   (associate_uct.hpp:153-175)
+static void fold_entry(const malio_pose_t &p, UncEntry &e) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) e.T[i * 4 + j] = p.T[i * 4 + j];
+  double S[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) S[i][j] = p.cov[i * 6 + j] * 10000;
+  double rr = 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) rr += p.T[i * 4 + j] * p.T[i * 4 + j];
+  e.k0 = S[0][0] + S[1][1] + S[2][2] + 0.1 * rr;
+  auto vee = [](double M[3][3], double v[3]) {
+    v[0] = M[1][2] - M[2][1], v[1] = M[2][0] - M[0][2], v[2] = M[0][1] - M[1][0];
+  };
+  double Str[3][3], Srt[3][3], Srr[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Str[i][j] = S[i][3 + j], Srt[i][j] = S[3 + i][j], Srr[i][j] = S[3 + i][3 + j];
+  double a[3], b[3];
+  vee(Str, a), vee(Srt, b);
+  for (int k = 0; k < 3; k++) e.lin[k] = a[k] - b[k];
+  double tr = Srr[0][0] + Srr[1][1] + Srr[2][2];
+  e.Q[0] = tr - Srr[0][0], e.Q[1] = tr - Srr[1][1], e.Q[2] = tr - Srr[2][2];
+  e.Q[3] = -0.5 * (Srr[0][1] + Srr[1][0]), e.Q[4] = -0.5 * (Srr[0][2] + Srr[2][0]),
+  e.Q[5] = -0.5 * (Srr[1][2] + Srr[2][1]);
+}
+
+__global__ void __launch_bounds__(BLK) k_gather_side(int N, const u32 *__restrict__ perm, const u32 *__restrict__ nbr,
+                                                     const float4 *__restrict__ map_pts, float4 *out_near /*[N][5]*/) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= N) return;
+  u32 o = perm[i];
+  for (int k = 0; k < 5; k++) {
+    u32 j = nbr[(size_t)k * N + i];
+    out_near[(size_t)o * 5 + k] = (j != 0xFFFFFFFFu) ? map_pts[j] : make_float4(0, 0, 0, 0);
+  }
+}
+
+}  // namespace malio
+
+static int check(malio_handle_t h) { return h ? MALIO_OK : MALIO_ERR_BAD_ARG; }
+
+extern "C" {
+
+const char *malio_version(void) { return "malio-hip 0.1 (gfx950, ABI 1)"; }
+
+const char *malio_last_error(malio_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int malio_create(const malio_params_t *params, int device, malio_handle_t *out) {
+  if (!params || !out) return MALIO_ERR_BAD_ARG;
+  if (params->lid_num < 1 || params->lid_num > MALIO_MAX_LIDAR) return MALIO_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MALIO_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return MALIO_ERR_NO_DEVICE;
+  malio_ctx *c = new malio_ctx();
+  c->prm = *params;
+  c->device = device;
+  c->cell = params->cell_size > 0.f ? params->cell_size : 2.25f;
+  if (c->cell < 2.2360681f) c->cell = 2.2360681f;  // must cover the sqrt(5) m acceptance radius
+  c->inv_cell = 1.0f / c->cell;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return MALIO_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return MALIO_OK;
+}
+
+int malio_destroy(malio_handle_t h) {
+  if (!h) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  auto fr = [](void *p) {
+    if (p) (void)hipFree(p);
+  };
+  free_grid(c->map);
+  fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
+  fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_minmax), fr(c->d_partials);
+  fr(c->d_sums), fr(c->d_rows);
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_minmax) (void)hipHostFree(c->h_minmax);
+  for (auto &e : c->ev) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete h;
+  return MALIO_OK;
+}
+
+int malio_set_stream(malio_handle_t h, void *hip_stream) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return MALIO_OK;
+}
+
+int malio_set_profiling(malio_handle_t h, int on) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->profiling = on != 0;
+  return MALIO_OK;
+}
+
+int malio_last_kernel_times(malio_handle_t h, const char **names, float *ms, int cap, int *out_n) {
+  if (check(h) || !out_n) return MALIO_ERR_BAD_ARG;
+  int n = std::min<int>(cap, (int)h->last_ms.size());
+  for (int i = 0; i < n; i++) {
+    if (names) names[i] = h->last_names[i];
+    if (ms) ms[i] = h->last_ms[i];
+  }
+  *out_n = n;
+  return MALIO_OK;
+}
+
+// ---- map ------------------------------------------------------------------------------------------
+int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
+  if (check(h) || !pts || n <= 0) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  float4 *stage = nullptr, *d_in = nullptr;
+  MALIO_HIP(hipHostMalloc(&stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
+  for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+  MALIO_HIP(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
+  MALIO_HIP(hipMemcpyAsync(d_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int rc = group_by_cell(c, d_in, n, c->inv_cell, c->map);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d_in);
+  (void)hipHostFree(stage);
+  if (rc != MALIO_OK) return rc;
+  c->map_n = n;
+  return MALIO_OK;
+}
+
+int malio_map_size(malio_handle_t h, int *out_size) {
+  if (check(h) || !out_size) return MALIO_ERR_BAD_ARG;
+  *out_size = h->map_n;
+  return MALIO_OK;
+}
+
+int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,
+                         float *out_d2, int *out_count) {
+  if (check(h) || !queries || n <= 0 || k < 1 || k > 5) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  if (c->map.n <= 0) return MALIO_ERR_NO_MAP;
+  MALIO_HIP(hipSetDevice(c->device));
+  std::vector<float4> hq(n);
+  for (int i = 0; i < n; i++) hq[i] = make_float4(queries[i].x, queries[i].y, queries[i].z, 0.f);
+  float4 *d_q = nullptr;
+  u32 *d_idx = nullptr;
+  float *d_d2 = nullptr;
+  int *d_cnt = nullptr;
+  MALIO_HIP(hipMalloc(&d_q, sizeof(float4) * (size_t)n));
+  MALIO_HIP(hipMalloc(&d_idx, sizeof(u32) * (size_t)n * k));
+  MALIO_HIP(hipMalloc(&d_d2, sizeof(float) * (size_t)n * k));
+  MALIO_HIP(hipMalloc(&d_cnt, sizeof(int) * (size_t)n));
+  MALIO_HIP(hipMemcpyAsync(d_q, hq.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int rc = nearest_search(c, d_q, n, k, d_idx, d_d2, d_cnt);
+  if (rc != MALIO_OK) return rc;
+  std::vector<u32> idx((size_t)n * k);
+  std::vector<float> d2((size_t)n * k);
+  std::vector<int> cnt(n);
+  MALIO_HIP(hipMemcpyAsync(idx.data(), d_idx, sizeof(u32) * idx.size(), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(d2.data(), d_d2, sizeof(float) * d2.size(), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float4> mp(c->map.n);
+  MALIO_HIP(hipMemcpyAsync(mp.data(), c->map.pts, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    if (out_count) out_count[i] = cnt[i];
+    for (int j = 0; j < k; j++) {
+      size_t o = (size_t)i * k + j;
+      if (out_d2) out_d2[o] = d2[o];
+      if (out_pts) {
+        malio_point_t p;
+        memset(&p, 0, sizeof(p));
+        if (idx[o] != 0xFFFFFFFFu) {
+          float4 m = mp[idx[o]];
+          p.x = m.x, p.y = m.y, p.z = m.z, p._pad0 = 1.f, p.normal_y = m.w;
+        }
+        out_pts[o] = p;
+      }
+    }
+  }
+  (void)hipFree(d_q), (void)hipFree(d_idx), (void)hipFree(d_d2), (void)hipFree(d_cnt);
+  return MALIO_OK;
+}
+
+int malio_map_add(malio_handle_t h, const malio_point_t *, int, int, int *) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->err = "malio_map_add: not implemented in this round (SURVEY.md §8 f-1)";
+  return MALIO_ERR_BAD_ARG;
+}
+int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *, int, int *) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->err = "malio_map_delete_boxes: not implemented in this round (SURVEY.md §8 f-1)";
+  return MALIO_ERR_BAD_ARG;
+}
+
+// ---- scan -----------------------------------------------------------------------------------------
+int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
+                   const int *pose_unc_len, const malio_pose_t *temporal_comp) {
+  if (check(h) || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  const int L = c->prm.lid_num;
+  if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP(hipSetDevice(c->device));
+  // uncertainty tables
+  int tot = 0;
+  for (int l = 0; l < L; l++) {
+    if (pose_unc_len[l] < 2 || !pose_unc[l]) return MALIO_ERR_BAD_ARG;  // the reference indexes size()-2
+    c->unc_off[l] = tot, c->unc_len[l] = pose_unc_len[l];
+    tot += pose_unc_len[l];
+  }
+  std::vector<UncEntry> ue(tot);
+  for (int l = 0; l < L; l++)
+    for (int k = 0; k < pose_unc_len[l]; k++) fold_entry(pose_unc[l][k], ue[c->unc_off[l] + k]);
+  if ((size_t)tot > c->cap_unc) {
+    if (c->d_unc) (void)hipFree(c->d_unc);
+    c->cap_unc = tot + 64;
+    MALIO_HIP(hipMalloc(&c->d_unc, sizeof(UncEntry) * c->cap_unc));
+  }
+  MALIO_HIP(hipMemcpyAsync(c->d_unc, ue.data(), sizeof(UncEntry) * tot, hipMemcpyHostToDevice, c->stream));
+  for (int l = 0; l + 1 < L; l++) {
+    for (int k = 0; k < 4; k++) c->tcq[l][k] = temporal_comp[l].q[k];
+    for (int k = 0; k < 3; k++) c->tct[l][k] = temporal_comp[l].t[k];
+  }
+  // partition by LiDAR slot (stable) and pack to 16 B: x y z (lid | int(normal_x) << 8)
+  c->N = n;
+  int cnt[MALIO_MAX_LIDAR] = {0};
+  for (int i = 0; i < n; i++) {
+    int lid = (int)body[i].intensity;  // laserMapping.cpp:570
+    if (lid < 0 || lid >= L) return MALIO_ERR_BAD_ARG;
+    cnt[lid]++;
+  }
+  c->seg_start[0] = 0;
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? cnt[l] : 0);
+  int rc = measure_alloc(c);
+  if (rc != MALIO_OK) return rc;
+  c->h_lidpart.resize(n);
+  c->h_normal_y_in.resize(n);
+  float4 *stage = nullptr;
+  MALIO_HIP(hipHostMalloc(&stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
+  int pos[MALIO_MAX_LIDAR];
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) pos[l] = c->seg_start[l];
+  for (int i = 0; i < n; i++) {
+    int lid = (int)body[i].intensity;
+    int idx = (int)body[i].normal_x;  // int(laser_p.normal_x), laserMapping.cpp:694,737
+    if (idx > 0x3FFFFF) idx = 0x3FFFFF;
+    if (idx < -0x3FFFFF) idx = -0x3FFFFF;
+    int packed = (int)(((unsigned)idx << 8) | (unsigned)lid);
+    float w;
+    memcpy(&w, &packed, 4);
+    int p = pos[lid]++;
+    stage[p] = make_float4(body[i].x, body[i].y, body[i].z, w);
+    c->h_lidpart[p] = (u32)i;
+    c->h_normal_y_in[i] = body[i].normal_y;
+  }
+  MALIO_HIP(hipMemcpyAsync(c->d_scan_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_sel, 0, (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_nfound, 0, (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_nbr, 0xFF, sizeof(u32) * 5 * (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  (void)hipHostFree(stage);
+  c->scan_sorted = false;
+  c->last_M = -1;
+  return MALIO_OK;
+}
+
+int malio_sums_len(malio_handle_t h) { return h ? sums_len(h) : 0; }
+
+int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax4) {
+  if (check(h) || !s || !d_minmax4) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP_H(hipSetDevice(h->device));
+  prof_begin(h);
+  return pass_stage1(h, s, converge, d_minmax4);
+}
+int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_sums) {
+  if (check(h) || !d_minmax4 || !d_sums) return MALIO_ERR_BAD_ARG;
+  int rc = pass_stage2(h, d_minmax4, d_sums, false);
+  return rc;
+}
+int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax4_host,
+                         malio_measure_out_t *out) {
+  if (check(h) || !sums_host || !minmax4_host || !out) return MALIO_ERR_BAD_ARG;
+  prof_end(h);
+  int rc = finish_host(h, sums_host, minmax4_host, out);
+  h->last_M = out->M;
+  return rc;
+}
+
+int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_measure_out_t *out) {
+  if (check(h) || !s || !out) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  const bool want_rows = out->h_x || out->h || out->R;
+  prof_begin(c);
+  double *d_mm = c->d_sums + MALIO_MAX_LIDAR * 97;  // 8 doubles after the sums
+  int rc = pass_stage1(c, s, converge, d_mm);
+  if (rc != MALIO_OK) return rc;
+  rc = pass_stage2(c, d_mm, c->d_sums, want_rows);
+  if (rc != MALIO_OK) return rc;
+  const int ns = sums_len(c);
+  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * ns, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(c->h_minmax, d_mm, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  prof_end(c);
+  rc = finish_host(c, c->h_sums, c->h_minmax, out);
+  c->last_M = out->M;
+  if (want_rows && out->valid) {
+    // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to
+    // C columns, scaled by w_loc (laserMapping.cpp:758-759), compacted in ascending original index.
+    const int N = c->N, L = c->prm.lid_num, C = 6 * (1 + L);
+    std::vector<double> rows((size_t)N * 14);
+    std::vector<u32> perm(N);
+    std::vector<unsigned char> sel(N);
+    MALIO_HIP(hipMemcpy(rows.data(), c->d_rows, sizeof(double) * rows.size(), hipMemcpyDeviceToHost));
+    MALIO_HIP(hipMemcpy(perm.data(), c->d_perm, sizeof(u32) * N, hipMemcpyDeviceToHost));
+    MALIO_HIP(hipMemcpy(sel.data(), c->d_sel, N, hipMemcpyDeviceToHost));
+    std::vector<int> src_of(N, -1);  // original index -> sorted index
+    for (int i = 0; i < N; i++) src_of[perm[i]] = i;
+    int m = 0;
+    for (int o = 0; o < N; o++) {
+      int i = src_of[o];
+      if (i < 0 || !sel[i]) continue;
+      int lid = 0;
+      for (int l = 1; l < L; l++)
+        if (i >= c->seg_start[l]) lid = l;
+      const double *r = &rows[(size_t)i * 14];
+      if (out->h_x) {
+        double *dst = out->h_x + (size_t)m * C;
+        for (int k = 0; k < C; k++) dst[k] = 0;
+        for (int k = 0; k < 6; k++) dst[k] = r[k] * out->w_loc;
+        for (int k = 0; k < 3; k++) {
+          dst[6 + 3 * lid + k] = r[6 + k] * out->w_loc;
+          dst[6 + 3 * (L + lid) + k] = r[9 + k] * out->w_loc;
+        }
+      }
+      if (out->h) out->h[m] = r[12] * out->w_loc;
+      if (out->R) out->R[m] = r[13];
+      m++;
+    }
+  }
+  return rc;
+}
+
+int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, int *nearest_count, uint8_t *selected,
+                   float *res_last, float *world_xyz, float *normvec4) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
+  MALIO_HIP(hipSetDevice(c->device));
+  const int N = c->N;
+  std::vector<u32> perm(N);
+  std::vector<unsigned char> sel(N), nf(N);
+  std::vector<double> tr(N);
+  std::vector<float> pd2(N), world((size_t)3 * N);
+  std::vector<float4> plane(N);
+  MALIO_HIP(hipMemcpyAsync(perm.data(), c->d_perm, sizeof(u32) * N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(sel.data(), c->d_sel, N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(tr.data(), c->d_trace, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(pd2.data(), c->d_pd2, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(plane.data(), c->d_plane, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
+  std::vector<float4> near;
+  if (nearest) {
+    float4 *d_near = nullptr;
+    MALIO_HIP(hipMalloc(&d_near, sizeof(float4) * 5 * (size_t)N));
+    hipLaunchKernelGGL(k_gather_side, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, N, c->d_perm, c->d_nbr,
+                       c->map.pts, d_near);
+    near.resize((size_t)5 * N);
+    MALIO_HIP(hipMemcpyAsync(near.data(), d_near, sizeof(float4) * near.size(), hipMemcpyDeviceToHost, c->stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_near);
+  }
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < N; i++) {
+    const u32 o = perm[i];
+    if (normal_y) {
+      // laserMapping.cpp:699,730,741; untouched when the pass bailed out (:635-639) or, for accepted
+      // points, when extrinsic_est_en is off (:681)
+      bool untouched = (c->last_M == 0) || (sel[i] && !c->prm.extrinsic_est_en);
+      normal_y[o] = untouched ? c->h_normal_y_in[o] : (float)tr[i];
+    }
+    if (nearest_count) nearest_count[o] = nf[i];
+    if (selected) selected[o] = sel[i];
+    if (res_last) res_last[o] = sel[i] ? fabsf(pd2[i]) : 0.f;
+    if (world_xyz) world_xyz[3 * o] = world[i], world_xyz[3 * o + 1] = world[N + i], world_xyz[3 * o + 2] = world[2 * N + i];
+    if (normvec4) {
+      normvec4[4 * o] = plane[i].x, normvec4[4 * o + 1] = plane[i].y, normvec4[4 * o + 2] = plane[i].z;
+      normvec4[4 * o + 3] = pd2[i];
+    }
+  }
+  if (nearest) {
+    for (size_t k = 0; k < (size_t)5 * N; k++) {
+      malio_point_t p;
+      memset(&p, 0, sizeof(p));
+      p.x = near[k].x, p.y = near[k].y, p.z = near[k].z, p._pad0 = 1.f, p.normal_y = near[k].w;
+      nearest[k] = p;
+    }
+  }
+  return MALIO_OK;
+}
+
+int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats, double *solve_time) {
+  if (check(h) || !x || !P) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP_H(hipSetDevice(h->device));
+  return ieskf_update(h, x, P, R, stats, solve_time);
+}
+
+int malio_undistort(malio_handle_t h, malio_point_t *, int, double, const double *, const double *, int, const double *,
+                    const double *, const double *, const double *, const double *, int, int, int *, int *) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->err = "malio_undistort: not built yet";
+  return MALIO_ERR_BAD_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// libmalio_hip internal declarations (gfx950 only). Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/malio.h"
+
+namespace malio {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u64 EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+constexpr int BLK = 256;  // 4 wave64 per workgroup
+
+// One spatial-hash entry: 16 B, read with a single dwordx4 load.
+struct alignas(16) Cell {
+  u64 key;
+  u32 start;
+  u32 count;
+};
+
+// Result of grouping a point set by hash cell (CSR over a compact open-addressing table).
+struct CellGrid {
+  Cell *table = nullptr;  // [tsize]
+  u32 tmask = 0;          // tsize - 1
+  u32 ncells = 0;
+  float4 *pts = nullptr;  // [n] sorted by cell: x, y, z, w (payload)
+  u32 *orig = nullptr;    // [n] original index of each sorted point
+  int n = 0;
+  size_t cap_pts = 0, cap_table = 0;
+};
+
+// Per-LiDAR constants of one pass (all double; rotation matrices row-major).
+struct LidarConst {
+  double Rl[9], tl[3];    // extrinsic of this LiDAR (iterated)   q_l, t_l
+  double Rtc[9], ttc[3];  // temporal compensation (identity for lid 0)
+};
+struct PassConst {
+  double Rw[9], pw[3];  // s.rot, s.pos
+  double R0[9], t0[3];  // extrinsic 0
+  LidarConst lid[MALIO_MAX_LIDAR];
+  int L, extrinsic_est_en;
+  float plane_th;
+  double cov_threshold;
+};
+struct WeightConst {
+  double plane_cov_max, plane_cov_min, point_cov_max, point_cov_min, range_min, range_max;
+};
+
+// Uncertainty-table entry folded for trace(Sigma_p) (associate_uct.hpp:153-175):
+// p' = T (0.05 p, 1);  trace = k0 + lin . p' + p'^T Q p'
+struct alignas(16) UncEntry {
+  double T[12];  // top 3 rows of pose.T_
+  double k0;
+  double lin[3];
+  double Q[6];  // xx yy zz xy xz yz
+};
+
+struct Ctx {
+  malio_params_t prm{};
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  float cell = 2.25f, inv_cell = 1.f / 2.25f;
+
+  // map
+  CellGrid map;
+  int map_n = 0;
+  // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
+  int N = 0;
+  bool scan_sorted = false;
+  float4 *d_scan_in = nullptr;  // [N] lid-partitioned upload order: x y z packed(lid | idx<<8)
+  float4 *d_scan = nullptr;     // [N] sorted
+  u32 *d_perm = nullptr;        // [N] sorted -> original index
+  std::vector<u32> h_lidpart;   // host: upload position -> original index
+  std::vector<float> h_normal_y_in;  // input normal_y (returned untouched where the reference does not write it)
+  int last_M = -1;
+  int seg_start[MALIO_MAX_LIDAR + 1] = {0};
+  size_t cap_scan = 0;
+  UncEntry *d_unc = nullptr;  // all tables concatenated
+  int unc_off[MALIO_MAX_LIDAR] = {0}, unc_len[MALIO_MAX_LIDAR] = {0};
+  size_t cap_unc = 0;
+  double tcq[MALIO_MAX_LIDAR][4], tct[MALIO_MAX_LIDAR][3];  // temporal_comp (index lid-1)
+  PassConst pc;  // matrix form of the state of the current pass (filled by stage 1)
+  // per-point pass state (sorted order)
+  u32 *d_nbr = nullptr;        // [5][N] map sorted index or 0xFFFFFFFF
+  float4 *d_plane = nullptr;   // [N] pabcd
+  float *d_pd2 = nullptr;      // [N]
+  float *d_world = nullptr;    // [3][N]
+  double *d_ucov = nullptr;    // [N] unit_cov
+  double *d_trace = nullptr;   // [N] trace(Sigma_p) (clamp rule by selected flag)
+  unsigned char *d_sel = nullptr;  // [N]
+  unsigned char *d_nfound = nullptr;  // [N]
+  // reductions
+  u64 *d_minmax = nullptr;   // [4] ordered-encoded: max_ucov, min_ucov, max_R, min_R ; [4] = M counter
+  double *d_partials = nullptr;  // [nblocks][NSUM]
+  double *d_sums = nullptr;      // [NSUM_OUT]
+  double *h_sums = nullptr;      // pinned
+  double *h_minmax = nullptr;    // pinned [5]
+  double *d_rows = nullptr;      // optional dense rows [N][C+2]
+  size_t cap_rows = 0;
+  size_t cap_partials = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<const char *> ev_names;
+  int ev_used = 0;
+  std::vector<float> last_ms;
+  std::vector<const char *> last_names;
+};
+
+#define MALIO_HIP(call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      c->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+      return MALIO_ERR_HIP;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+#define MALIO_HIP_H(call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+      return MALIO_ERR_HIP;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+// group `n` device points (float4, xyz used) by spatial-hash cell into `g` (allocates/grows g's buffers)
+int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig = nullptr);
+void free_grid(CellGrid &g);
+
+// measure.hip
+int measure_alloc(Ctx *c);
+int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out);
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_sums_out, bool want_rows);
+int sums_len(const Ctx *c);
+int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
+int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt);
+
+// host/ieskf.cpp
+int ieskf_update(Ctx *c, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+
+// profiling helpers
+void prof_begin(Ctx *c);
+void prof_mark(Ctx *c, const char *name);  // records an event AFTER the kernel named `name`
+void prof_end(Ctx *c);
+
+}  // namespace malio
+
+struct malio_ctx : malio::Ctx {};

@@ -1,0 +1,998 @@
+// The per-pass hot path: one h_share_model pass (laserMapping.cpp:552-760) fused with the
+// H^T R^-1 H / H^T R^-1 h accumulation of esekfom.hpp:621-635, as three gfx950 kernels:
+//   k_pass1<SEARCH>  a1-a3 (+a6 trace): world transform, 5-NN in the spatial hash, float plane fit, gates
+//   k_rows_reduce    a5/a7/a10: Jacobian row, FIC weights, per-workgroup LDS outer-product reduction
+//   k_final_reduce   deterministic fixed-order sum of the workgroup partials
+// Compiled with -ffp-contract=off: the float stages (distances, QR plane fit, gates) and the double
+// world transform follow the reference's operation order without FMA contraction, so discrete outcomes
+// (neighbour sets, accept flags) are reproducible against the CPU restatement.
+#include "malio_internal.hpp"
+
+namespace malio {
+
+constexpr int NSUM = 97;  // 78 (12x12 upper) + 12 (rhs) + 6 (c^2 n n^T) + 1 (count)
+constexpr u32 INVALID = 0xFFFFFFFFu;
+
+struct D3 {
+  double x, y, z;
+};
+struct Q4 {
+  double x, y, z, w;
+};
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Q4 qconj(Q4 q) { return {-q.x, -q.y, -q.z, q.w}; }
+// Eigen::QuaternionBase::_transformVector order: v + w*uv + qv x uv, uv = 2 (qv x v)
+__device__ __forceinline__ D3 qrot(Q4 q, D3 v) {
+  D3 qv{q.x, q.y, q.z};
+  D3 uv = cross(qv, v);
+  uv = uv + uv;
+  D3 c2 = cross(qv, uv);
+  return {(v.x + q.w * uv.x) + c2.x, (v.y + q.w * uv.y) + c2.y, (v.z + q.w * uv.z) + c2.z};
+}
+__device__ __forceinline__ D3 mulR(const double *R, D3 v) {
+  return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z,
+          R[6] * v.x + R[7] * v.y + R[8] * v.z};
+}
+__device__ __forceinline__ D3 mulRt(const double *R, D3 v) {
+  return {R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z,
+          R[2] * v.x + R[5] * v.y + R[8] * v.z};
+}
+
+// order-preserving double <-> u64 encoding for atomicMin/Max
+__device__ __forceinline__ u64 enc_d(double d) {
+  u64 b = (u64)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static inline double dec_d_host(u64 e) {
+  u64 b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+static inline u64 enc_d_host(double d) {
+  u64 b;
+  memcpy(&b, &d, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+struct QuatConst {
+  Q4 rot;
+  D3 pos;
+  Q4 q0;
+  D3 t0;
+  Q4 ql[MALIO_MAX_LIDAR];
+  D3 tl[MALIO_MAX_LIDAR];
+  Q4 qtc[MALIO_MAX_LIDAR];  // index lid (0 unused)
+  D3 ttc[MALIO_MAX_LIDAR];
+};
+
+struct Pass1Args {
+  int N;
+  const float4 *scan;
+  // map
+  const float4 *map_pts;
+  const u32 *map_orig;
+  const Cell *table;
+  u32 tmask;
+  float cell, inv_cell;
+  // tables
+  const UncEntry *unc;
+  int unc_off[MALIO_MAX_LIDAR], unc_len[MALIO_MAX_LIDAR];
+  // state
+  QuatConst qc;
+  float plane_th;
+  double cov_threshold;
+  int extrinsic_est_en;
+  // per-point outputs (sorted order)
+  u32 *nbr;  // [5][N]
+  float4 *plane;
+  float *pd2;
+  float *world;  // [3][N]
+  double *ucov;
+  double *trace;
+  unsigned char *sel;
+  unsigned char *nfound;
+  u64 *minmax;  // [0]=max ucov [1]=min ucov [2]=max R [3]=min R (encoded) [4]=M
+};
+
+// 27 neighbour offsets, nearest shells first (centre, 6 faces, 12 edges, 8 corners)
+__constant__ signed char c_off[27][3] = {
+    {0, 0, 0},  {-1, 0, 0},  {1, 0, 0},   {0, -1, 0},  {0, 1, 0},   {0, 0, -1},  {0, 0, 1},
+    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0},  {1, 1, 0},   {-1, 0, -1}, {-1, 0, 1},  {1, 0, -1},
+    {1, 0, 1},  {0, -1, -1}, {0, -1, 1},  {0, 1, -1},  {0, 1, 1},   {-1, -1, -1}, {-1, -1, 1},
+    {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},  {1, 1, -1},  {1, 1, 1}};
+
+__device__ __forceinline__ u64 cell_key_d(int ix, int iy, int iz) {
+  const long long B = 1ll << 20;
+  return ((u64)(ix + B) & 0x1FFFFF) | (((u64)(iy + B) & 0x1FFFFF) << 21) | (((u64)(iz + B) & 0x1FFFFF) << 42);
+}
+__device__ __forceinline__ u32 hash_key_d(u64 k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (u32)k;
+}
+
+// Sorted (ascending) 5-slot candidate list with total order (d2, original map index).
+struct Top5 {
+  float d[5];
+  u32 id[5];
+};
+__device__ __forceinline__ bool cand_less(float da, u32 ia, float db, u32 ib, const u32 *__restrict__ orig) {
+  if (da < db) return true;
+  if (da > db) return false;
+  if (ib == INVALID) return false;  // sentinel slots only lose to strictly smaller distances
+  if (ia == INVALID) return false;
+  return orig[ia] < orig[ib];
+}
+__device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 j, const u32 *__restrict__ orig) {
+  if (!cand_less(d2, j, t.d[4], t.id[4], orig)) return;
+  t.d[4] = d2;
+  t.id[4] = j;
+#pragma unroll
+  for (int k = 4; k > 0; k--) {
+    bool sw = cand_less(t.d[k], t.id[k], t.d[k - 1], t.id[k - 1], orig);
+    float dk = t.d[k], dk1 = t.d[k - 1];
+    u32 ik = t.id[k], ik1 = t.id[k - 1];
+    t.d[k] = sw ? dk1 : dk;
+    t.d[k - 1] = sw ? dk : dk1;
+    t.id[k] = sw ? ik1 : ik;
+    t.id[k - 1] = sw ? ik : ik1;
+  }
+}
+
+// Exact radius-limited 5-NN in the hash grid. Keeps candidates with d2 <= limit2 (float compare as
+// `pointSearchSqDis[4] > 5` laserMapping.cpp:587); squared distance arithmetic as ikd_Tree.cpp:1697.
+__device__ __forceinline__ void knn5(float wx, float wy, float wz, const float4 *__restrict__ map_pts,
+                                     const u32 *__restrict__ map_orig, const Cell *__restrict__ table, u32 tmask,
+                                     float cell, float inv_cell, float limit2, Top5 &t) {
+  const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
+#pragma unroll
+  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.id[k] = INVALID;
+  float gx = wx * inv_cell, gy = wy * inv_cell, gz = wz * inv_cell;
+  float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
+  int kx = (int)kxf, ky = (int)kyf, kz = (int)kzf;
+  float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
+  // conservative allowance for the float rounding of the cell coordinates
+  float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * cell;
+  float lo_x = fmaxf(fx * cell - margin, 0.f), hi_x = fmaxf((1.f - fx) * cell - margin, 0.f);
+  float lo_y = fmaxf(fy * cell - margin, 0.f), hi_y = fmaxf((1.f - fy) * cell - margin, 0.f);
+  float lo_z = fmaxf(fz * cell - margin, 0.f), hi_z = fmaxf((1.f - fz) * cell - margin, 0.f);
+  for (int o = 0; o < 27; o++) {
+    int dx = c_off[o][0], dy = c_off[o][1], dz = c_off[o][2];
+    float ax = dx < 0 ? lo_x : (dx > 0 ? hi_x : 0.f);
+    float ay = dy < 0 ? lo_y : (dy > 0 ? hi_y : 0.f);
+    float az = dz < 0 ? lo_z : (dz > 0 ? hi_z : 0.f);
+    float bd2 = (ax * ax + ay * ay + az * az) * 0.999999f;
+    if (bd2 > t.d[4]) continue;
+    u64 key = cell_key_d(kx + dx, ky + dy, kz + dz);
+    u32 s = hash_key_d(key) & tmask;
+    u32 start = 0, count = 0;
+    while (true) {
+      Cell c = table[s];
+      if (c.key == key) {
+        start = c.start, count = c.count;
+        break;
+      }
+      if (c.key == EMPTY_KEY) break;
+      s = (s + 1) & tmask;
+    }
+    for (u32 j = start; j < start + count; j++) {
+      float4 m = map_pts[j];
+      float ddx = wx - m.x, ddy = wy - m.y, ddz = wz - m.z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+      top5_insert(t, d2, j, map_orig);
+    }
+  }
+}
+
+// Eigen ColPivHouseholderQR<Matrix<float,5,3>>::solve(b = -1) restated with static register indexing
+// (common_lib.h:174). Same operation order as the CPU restatement; no runtime-indexed arrays.
+__device__ __forceinline__ void qr_solve_5x3(float A[5][3], float x[3]) {
+  const float eps = 1.1920929e-07f;
+  float hC[3];
+  int tr[3];
+  float nU[3], nD[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) s += A[i][k] * A[i][k];
+    nD[k] = sqrtf(s);
+    nU[k] = nD[k];
+  }
+  float maxn = nU[0];
+  if (nU[1] > maxn) maxn = nU[1];
+  if (nU[2] > maxn) maxn = nU[2];
+  float th = maxn * eps;
+  float threshold_helper = (th * th) / 5.0f;
+  float ndt = sqrtf(eps);
+  int nonzero = 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int big = k;
+    float bigv = nU[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; j++)
+      if (nU[j] > bigv) bigv = nU[j], big = j;
+    float big_sq = bigv * bigv;
+    if (nonzero == 3 && big_sq < threshold_helper * (float)(5 - k)) nonzero = k;
+    tr[k] = big;
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      if (big == j) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          float tmp = A[i][k];
+          A[i][k] = A[i][j];
+          A[i][j] = tmp;
+        }
+        float tn = nU[k];
+        nU[k] = nU[j];
+        nU[j] = tn;
+        tn = nD[k];
+        nD[k] = nD[j];
+        nD[j] = tn;
+      }
+    }
+    float tailSq = 0.f;
+#pragma unroll
+    for (int i = k + 1; i < 5; i++) tailSq += A[i][k] * A[i][k];
+    float c0 = A[k][k];
+    float tau, beta;
+    if (tailSq <= 1.17549435e-38f) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) A[i][k] = 0.f;
+    } else {
+      beta = sqrtf(c0 * c0 + tailSq);
+      if (c0 >= 0.f) beta = -beta;
+      float den = c0 - beta;
+#pragma unroll
+      for (int i = k + 1; i < 5; i++) A[i][k] = A[i][k] / den;
+      tau = (beta - c0) / beta;
+    }
+    hC[k] = tau;
+    A[k][k] = beta;
+    if (tau != 0.f) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) tmp += A[i][k] * A[i][j];
+        tmp += A[k][j];
+        A[k][j] -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) A[i][j] -= tau * A[i][k] * tmp;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      if (nU[j] != 0.f) {
+        float temp = fabsf(A[k][j]) / nU[j];
+        temp = (1.f + temp) * (1.f - temp);
+        temp = temp < 0.f ? 0.f : temp;
+        float r = nU[j] / nD[j];
+        float temp2 = temp * (r * r);
+        if (temp2 <= ndt) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = k + 1; i < 5; i++) s += A[i][j] * A[i][j];
+          nD[j] = sqrtf(s);
+          nU[j] = nD[j];
+        } else {
+          nU[j] *= sqrtf(temp);
+        }
+      }
+    }
+  }
+  // permutation: perm = identity; swap(perm[k], perm[tr[k]]) for k = 0,1,2
+  int p0 = 0, p1 = 1, p2 = 2;
+  {
+    if (tr[0] == 1) { int t_ = p0; p0 = p1; p1 = t_; }
+    if (tr[0] == 2) { int t_ = p0; p0 = p2; p2 = t_; }
+    if (tr[1] == 2) { int t_ = p1; p1 = p2; p2 = t_; }
+  }
+  float c[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < nonzero) {
+      float tau = hC[k];
+      if (tau != 0.f) {
+        float tmp = 0.f;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) tmp += A[i][k] * c[i];
+        tmp += c[k];
+        c[k] -= tau * tmp;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) c[i] -= tau * A[i][k] * tmp;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 2; i >= 0; i--) {
+    if (i < nonzero) {
+      float s = c[i];
+#pragma unroll
+      for (int j = i + 1; j < 3; j++)
+        if (j < nonzero) s -= A[i][j] * c[j];
+      c[i] = s / A[i][i];
+    }
+  }
+  float y0 = nonzero > 0 ? c[0] : 0.f, y1 = nonzero > 1 ? c[1] : 0.f, y2 = nonzero > 2 ? c[2] : 0.f;
+  x[0] = x[1] = x[2] = 0.f;
+  // x[perm[i]] = y_i
+  x[0] = (p0 == 0) ? y0 : (p1 == 0) ? y1 : y2;
+  x[1] = (p0 == 1) ? y0 : (p1 == 1) ? y1 : y2;
+  x[2] = (p0 == 2) ? y0 : (p1 == 2) ? y1 : y2;
+  if (nonzero < 3) {  // columns whose pivot position >= nonzero stay 0
+    if (p2 == 0) x[0] = 0.f;
+    if (p2 == 1) x[1] = 0.f;
+    if (p2 == 2) x[2] = 0.f;
+    if (nonzero < 2) {
+      if (p1 == 0) x[0] = 0.f;
+      if (p1 == 1) x[1] = 0.f;
+      if (p1 == 2) x[2] = 0.f;
+    }
+    if (nonzero < 1) x[0] = x[1] = x[2] = 0.f;
+  }
+}
+
+// trace(Sigma_p) (associate_uct.hpp:153-175 as the caller uses it, laserMapping.cpp:697-699,740-741)
+__device__ __forceinline__ double point_trace(const UncEntry &e, float px, float py, float pz) {
+  double x = (double)px * 0.05, y = (double)py * 0.05, z = (double)pz * 0.05;
+  double a = e.T[0] * x + e.T[1] * y + e.T[2] * z + e.T[3];
+  double b = e.T[4] * x + e.T[5] * y + e.T[6] * z + e.T[7];
+  double c = e.T[8] * x + e.T[9] * y + e.T[10] * z + e.T[11];
+  return e.k0 + (e.lin[0] * a + e.lin[1] * b + e.lin[2] * c) +
+         (e.Q[0] * a * a + e.Q[1] * b * b + e.Q[2] * c * c + 2.0 * (e.Q[3] * a * b + e.Q[4] * a * c + e.Q[5] * b * c));
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_xor(v, d));
+  return v;
+}
+
+template <bool SEARCH>
+__global__ void __launch_bounds__(BLK) k_pass1(Pass1Args a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  const bool active = i < a.N;
+  bool selected = false;
+  double ucov = 0.0, tr = 0.0;
+  if (active) {
+    const float4 q = a.scan[i];
+    const int packed = __float_as_int(q.w);
+    const int lid = packed & 0xFF;
+    const int tidx = packed >> 8;  // int(normal_x), sign preserved
+    // ---- a1: p' (LiDAR-0 frame) and world point, double -> float (laserMapping.cpp:569-578) ----
+    D3 p_body{(double)q.x, (double)q.y, (double)q.z};
+    if (lid != 0)
+      p_body = qrot(qconj(a.qc.q0),
+                    (qrot(a.qc.qtc[lid], qrot(a.qc.ql[lid], p_body) + a.qc.tl[lid]) + a.qc.ttc[lid]) - a.qc.t0);
+    D3 pg = qrot(a.qc.rot, qrot(a.qc.q0, p_body) + a.qc.t0) + a.qc.pos;
+    const float wx = (float)pg.x, wy = (float)pg.y, wz = (float)pg.z;
+    a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
+
+    bool cand;
+    u32 id[5];
+    if (SEARCH) {
+      // ---- a2: 5-NN (ikdtree.Nearest_Search, :586) + gate `size < 5 || d2[4] > 5` (:587) ----
+      Top5 t;
+      knn5(wx, wy, wz, a.map_pts, a.map_orig, a.table, a.tmask, a.cell, a.inv_cell, 5.0f, t);
+      int nf = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        id[k] = t.id[k];
+        a.nbr[(size_t)k * a.N + i] = t.id[k];
+        nf += (t.id[k] != INVALID);
+      }
+      a.nfound[i] = (unsigned char)nf;
+      cand = nf == 5;
+    } else {
+      cand = a.sel[i] != 0;  // neighbours and flag reused when !converge (:583-591)
+    }
+    float pabcd[4] = {0, 0, 0, 0};
+    bool plane_ok = false;
+    if (cand) {
+      if (SEARCH) {
+        // ---- a3: esti_plane<float> (common_lib.h:144-190) ----
+        float A[5][3], W[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          float4 m = a.map_pts[id[k]];
+          A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
+        }
+        double cov_sum = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
+        if ((double)W[0] > 0.00001) {
+#pragma unroll
+          for (int k = 0; k < 5; k++) {
+            double w = (a.cov_threshold - (double)W[k]) / cov_sum;
+            ucov += w * w * (double)W[k];
+          }
+        }
+        float P[5][3];
+#pragma unroll
+        for (int k = 0; k < 5; k++) P[k][0] = A[k][0], P[k][1] = A[k][1], P[k][2] = A[k][2];
+        float nv[3];
+        qr_solve_5x3(A, nv);
+        float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
+        pabcd[3] = (float)(1.0 / (double)n);
+        plane_ok = true;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+          if (fabsf(pabcd[0] * P[k][0] + pabcd[1] * P[k][1] + pabcd[2] * P[k][2] + pabcd[3]) > a.plane_th)
+            plane_ok = false;
+        a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+        a.ucov[i] = ucov;
+      } else {
+        float4 pl = a.plane[i];
+        pabcd[0] = pl.x, pabcd[1] = pl.y, pabcd[2] = pl.z, pabcd[3] = pl.w;
+        ucov = a.ucov[i];
+        plane_ok = true;  // same neighbours -> esti_plane returns the same plane and verdict
+      }
+      if (plane_ok) {
+        // ---- residual + range gate (laserMapping.cpp:598-601) ----
+        float pd2 = pabcd[0] * wx + pabcd[1] * wy + pabcd[2] * wz + pabcd[3];
+        double nb = sqrt(p_body.x * p_body.x + p_body.y * p_body.y + p_body.z * p_body.z);
+        float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb));
+        if ((double)s > 0.1) {
+          selected = true;
+          a.pd2[i] = pd2;
+        }
+      }
+    }
+    a.sel[i] = selected ? 1 : 0;
+    // ---- a6/a8: trace(Sigma_p); index clamps differ for accepted (:694-696) / rejected (:737-739) ----
+    {
+      int len = a.unc_len[lid];
+      int k = tidx;
+      if (selected) {
+        if ((unsigned)k >= (unsigned)len) k = len - 2;
+      } else {
+        if ((unsigned)k >= (unsigned)(len - 1)) k = len - 2;
+      }
+      if (selected && !a.extrinsic_est_en) {
+        tr = 0.0;  // R(i,0) stays 0 and normal_y is not rewritten (:681-704); see scan_get
+      } else {
+        tr = point_trace(a.unc[a.unc_off[lid] + k], q.x, q.y, q.z);
+      }
+      a.trace[i] = tr;
+    }
+  }
+  // ---- a4: min/max unit_cov, min/max R over accepted points, M ----
+  double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
+  bool rsel = selected && a.extrinsic_est_en;
+  double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
+  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
+  unsigned long long bal = __ballot(selected);
+  if ((threadIdx.x & 63) == 0) {
+    int cnt = __popcll(bal);
+    if (cnt) {
+      atomicMax(&a.minmax[0], enc_d(mxu));
+      atomicMin(&a.minmax[1], enc_d(mnu));
+      if (a.extrinsic_est_en) {
+        atomicMax(&a.minmax[2], enc_d(mxr));
+        atomicMin(&a.minmax[3], enc_d(mnr));
+      }
+      atomicAdd(&a.minmax[4], (u64)cnt);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Pass2Args {
+  int N, L, extrinsic_est_en;
+  const float4 *scan;
+  const float4 *plane;
+  const float *pd2;
+  const double *ucov;
+  const double *trace;
+  const unsigned char *sel;
+  int seg_block0[MALIO_MAX_LIDAR + 1];  // first workgroup of each LiDAR segment
+  int seg_start[MALIO_MAX_LIDAR + 1];   // first sorted point of each LiDAR segment
+  PassConst pc;
+  WeightConst wc;
+  const double *minmax4;  // decoded doubles: max_ucov, -min_ucov, max_R, -min_R
+  double *partials;       // [nblocks][NSUM]
+  double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
+};
+
+// a5 + a7: weights and the 12 non-zero entries of the (c_i-scaled) Jacobian row of one accepted point
+__device__ __forceinline__ void point_row(const Pass2Args &a, int i, int lid, double u[12], double &hs, double &r) {
+  const float4 q = a.scan[i];
+  const float4 pl = a.plane[i];
+  const double max_u = a.minmax4[0], min_u = -a.minmax4[1], max_c = a.minmax4[2], min_c = -a.minmax4[3];
+  // plane weight c_i (laserMapping.cpp:651-656)
+  double cp = a.ucov[i];
+  if (cp == 0)
+    cp = 1;
+  else if (max_u == min_u)
+    cp = (a.wc.plane_cov_max + a.wc.plane_cov_min) / 2;
+  else
+    cp = 1 / ((a.wc.plane_cov_max - a.wc.plane_cov_min) * (cp - min_u) / (max_u - min_u) + a.wc.plane_cov_min);
+  // geometry (:658-693)
+  D3 p{(double)q.x, (double)q.y, (double)q.z};
+  const LidarConst &lc = a.pc.lid[lid];
+  D3 X;  // q0 * p_be + t0  == point_this (IMU frame at LiDAR-0 scan end)
+  D3 p_be;
+  if (lid == 0) {
+    p_be = p;
+    X = mulR(a.pc.R0, p) + D3{a.pc.t0[0], a.pc.t0[1], a.pc.t0[2]};
+  } else {
+    D3 y = mulR(lc.Rl, p) + D3{lc.tl[0], lc.tl[1], lc.tl[2]};
+    X = mulR(lc.Rtc, y) + D3{lc.ttc[0], lc.ttc[1], lc.ttc[2]};
+    p_be = p;  // unused for lid != 0
+  }
+  D3 n{(double)pl.x, (double)pl.y, (double)pl.z};
+  D3 Cv = mulRt(a.pc.Rw, n);  // s.rot.conjugate() * norm_vec (:676)
+  D3 A = cross(X, Cv);        // point_crossmat * C (:677)
+  D3 B{0, 0, 0}, Cb{0, 0, 0};
+  if (a.extrinsic_est_en) {
+    if (lid == 0) {
+      B = cross(p_be, mulRt(a.pc.R0, Cv));  // :684
+      Cb = Cv;
+    } else {
+      Cb = mulRt(lc.Rtc, Cv);            // :689
+      B = cross(p, mulRt(lc.Rl, Cb));    // :690
+    }
+  }
+  u[0] = n.x * cp, u[1] = n.y * cp, u[2] = n.z * cp;  // row * cov_plane[i] (:714)
+  u[3] = A.x * cp, u[4] = A.y * cp, u[5] = A.z * cp;
+  u[6] = B.x * cp, u[7] = B.y * cp, u[8] = B.z * cp;
+  u[9] = Cb.x * cp, u[10] = Cb.y * cp, u[11] = Cb.z * cp;
+  hs = (-1.0) * (double)a.pd2[i] * cp;  // :707,715
+  // point noise R_i by FIC (:716-721)
+  double R = a.extrinsic_est_en ? a.trace[i] : 0.0;
+  const double lo = min_c + (max_c - min_c) * a.wc.range_min, hi = min_c + (max_c - min_c) * a.wc.range_max;
+  if (R < lo)
+    R = a.wc.point_cov_min;
+  else if (R > hi)
+    R = a.wc.point_cov_max;
+  else
+    R = (a.wc.point_cov_max - a.wc.point_cov_min) * (R - lo) / ((a.wc.range_max - a.wc.range_min) * (max_c - min_c)) +
+        a.wc.point_cov_min;
+  r = R;
+}
+
+// One workgroup = 256 consecutive sorted points of ONE LiDAR. Rows go to LDS, then the 97 sums of
+// the workgroup are formed by 2 x 97 threads reading LDS with wave-uniform (broadcast) addresses.
+__global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
+  __shared__ double X[BLK][13];  // u[0..11], hs
+  __shared__ double Y[BLK][12];  // u / r (r clamped as esekfom.hpp:624-626)
+  __shared__ double half1[NSUM];
+  int lid = 0;
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (l < a.L && (int)blockIdx.x >= a.seg_block0[l]) lid = l;
+  const int i = a.seg_start[lid] + ((int)blockIdx.x - a.seg_block0[lid]) * BLK + threadIdx.x;
+  const bool in = i < a.seg_start[lid + 1];
+  const bool selected = in && a.sel[i] != 0;
+  double u[12], hs = 0, r = 1;
+#pragma unroll
+  for (int k = 0; k < 12; k++) u[k] = 0;
+  if (selected) point_row(a, i, lid, u, hs, r);
+  if (a.rows && in) {
+    double *row = a.rows + (size_t)i * 14;
+#pragma unroll
+    for (int k = 0; k < 12; k++) row[k] = u[k];
+    row[12] = hs;
+    row[13] = selected ? r : 0.0;
+  }
+  double rc = r;
+  if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+  double rinv = 1.0 / rc;
+#pragma unroll
+  for (int k = 0; k < 12; k++) X[threadIdx.x][k] = u[k], Y[threadIdx.x][k] = selected ? u[k] / rc : 0.0;
+  X[threadIdx.x][12] = hs;
+  (void)rinv;
+  unsigned long long bal = __ballot(selected);
+  __shared__ int wcnt[BLK / 64];
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  // entry e: 0..77 -> (ra, cb) upper triangle of Y^T X ; 78..89 -> rhs Y^T hs ; 90..95 -> X^T X (3x3) ; 96 count
+  const int e = threadIdx.x & 127, half = threadIdx.x >> 7;
+  double acc = 0;
+  if (e < NSUM - 1) {
+    int ra, cb;
+    bool xx = false;
+    if (e < 78) {
+      int rem = e;
+      ra = 0;
+      while (rem >= 12 - ra) rem -= 12 - ra, ra++;
+      cb = ra + rem;
+    } else if (e < 90) {
+      ra = e - 78, cb = 12;
+    } else {
+      const int m6[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+      ra = m6[e - 90][0], cb = m6[e - 90][1], xx = true;
+    }
+    const int p0 = half * 128;
+    if (xx) {
+#pragma unroll 8
+      for (int p = p0; p < p0 + 128; p++) acc += X[p][ra] * X[p][cb];
+    } else {
+#pragma unroll 8
+      for (int p = p0; p < p0 + 128; p++) acc += Y[p][ra] * X[p][cb];
+    }
+  } else if (e == NSUM - 1) {
+    acc = half == 0 ? (double)(wcnt[0] + wcnt[1]) : (double)(wcnt[2] + wcnt[3]);
+  }
+  if (half == 1 && e < NSUM) half1[e] = acc;
+  __syncthreads();
+  if (half == 0 && e < NSUM) a.partials[(size_t)blockIdx.x * NSUM + e] = acc + half1[e];
+}
+
+// Fixed-order final sum: one workgroup per LiDAR, 8 groups of 128 lanes stride over that LiDAR's
+// workgroups, then the 8 group sums are added in order. out: [L][NSUM].
+struct SegBlocks {
+  int b[MALIO_MAX_LIDAR + 1];
+};
+__global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict__ partials, SegBlocks sb, double *out) {
+  __shared__ double g[8][128];
+  const int lid = blockIdx.x;
+  const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
+  const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  double acc = 0;
+  if (e < NSUM)
+    for (int b = b0 + grp; b < b1; b += 8) acc += partials[(size_t)b * NSUM + e];
+  g[grp][e] = acc;
+  __syncthreads();
+  if (grp == 0 && e < NSUM) {
+    double s = g[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; k++) s += g[k][e];
+    out[lid * NSUM + e] = s;
+  }
+}
+
+__global__ void k_init_minmax(u64 *mm, u64 e_max_u, u64 e_min_u, u64 e_max_r, u64 e_min_r) {
+  mm[0] = e_max_u, mm[1] = e_min_u, mm[2] = e_max_r, mm[3] = e_min_r, mm[4] = 0;
+}
+// decode to the all-reduce-friendly form [max_u, -min_u, max_R, -min_R, M]
+__global__ void k_decode_minmax(const u64 *mm, double *out) {
+  int t = threadIdx.x;
+  if (t < 4) {
+    u64 e = mm[t];
+    u64 b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+    double d = __longlong_as_double((long long)b);
+    out[t] = (t & 1) ? -d : d;
+  } else if (t == 4) {
+    out[4] = (double)mm[4];
+  }
+}
+
+// ---- batched Nearest_Search -----------------------------------------------------------------------
+__global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, int n, int k,
+                                                 const float4 *__restrict__ map_pts, const u32 *__restrict__ map_orig,
+                                                 const Cell *__restrict__ table, u32 tmask, float cell, float inv_cell,
+                                                 u32 *out_idx, float *out_d2, int *out_cnt) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = q[i];
+  Top5 t;
+  // radius limit = cell edge (>= sqrt 5): everything within it is inside the 27-cell block
+  knn5(p.x, p.y, p.z, map_pts, map_orig, table, tmask, cell, inv_cell, cell * cell * 0.999f, t);
+  int c = 0;
+  for (int j = 0; j < 5; j++) {
+    if (j < k) {
+      bool ok = t.id[j] != INVALID;
+      out_idx[(size_t)i * k + j] = ok ? t.id[j] : INVALID;
+      out_d2[(size_t)i * k + j] = ok ? t.d[j] : INFINITY;
+      c += ok;
+    }
+  }
+  out_cnt[i] = c;
+}
+
+int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
+  hipLaunchKernelGGL(k_nearest, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_q, n, k, c->map.pts, c->map.orig,
+                     c->map.table, c->map.tmask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+// ---- host side of a pass -------------------------------------------------------------------------
+static void q_to_R(const double q[4], double R[9]) {  // (x,y,z,w) -> row-major, Eigen toRotationMatrix
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+         tzz = tz * z;
+  R[0] = 1 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
+  R[3] = txy + twz, R[4] = 1 - (txx + tzz), R[5] = tyz - twx;
+  R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
+}
+
+int sums_len(const Ctx *c) { return c->prm.lid_num * NSUM; }
+
+static int nblocks_total(const Ctx *c, int seg_block0[MALIO_MAX_LIDAR + 1]) {
+  int b = 0;
+  for (int l = 0; l < c->prm.lid_num; l++) {
+    seg_block0[l] = b;
+    b += (c->seg_start[l + 1] - c->seg_start[l] + BLK - 1) / BLK;
+  }
+  for (int l = c->prm.lid_num; l <= MALIO_MAX_LIDAR; l++) seg_block0[l] = b;
+  return b;
+}
+
+int measure_alloc(Ctx *c) {
+  size_t N = (size_t)c->N;
+  if (N > c->cap_scan) {
+    auto fr = [](void *p) {
+      if (p) (void)hipFree(p);
+    };
+    fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in);
+    c->cap_scan = N + N / 8 + 1024;
+    size_t K = c->cap_scan;
+    MALIO_HIP(hipMalloc(&c->d_scan_in, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_scan, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_perm, sizeof(u32) * K));
+    MALIO_HIP(hipMalloc(&c->d_nbr, sizeof(u32) * 5 * K));
+    MALIO_HIP(hipMalloc(&c->d_plane, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_pd2, sizeof(float) * K));
+    MALIO_HIP(hipMalloc(&c->d_world, sizeof(float) * 3 * K));
+    MALIO_HIP(hipMalloc(&c->d_ucov, sizeof(double) * K));
+    MALIO_HIP(hipMalloc(&c->d_trace, sizeof(double) * K));
+    MALIO_HIP(hipMalloc(&c->d_sel, K));
+    MALIO_HIP(hipMalloc(&c->d_nfound, K));
+  }
+  size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
+  if (nb > c->cap_partials) {
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    c->cap_partials = nb + nb / 8 + 16;
+    MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));
+  }
+  if (!c->d_minmax) {
+    MALIO_HIP(hipMalloc(&c->d_minmax, sizeof(u64) * 8));
+    MALIO_HIP(hipMalloc(&c->d_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8 + 16)));
+    MALIO_HIP(hipHostMalloc(&c->h_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8), hipHostMallocDefault));
+    MALIO_HIP(hipHostMalloc(&c->h_minmax, sizeof(double) * 8, hipHostMallocDefault));
+  }
+  return MALIO_OK;
+}
+
+// world positions for the spatial sort of the scan (float is enough: ordering only)
+__global__ void __launch_bounds__(BLK) k_scan_world(const float4 *__restrict__ in, int n, QuatConst qc, float4 *out) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float4 q = in[i];
+  int lid = __float_as_int(q.w) & 0xFF;
+  D3 p{(double)q.x, (double)q.y, (double)q.z};
+  D3 X = (lid == 0) ? qrot(qc.q0, p) + qc.t0 : qrot(qc.qtc[lid], qrot(qc.ql[lid], p) + qc.tl[lid]) + qc.ttc[lid];
+  D3 pg = qrot(qc.rot, X) + qc.pos;
+  out[i] = make_float4((float)pg.x, (float)pg.y, (float)pg.z, 0.f);
+}
+__global__ void __launch_bounds__(BLK) k_gather_scan(const float4 *__restrict__ in, const u32 *__restrict__ src, int n,
+                                                     int dst0, float4 *out_scan, u32 *out_perm,
+                                                     const u32 *__restrict__ part_orig) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  u32 s = src[i];  // index inside the LiDAR segment upload
+  out_scan[dst0 + i] = in[s];
+  out_perm[dst0 + i] = part_orig[s];
+}
+
+static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
+  auto Q = [](const double q[4]) { return Q4{q[0], q[1], q[2], q[3]}; };
+  auto V = [](const double t[3]) { return D3{t[0], t[1], t[2]}; };
+  qc.rot = Q(s->rot), qc.pos = V(s->pos);
+  qc.q0 = Q(s->offset_R[0]), qc.t0 = V(s->offset_T[0]);
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
+    int ll = l < c->prm.lid_num ? l : 0;
+    qc.ql[l] = Q(s->offset_R[ll]), qc.tl[l] = V(s->offset_T[ll]);
+    if (l >= 1 && l < c->prm.lid_num) {
+      qc.qtc[l] = Q(c->tcq[l - 1]), qc.ttc[l] = V(c->tct[l - 1]);
+    } else {
+      qc.qtc[l] = Q4{0, 0, 0, 1}, qc.ttc[l] = D3{0, 0, 0};
+    }
+  }
+}
+
+// Spatial sort of the scan, once per scan, with the first pass' state (coherence only, not results).
+static int sort_scan(Ctx *c, const QuatConst &qc) {
+  const int L = c->prm.lid_num;
+  float4 *d_w = nullptr;
+  u32 *d_part_orig = nullptr;
+  MALIO_HIP(hipMalloc(&d_w, sizeof(float4) * (size_t)c->N));
+  MALIO_HIP(hipMalloc(&d_part_orig, sizeof(u32) * (size_t)c->N));
+  MALIO_HIP(hipMemcpyAsync(d_part_orig, c->h_lidpart.data(), sizeof(u32) * (size_t)c->N, hipMemcpyHostToDevice,
+                           c->stream));
+  hipLaunchKernelGGL(k_scan_world, dim3((c->N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_scan_in, c->N, qc, d_w);
+  CellGrid g;
+  for (int l = 0; l < L; l++) {
+    int n = c->seg_start[l + 1] - c->seg_start[l];
+    if (n <= 0) continue;
+    int rc = group_by_cell(c, d_w + c->seg_start[l], n, c->inv_cell, g);
+    if (rc != MALIO_OK) return rc;
+    hipLaunchKernelGGL(k_gather_scan, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+                       c->d_scan_in + c->seg_start[l], g.orig, n, c->seg_start[l], c->d_scan, c->d_perm,
+                       d_part_orig + c->seg_start[l]);
+  }
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  free_grid(g);
+  (void)hipFree(d_w);
+  (void)hipFree(d_part_orig);
+  c->scan_sorted = true;
+  return MALIO_OK;
+}
+
+int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
+  if (c->map.n <= 0) return MALIO_ERR_NO_MAP;
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  Pass1Args a;
+  fill_quat_const(c, s, a.qc);
+  if (!c->scan_sorted) {
+    int rc = sort_scan(c, a.qc);
+    if (rc != MALIO_OK) return rc;
+  }
+  a.N = c->N;
+  a.scan = c->d_scan;
+  a.map_pts = c->map.pts, a.map_orig = c->map.orig, a.table = c->map.table, a.tmask = c->map.tmask;
+  a.cell = c->cell, a.inv_cell = c->inv_cell;
+  a.unc = c->d_unc;
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
+  a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
+  a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
+  a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound, a.minmax = c->d_minmax;
+  // initial values of laserMapping.cpp:615-616,646-647
+  hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(1), 0, c->stream, c->d_minmax, enc_d_host(0.0), enc_d_host(1000.0),
+                     enc_d_host(0.0), enc_d_host(9999.0));
+  dim3 grid((c->N + BLK - 1) / BLK);
+  if (converge)
+    hipLaunchKernelGGL(k_pass1<true>, grid, dim3(BLK), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(k_pass1<false>, grid, dim3(BLK), 0, c->stream, a);
+  prof_mark(c, converge ? "k_pass1<search>" : "k_pass1<reuse>");
+  hipLaunchKernelGGL(k_decode_minmax, dim3(1), dim3(64), 0, c->stream, c->d_minmax, d_minmax4_out);
+  MALIO_HIP(hipGetLastError());
+  // matrix form of the same state for stage 2
+  PassConst &pc = c->pc;
+  q_to_R(s->rot, pc.Rw);
+  q_to_R(s->offset_R[0], pc.R0);
+  for (int k = 0; k < 3; k++) pc.pw[k] = s->pos[k], pc.t0[k] = s->offset_T[0][k];
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
+    int ll = l < c->prm.lid_num ? l : 0;
+    q_to_R(s->offset_R[ll], pc.lid[l].Rl);
+    for (int k = 0; k < 3; k++) pc.lid[l].tl[k] = s->offset_T[ll][k];
+    if (l >= 1 && l < c->prm.lid_num) {
+      q_to_R(c->tcq[l - 1], pc.lid[l].Rtc);
+      for (int k = 0; k < 3; k++) pc.lid[l].ttc[k] = c->tct[l - 1][k];
+    } else {
+      const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      memcpy(pc.lid[l].Rtc, I, sizeof(I));
+      pc.lid[l].ttc[0] = pc.lid[l].ttc[1] = pc.lid[l].ttc[2] = 0;
+    }
+  }
+  pc.L = c->prm.lid_num, pc.extrinsic_est_en = c->prm.extrinsic_est_en;
+  pc.plane_th = c->prm.plane_th, pc.cov_threshold = c->prm.cov_threshold;
+  return MALIO_OK;
+}
+
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_sums_out, bool want_rows) {
+  Pass2Args a;
+  a.N = c->N, a.L = c->prm.lid_num, a.extrinsic_est_en = c->prm.extrinsic_est_en;
+  a.scan = c->d_scan, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.ucov = c->d_ucov, a.trace = c->d_trace, a.sel = c->d_sel;
+  int nb = nblocks_total(c, a.seg_block0);
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) a.seg_start[l] = c->seg_start[l < c->prm.lid_num ? l : c->prm.lid_num];
+  a.pc = c->pc;
+  a.wc.plane_cov_max = c->prm.plane_cov_max, a.wc.plane_cov_min = c->prm.plane_cov_min;
+  a.wc.point_cov_max = c->prm.point_cov_max, a.wc.point_cov_min = c->prm.point_cov_min;
+  a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
+  a.minmax4 = d_minmax4_in;
+  a.partials = c->d_partials;
+  a.rows = nullptr;
+  if (want_rows) {
+    size_t need = (size_t)c->N * 14;
+    if (need > c->cap_rows) {
+      if (c->d_rows) (void)hipFree(c->d_rows);
+      c->cap_rows = need + need / 8;
+      MALIO_HIP(hipMalloc(&c->d_rows, sizeof(double) * c->cap_rows));
+    }
+    a.rows = c->d_rows;
+  }
+  hipLaunchKernelGGL(k_rows_reduce, dim3(nb), dim3(BLK), 0, c->stream, a);
+  prof_mark(c, "k_rows_reduce");
+  SegBlocks sb;
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
+  hipLaunchKernelGGL(k_final_reduce, dim3(c->prm.lid_num), dim3(1024), 0, c->stream, c->d_partials, sb, d_sums_out);
+  prof_mark(c, "k_final_reduce");
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+// 3x3 symmetric eigenvalues by cyclic Jacobi (sigma_3/sigma_1 of h_x[:,0:3] = sqrt(l_min/l_max) of N^T N)
+static void sym3_eig_host(double a[3][3], double ev[3]) {
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (a[p][q] == 0) continue;
+        double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+        for (int k = 0; k < 3; k++) {
+          double akp = a[k][p], akq = a[k][q];
+          a[k][p] = cs * akp - sn * akq, a[k][q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; k++) {
+          double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = cs * apk - sn * aqk, a[q][k] = sn * apk + cs * aqk;
+        }
+      }
+  }
+  ev[0] = a[0][0], ev[1] = a[1][1], ev[2] = a[2][2];
+  if (ev[0] > ev[1]) std::swap(ev[0], ev[1]);
+  if (ev[1] > ev[2]) std::swap(ev[1], ev[2]);
+  if (ev[0] > ev[1]) std::swap(ev[0], ev[1]);
+}
+
+// Assemble the C x C normal equations from the per-LiDAR 12 x 12 blocks, apply the localization
+// weight (laserMapping.cpp:745-759). sums: [L][NSUM]; minmax4: [max_u, -min_u, max_R, -min_R].
+int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out) {
+  const int L = c->prm.lid_num, C = 6 * (1 + L);
+  double NtN[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double M = 0;
+  memset(out->HtRinvH, 0, sizeof(out->HtRinvH));
+  memset(out->HtRinvh, 0, sizeof(out->HtRinvh));
+  for (int l = 0; l < L; l++) {
+    const double *s = sums + (size_t)l * NSUM;
+    int gi[12];
+    for (int k = 0; k < 6; k++) gi[k] = k;
+    for (int k = 0; k < 3; k++) gi[6 + k] = 6 + 3 * l + k, gi[9 + k] = 6 + 3 * (L + l) + k;
+    int e = 0;
+    for (int a = 0; a < 12; a++)
+      for (int b = a; b < 12; b++, e++) {
+        out->HtRinvH[gi[a] * C + gi[b]] += s[e];
+        if (a != b) out->HtRinvH[gi[b] * C + gi[a]] += s[e];
+      }
+    for (int a = 0; a < 12; a++) out->HtRinvh[gi[a]] += s[78 + a];
+    NtN[0][0] += s[90], NtN[1][1] += s[91], NtN[2][2] += s[92];
+    NtN[0][1] += s[93], NtN[0][2] += s[94], NtN[1][2] += s[95];
+    M += s[96];
+  }
+  NtN[1][0] = NtN[0][1], NtN[2][0] = NtN[0][2], NtN[2][1] = NtN[1][2];
+  out->M = (int)(M + 0.5);
+  out->unit_cov_minmax[0] = -minmax4[1], out->unit_cov_minmax[1] = minmax4[0];
+  out->R_minmax[0] = -minmax4[3], out->R_minmax[1] = minmax4[2];
+  if (out->M < 1) {  // laserMapping.cpp:635-639
+    out->valid = 0;
+    out->w_loc = 0;
+    return MALIO_NO_EFFECTIVE_POINTS;
+  }
+  out->valid = 1;
+  double ev[3];
+  sym3_eig_host(NtN, ev);
+  double weight = sqrt(ev[0] > 0 ? ev[0] : 0.0) / sqrt(ev[2]);
+  if (weight > c->prm.localize_thresh_max)
+    weight = c->prm.localize_cov_max;
+  else if (weight < c->prm.localize_thresh_min)
+    weight = c->prm.localize_cov_min;
+  else
+    weight = (c->prm.localize_cov_max - c->prm.localize_cov_min) * (weight - c->prm.localize_thresh_min) /
+                 (c->prm.localize_thresh_max - c->prm.localize_thresh_min) +
+             c->prm.localize_cov_min;
+  out->w_loc = weight;
+  const double w2 = weight * weight;
+  for (int k = 0; k < C * C; k++) out->HtRinvH[k] *= w2;
+  for (int k = 0; k < C; k++) out->HtRinvh[k] *= w2;
+  return MALIO_OK;
+}
+
+}  // namespace malio

@@ -1,0 +1,422 @@
+// Host side of the iterated error-state Kalman update that drives the fused GPU measurement pass:
+// the n x n algebra of esekf::update_iterated_dyn_share_modified
+// (/root/reference/MA_LIO/include/IKFoM_toolkit/esekfom/esekfom.hpp:495-721) with
+// malio_measure() standing where the reference calls h_dyn_share (esekfom.hpp:512) and consuming the
+// reduced H^T R^-1 H / H^T R^-1 h instead of M x C rows (esekfom.hpp:621-637).
+// State manifold: pos, rot(SO3), offset_R[L](SO3), offset_T[L], vel, bg, ba, grav(S2, |g| = 9.809),
+// tangent layout SURVEY.md §2.1 (src/use-ikfom.hpp:14-27, runtime-parametric in L).
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../csrc/malio_internal.hpp"
+
+namespace malio {
+namespace {
+
+constexpr double TOL = 1e-11;               // MTK::tolerance<double>, mtkmath.hpp:122
+constexpr double G_LEN = 98090.0 / 10000.0;  // S2<double, 98090, 10000, 1>, use-ikfom.hpp:8
+
+struct Vec3 {
+  double v[3];
+};
+inline Vec3 cross3(const double *a, const double *b) {
+  return {{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
+}
+// Hamilton product of (x,y,z,w) quaternions
+inline void qmul(const double *a, const double *b, double *r) {
+  double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  r[0] = x, r[1] = y, r[2] = z, r[3] = w;
+}
+inline void quat_R(const double *q, double R[3][3]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0][0] = 1 - 2 * (y * y + z * z), R[0][1] = 2 * (x * y - w * z), R[0][2] = 2 * (x * z + w * y);
+  R[1][0] = 2 * (x * y + w * z), R[1][1] = 1 - 2 * (x * x + z * z), R[1][2] = 2 * (y * z - w * x);
+  R[2][0] = 2 * (x * z - w * y), R[2][1] = 2 * (y * z + w * x), R[2][2] = 1 - 2 * (x * x + y * y);
+}
+// cos / sinc of sqrt(x2) with the Taylor branch of mtkmath.hpp:142-174
+inline void cos_sinc(double x2, double &c, double &s) {
+  const double bound = 1.2207031250000000e-04;  // sqrt(sqrt(DBL_EPSILON))
+  if (x2 >= bound) {
+    double x = std::sqrt(x2);
+    c = std::cos(x), s = std::sin(x) / x;
+    return;
+  }
+  const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
+  c = 1., s = 1.;
+  double term = -0.5 * x2;
+  for (int i = 0; i < 3; ++i) {
+    c += term;
+    term *= inv[2 * i];
+    s += term;
+    term *= -inv[2 * i + 1] * x2;
+  }
+}
+// quaternion of the rotation vector `v` scaled by `scale` (MTK::exp with half-angle, SOn.hpp:332-336)
+inline void rotvec_quat(const double *v, double scale, double *q) {
+  double h = scale / 2, c, s;
+  cos_sinc(h * h * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), c, s);
+  q[0] = s * h * v[0], q[1] = s * h * v[1], q[2] = s * h * v[2], q[3] = c;
+}
+// log of a unit quaternion as a rotation vector (SOn.hpp:341-345 -> mtkmath.hpp:268-288)
+inline void quat_rotvec(const double *q, double *v) {
+  double nv = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  if (nv < TOL) nv = TOL;
+  double s = 2.0 / nv * std::atan(nv / q[3]);
+  v[0] = s * q[0], v[1] = s * q[1], v[2] = s * q[2];
+}
+inline void hat3(const double *v, double H[3][3]) {
+  H[0][0] = 0, H[0][1] = -v[2], H[0][2] = v[1];
+  H[1][0] = v[2], H[1][1] = 0, H[1][2] = -v[0];
+  H[2][0] = -v[1], H[2][1] = v[0], H[2][2] = 0;
+}
+// MTK::A_matrix(v)^T (mtkmath.hpp:235-247), row-major 3x3
+inline void A_matrix_T(const double *v, double At[9]) {
+  double sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], n = std::sqrt(sq);
+  double A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (!(n < TOL)) {
+    double H[3][3], H2[3][3];
+    hat3(v, H);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) H2[i][j] = H[i][0] * H[0][j] + H[i][1] * H[1][j] + H[i][2] * H[2][j];
+    double a = (1 - std::cos(n)) / sq, b = (1 - std::sin(n) / n) / sq;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A[i][j] += a * H[i][j] + b * H2[i][j];
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) At[i * 3 + j] = A[j][i];
+}
+
+// ---- S2 (gravity) : S2.hpp, S2_typ == 1 ------------------------------------------------------------
+inline void s2_Bx(const double *g, double B[3][2]) {  // S2.hpp:225-241
+  if (g[0] + G_LEN > TOL) {
+    double d = G_LEN + g[0];
+    B[0][0] = -g[1], B[0][1] = -g[2];
+    B[1][0] = G_LEN - g[1] * g[1] / d, B[1][1] = -g[2] * g[1] / d;
+    B[2][0] = -g[2] * g[1] / d, B[2][1] = G_LEN - g[2] * g[2] / d;
+    for (int i = 0; i < 3; i++) B[i][0] /= G_LEN, B[i][1] /= G_LEN;
+  } else {
+    memset(B, 0, sizeof(double) * 6);
+    B[1][1] = -1, B[2][0] = 1;
+  }
+}
+inline void s2_boxplus(double *g, double d0, double d1) {  // S2.hpp:136-142
+  double B[3][2];
+  s2_Bx(g, B);
+  double Bu[3] = {B[0][0] * d0 + B[0][1] * d1, B[1][0] * d0 + B[1][1] * d1, B[2][0] * d0 + B[2][1] * d1};
+  double q[4], R[3][3];
+  rotvec_quat(Bu, 1.0, q);
+  quat_R(q, R);
+  double r[3];
+  for (int i = 0; i < 3; i++) r[i] = R[i][0] * g[0] + R[i][1] * g[1] + R[i][2] * g[2];
+  g[0] = r[0], g[1] = r[1], g[2] = r[2];
+}
+inline void s2_boxminus(const double *g, const double *o, double res[2]) {  // S2.hpp:144-167
+  Vec3 c = cross3(g, o);
+  double v_sin = std::sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]);
+  double v_cos = g[0] * o[0] + g[1] * o[1] + g[2] * o[2];
+  double theta = std::atan2(v_sin, v_cos);
+  if (v_sin < TOL) {
+    res[0] = std::fabs(theta) > TOL ? 3.1415926 : 0.0;
+    res[1] = 0;
+    return;
+  }
+  double B[3][2];
+  s2_Bx(o, B);
+  Vec3 hv = cross3(o, g);  // hat(other) * vec
+  for (int j = 0; j < 2; j++) res[j] = theta / v_sin * (B[0][j] * hv.v[0] + B[1][j] * hv.v[1] + B[2][j] * hv.v[2]);
+}
+// res_temp_S2 = Nx(x_.grav) * Mx(x_propagated.grav, delta)   (esekfom.hpp:560-564, S2.hpp:269-290)
+inline void s2_NxMx(const double *g_cur, const double *g_prop, double d0, double d1, double out[4]) {
+  double Bc[3][2], Hc[3][3], Nx[2][3];
+  s2_Bx(g_cur, Bc);
+  hat3(g_cur, Hc);
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++)
+      Nx[i][j] = (Bc[0][i] * Hc[0][j] + Bc[1][i] * Hc[1][j] + Bc[2][i] * Hc[2][j]) / G_LEN / G_LEN;
+  double Bp[3][2], Hp[3][3], left[3][3];
+  s2_Bx(g_prop, Bp);
+  hat3(g_prop, Hp);
+  if (std::sqrt(d0 * d0 + d1 * d1) < TOL) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) left[i][j] = -Hp[i][j];
+  } else {
+    // exp(Bu, scalar(1/2)): 1/2 is INTEGER division == 0 in the reference (S2.hpp:287), so the
+    // exponential factor is the identity; only -hat(vec) * A_matrix(Bu)^T * Bx remains.
+    double Bu[3] = {Bp[0][0] * d0 + Bp[0][1] * d1, Bp[1][0] * d0 + Bp[1][1] * d1, Bp[2][0] * d0 + Bp[2][1] * d1};
+    double At[9];
+    A_matrix_T(Bu, At);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        left[i][j] = -(Hp[i][0] * At[0 * 3 + j] + Hp[i][1] * At[1 * 3 + j] + Hp[i][2] * At[2 * 3 + j]);
+  }
+  double Mx[3][2];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 2; j++) Mx[i][j] = left[i][0] * Bp[0][j] + left[i][1] * Bp[1][j] + left[i][2] * Bp[2][j];
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) out[i * 2 + j] = Nx[i][0] * Mx[0][j] + Nx[i][1] * Mx[1][j] + Nx[i][2] * Mx[2][j];
+}
+
+// ---- whole-state boxplus / boxminus ------------------------------------------------------------------
+void state_boxplus(malio_state_t &x, int L, const double *dx) {
+  for (int k = 0; k < 3; k++) x.pos[k] += dx[k];
+  double q[4];
+  rotvec_quat(dx + 3, 1.0, q);
+  qmul(x.rot, q, x.rot);
+  for (int l = 0; l < L; l++) {
+    rotvec_quat(dx + 6 + 3 * l, 1.0, q);
+    qmul(x.offset_R[l], q, x.offset_R[l]);
+  }
+  for (int l = 0; l < L; l++)
+    for (int k = 0; k < 3; k++) x.offset_T[l][k] += dx[6 + 3 * L + 3 * l + k];
+  for (int k = 0; k < 3; k++) x.vel[k] += dx[6 + 6 * L + k], x.bg[k] += dx[9 + 6 * L + k], x.ba[k] += dx[12 + 6 * L + k];
+  s2_boxplus(x.grav, dx[15 + 6 * L], dx[16 + 6 * L]);
+}
+void state_boxminus(const malio_state_t &x, const malio_state_t &o, int L, double *res) {
+  auto so3 = [](const double *a, const double *b, double *out) {  // log(b^-1 a)
+    double bc[4] = {-b[0], -b[1], -b[2], b[3]}, d[4];
+    qmul(bc, a, d);
+    quat_rotvec(d, out);
+  };
+  for (int k = 0; k < 3; k++) res[k] = x.pos[k] - o.pos[k];
+  so3(x.rot, o.rot, res + 3);
+  for (int l = 0; l < L; l++) so3(x.offset_R[l], o.offset_R[l], res + 6 + 3 * l);
+  for (int l = 0; l < L; l++)
+    for (int k = 0; k < 3; k++) res[6 + 3 * L + 3 * l + k] = x.offset_T[l][k] - o.offset_T[l][k];
+  for (int k = 0; k < 3; k++) {
+    res[6 + 6 * L + k] = x.vel[k] - o.vel[k];
+    res[9 + 6 * L + k] = x.bg[k] - o.bg[k];
+    res[12 + 6 * L + k] = x.ba[k] - o.ba[k];
+  }
+  s2_boxminus(x.grav, o.grav, res + 15 + 6 * L);
+}
+
+// ---- dense helpers (row-major, n <= 41) -----------------------------------------------------------------
+using Mat = std::vector<double>;
+// in-place inverse by LU with partial pivoting (what Eigen's inverse() does for n > 4)
+bool invert(Mat &A, int n) {
+  std::vector<int> piv(n);
+  for (int i = 0; i < n; i++) piv[i] = i;
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double best = std::fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; i++)
+      if (std::fabs(A[i * n + k]) > best) best = std::fabs(A[i * n + k]), p = i;
+    if (best == 0) return false;
+    if (p != k) {
+      for (int j = 0; j < n; j++) std::swap(A[k * n + j], A[p * n + j]);
+      std::swap(piv[k], piv[p]);
+    }
+    double d = A[k * n + k];
+    for (int i = k + 1; i < n; i++) {
+      double l = (A[i * n + k] /= d);
+      if (l != 0)
+        for (int j = k + 1; j < n; j++) A[i * n + j] -= l * A[k * n + j];
+    }
+  }
+  Mat X((size_t)n * n);
+  std::vector<double> y(n);
+  for (int col = 0; col < n; col++) {
+    for (int i = 0; i < n; i++) y[i] = piv[i] == col ? 1.0 : 0.0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < i; j++) y[i] -= A[i * n + j] * y[j];
+    for (int i = n - 1; i >= 0; i--) {
+      for (int j = i + 1; j < n; j++) y[i] -= A[i * n + j] * y[j];
+      y[i] /= A[i * n + i];
+    }
+    for (int i = 0; i < n; i++) X[i * n + col] = y[i];
+  }
+  A.swap(X);
+  return true;
+}
+// rows [idx, idx+d) of Dst <- B * rows of Src (first ncols columns); cols of P <- P cols * B^T
+void rows_apply(Mat &Dst, const Mat &Src, int n, int idx, int d, const double *B, int ncols) {
+  double t[3];
+  for (int c = 0; c < ncols; c++) {
+    for (int i = 0; i < d; i++) {
+      double s = 0;
+      for (int k = 0; k < d; k++) s += B[i * d + k] * Src[(idx + k) * n + c];
+      t[i] = s;
+    }
+    for (int i = 0; i < d; i++) Dst[(idx + i) * n + c] = t[i];
+  }
+}
+void cols_applyT(Mat &P, int n, int idx, int d, const double *B) {
+  double t[3];
+  for (int r = 0; r < n; r++) {
+    for (int j = 0; j < d; j++) {
+      double s = 0;
+      for (int k = 0; k < d; k++) s += P[r * n + idx + k] * B[j * d + k];
+      t[j] = s;
+    }
+    for (int j = 0; j < d; j++) P[r * n + idx + j] = t[j];
+  }
+}
+
+}  // namespace
+
+int ieskf_update(Ctx *c, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
+  const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
+  malio_state_t x_ = *xio;
+  const malio_state_t x_propagated = x_;
+  Mat P_prop(Pio, Pio + (size_t)n * n), P_(P_prop);
+  std::vector<int> so3_idx;
+  so3_idx.push_back(3);
+  for (int l = 0; l < L; l++) so3_idx.push_back(6 + 3 * l);
+  const int s2_idx = 15 + 6 * L;
+  bool converge = true;
+  int t = 0, passes = 0, searches = 0, lastM = 0;
+  double solve = 0;
+  std::vector<double> dx(n), dx_new(n), dx_(n), K_h(n);
+  Mat K_x((size_t)n * n);
+  malio_measure_out_t mo;
+  std::vector<double> rows_hx, rows_h, rows_R;
+
+  for (int i = -1; i < maximum_iter; i++) {  // esekfom.hpp:509
+    memset(&mo, 0, sizeof(mo));
+    searches += converge ? 1 : 0;
+    int rc = malio_measure((malio_handle_t)c, &x_, converge ? 1 : 0, &mo);
+    passes++;
+    if (rc < 0) return rc;
+    if (!mo.valid) continue;  // :514-517
+    lastM = mo.M;
+    auto t0 = std::chrono::steady_clock::now();
+    state_boxminus(x_, x_propagated, L, dx.data());  // :526
+    dx_new = dx;
+    P_ = P_prop;
+    for (int idx : so3_idx) {  // :534-549
+      double B[9];
+      A_matrix_T(&dx[idx], B);
+      double tmp[3];
+      for (int a = 0; a < 3; a++) tmp[a] = B[a * 3] * dx_new[idx] + B[a * 3 + 1] * dx_new[idx + 1] + B[a * 3 + 2] * dx_new[idx + 2];
+      for (int a = 0; a < 3; a++) dx_new[idx + a] = tmp[a];
+      rows_apply(P_, P_, n, idx, 3, B, n);
+      cols_applyT(P_, n, idx, 3, B);
+    }
+    {  // :551-572
+      double B[4];
+      s2_NxMx(x_.grav, x_propagated.grav, dx[s2_idx], dx[s2_idx + 1], B);
+      double a0 = B[0] * dx_new[s2_idx] + B[1] * dx_new[s2_idx + 1], a1 = B[2] * dx_new[s2_idx] + B[3] * dx_new[s2_idx + 1];
+      dx_new[s2_idx] = a0, dx_new[s2_idx + 1] = a1;
+      rows_apply(P_, P_, n, s2_idx, 2, B, n);
+      cols_applyT(P_, n, s2_idx, 2, B);
+    }
+    std::fill(K_x.begin(), K_x.end(), 0.0);
+    if (n > mo.M) {
+      // :574-582 small-M fallback: K = P H^T (H P H^T / R + I)^-1 / R with scalar R, needs the rows
+      const int M = mo.M;
+      rows_hx.assign((size_t)c->N * C, 0.0), rows_h.assign(c->N, 0.0), rows_R.assign(c->N, 0.0);
+      malio_measure_out_t mr;
+      memset(&mr, 0, sizeof(mr));
+      mr.h_x = rows_hx.data(), mr.h = rows_h.data(), mr.R = rows_R.data();
+      // same state, neighbours reused; the accept flags of the pass above stand, so the rows are
+      // those of that pass (reuse pass on an unchanged state is idempotent)
+      rc = malio_measure((malio_handle_t)c, &x_, 0, &mr);
+      if (rc < 0) return rc;
+      Mat S((size_t)M * M, 0.0), PHt((size_t)n * M, 0.0);
+      for (int a = 0; a < n; a++)
+        for (int m = 0; m < M; m++) {
+          double s = 0;
+          for (int b = 0; b < C; b++) s += P_[a * n + b] * rows_hx[(size_t)m * C + b];
+          PHt[a * M + m] = s;
+        }
+      for (int m = 0; m < M; m++)
+        for (int k = 0; k < M; k++) {
+          double s = 0;
+          for (int b = 0; b < C; b++) s += rows_hx[(size_t)m * C + b] * PHt[b * M + k];
+          S[m * M + k] = s / R + (m == k ? 1.0 : 0.0);
+        }
+      if (!invert(S, M)) return MALIO_ERR_BAD_ARG;
+      Mat K((size_t)n * M, 0.0);
+      for (int a = 0; a < n; a++)
+        for (int k = 0; k < M; k++) {
+          double s = 0;
+          for (int m = 0; m < M; m++) s += PHt[a * M + m] * S[m * M + k];
+          K[a * M + k] = s / R;
+        }
+      for (int a = 0; a < n; a++) {
+        double s = 0;
+        for (int m = 0; m < M; m++) s += K[a * M + m] * rows_h[m];
+        K_h[a] = s;
+        for (int b = 0; b < C; b++) {
+          double s2 = 0;
+          for (int m = 0; m < M; m++) s2 += K[a * M + m] * rows_hx[(size_t)m * C + b];
+          K_x[a * n + b] = s2;
+        }
+      }
+    } else {
+      // :621-637 with the reduced normal equations: P_inv = (P^-1 + blk(HtRinvH))^-1,
+      // K_h = P_inv[:, 0:C] HtRinvh, K_x[:, 0:C] = P_inv[:, 0:C] HtRinvH
+      Mat Pt(P_);
+      if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+      for (int a = 0; a < C; a++)
+        for (int b = 0; b < C; b++) Pt[a * n + b] += mo.HtRinvH[a * C + b];
+      if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+      for (int a = 0; a < n; a++) {
+        double s = 0;
+        for (int b = 0; b < C; b++) s += Pt[a * n + b] * mo.HtRinvh[b];
+        K_h[a] = s;
+        for (int b = 0; b < C; b++) {
+          double s2 = 0;
+          for (int k = 0; k < C; k++) s2 += Pt[a * n + k] * mo.HtRinvH[k * C + b];
+          K_x[a * n + b] = s2;
+        }
+      }
+    }
+    for (int a = 0; a < n; a++) {  // :642
+      double s = K_h[a];
+      for (int b = 0; b < n; b++) s += (K_x[a * n + b] - (a == b ? 1.0 : 0.0)) * dx_new[b];
+      dx_[a] = s;
+    }
+    state_boxplus(x_, L, dx_.data());  // :646
+    converge = true;                   // :649-657
+    for (int a = 0; a < n; a++)
+      if (std::fabs(dx_[a]) > 0.001) {
+        converge = false;
+        break;
+      }
+    if (converge) t++;
+    if (!t && i == maximum_iter - 2) converge = true;  // :660-663
+    if (t > 1 || i == maximum_iter - 1) {               // :665-718
+      Mat L_(P_);
+      for (int idx : so3_idx) {
+        double B[9];
+        A_matrix_T(&dx_[idx], B);
+        rows_apply(L_, P_, n, idx, 3, B, n);
+        rows_apply(K_x, K_x, n, idx, 3, B, C);
+        cols_applyT(L_, n, idx, 3, B);
+        cols_applyT(P_, n, idx, 3, B);
+      }
+      {
+        double B[4];
+        s2_NxMx(x_.grav, x_propagated.grav, dx_[s2_idx], dx_[s2_idx + 1], B);
+        rows_apply(L_, P_, n, s2_idx, 2, B, n);
+        rows_apply(K_x, K_x, n, s2_idx, 2, B, C);
+        cols_applyT(L_, n, s2_idx, 2, B);
+        cols_applyT(P_, n, s2_idx, 2, B);
+      }
+      for (int a = 0; a < n; a++)  // :714
+        for (int b = 0; b < n; b++) {
+          double s = 0;
+          for (int k = 0; k < C; k++) s += K_x[a * n + k] * P_[k * n + b];
+          Pio[a * n + b] = L_[a * n + b] - s;
+        }
+      solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      *xio = x_;
+      if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
+      if (solve_time) *solve_time += solve;
+      return MALIO_OK;
+    }
+    solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // every pass was invalid (no effective points): the reference leaves x_ and P_ as propagated
+  *xio = x_;
+  if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
+  if (solve_time) *solve_time += solve;
+  return MALIO_OK;
+}
+
+}  // namespace malio

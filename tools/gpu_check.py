@@ -1,0 +1,71 @@
+"""Developer diagnostic (not a test): per-point comparison of the HIP path with the CPU oracle."""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+ge.load_package()
+from malio_amd import capi, scenes
+from oracle import orc
+
+def run(N, Nmap, L, seed=7, kind="city", map_unc=False):
+    sc = scenes.make_scene(seed=seed, N=N, Nmap=Nmap, L=L, kind=kind, map_unc=map_unc)
+    eng = capi.Engine(sc["params"], device=0)
+    t = time.time(); eng.map_build(sc["map"]); print("map_build %.3fs" % (time.time() - t))
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    t = time.time(); g = eng.measure(sc["state0"], True, want_rows=True); print("measure(first, incl sort) %.4fs" % (time.time() - t))
+    o = orc.Oracle(sc["params"], threads=8, use_ref=True)
+    print("oracle ref ikd:", o.is_ref)
+    o.map_build(sc["map"]); o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    t = time.time(); r = o.h_share_model(sc["state0"], True); print("oracle pass %.3fs" % (time.time() - t))
+    gs, os_ = eng.scan_get(), o.scan_get()
+    print("M gpu/orc", g["M"], r["M"], "w", g["w_loc"], r["weight"])
+    print("world max|d|", np.abs(gs["world"] - os_["world"]).max(), "exact frac", (gs["world"] == os_["world"]).all(1).mean())
+    print("sel mismatch", int((gs["selected"] != os_["selected"]).sum()), "cnt mismatch", int((gs["nearest_cnt"] != np.minimum(os_["nearest_cnt"], 5)).sum()))
+    both = (gs["selected"] == 1) & (os_["selected"] == 1)
+    dn = np.abs(gs["nearest"][both][:, :, :3] - os_["nearest"][both][:, :, :3]).max() if both.any() else 0
+    print("nearest xyz max|d| (selected)", dn)
+    print("normvec max|d|", np.abs(gs["normvec"][both] - os_["normvec"][both]).max(), "exact frac", (gs["normvec"][both] == os_["normvec"][both]).all(1).mean())
+    ny_g, ny_o = gs["normal_y"], os_["normal_y"]
+    print("normal_y rel err max", (np.abs(ny_g - ny_o) / np.maximum(np.abs(ny_o), 1e-12)).max())
+    if g["M"] == r["M"]:
+        print("h_x max|d|", np.abs(g["h_x"] - r["h_x"]).max(), "h", np.abs(g["h"] - r["h"]).max(), "R", np.abs(g["R"] - r["R"]).max())
+    Rc = np.where(r["R"] < 1e-4, 1e-3, r["R"])
+    HtH = (r["h_x"].T / Rc) @ r["h_x"]; Hth = (r["h_x"].T / Rc) @ r["h"]
+    print("HtH rel", np.abs(g["HtRinvH"] - HtH).max() / np.abs(HtH).max(), "Hth rel", np.abs(g["HtRinvh"] - Hth).max() / np.abs(Hth).max())
+    # reuse pass at a slightly different state
+    s2 = sc["state0"].copy(); s2[0:3] += [0.01, -0.02, 0.005]
+    g2 = eng.measure(s2, False, want_rows=True); r2 = o.h_share_model(s2, False)
+    print("reuse: M", g2["M"], r2["M"], "h_x", np.abs(g2["h_x"] - r2["h_x"]).max() if g2["M"] == r2["M"] else None)
+    # full update
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"]); o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    t = time.time(); u = eng.update_iterated(sc["state0"], sc["P0"]); tg = time.time() - t
+    t = time.time(); v = o.update_iterated(sc["state0"], sc["P0"]); to = time.time() - t
+    print("update: passes", u["passes"], v["passes"], "searches", u["searches"], v["searches"], "M", u["M"], v["M"])
+    print("state max|d|", np.abs(u["state"] - v["state"]).max(), "P max|d|", np.abs(u["P"] - v["P"]).max(), "gpu %.4fs oracle %.3fs" % (tg, to))
+    # timing of passes
+    eng.set_profiling(True)
+    for k in range(3):
+        eng.measure(sc["state0"], True)
+        print("search pass kernels:", [(n, round(ms * 1000, 1)) for n, ms in eng.last_kernel_times()], "us")
+    eng.measure(sc["state0"], False); print("reuse pass kernels:", [(n, round(ms * 1000, 1)) for n, ms in eng.last_kernel_times()], "us")
+    eng.set_profiling(False)
+    ts = []
+    for k in range(20):
+        t = time.perf_counter(); eng.measure(sc["state0"], True); ts.append(time.perf_counter() - t)
+    print("search pass wall: median %.1f us min %.1f us" % (np.median(ts) * 1e6, np.min(ts) * 1e6))
+    ts = []
+    for k in range(20):
+        t = time.perf_counter(); eng.measure(sc["state0"], False); ts.append(time.perf_counter() - t)
+    print("reuse pass wall: median %.1f us" % (np.median(ts) * 1e6))
+    # knn API vs ref
+    q = sc["map"][:2000].copy(); q[:, :3] += 0.1
+    po, d2o, co = o.knn(q); pg, d2g, cg = eng.nearest_search(q)
+    m = d2o[:, 4] <= 5.0
+    print("knn d2 equal (within gate):", (d2g[m] == d2o[m]).all(), "cnt", (cg[m] == 5).all())
+
+if __name__ == "__main__":
+    run(4000, 40000, 3)
+    run(10000, 50000, 1, seed=8)
+    if len(sys.argv) > 1:
+        run(100000, 1000000, 3, seed=20230627)
