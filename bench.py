@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py - hot-path benchmark for the MI355X measurement-update engine (BASELINE.json metric).
+
+A "step" is ONE search pass of the per-scan measurement update (h_share_model with converge = true:
+world transform -> 5-NN in the GPU map -> plane fit -> gates -> Jacobian rows -> H^T R^-1 H /
+H^T R^-1 h reduction, including the host-side finish that hands the normal equations to the filter)
+over one fused multi-LiDAR scan that is already resident in HBM, against the resident map.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map.
+N > 1 (weak scaling): every rank holds the replicated map and its own 100k-point shard of an
+N x 100k-point scan; each pass does the two tiny all-reduces of SURVEY.md §8(e) over RCCL
+(MAX of 5 doubles, SUM of 97 L doubles).
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields). The CPU oracle is used only for
+the `cpu_baseline` leg (rank 0, N = 1), never inside the timed GPU region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+ALG_BYTES_SEARCH_PASS = 120.0  # algorithmic bytes per scan point of a search pass
+DOMINANT_KERNEL = "k_knn"
+
+
+def cpu_baseline(sc, budget_s=20.0):
+    """Reference-side timing on this host: the reference's own ikd-Tree (oracle/_ref, when built) + the
+    restated h_share_model, one search pass over the same scan. Threads: 3 (the reference's shipped
+    MP_PROC_NUM) is the reported value; the all-core rate is given in `sample`."""
+    from oracle import orc
+    ncpu = os.cpu_count() or 1
+    t0 = time.time()
+    o = orc.Oracle(sc["params"], threads=3, use_ref=True)
+    o.map_build(sc["map"])
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    build_s = time.time() - t0
+    res = {}
+    for thr in (3, ncpu):
+        o.set_threads(thr)
+        o.h_share_model(sc["state0"], True)  # warm-up
+        ts = []
+        t_start = time.time()
+        while len(ts) < 10 and (time.time() - t_start) < budget_s / 2:
+            t = time.perf_counter()
+            o.h_share_model(sc["state0"], True)
+            ts.append(time.perf_counter() - t)
+        res[thr] = float(np.median(ts))
+    N = sc["N"]
+    return {
+        "value": N / res[3], "unit": "points/s", "cores": 3, "kind": "reference" if o.is_ref else "port",
+        "ms_per_pass": res[3] * 1e3,
+        "sample": "%d search passes of h_share_model over the same %d-pt scan vs %d-pt map, median; k-NN = "
+                  "%s; 3 OMP threads (reference MP_PROC_NUM) -> value; all %d cores: %.3g points/s (%.1f ms/pass); "
+                  "tree build %.1f s not counted" % (
+                      10, N, sc["Nmap"], "reference ikd-Tree compiled from source" if o.is_ref else "oracle k-d tree",
+                      ncpu, N / res[ncpu], res[ncpu] * 1e3, build_s),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (1-based)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    ge.load_package()
+    from malio_amd import capi, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world or not distributed, "--gpus must equal WORLD_SIZE"
+
+    cfg = scenes.CONFIGS[args.config]
+    # same map (seed of the config) on every rank; the scan shard differs per rank (weak scaling)
+    sc = scenes.make_scene(cfg=args.config)
+    if distributed and rank > 0:
+        sc_r = scenes.make_scene(cfg=args.config, scan_seed=1000 + rank)
+        sc["scan"] = sc_r["scan"]
+    N, L = sc["N"], sc["L"]
+
+    eng = capi.Engine(sc["params"], device=local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    state = sc["state0"]
+
+    if distributed:
+        nsum = eng.sums_len()
+        d_mm = torch.zeros(8, dtype=torch.float64, device="cuda")
+        d_sums = torch.zeros(nsum, dtype=torch.float64, device="cuda")
+        h_mm = torch.zeros(8, dtype=torch.float64).pin_memory()
+        h_sums = torch.zeros(nsum, dtype=torch.float64).pin_memory()
+
+        def step():
+            eng.stage1(state, True, d_mm.data_ptr())
+            dist.all_reduce(d_mm[:4], op=dist.ReduceOp.MAX)   # [max_u, -min_u, max_R, -min_R]
+            eng.stage2(d_mm.data_ptr(), d_sums.data_ptr())
+            dist.all_reduce(d_sums, op=dist.ReduceOp.SUM)
+            h_sums.copy_(d_sums, non_blocking=True)
+            h_mm.copy_(d_mm, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return eng.finish(h_sums.numpy(), h_mm.numpy())
+    else:
+        def step():
+            return eng.measure(state, True)
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = (N * world) / (dt / args.steps)
+
+    # ---- secondary metric: whole iterated update (ESKF iteration ms), single GPU only ----
+    eskf = None
+    if not distributed:
+        ts, passes = [], 0
+        for _ in range(10):
+            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            eng.measure(state, True)  # per-scan spatial sort happens on the first pass; keep it out
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            u = eng.update_iterated(state, sc["P0"])
+            ts.append(time.perf_counter() - t)
+            passes = u["passes"]
+        eskf = {"update_ms": float(np.median(ts) * 1e3), "passes": passes,
+                "iter_ms": float(np.median(ts) * 1e3 / max(passes, 1))}
+
+    # ---- roofline of the dominant kernel: hipEvents on the engine's stream, same command ----
+    roofline = None
+    if rank == 0:
+        eng.set_profiling(True)
+        per = {}
+        for _ in range(min(50, max(10, args.steps))):
+            if distributed:
+                eng.stage1(state, True, d_mm.data_ptr())
+                eng.stage2(d_mm.data_ptr(), d_sums.data_ptr())
+                torch.cuda.synchronize()
+                eng.finish(h_sums.numpy(), h_mm.numpy())
+            else:
+                eng.measure(state, True)
+            for name, ms in eng.last_kernel_times():
+                per.setdefault(name, []).append(ms)
+        eng.set_profiling(False)
+        kt = {k: float(np.mean(v)) for k, v in per.items()}
+        dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
+        achieved = ALG_BYTES_SEARCH_PASS * N / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * N, "kernel_ms": dom_ms,
+                    "kernel_event_ms": kt}
+    if distributed:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sc)
+
+    if rank == 0:
+        line = {
+            "metric": "points/sec through k-NN+residual step (100k-pt scan vs 1M-pt map); ESKF iter ms",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
+            "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step%s" % (
+                cfg["name"], N, L, sc["Nmap"], "" if not distributed else
+                "; scan sharded %d x %d pts, map replicated, 2 RCCL all-reduces per pass" % (world, N)),
+                "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"]),
+                "seed": sc["seed"]},
+            "eskf": eskf, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

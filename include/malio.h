@@ -83,7 +83,7 @@ typedef struct malio_params {
   double localize_cov_max, localize_cov_min;
   double localize_thresh_max, localize_thresh_min;
   double filter_size_map; /* filter_size_map_min: ikdtree.set_downsample_param, laserMapping.cpp:999 */
-  float cell_size;        /* spatial-hash cell edge [m]; 0 = default (2.25 m >= sqrt(5)) */
+  float cell_size;        /* spatial-hash cell edge [m]; 0 = default (1.125 m >= sqrt(5)/2) */
   int32_t reserved[3];
 } malio_params_t;
 
@@ -133,7 +133,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n);
 /* ikdtree.size()                                     laserMapping.cpp:824 */
 int malio_map_size(malio_handle_t h, int *out_size);
 /* ikdtree.Nearest_Search(point, k, near, d2), batched laserMapping.cpp:586 / ikd_Tree.cpp:426-461.
- * Exact k-NN (k <= 5) inside radius cell_size (>= sqrt(5) m, the reference's own acceptance gate
+ * Exact k-NN (k <= 5) inside radius 2*cell_size (>= sqrt(5) m, the reference's own acceptance gate
  * laserMapping.cpp:587); float32 squared distances computed as ikd_Tree.cpp:1697; ascending.
  * out_pts [n*k], out_d2 [n*k] (INFINITY-padded), out_count [n]. */
 int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,

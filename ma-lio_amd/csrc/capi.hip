@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(BLK) k_gather_side(int N, const u32 *__restric
   if (i >= N) return;
   u32 o = perm[i];
   for (int k = 0; k < 5; k++) {
-    u32 j = nbr[(size_t)k * N + i];
+    u32 j = nbr[(size_t)k * N + i];  // original map index
     out_near[(size_t)o * 5 + k] = (j != 0xFFFFFFFFu) ? map_pts[j] : make_float4(0, 0, 0, 0);
   }
 }
@@ -95,8 +95,8 @@ int malio_create(const malio_params_t *params, int device, malio_handle_t *out) 
   malio_ctx *c = new malio_ctx();
   c->prm = *params;
   c->device = device;
-  c->cell = params->cell_size > 0.f ? params->cell_size : 2.25f;
-  if (c->cell < 2.2360681f) c->cell = 2.2360681f;  // must cover the sqrt(5) m acceptance radius
+  c->cell = params->cell_size > 0.f ? params->cell_size : 1.125f;
+  if (c->cell < 1.1180341f) c->cell = 1.1180341f;  // two cell edges must cover the sqrt(5) m acceptance radius
   c->inv_cell = 1.0f / c->cell;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -116,8 +116,9 @@ int malio_destroy(malio_handle_t h) {
     if (p) (void)hipFree(p);
   };
   free_grid(c->map);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
-  fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_minmax), fr(c->d_partials);
+  fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
@@ -155,14 +156,18 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   if (check(h) || !pts || n <= 0) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
   MALIO_HIP(hipSetDevice(c->device));
-  float4 *stage = nullptr, *d_in = nullptr;
+  float4 *stage = nullptr;
   MALIO_HIP(hipHostMalloc(&stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
   for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
-  MALIO_HIP(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
-  MALIO_HIP(hipMemcpyAsync(d_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  int rc = group_by_cell(c, d_in, n, c->inv_cell, c->map);
+  if ((size_t)n > c->cap_map_in) {
+    if (c->d_map_in) (void)hipFree(c->d_map_in);
+    c->d_map_in = nullptr;
+    c->cap_map_in = (size_t)n + (size_t)n / 8 + 1024;
+    MALIO_HIP(hipMalloc(&c->d_map_in, sizeof(float4) * c->cap_map_in));
+  }
+  MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int rc = group_by_cell(c, c->d_map_in, n, c->inv_cell, c->map);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(d_in);
   (void)hipHostFree(stage);
   if (rc != MALIO_OK) return rc;
   c->map_n = n;
@@ -200,8 +205,8 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
   MALIO_HIP(hipMemcpyAsync(idx.data(), d_idx, sizeof(u32) * idx.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(d2.data(), d_d2, sizeof(float) * d2.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
-  std::vector<float4> mp(c->map.n);
-  MALIO_HIP(hipMemcpyAsync(mp.data(), c->map.pts, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float4> mp(c->map.n);  // original order
+  MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) {
     if (out_count) out_count[i] = cnt[i];
@@ -408,7 +413,7 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
     float4 *d_near = nullptr;
     MALIO_HIP(hipMalloc(&d_near, sizeof(float4) * 5 * (size_t)N));
     hipLaunchKernelGGL(k_gather_side, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, N, c->d_perm, c->d_nbr,
-                       c->map.pts, d_near);
+                       c->d_map_in, d_near);
     near.resize((size_t)5 * N);
     MALIO_HIP(hipMemcpyAsync(near.data(), d_near, sizeof(float4) * near.size(), hipMemcpyDeviceToHost, c->stream));
     MALIO_HIP(hipStreamSynchronize(c->stream));

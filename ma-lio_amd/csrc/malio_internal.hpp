@@ -28,7 +28,7 @@ struct CellGrid {
   Cell *table = nullptr;  // [tsize]
   u32 tmask = 0;          // tsize - 1
   u32 ncells = 0;
-  float4 *pts = nullptr;  // [n] sorted by cell: x, y, z, w (payload)
+  float4 *pts = nullptr;  // [n] sorted by cell: x, y, z, bits(original index)
   u32 *orig = nullptr;    // [n] original index of each sorted point
   int n = 0;
   size_t cap_pts = 0, cap_table = 0;
@@ -65,10 +65,12 @@ struct Ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
-  float cell = 2.25f, inv_cell = 1.f / 2.25f;
+  float cell = 1.125f, inv_cell = 1.f / 1.125f;
 
   // map
   CellGrid map;
+  float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
+  size_t cap_map_in = 0;
   int map_n = 0;
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
@@ -91,12 +93,14 @@ struct Ctx {
   float4 *d_plane = nullptr;   // [N] pabcd
   float *d_pd2 = nullptr;      // [N]
   float *d_world = nullptr;    // [3][N]
+  float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_transform -> k_knn/k_plane)
+  double *d_pbnorm = nullptr;  // [N]
   double *d_ucov = nullptr;    // [N] unit_cov
   double *d_trace = nullptr;   // [N] trace(Sigma_p) (clamp rule by selected flag)
   unsigned char *d_sel = nullptr;  // [N]
   unsigned char *d_nfound = nullptr;  // [N]
   // reductions
-  u64 *d_minmax = nullptr;   // [4] ordered-encoded: max_ucov, min_ucov, max_R, min_R ; [4] = M counter
+  double *d_blockmm = nullptr;  // [nblocks][5] per-workgroup max_u, min_u, max_R, min_R, count
   double *d_partials = nullptr;  // [nblocks][NSUM]
   double *d_sums = nullptr;      // [NSUM_OUT]
   double *h_sums = nullptr;      // pinned
@@ -141,7 +145,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
 int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_sums_out, bool want_rows);
 int sums_len(const Ctx *c);
 int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
-int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt);
+int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*original map index*/, float *d_d2, int *d_cnt);
 
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_state_t *x, double *P, double R, int *stats, double *solve_time);

@@ -1,6 +1,7 @@
 // GPU-resident spatial hash that replaces the ikd-Tree as the 5-NN search structure
 // (reference: KD_TREE<PointType>, include/ikd-Tree/ikd_Tree.{h,cpp}; Build :369-397).
-// Layout in HBM: points sorted by cell as float4 (x,y,z,normal_y) + a compact open-addressing table
+// Layout in HBM: points sorted by cell as float4 (x,y,z,bits(original index)) + the original-order
+// float4 (x,y,z,normal_y) array the plane fit gathers from + a compact open-addressing table
 // of 16-byte {key,start,count} entries. Cell edge c >= sqrt(5) m so the 27 cells around a query
 // contain every map point within the reference's acceptance radius (laserMapping.cpp:587).
 #include "malio_internal.hpp"
@@ -112,8 +113,10 @@ __global__ void __launch_bounds__(BLK) k_gbc_scatter(const float4 *__restrict__ 
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   u32 dst = start[slot_of[i]] + rank_of[i];
-  out_pts[dst] = pts[i];
-  out_orig[dst] = in_orig ? in_orig[i] : (u32)i;
+  u32 og = in_orig ? in_orig[i] : (u32)i;
+  float4 p = pts[i];
+  out_pts[dst] = make_float4(p.x, p.y, p.z, __uint_as_float(og));
+  out_orig[dst] = og;
 }
 
 // Pass 3: move the occupied scratch slots into the compact table the queries use.

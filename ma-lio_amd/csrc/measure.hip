@@ -42,23 +42,6 @@ __device__ __forceinline__ D3 mulRt(const double *R, D3 v) {
           R[2] * v.x + R[5] * v.y + R[8] * v.z};
 }
 
-// order-preserving double <-> u64 encoding for atomicMin/Max
-__device__ __forceinline__ u64 enc_d(double d) {
-  u64 b = (u64)__double_as_longlong(d);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-static inline double dec_d_host(u64 e) {
-  u64 b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
-  double d;
-  memcpy(&d, &b, 8);
-  return d;
-}
-static inline u64 enc_d_host(double d) {
-  u64 b;
-  memcpy(&b, &d, 8);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-
 struct QuatConst {
   Q4 rot;
   D3 pos;
@@ -74,8 +57,7 @@ struct Pass1Args {
   int N;
   const float4 *scan;
   // map
-  const float4 *map_pts;
-  const u32 *map_orig;
+  const float4 *map_pts;  // sorted by cell: x y z bits(original index)
   const Cell *table;
   u32 tmask;
   float cell, inv_cell;
@@ -87,8 +69,12 @@ struct Pass1Args {
   float plane_th;
   double cov_threshold;
   int extrinsic_est_en;
+  const float4 *map_in;  // [Nmap] original order: x y z normal_y
   // per-point outputs (sorted order)
-  u32 *nbr;  // [5][N]
+  float4 *world4;  // [N] world point of the search pass
+  double *pbnorm;  // [N] |p'| (double), range gate :599
+  double *blockmm; // [nblocks][5]
+  u32 *nbr;  // [5][N] ORIGINAL map indices (INVALID when fewer than 5 inside the radius)
   float4 *plane;
   float *pd2;
   float *world;  // [3][N]
@@ -96,15 +82,27 @@ struct Pass1Args {
   double *trace;
   unsigned char *sel;
   unsigned char *nfound;
-  u64 *minmax;  // [0]=max ucov [1]=min ucov [2]=max R [3]=min R (encoded) [4]=M
 };
 
-// 27 neighbour offsets, nearest shells first (centre, 6 faces, 12 edges, 8 corners)
-__constant__ signed char c_off[27][3] = {
-    {0, 0, 0},  {-1, 0, 0},  {1, 0, 0},   {0, -1, 0},  {0, 1, 0},   {0, 0, -1},  {0, 0, 1},
-    {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0},  {1, 1, 0},   {-1, 0, -1}, {-1, 0, 1},  {1, 0, -1},
-    {1, 0, 1},  {0, -1, -1}, {0, -1, 1},  {0, 1, -1},  {0, 1, 1},   {-1, -1, -1}, {-1, -1, 1},
-    {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1},  {1, 1, -1},  {1, 1, 1}};
+// generated: 27 ring-1 offsets (|d|_inf <= 1) then the 98 cells of the 5x5x5 shell, each sorted by |d|_2
+__constant__ signed char c_off[125][3] = {
+    {0, 0, 0}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}, {-1, -1, 0},
+    {-1, 0, -1}, {-1, 0, 1}, {-1, 1, 0}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1}, {1, -1, 0},
+    {1, 0, -1}, {1, 0, 1}, {1, 1, 0}, {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1},
+    {1, -1, 1}, {1, 1, -1}, {1, 1, 1}, {-2, 0, 0}, {0, -2, 0}, {0, 0, -2}, {0, 0, 2}, {0, 2, 0},
+    {2, 0, 0}, {-2, -1, 0}, {-2, 0, -1}, {-2, 0, 1}, {-2, 1, 0}, {-1, -2, 0}, {-1, 0, -2}, {-1, 0, 2},
+    {-1, 2, 0}, {0, -2, -1}, {0, -2, 1}, {0, -1, -2}, {0, -1, 2}, {0, 1, -2}, {0, 1, 2}, {0, 2, -1},
+    {0, 2, 1}, {1, -2, 0}, {1, 0, -2}, {1, 0, 2}, {1, 2, 0}, {2, -1, 0}, {2, 0, -1}, {2, 0, 1},
+    {2, 1, 0}, {-2, -1, -1}, {-2, -1, 1}, {-2, 1, -1}, {-2, 1, 1}, {-1, -2, -1}, {-1, -2, 1}, {-1, -1, -2},
+    {-1, -1, 2}, {-1, 1, -2}, {-1, 1, 2}, {-1, 2, -1}, {-1, 2, 1}, {1, -2, -1}, {1, -2, 1}, {1, -1, -2},
+    {1, -1, 2}, {1, 1, -2}, {1, 1, 2}, {1, 2, -1}, {1, 2, 1}, {2, -1, -1}, {2, -1, 1}, {2, 1, -1},
+    {2, 1, 1}, {-2, -2, 0}, {-2, 0, -2}, {-2, 0, 2}, {-2, 2, 0}, {0, -2, -2}, {0, -2, 2}, {0, 2, -2},
+    {0, 2, 2}, {2, -2, 0}, {2, 0, -2}, {2, 0, 2}, {2, 2, 0}, {-2, -2, -1}, {-2, -2, 1}, {-2, -1, -2},
+    {-2, -1, 2}, {-2, 1, -2}, {-2, 1, 2}, {-2, 2, -1}, {-2, 2, 1}, {-1, -2, -2}, {-1, -2, 2}, {-1, 2, -2},
+    {-1, 2, 2}, {1, -2, -2}, {1, -2, 2}, {1, 2, -2}, {1, 2, 2}, {2, -2, -1}, {2, -2, 1}, {2, -1, -2},
+    {2, -1, 2}, {2, 1, -2}, {2, 1, 2}, {2, 2, -1}, {2, 2, 1}, {-2, -2, -2}, {-2, -2, 2}, {-2, 2, -2},
+    {-2, 2, 2}, {2, -2, -2}, {2, -2, 2}, {2, 2, -2}, {2, 2, 2},
+};
 
 __device__ __forceinline__ u64 cell_key_d(int ix, int iy, int iz) {
   const long long B = 1ll << 20;
@@ -119,77 +117,164 @@ __device__ __forceinline__ u32 hash_key_d(u64 k) {
   return (u32)k;
 }
 
-// Sorted (ascending) 5-slot candidate list with total order (d2, original map index).
+// Sorted (ascending) 5-slot candidate list with the total order (d2, original map index).
 struct Top5 {
   float d[5];
-  u32 id[5];
+  u32 og[5];
 };
-__device__ __forceinline__ bool cand_less(float da, u32 ia, float db, u32 ib, const u32 *__restrict__ orig) {
-  if (da < db) return true;
-  if (da > db) return false;
-  if (ib == INVALID) return false;  // sentinel slots only lose to strictly smaller distances
-  if (ia == INVALID) return false;
-  return orig[ia] < orig[ib];
-}
-__device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 j, const u32 *__restrict__ orig) {
-  if (!cand_less(d2, j, t.d[4], t.id[4], orig)) return;
+__device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 og) {
+  if (!(d2 < t.d[4] || (d2 == t.d[4] && og < t.og[4]))) return;
   t.d[4] = d2;
-  t.id[4] = j;
+  t.og[4] = og;
 #pragma unroll
   for (int k = 4; k > 0; k--) {
-    bool sw = cand_less(t.d[k], t.id[k], t.d[k - 1], t.id[k - 1], orig);
+    bool sw = t.d[k] < t.d[k - 1] || (t.d[k] == t.d[k - 1] && t.og[k] < t.og[k - 1]);
     float dk = t.d[k], dk1 = t.d[k - 1];
-    u32 ik = t.id[k], ik1 = t.id[k - 1];
+    u32 ik = t.og[k], ik1 = t.og[k - 1];
     t.d[k] = sw ? dk1 : dk;
     t.d[k - 1] = sw ? dk : dk1;
-    t.id[k] = sw ? ik1 : ik;
-    t.id[k - 1] = sw ? ik : ik1;
+    t.og[k] = sw ? ik1 : ik;
+    t.og[k - 1] = sw ? ik : ik1;
   }
 }
 
-// Exact radius-limited 5-NN in the hash grid. Keeps candidates with d2 <= limit2 (float compare as
-// `pointSearchSqDis[4] > 5` laserMapping.cpp:587); squared distance arithmetic as ikd_Tree.cpp:1697.
-__device__ __forceinline__ void knn5(float wx, float wy, float wz, const float4 *__restrict__ map_pts,
-                                     const u32 *__restrict__ map_orig, const Cell *__restrict__ table, u32 tmask,
-                                     float cell, float inv_cell, float limit2, Top5 &t) {
+// One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
+__device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 tmask, u64 key, Cell first, u32 slot,
+                                            u32 &start, u32 &count) {
+  Cell c = first;
+  while (true) {
+    if (c.key == key) {
+      start = c.start, count = c.count;
+      return;
+    }
+    if (c.key == EMPTY_KEY) {
+      start = 0, count = 0;
+      return;
+    }
+    slot = (slot + 1) & tmask;
+    c = table[slot];
+  }
+}
+
+// Scan one cell's points (4 independent 16-byte loads in flight), keep those with d2 <= limit2.
+__device__ __forceinline__ void scan_cell(const float4 *__restrict__ map_pts, u32 start, u32 count, float wx, float wy,
+                                          float wz, float limit2, Top5 &t) {
+  const u32 end = start + count;
+  for (u32 j = start; j < end; j += 4) {
+    float4 m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) m[u] = map_pts[min(j + u, end - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+      if (j + u < end && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(m[u].w));
+    }
+  }
+}
+
+// Merge the G lane-local sorted lists into the global top-5 (identical in every lane of the group):
+// 5 rounds of a 64-bit (d2 bits | map index) min-reduction over xor-shuffles.
+template <int G>
+__device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
+  Top5 out;
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    u64 key = ((u64)__float_as_uint(t.d[0]) << 32) | (u64)t.og[0];
+    u64 mn = key;
+#pragma unroll
+    for (int sft = G / 2; sft > 0; sft >>= 1) {
+      u64 other = __shfl_xor(mn, sft);
+      mn = other < mn ? other : mn;
+    }
+    out.d[r] = __uint_as_float((u32)(mn >> 32));
+    out.og[r] = (u32)mn;
+    if (key == mn && t.og[0] != INVALID) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) t.d[k] = t.d[k + 1], t.og[k] = t.og[k + 1];
+      t.d[4] = sentinel, t.og[4] = INVALID;
+    }
+  }
+  t = out;
+}
+
+// Exact radius-limited 5-NN in the hash grid, G lanes of a wave per query. Cell edge c >= sqrt(5)/2,
+// so the 5x5x5 block around the query's cell holds every map point within the acceptance radius
+// (laserMapping.cpp:587). Ring 1 (27 cells) is split over the G lanes: each lane issues its probes
+// together, scans its cells, then the lists are merged; the query is finished when the 5th distance is
+// inside the radius ring 1 guarantees. Otherwise the 98 shell cells are searched the same way, pruned
+// by the current 5th distance. Keeps candidates with d2 <= limit2 (float compare, as
+// `pointSearchSqDis[4] > 5`); map_pts[j] = (x, y, z, bits(original index)).
+template <int G>
+__device__ __forceinline__ void knn5_group(float wx, float wy, float wz, int sub, const float4 *__restrict__ map_pts,
+                                           const Cell *__restrict__ table, u32 tmask, float cell, float inv_cell,
+                                           float limit2, Top5 &t) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
-  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.id[k] = INVALID;
+  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.og[k] = INVALID;
   float gx = wx * inv_cell, gy = wy * inv_cell, gz = wz * inv_cell;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
   int kx = (int)kxf, ky = (int)kyf, kz = (int)kzf;
   float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
-  // conservative allowance for the float rounding of the cell coordinates
+  // conservative allowance for the float rounding of the cell coordinates (k_knn)
   float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * cell;
   float lo_x = fmaxf(fx * cell - margin, 0.f), hi_x = fmaxf((1.f - fx) * cell - margin, 0.f);
   float lo_y = fmaxf(fy * cell - margin, 0.f), hi_y = fmaxf((1.f - fy) * cell - margin, 0.f);
   float lo_z = fmaxf(fz * cell - margin, 0.f), hi_z = fmaxf((1.f - fz) * cell - margin, 0.f);
-  for (int o = 0; o < 27; o++) {
-    int dx = c_off[o][0], dy = c_off[o][1], dz = c_off[o][2];
-    float ax = dx < 0 ? lo_x : (dx > 0 ? hi_x : 0.f);
-    float ay = dy < 0 ? lo_y : (dy > 0 ? hi_y : 0.f);
-    float az = dz < 0 ? lo_z : (dz > 0 ? hi_z : 0.f);
-    float bd2 = (ax * ax + ay * ay + az * az) * 0.999999f;
-    if (bd2 > t.d[4]) continue;
-    u64 key = cell_key_d(kx + dx, ky + dy, kz + dz);
-    u32 s = hash_key_d(key) & tmask;
-    u32 start = 0, count = 0;
-    while (true) {
-      Cell c = table[s];
-      if (c.key == key) {
-        start = c.start, count = c.count;
-        break;
-      }
-      if (c.key == EMPTY_KEY) break;
-      s = (s + 1) & tmask;
+
+  // ---- ring 1: 27 cells, ceil(27/G) per lane, probes issued together ----
+  constexpr int CPL = (27 + G - 1) / G;
+  {
+    u64 key[CPL];
+    u32 slot[CPL];
+    Cell rec[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      int o = sub + k * G;
+      int oo = o < 27 ? o : 0;
+      key[k] = cell_key_d(kx + c_off[oo][0], ky + c_off[oo][1], kz + c_off[oo][2]);
+      slot[k] = hash_key_d(key[k]) & tmask;
+      rec[k] = table[slot[k]];
     }
-    for (u32 j = start; j < start + count; j++) {
-      float4 m = map_pts[j];
-      float ddx = wx - m.x, ddy = wy - m.y, ddz = wz - m.z;
-      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-      top5_insert(t, d2, j, map_orig);
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      if (sub + k * G < 27) {
+        u32 start, count;
+        cell_lookup(table, tmask, key[k], rec[k], slot[k], start, count);
+        scan_cell(map_pts, start, count, wx, wy, wz, limit2, t);
+      }
     }
   }
+  merge_group<G>(t, sentinel);
+  // radius ring 1 guarantees: one cell edge plus the distance to the nearest face of the own cell
+  float g1 = cell + fminf(fminf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
+  bool done = (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
+  if (done) return;  // group-uniform: every lane holds the same merged list
+
+  // ---- ring 2: the 98 cells of the 5x5x5 shell, pruned by the current 5th distance ----
+  const float bound = t.d[4];  // <= sentinel
+  Top5 loc;
+  if (sub == 0) {
+    loc = t;  // lane 0 carries the ring-1 result into the merge
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; k++) loc.d[k] = sentinel, loc.og[k] = INVALID;
+  }
+  for (int o = 27 + sub; o < 125; o += G) {
+    int dx = c_off[o][0], dy = c_off[o][1], dz = c_off[o][2];
+    float ax = dx == 0 ? 0.f : (dx < 0 ? lo_x + (float)(-dx - 1) * cell : hi_x + (float)(dx - 1) * cell);
+    float ay = dy == 0 ? 0.f : (dy < 0 ? lo_y + (float)(-dy - 1) * cell : hi_y + (float)(dy - 1) * cell);
+    float az = dz == 0 ? 0.f : (dz < 0 ? lo_z + (float)(-dz - 1) * cell : hi_z + (float)(dz - 1) * cell);
+    float bd2 = (ax * ax + ay * ay + az * az) * 0.99999f;
+    if (bd2 > bound) continue;
+    u64 key = cell_key_d(kx + dx, ky + dy, kz + dz);
+    u32 slot = hash_key_d(key) & tmask;
+    u32 start, count;
+    cell_lookup(table, tmask, key, table[slot], slot, start, count);
+    scan_cell(map_pts, start, count, wx, wy, wz, limit2, loc);
+  }
+  t = loc;
+  merge_group<G>(t, sentinel);
 }
 
 // Eigen ColPivHouseholderQR<Matrix<float,5,3>>::solve(b = -1) restated with static register indexing
@@ -366,132 +451,208 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
-template <bool SEARCH>
-__global__ void __launch_bounds__(BLK) k_pass1(Pass1Args a) {
+// ---- a1: p' (LiDAR-0 frame) and the world point, double -> float (laserMapping.cpp:569-578) --------
+__device__ __forceinline__ void world_point(const QuatConst &qc, const float4 q, int lid, float &wx, float &wy,
+                                            float &wz, double &nb) {
+  D3 p_body{(double)q.x, (double)q.y, (double)q.z};
+  if (lid != 0)
+    p_body = qrot(qconj(qc.q0), (qrot(qc.qtc[lid], qrot(qc.ql[lid], p_body) + qc.tl[lid]) + qc.ttc[lid]) - qc.t0);
+  D3 pg = qrot(qc.rot, qrot(qc.q0, p_body) + qc.t0) + qc.pos;
+  wx = (float)pg.x, wy = (float)pg.y, wz = (float)pg.z;
+  nb = sqrt(p_body.x * p_body.x + p_body.y * p_body.y + p_body.z * p_body.z);  // p_body.norm(), :599
+}
+
+// residual + range gate (laserMapping.cpp:598-601)
+__device__ __forceinline__ bool residual_gate(const float pabcd[4], float wx, float wy, float wz, double nb,
+                                              float &pd2) {
+  pd2 = pabcd[0] * wx + pabcd[1] * wy + pabcd[2] * wz + pabcd[3];
+  float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb));
+  return (double)s > 0.1;
+}
+
+// a6/a8: trace(Sigma_p); the index clamp differs for accepted (:694-696) and rejected (:737-739) points
+__device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, int lid, int tidx, bool selected) {
+  int len = a.unc_len[lid];
+  int k = tidx;
+  if (selected) {
+    if ((unsigned)k >= (unsigned)len) k = len - 2;
+  } else {
+    if ((unsigned)k >= (unsigned)(len - 1)) k = len - 2;
+  }
+  if (selected && !a.extrinsic_est_en) return 0.0;  // R(i,0) stays 0, normal_y not rewritten (:681-704)
+  return point_trace(a.unc[a.unc_off[lid] + k], q.x, q.y, q.z);
+}
+
+// a4: per-workgroup min/max of unit_cov and R over accepted points, and their count
+__device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, double ucov, double tr) {
+  __shared__ double sm[BLK / 64][5];
+  double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
+  bool rsel = selected && a.extrinsic_est_en;
+  double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
+  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
+  unsigned long long bal = __ballot(selected);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[wave][0] = mxu, sm[wave][1] = mnu, sm[wave][2] = mxr, sm[wave][3] = mnr, sm[wave][4] = (double)__popcll(bal);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r0 = sm[0][0], r1 = sm[0][1], r2 = sm[0][2], r3 = sm[0][3], r4 = sm[0][4];
+#pragma unroll
+    for (int w = 1; w < BLK / 64; w++) {
+      r0 = fmax(r0, sm[w][0]), r1 = fmin(r1, sm[w][1]), r2 = fmax(r2, sm[w][2]), r3 = fmin(r3, sm[w][3]);
+      r4 += sm[w][4];
+    }
+    double *o = a.blockmm + (size_t)blockIdx.x * 5;
+    o[0] = r0, o[1] = r1, o[2] = r2, o[3] = r3, o[4] = r4;
+  }
+}
+
+__global__ void __launch_bounds__(BLK) k_transform(Pass1Args a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
-  const bool active = i < a.N;
+  if (i >= a.N) return;
+  const float4 q = a.scan[i];
+  float wx, wy, wz;
+  double nb;
+  world_point(a.qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
+  a.world4[i] = make_float4(wx, wy, wz, 0.f);
+  a.pbnorm[i] = nb;
+}
+
+// a2: ikdtree.Nearest_Search (laserMapping.cpp:586), G lanes per query.
+template <int G>
+__global__ void __launch_bounds__(BLK) k_knn(Pass1Args a) {
+  const int tid = blockIdx.x * BLK + threadIdx.x;
+  const int qi = tid / G, sub = tid % G;
+  const bool active = qi < a.N;
+  const float4 w = a.world4[active ? qi : a.N - 1];
+  Top5 t;
+  knn5_group<G>(w.x, w.y, w.z, sub, a.map_pts, a.table, a.tmask, a.cell, a.inv_cell, 5.0f, t);
+  if (!active) return;
+  if (sub < 5) {
+    u32 v = sub == 0 ? t.og[0] : sub == 1 ? t.og[1] : sub == 2 ? t.og[2] : sub == 3 ? t.og[3] : t.og[4];
+    a.nbr[(size_t)sub * a.N + qi] = v;
+  } else if (sub == 5) {
+    int nf = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+    a.nfound[qi] = (unsigned char)nf;
+  }
+}
+
+// a3 + gates + a6 of a SEARCH pass: thread per query.
+__global__ void __launch_bounds__(BLK) k_plane(Pass1Args a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
-  if (active) {
+  if (i < a.N) {
     const float4 q = a.scan[i];
     const int packed = __float_as_int(q.w);
-    const int lid = packed & 0xFF;
-    const int tidx = packed >> 8;  // int(normal_x), sign preserved
-    // ---- a1: p' (LiDAR-0 frame) and world point, double -> float (laserMapping.cpp:569-578) ----
-    D3 p_body{(double)q.x, (double)q.y, (double)q.z};
-    if (lid != 0)
-      p_body = qrot(qconj(a.qc.q0),
-                    (qrot(a.qc.qtc[lid], qrot(a.qc.ql[lid], p_body) + a.qc.tl[lid]) + a.qc.ttc[lid]) - a.qc.t0);
-    D3 pg = qrot(a.qc.rot, qrot(a.qc.q0, p_body) + a.qc.t0) + a.qc.pos;
-    const float wx = (float)pg.x, wy = (float)pg.y, wz = (float)pg.z;
-    a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
-
-    bool cand;
-    u32 id[5];
-    if (SEARCH) {
-      // ---- a2: 5-NN (ikdtree.Nearest_Search, :586) + gate `size < 5 || d2[4] > 5` (:587) ----
-      Top5 t;
-      knn5(wx, wy, wz, a.map_pts, a.map_orig, a.table, a.tmask, a.cell, a.inv_cell, 5.0f, t);
-      int nf = 0;
+    const int lid = packed & 0xFF, tidx = packed >> 8;
+    const float4 w = a.world4[i];
+    a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+    if (a.nfound[i] == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
+      // ---- esti_plane<float> (common_lib.h:144-190) ----
+      float A[5][3], P[5][3], W[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        id[k] = t.id[k];
-        a.nbr[(size_t)k * a.N + i] = t.id[k];
-        nf += (t.id[k] != INVALID);
+        float4 m = a.map_in[a.nbr[(size_t)k * a.N + i]];
+        A[k][0] = P[k][0] = m.x, A[k][1] = P[k][1] = m.y, A[k][2] = P[k][2] = m.z, W[k] = m.w;
       }
-      a.nfound[i] = (unsigned char)nf;
-      cand = nf == 5;
-    } else {
-      cand = a.sel[i] != 0;  // neighbours and flag reused when !converge (:583-591)
-    }
-    float pabcd[4] = {0, 0, 0, 0};
-    bool plane_ok = false;
-    if (cand) {
-      if (SEARCH) {
-        // ---- a3: esti_plane<float> (common_lib.h:144-190) ----
-        float A[5][3], W[5];
+      double cov_sum = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
+      if ((double)W[0] > 0.00001) {
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-          float4 m = a.map_pts[id[k]];
-          A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
+          double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
+          ucov += wk * wk * (double)W[k];
         }
-        double cov_sum = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
-        if ((double)W[0] > 0.00001) {
-#pragma unroll
-          for (int k = 0; k < 5; k++) {
-            double w = (a.cov_threshold - (double)W[k]) / cov_sum;
-            ucov += w * w * (double)W[k];
-          }
-        }
-        float P[5][3];
-#pragma unroll
-        for (int k = 0; k < 5; k++) P[k][0] = A[k][0], P[k][1] = A[k][1], P[k][2] = A[k][2];
-        float nv[3];
-        qr_solve_5x3(A, nv);
-        float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-        pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
-        pabcd[3] = (float)(1.0 / (double)n);
-        plane_ok = true;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-          if (fabsf(pabcd[0] * P[k][0] + pabcd[1] * P[k][1] + pabcd[2] * P[k][2] + pabcd[3]) > a.plane_th)
-            plane_ok = false;
-        a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
-        a.ucov[i] = ucov;
-      } else {
-        float4 pl = a.plane[i];
-        pabcd[0] = pl.x, pabcd[1] = pl.y, pabcd[2] = pl.z, pabcd[3] = pl.w;
-        ucov = a.ucov[i];
-        plane_ok = true;  // same neighbours -> esti_plane returns the same plane and verdict
       }
+      float nv[3], pabcd[4];
+      qr_solve_5x3(A, nv);
+      float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+      pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
+      pabcd[3] = (float)(1.0 / (double)n);
+      bool plane_ok = true;
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+        if (fabsf(pabcd[0] * P[k][0] + pabcd[1] * P[k][1] + pabcd[2] * P[k][2] + pabcd[3]) > a.plane_th)
+          plane_ok = false;
+      a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+      a.ucov[i] = ucov;
       if (plane_ok) {
-        // ---- residual + range gate (laserMapping.cpp:598-601) ----
-        float pd2 = pabcd[0] * wx + pabcd[1] * wy + pabcd[2] * wz + pabcd[3];
-        double nb = sqrt(p_body.x * p_body.x + p_body.y * p_body.y + p_body.z * p_body.z);
-        float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb));
-        if ((double)s > 0.1) {
+        float pd2;
+        if (residual_gate(pabcd, w.x, w.y, w.z, a.pbnorm[i], pd2)) {
           selected = true;
           a.pd2[i] = pd2;
         }
       }
     }
     a.sel[i] = selected ? 1 : 0;
-    // ---- a6/a8: trace(Sigma_p); index clamps differ for accepted (:694-696) / rejected (:737-739) ----
-    {
-      int len = a.unc_len[lid];
-      int k = tidx;
-      if (selected) {
-        if ((unsigned)k >= (unsigned)len) k = len - 2;
-      } else {
-        if ((unsigned)k >= (unsigned)(len - 1)) k = len - 2;
-      }
-      if (selected && !a.extrinsic_est_en) {
-        tr = 0.0;  // R(i,0) stays 0 and normal_y is not rewritten (:681-704); see scan_get
-      } else {
-        tr = point_trace(a.unc[a.unc_off[lid] + k], q.x, q.y, q.z);
-      }
-      a.trace[i] = tr;
-    }
+    tr = trace_for(a, q, lid, tidx, selected);
+    a.trace[i] = tr;
   }
-  // ---- a4: min/max unit_cov, min/max R over accepted points, M ----
-  double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
-  bool rsel = selected && a.extrinsic_est_en;
-  double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
-  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
-  unsigned long long bal = __ballot(selected);
-  if ((threadIdx.x & 63) == 0) {
-    int cnt = __popcll(bal);
-    if (cnt) {
-      atomicMax(&a.minmax[0], enc_d(mxu));
-      atomicMin(&a.minmax[1], enc_d(mnu));
-      if (a.extrinsic_est_en) {
-        atomicMax(&a.minmax[2], enc_d(mxr));
-        atomicMin(&a.minmax[3], enc_d(mnr));
+  block_minmax(a, selected, ucov, tr);
+}
+
+// REUSE pass (ekfom_data.converge == false, :583-595): neighbours, plane and flag are kept; the
+// residual and the range gate are re-evaluated at the new state.
+__global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  bool selected = false;
+  double ucov = 0.0, tr = 0.0;
+  if (i < a.N) {
+    const float4 q = a.scan[i];
+    const int packed = __float_as_int(q.w);
+    const int lid = packed & 0xFF, tidx = packed >> 8;
+    float wx, wy, wz;
+    double nb;
+    world_point(a.qc, q, lid, wx, wy, wz, nb);
+    a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
+    if (a.sel[i]) {
+      const float4 pl = a.plane[i];
+      const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
+      ucov = a.ucov[i];
+      float pd2;
+      if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
+        selected = true;
+        a.pd2[i] = pd2;
       }
-      atomicAdd(&a.minmax[4], (u64)cnt);
     }
+    a.sel[i] = selected ? 1 : 0;
+    tr = trace_for(a, q, lid, tidx, selected);
+    a.trace[i] = tr;
+  }
+  block_minmax(a, selected, ucov, tr);
+}
+
+// One workgroup folds the per-workgroup (max_u, min_u, max_R, min_R, M) rows with the reference's
+// initial values (laserMapping.cpp:615-616,646-647) into [max_u, -min_u, max_R, -min_R, M].
+__global__ void __launch_bounds__(1024) k_minmax_reduce(const double *__restrict__ blockmm, int nb, int extrinsic_est_en,
+                                                        double *out) {
+  __shared__ double sm[16][5];
+  double r0 = -INFINITY, r1 = INFINITY, r2 = -INFINITY, r3 = INFINITY, r4 = 0;
+  for (int b = threadIdx.x; b < nb; b += 1024) {
+    const double *v = blockmm + (size_t)b * 5;
+    r0 = fmax(r0, v[0]), r1 = fmin(r1, v[1]), r2 = fmax(r2, v[2]), r3 = fmin(r3, v[3]), r4 += v[4];
+  }
+  r0 = wave_max(r0), r1 = wave_min(r1), r2 = wave_max(r2), r3 = wave_min(r3);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) r4 += __shfl_xor(r4, d);
+  if ((threadIdx.x & 63) == 0) {
+    int w = threadIdx.x >> 6;
+    sm[w][0] = r0, sm[w][1] = r1, sm[w][2] = r2, sm[w][3] = r3, sm[w][4] = r4;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m0 = 0.0, m1 = 1000.0, m2 = 0.0, m3 = 9999.0, cnt = 0;
+    for (int w = 0; w < 16; w++) {
+      m0 = fmax(m0, sm[w][0]), m1 = fmin(m1, sm[w][1]);
+      if (extrinsic_est_en) m2 = fmax(m2, sm[w][2]), m3 = fmin(m3, sm[w][3]);
+      cnt += sm[w][4];
+    }
+    out[0] = m0, out[1] = -m1, out[2] = m2, out[3] = -m3, out[4] = cnt;
   }
 }
 
@@ -649,8 +810,19 @@ __global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict_
   const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
   const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
   double acc = 0;
-  if (e < NSUM)
-    for (int b = b0 + grp; b < b1; b += 8) acc += partials[(size_t)b * NSUM + e];
+  if (e < NSUM) {
+    // 8 independent loads in flight per lane; the summation order is fixed (b ascending within a group)
+    for (int b = b0 + grp; b < b1; b += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int bb = b + 8 * u;
+        v[u] = bb < b1 ? partials[(size_t)bb * NSUM + e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc += v[u];
+    }
+  }
   g[grp][e] = acc;
   __syncthreads();
   if (grp == 0 && e < NSUM) {
@@ -661,48 +833,37 @@ __global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict_
   }
 }
 
-__global__ void k_init_minmax(u64 *mm, u64 e_max_u, u64 e_min_u, u64 e_max_r, u64 e_min_r) {
-  mm[0] = e_max_u, mm[1] = e_min_u, mm[2] = e_max_r, mm[3] = e_min_r, mm[4] = 0;
-}
-// decode to the all-reduce-friendly form [max_u, -min_u, max_R, -min_R, M]
-__global__ void k_decode_minmax(const u64 *mm, double *out) {
-  int t = threadIdx.x;
-  if (t < 4) {
-    u64 e = mm[t];
-    u64 b = (e >> 63) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
-    double d = __longlong_as_double((long long)b);
-    out[t] = (t & 1) ? -d : d;
-  } else if (t == 4) {
-    out[4] = (double)mm[4];
-  }
-}
-
 // ---- batched Nearest_Search -----------------------------------------------------------------------
+constexpr int KNN_G = 8;  // lanes per query (measured 4/8/16)
+
 __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, int n, int k,
-                                                 const float4 *__restrict__ map_pts, const u32 *__restrict__ map_orig,
-                                                 const Cell *__restrict__ table, u32 tmask, float cell, float inv_cell,
-                                                 u32 *out_idx, float *out_d2, int *out_cnt) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = q[i];
+                                                 const float4 *__restrict__ map_pts, const Cell *__restrict__ table,
+                                                 u32 tmask, float cell, float inv_cell, u32 *out_idx, float *out_d2,
+                                                 int *out_cnt) {
+  const int tid = blockIdx.x * BLK + threadIdx.x;
+  const int qi = tid / KNN_G, sub = tid % KNN_G;
+  const bool active = qi < n;
+  float4 p = q[active ? qi : n - 1];
   Top5 t;
-  // radius limit = cell edge (>= sqrt 5): everything within it is inside the 27-cell block
-  knn5(p.x, p.y, p.z, map_pts, map_orig, table, tmask, cell, inv_cell, cell * cell * 0.999f, t);
+  // radius limit = a hair under two cell edges (>= sqrt 5): everything inside it is in the 5x5x5 block
+  knn5_group<KNN_G>(p.x, p.y, p.z, sub, map_pts, table, tmask, cell, inv_cell, 4.f * cell * cell * 0.999f, t);
+  if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {
     if (j < k) {
-      bool ok = t.id[j] != INVALID;
-      out_idx[(size_t)i * k + j] = ok ? t.id[j] : INVALID;
-      out_d2[(size_t)i * k + j] = ok ? t.d[j] : INFINITY;
+      bool ok = t.og[j] != INVALID;
+      out_idx[(size_t)qi * k + j] = t.og[j];
+      out_d2[(size_t)qi * k + j] = ok ? t.d[j] : INFINITY;
       c += ok;
     }
   }
-  out_cnt[i] = c;
+  out_cnt[qi] = c;
 }
 
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
-  hipLaunchKernelGGL(k_nearest, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_q, n, k, c->map.pts, c->map.orig,
-                     c->map.table, c->map.tmask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
+  long long threads = (long long)n * KNN_G;
+  hipLaunchKernelGGL(k_nearest, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_q, n, k,
+                     c->map.pts, c->map.table, c->map.tmask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -737,7 +898,7 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in), fr(c->d_world4), fr(c->d_pbnorm);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
     MALIO_HIP(hipMalloc(&c->d_scan_in, sizeof(float4) * K));
@@ -751,15 +912,18 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_trace, sizeof(double) * K));
     MALIO_HIP(hipMalloc(&c->d_sel, K));
     MALIO_HIP(hipMalloc(&c->d_nfound, K));
+    MALIO_HIP(hipMalloc(&c->d_world4, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_pbnorm, sizeof(double) * K));
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
   if (nb > c->cap_partials) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     c->cap_partials = nb + nb / 8 + 16;
     MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));
+    if (c->d_blockmm) (void)hipFree(c->d_blockmm);
+    MALIO_HIP(hipMalloc(&c->d_blockmm, sizeof(double) * 5 * c->cap_partials));
   }
-  if (!c->d_minmax) {
-    MALIO_HIP(hipMalloc(&c->d_minmax, sizeof(u64) * 8));
+  if (!c->d_sums) {
     MALIO_HIP(hipMalloc(&c->d_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8 + 16)));
     MALIO_HIP(hipHostMalloc(&c->h_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8), hipHostMallocDefault));
     MALIO_HIP(hipHostMalloc(&c->h_minmax, sizeof(double) * 8, hipHostMallocDefault));
@@ -843,23 +1007,30 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   }
   a.N = c->N;
   a.scan = c->d_scan;
-  a.map_pts = c->map.pts, a.map_orig = c->map.orig, a.table = c->map.table, a.tmask = c->map.tmask;
+  a.map_pts = c->map.pts, a.table = c->map.table, a.tmask = c->map.tmask, a.map_in = c->d_map_in;
   a.cell = c->cell, a.inv_cell = c->inv_cell;
   a.unc = c->d_unc;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
+  a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm, a.blockmm = c->d_blockmm;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
-  a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound, a.minmax = c->d_minmax;
-  // initial values of laserMapping.cpp:615-616,646-647
-  hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(1), 0, c->stream, c->d_minmax, enc_d_host(0.0), enc_d_host(1000.0),
-                     enc_d_host(0.0), enc_d_host(9999.0));
-  dim3 grid((c->N + BLK - 1) / BLK);
-  if (converge)
-    hipLaunchKernelGGL(k_pass1<true>, grid, dim3(BLK), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL(k_pass1<false>, grid, dim3(BLK), 0, c->stream, a);
-  prof_mark(c, converge ? "k_pass1<search>" : "k_pass1<reuse>");
-  hipLaunchKernelGGL(k_decode_minmax, dim3(1), dim3(64), 0, c->stream, c->d_minmax, d_minmax4_out);
+  a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
+  const int nb = (c->N + BLK - 1) / BLK;
+  if (converge) {
+    hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);
+    prof_mark(c, "k_transform");
+    long long threads = (long long)c->N * KNN_G;
+    hipLaunchKernelGGL(k_knn<KNN_G>, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, a);
+    prof_mark(c, "k_knn");
+    hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a);
+    prof_mark(c, "k_plane");
+  } else {
+    hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
+    prof_mark(c, "k_reuse");
+  }
+  hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, c->stream, c->d_blockmm, nb, c->prm.extrinsic_est_en,
+                     d_minmax4_out);
+  prof_mark(c, "k_minmax_reduce");
   MALIO_HIP(hipGetLastError());
   // matrix form of the same state for stage 2
   PassConst &pc = c->pc;

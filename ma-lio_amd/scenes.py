@@ -20,6 +20,8 @@ CITY_EXT_Q_WXYZ = np.array([[1, 0, 0, 0], [0.6965018, -0.0037329, -0.0038405, 0.
 URBAN_EXT_T = np.array([[0, 0, 0.28], [0.3237, -0.0012, 0.0791]])
 URBAN_EXT_Q_WXYZ = np.array([[1, 0, 0, 0], [0.8849, 0.0027, 0.4654, -0.0182]])
 
+SURFACE_SHIFT = np.array([17.0, 23.0, -1.8])
+
 DEFAULT_PARAMS = dict(  # City.yaml:41-49, mapping_city.launch:9-15
     lid_num=3, max_iteration=3, extrinsic_est_en=1, plane_th=0.4, cov_threshold=0.5, range_min=0.0, range_max=1.0,
     point_cov_max=0.00125, point_cov_min=0.00075, plane_cov_max=1.0, plane_cov_min=0.8, localize_cov_max=2.0,
@@ -146,6 +148,13 @@ def _surface_voxels(kind, half_w, rng, origin):
             m = Xw.size
             pts.append(np.stack([Xw.ravel() + rng.uniform(0, v, m), 60.0 * j + rng.normal(0, 0.02, m),
                                  Zw.ravel() + rng.uniform(0, v, m)], 1))
+    elif kind == "plain":  # ground plane only: two unobservable translations (localization-weight min branch)
+        nx = int(np.floor(half_w / v))
+        gx = (np.arange(-nx, nx) + 0.0) * v
+        X, Y = np.meshgrid(gx, gx, indexing="ij")
+        n = X.size
+        pts.append(np.stack([X.ravel() + rng.uniform(0, v, n), Y.ravel() + rng.uniform(0, v, n),
+                             rng.normal(0, 0.02, n)], 1))
     else:  # tunnel along +x: walls y = +-5, floor z = 0, ceiling z = 6, no cross features
         nx = int(np.floor(half_w / v))
         gx = (np.arange(-nx, nx) + 0.0) * v
@@ -170,6 +179,8 @@ def _count_for(kind, half_w):
     nx = 2 * int(np.floor(half_w / v))
     if kind == "city":
         return nx * nx + (2 * int(half_w // 40) + 1) * nx * 40 + (2 * int(half_w // 60) + 1) * nx * 40
+    if kind == "plain":
+        return nx * nx
     return 2 * nx * 20 + 2 * nx * 12
 
 
@@ -197,7 +208,7 @@ def make_map(kind, Nmap, rng, origin=(0, 0, 0), map_unc=False):
 
 def make_scene(cfg=None, seed=None, N=None, Nmap=None, L=None, kind="city", map_unc=False, origin=(0, 0, 0),
                max_iteration=3, extrinsic_est_en=1, n_table=10, prior_dpos=0.10, prior_drot_deg=0.5,
-               det_range=100.0):
+               det_range=100.0, scan_seed=None):
     """Build one synthetic scan-vs-map problem. `cfg` selects a BASELINE.json config (1..5)."""
     if cfg is not None:
         c = CONFIGS[cfg]
@@ -210,7 +221,10 @@ def make_scene(cfg=None, seed=None, N=None, Nmap=None, L=None, kind="city", map_
     if seed is None:
         seed = 20230625
     rng = np.random.default_rng(seed)
-    origin = np.asarray(origin, float)
+    # The reference fits planes as a x + b y + c z = -1 (common_lib.h:156-174), which is singular for planes
+    # through the world origin; real maps start at the first IMU pose (ground ~1.8 m below, no wall through
+    # the origin), so the synthetic surfaces are shifted accordingly. `origin` adds on top (0 m / 1000 m).
+    origin = np.asarray(origin, float) + SURFACE_SHIFT
     map_pts, half_w = make_map(kind, Nmap, rng, origin, map_unc)
 
     # ground-truth pose
@@ -255,6 +269,8 @@ def make_scene(cfg=None, seed=None, N=None, Nmap=None, L=None, kind="city", map_
         tables.append(np.array(tab))
 
     # scan: N surface points within det_range of the sensor, one per 0.5 m voxel, noise N(0,0.02)
+    if scan_seed is not None:  # a different scan over the same map / tables (multi-GPU weak scaling shards)
+        rng = np.random.default_rng(scan_seed)
     rel = map_pts[:, 0:3].astype(np.float64) - pos_gt[None, :]
     near = np.nonzero(np.einsum("ij,ij->i", rel, rel) < det_range * det_range)[0]
     if near.size < N:
@@ -313,6 +329,8 @@ def _offplane_hint(kind, rel):
         d[:, 2] = np.abs(rel[:, 2])  # ground z = 0
         d[:, 0] = np.abs(rel[:, 0] - 40.0 * np.round(rel[:, 0] / 40.0))
         d[:, 1] = np.abs(rel[:, 1] - 60.0 * np.round(rel[:, 1] / 60.0))
+    elif kind == "plain":
+        d[:, 2] = np.abs(rel[:, 2])
     else:
         d[:, 2] = np.minimum(np.abs(rel[:, 2]), np.abs(rel[:, 2] - 6.0))
         d[:, 1] = np.minimum(np.abs(rel[:, 1] - 5.0), np.abs(rel[:, 1] + 5.0))

@@ -1,0 +1,49 @@
+"""C-ABI surface: the library loads, exports every symbol include/malio.h declares, struct layouts
+match, and creating a handle without a GPU fails loudly (no CPU fallback). No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "malio.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(malio_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(capi):
+    lib = capi.lib()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/malio.h but not exported"
+    assert set(syms) == set(capi.EXPORTS)
+
+
+def test_struct_layouts(capi):
+    assert C.sizeof(capi.Point) == 48          # pcl::PointXYZINormal
+    assert C.sizeof(capi.Pose) == 59 * 8        # common_lib.h:57-63
+    assert C.sizeof(capi.State) == (3 + 4 + 4 * 4 + 4 * 3 + 12) * 8
+    assert capi.Point.intensity.offset == 32 and capi.Point.normal_x.offset == 16 and capi.Point.curvature.offset == 36
+    assert b"gfx950" in capi.lib().malio_version()
+
+
+def test_create_without_gpu_fails_loudly(capi, scenes):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.MalioError):
+        capi.Engine(scenes.DEFAULT_PARAMS, device=0)
+
+
+def test_bad_args(capi):
+    lib = capi.lib()
+    h = C.c_void_p()
+    assert lib.malio_create(None, 0, C.byref(h)) == -3
+    prm = capi.make_params(dict(lid_num=9))
+    assert lib.malio_create(C.byref(prm), 0, C.byref(h)) == -3
+    assert lib.malio_destroy(None) == -3
