@@ -116,7 +116,7 @@ int malio_destroy(malio_handle_t h) {
     if (p) (void)hipFree(p);
   };
   free_grid(c->map);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm), fr(c->d_ny);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
@@ -399,12 +399,14 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   std::vector<u32> perm(N);
   std::vector<unsigned char> sel(N), nf(N);
   std::vector<double> tr(N);
+  std::vector<float> ny(N);
   std::vector<float> pd2(N), world((size_t)3 * N);
   std::vector<float4> plane(N);
   MALIO_HIP(hipMemcpyAsync(perm.data(), c->d_perm, sizeof(u32) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(sel.data(), c->d_sel, N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(tr.data(), c->d_trace, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(ny.data(), c->d_ny, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(pd2.data(), c->d_pd2, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(plane.data(), c->d_plane, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
@@ -423,10 +425,10 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   for (int i = 0; i < N; i++) {
     const u32 o = perm[i];
     if (normal_y) {
-      // laserMapping.cpp:699,730,741; untouched when the pass bailed out (:635-639) or, for accepted
-      // points, when extrinsic_est_en is off (:681)
-      bool untouched = (c->last_M == 0) || (sel[i] && !c->prm.extrinsic_est_en);
-      normal_y[o] = untouched ? c->h_normal_y_in[o] : (float)tr[i];
+      // laserMapping.cpp:699,730,741: the last pass' rewrite is still pending (see commit_normal_y);
+      // untouched when that pass bailed out (:635-639) or, for accepted points, extrinsic_est_en is off
+      bool untouched = (c->last_M <= 0) || (sel[i] && !c->prm.extrinsic_est_en);
+      normal_y[o] = untouched ? ny[i] : (float)tr[i];
     }
     if (nearest_count) nearest_count[o] = nf[i];
     if (selected) selected[o] = sel[i];

@@ -95,6 +95,7 @@ struct Ctx {
   float *d_world = nullptr;    // [3][N]
   float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_transform -> k_knn/k_plane)
   double *d_pbnorm = nullptr;  // [N]
+  float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
   double *d_ucov = nullptr;    // [N] unit_cov
   double *d_trace = nullptr;   // [N] trace(Sigma_p) (clamp rule by selected flag)
   unsigned char *d_sel = nullptr;  // [N]

@@ -82,6 +82,8 @@ struct Pass1Args {
   double *trace;
   unsigned char *sel;
   unsigned char *nfound;
+  float *ny;        // [N] feats_down_body[i].normal_y as the reference would hold it (committed lazily)
+  int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
 };
 
 // generated: 27 ring-1 offsets (|d|_inf <= 1) then the 98 cells of the 5x5x5 shell, each sorted by |d|_2
@@ -483,6 +485,16 @@ __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, 
   return point_trace(a.unc[a.unc_off[lid] + k], q.x, q.y, q.z);
 }
 
+// feats_down_body[i].normal_y bookkeeping (laserMapping.cpp:699,730,741): a pass that reached the end
+// rewrites it with trace(Sigma_p), except for accepted points when extrinsic_est_en is off (:681).
+// A pass that bailed out with no effective points (:635-639) rewrites nothing, which is only known on the
+// host after the pass - so the fold happens at the start of the NEXT pass (or in malio_scan_get).
+__device__ __forceinline__ void commit_normal_y(const Pass1Args &a, int i) {
+  if (!a.commit_prev) return;
+  if (a.sel[i] && !a.extrinsic_est_en) return;
+  a.ny[i] = (float)a.trace[i];
+}
+
 // a4: per-workgroup min/max of unit_cov and R over accepted points, and their count
 __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, double ucov, double tr) {
   __shared__ double sm[BLK / 64][5];
@@ -551,6 +563,7 @@ __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a) {
     const int lid = packed & 0xFF, tidx = packed >> 8;
     const float4 w = a.world4[i];
     a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+    commit_normal_y(a, i);
     if (a.nfound[i] == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
       // ---- esti_plane<float> (common_lib.h:144-190) ----
       float A[5][3], P[5][3], W[5];
@@ -610,6 +623,7 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
     double nb;
     world_point(a.qc, q, lid, wx, wy, wz, nb);
     a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
+    commit_normal_y(a, i);
     if (a.sel[i]) {
       const float4 pl = a.plane[i];
       const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
@@ -898,7 +912,7 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in), fr(c->d_world4), fr(c->d_pbnorm);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_ny);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
     MALIO_HIP(hipMalloc(&c->d_scan_in, sizeof(float4) * K));
@@ -914,6 +928,7 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_nfound, K));
     MALIO_HIP(hipMalloc(&c->d_world4, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_pbnorm, sizeof(double) * K));
+    MALIO_HIP(hipMalloc(&c->d_ny, sizeof(float) * K));
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
   if (nb > c->cap_partials) {
@@ -944,12 +959,14 @@ __global__ void __launch_bounds__(BLK) k_scan_world(const float4 *__restrict__ i
 }
 __global__ void __launch_bounds__(BLK) k_gather_scan(const float4 *__restrict__ in, const u32 *__restrict__ src, int n,
                                                      int dst0, float4 *out_scan, u32 *out_perm,
-                                                     const u32 *__restrict__ part_orig) {
+                                                     const u32 *__restrict__ part_orig,
+                                                     const float *__restrict__ ny_in, float *out_ny) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   u32 s = src[i];  // index inside the LiDAR segment upload
   out_scan[dst0 + i] = in[s];
   out_perm[dst0 + i] = part_orig[s];
+  out_ny[dst0 + i] = ny_in[s];
 }
 
 static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
@@ -977,6 +994,11 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(hipMalloc(&d_part_orig, sizeof(u32) * (size_t)c->N));
   MALIO_HIP(hipMemcpyAsync(d_part_orig, c->h_lidpart.data(), sizeof(u32) * (size_t)c->N, hipMemcpyHostToDevice,
                            c->stream));
+  float *d_ny_in = nullptr;  // input normal_y in upload (LiDAR-partitioned) order
+  std::vector<float> ny_part(c->N);
+  for (int p = 0; p < c->N; p++) ny_part[p] = c->h_normal_y_in[c->h_lidpart[p]];
+  MALIO_HIP(hipMalloc(&d_ny_in, sizeof(float) * (size_t)c->N));
+  MALIO_HIP(hipMemcpyAsync(d_ny_in, ny_part.data(), sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_scan_world, dim3((c->N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_scan_in, c->N, qc, d_w);
   CellGrid g;
   for (int l = 0; l < L; l++) {
@@ -986,12 +1008,13 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
     if (rc != MALIO_OK) return rc;
     hipLaunchKernelGGL(k_gather_scan, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
                        c->d_scan_in + c->seg_start[l], g.orig, n, c->seg_start[l], c->d_scan, c->d_perm,
-                       d_part_orig + c->seg_start[l]);
+                       d_part_orig + c->seg_start[l], d_ny_in + c->seg_start[l], c->d_ny);
   }
   MALIO_HIP(hipStreamSynchronize(c->stream));
   free_grid(g);
   (void)hipFree(d_w);
   (void)hipFree(d_part_orig);
+  (void)hipFree(d_ny_in);
   c->scan_sorted = true;
   return MALIO_OK;
 }
@@ -1015,6 +1038,8 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm, a.blockmm = c->d_blockmm;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
+  a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;
+  c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
   const int nb = (c->N + BLK - 1) / BLK;
   if (converge) {
     hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);

@@ -44,3 +44,19 @@ def fused_from_rows(r):
     Rc = np.where(r["R"] < 1e-4, 1e-3, r["R"])
     HT = r["h_x"].T / Rc
     return HT @ r["h_x"], HT @ r["h"]
+
+
+def assert_P_close(P, Q, rel=2e-3, HtH=None, P0=None):
+    """Posterior covariances, compared element-wise against the LARGER of two scale-aware bounds:
+      correlation scale      |dP_ij| <= rel * sqrt(Q_ii Q_jj)
+      rounding of the reference's own formula (needs HtH, P0): the reference forms K_x = P_inv[:, :C] * HtH and
+      P = L - K_x P (esekfom.hpp:637,714); with |HtH| ~ 1e11 (lever arm^2 x 1e5 points / R) against |P_inv| ~ 1e-7
+      the products cancel over ~11 digits, so any implementation of that formula - the reference's Eigen build
+      included - carries an absolute error ~ 64 ulp * (|P_inv| |HtH| |P0|)_ij in the pose/rotation cross block."""
+    dg = np.sqrt(np.abs(np.diag(Q)))
+    bound = rel * np.outer(dg, dg) + 1e-18
+    if HtH is not None and P0 is not None:
+        C = HtH.shape[0]
+        bound = np.maximum(bound, 64 * 2.3e-16 * (np.abs(Q[:, :C]) @ np.abs(HtH) @ np.abs(P0[:C, :])))
+    bad = np.abs(P - Q) > bound
+    assert not bad.any(), (int(bad.sum()), float((np.abs(P - Q) / bound).max()))

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import assert_P_close
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "golden", "*.npz")))
 
@@ -90,7 +92,7 @@ def test_hip_reproduces_golden(capi, orc, name):
     u = eng.update_iterated(z["state0"], z["P0"])
     assert u["passes"] == int(z["upd_passes"]) and u["searches"] == int(z["upd_searches"]) and u["M"] == int(z["upd_M"])
     assert np.allclose(u["state"], z["upd_state"], rtol=0, atol=1e-9)
-    assert np.allclose(u["P"], z["upd_P"], rtol=1e-5, atol=1e-12)
+    assert_P_close(u["P"], z["upd_P"])
     _, d2, cnt = eng.nearest_search(z["knn_q"])
     inside = z["knn_d2"] <= 5.0  # exact inside the sqrt(5) m acceptance radius (laserMapping.cpp:587)
     assert np.array_equal(d2[inside], z["knn_d2"][inside])
