@@ -80,6 +80,7 @@ def main():
     import torch.distributed as dist
     ge.load_package()
     from malio_amd import capi, scenes
+    from malio_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,11 +88,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert args.gpus == world or not distributed, "--gpus must equal WORLD_SIZE"
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE"
 
     cfg = scenes.CONFIGS[args.config]
     # same map (seed of the config) on every rank; the scan shard differs per rank (weak scaling)
@@ -108,21 +109,10 @@ def main():
     state = sc["state0"]
 
     if distributed:
-        nsum = eng.sums_len()
-        d_mm = torch.zeros(8, dtype=torch.float64, device="cuda")
-        d_sums = torch.zeros(nsum, dtype=torch.float64, device="cuda")
-        h_mm = torch.zeros(8, dtype=torch.float64).pin_memory()
-        h_sums = torch.zeros(nsum, dtype=torch.float64).pin_memory()
+        be = mdist.HipBackend(eng)
 
         def step():
-            eng.stage1(state, True, d_mm.data_ptr())
-            dist.all_reduce(d_mm[:4], op=dist.ReduceOp.MAX)   # [max_u, -min_u, max_R, -min_R]
-            eng.stage2(d_mm.data_ptr(), d_sums.data_ptr())
-            dist.all_reduce(d_sums, op=dist.ReduceOp.SUM)
-            h_sums.copy_(d_sums, non_blocking=True)
-            h_mm.copy_(d_mm, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            return eng.finish(h_sums.numpy(), h_mm.numpy())
+            return mdist.sharded_measure(be, state, True)
     else:
         def step():
             return eng.measure(state, True)
@@ -170,13 +160,7 @@ def main():
         eng.set_profiling(True)
         per = {}
         for _ in range(min(50, max(10, args.steps))):
-            if distributed:
-                eng.stage1(state, True, d_mm.data_ptr())
-                eng.stage2(d_mm.data_ptr(), d_sums.data_ptr())
-                torch.cuda.synchronize()
-                eng.finish(h_sums.numpy(), h_mm.numpy())
-            else:
-                eng.measure(state, True)
+            eng.measure(state, True)  # same kernels as the sharded pass, without the collectives in between
             for name, ms in eng.last_kernel_times():
                 per.setdefault(name, []).append(ms)
         eng.set_profiling(False)
@@ -207,8 +191,9 @@ def main():
                 "seed": sc["seed"]},
             "eskf": eskf, "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -169,6 +169,16 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
 int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats,
                           double *solve_time);
 
+/* One iteration of the update loop AFTER its measurement pass (esekfom.hpp:521-720, the M >= n branch
+ * :621-637), on the reduced normal equations. Pure host code, needs no handle and no GPU: a multi-GPU
+ * driver calls it between its collectives. iter_index = loop index i of esekfom.hpp:509 (-1 ...
+ * max_iteration-1); x: in = state the pass was evaluated at, out = x [+] dx; t_io = converged-iteration
+ * counter (:658); converge_out = ekfom_data.converge for the next pass; done_out = 1 when P_out (n x n)
+ * holds the posterior and the loop ends (:665-718). */
+int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state_t *x,
+                     const malio_state_t *x_propagated, const double *P_propagated, const double *HtRinvH,
+                     const double *HtRinvh, int *t_io, int *converge_out, int *done_out, double *P_out);
+
 /* ---- undistortion (IMU_Processing.hpp:475-507 + BsplineSE3.cpp:84-118) --------------------- */
 /* Per-raw-point SE(3) cubic B-spline pose + rigid compensation into the LiDAR's own scan-end frame.
  * pts (in/out, sorted by curvature as :229-233): x,y,z rewritten, intensity <- uncertainty-interval

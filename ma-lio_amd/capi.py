@@ -21,7 +21,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling",
+    "malio_set_profiling", "malio_ieskf_step",
 ]
 
 
@@ -258,3 +258,21 @@ class Engine:
         Cc = self.C
         return dict(rc=rc, valid=bool(out.valid), M=int(out.M), w_loc=float(out.w_loc),
                     HtRinvH=np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), HtRinvh=np.array(out.HtRinvh[:Cc]))
+
+
+def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh, t):
+    """malio_ieskf_step (pure host, no GPU). Returns (x_new_flat, t, converge, done, P_out)."""
+    n = 17 + 6 * L
+    x = state_from_flat(x_flat, L)
+    xp = state_from_flat(xprop_flat, L)
+    P_prop = np.ascontiguousarray(P_prop, np.float64)
+    H = np.ascontiguousarray(HtRinvH, np.float64)
+    hv = np.ascontiguousarray(HtRinvh, np.float64)
+    P_out = np.zeros((n, n), np.float64)
+    t_io, conv, done = C.c_int(int(t)), C.c_int(0), C.c_int(0)
+    rc = lib().malio_ieskf_step(int(L), int(max_iteration), int(i), C.byref(x), C.byref(xp), _p(P_prop, C.c_double),
+                                _p(H, C.c_double), _p(hv, C.c_double), C.byref(t_io), C.byref(conv), C.byref(done),
+                                _p(P_out, C.c_double))
+    if rc != OK:
+        raise MalioError(f"malio_ieskf_step rc={rc}")
+    return state_to_flat(x, L), t_io.value, bool(conv.value), bool(done.value), P_out

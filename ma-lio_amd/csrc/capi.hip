@@ -456,6 +456,16 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
   return ieskf_update(h, x, P, R, stats, solve_time);
 }
 
+int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state_t *x, const malio_state_t *x_propagated,
+                     const double *P_propagated, const double *HtRinvH, const double *HtRinvh, int *t_io,
+                     int *converge_out, int *done_out, double *P_out) {
+  if (lid_num < 1 || lid_num > MALIO_MAX_LIDAR || !x || !x_propagated || !P_propagated || !HtRinvH || !HtRinvh ||
+      !t_io || !converge_out || !done_out || !P_out)
+    return MALIO_ERR_BAD_ARG;
+  return ieskf_step(lid_num, max_iteration, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
+                    converge_out, done_out, P_out);
+}
+
 int malio_undistort(malio_handle_t h, malio_point_t *, int, double, const double *, const double *, int, const double *,
                     const double *, const double *, const double *, const double *, int, int, int *, int *) {
   if (check(h)) return MALIO_ERR_BAD_ARG;

@@ -150,6 +150,9 @@ int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*origina
 
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+               const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
+               int *done_out, double *P_out);
 
 // profiling helpers
 void prof_begin(Ctx *c);

@@ -258,161 +258,203 @@ void cols_applyT(Mat &P, int n, int idx, int d, const double *B) {
 
 }  // namespace
 
-int ieskf_update(Ctx *c, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
-  const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
-  malio_state_t x_ = *xio;
-  const malio_state_t x_propagated = x_;
-  Mat P_prop(Pio, Pio + (size_t)n * n), P_(P_prop);
+}  // namespace malio (reopened below; step_core needs <functional>)
+#include <functional>
+namespace malio {
+
+// gain(P_projected, K_h, K_x): fills K_h (n) and K_x[:, 0:C] (n x n, rest zero) for the current pass.
+using GainFn = std::function<int(const std::vector<double> &, std::vector<double> &, std::vector<double> &)>;
+
+// One iteration of esekfom.hpp:509-720 AFTER the measurement pass. Pure host code.
+//   i          loop index of esekfom.hpp:509 (-1 .. max_iteration-1)
+//   x          in: state the pass was evaluated at; out: x boxplus dx
+//   t_io       in/out: number of converged iterations so far (esekfom.hpp:658)
+//   converge   out: ekfom_data.converge for the NEXT pass (:649-663)
+//   done       out: 1 when the posterior covariance was written to P_out and the loop must stop (:665-718)
+static int step_core(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+                     const double *P_prop, const GainFn &gain, int *t_io, int *converge_out, int *done_out,
+                     double *P_out) {
+  const int n = 17 + 6 * L, C = 6 * (L + 1);
+  malio_state_t &x_ = *x;
+  Mat P_(P_prop, P_prop + (size_t)n * n);
   std::vector<int> so3_idx;
   so3_idx.push_back(3);
   for (int l = 0; l < L; l++) so3_idx.push_back(6 + 3 * l);
   const int s2_idx = 15 + 6 * L;
-  bool converge = true;
-  int t = 0, passes = 0, searches = 0, lastM = 0;
-  double solve = 0;
   std::vector<double> dx(n), dx_new(n), dx_(n), K_h(n);
-  Mat K_x((size_t)n * n);
+  Mat K_x((size_t)n * n, 0.0);
+  state_boxminus(x_, *x_propagated, L, dx.data());  // :526
+  dx_new = dx;
+  for (int idx : so3_idx) {  // :534-549
+    double B[9];
+    A_matrix_T(&dx[idx], B);
+    double tmp[3];
+    for (int a = 0; a < 3; a++) tmp[a] = B[a * 3] * dx_new[idx] + B[a * 3 + 1] * dx_new[idx + 1] + B[a * 3 + 2] * dx_new[idx + 2];
+    for (int a = 0; a < 3; a++) dx_new[idx + a] = tmp[a];
+    rows_apply(P_, P_, n, idx, 3, B, n);
+    cols_applyT(P_, n, idx, 3, B);
+  }
+  {  // :551-572
+    double B[4];
+    s2_NxMx(x_.grav, x_propagated->grav, dx[s2_idx], dx[s2_idx + 1], B);
+    double a0 = B[0] * dx_new[s2_idx] + B[1] * dx_new[s2_idx + 1], a1 = B[2] * dx_new[s2_idx] + B[3] * dx_new[s2_idx + 1];
+    dx_new[s2_idx] = a0, dx_new[s2_idx + 1] = a1;
+    rows_apply(P_, P_, n, s2_idx, 2, B, n);
+    cols_applyT(P_, n, s2_idx, 2, B);
+  }
+  int rc = gain(P_, K_h, K_x);  // :574-640
+  if (rc != MALIO_OK) return rc;
+  for (int a = 0; a < n; a++) {  // :642
+    double s = K_h[a];
+    for (int b = 0; b < n; b++) s += (K_x[a * n + b] - (a == b ? 1.0 : 0.0)) * dx_new[b];
+    dx_[a] = s;
+  }
+  state_boxplus(x_, L, dx_.data());  // :646
+  bool converge = true;              // :649-657 (limit = 0.001 on every component, esekfom.hpp:160-163)
+  for (int a = 0; a < n; a++)
+    if (std::fabs(dx_[a]) > 0.001) {
+      converge = false;
+      break;
+    }
+  int t = *t_io;
+  if (converge) t++;
+  if (!t && i == maximum_iter - 2) converge = true;  // :660-663
+  *t_io = t;
+  *converge_out = converge ? 1 : 0;
+  *done_out = 0;
+  if (t > 1 || i == maximum_iter - 1) {  // :665-718
+    Mat L_(P_);
+    for (int idx : so3_idx) {
+      double B[9];
+      A_matrix_T(&dx_[idx], B);
+      rows_apply(L_, P_, n, idx, 3, B, n);
+      rows_apply(K_x, K_x, n, idx, 3, B, C);
+      cols_applyT(L_, n, idx, 3, B);
+      cols_applyT(P_, n, idx, 3, B);
+    }
+    {
+      double B[4];
+      s2_NxMx(x_.grav, x_propagated->grav, dx_[s2_idx], dx_[s2_idx + 1], B);
+      rows_apply(L_, P_, n, s2_idx, 2, B, n);
+      rows_apply(K_x, K_x, n, s2_idx, 2, B, C);
+      cols_applyT(L_, n, s2_idx, 2, B);
+      cols_applyT(P_, n, s2_idx, 2, B);
+    }
+    for (int a = 0; a < n; a++)  // :714
+      for (int b = 0; b < n; b++) {
+        double s = 0;
+        for (int k = 0; k < C; k++) s += K_x[a * n + k] * P_[k * n + b];
+        P_out[a * n + b] = L_[a * n + b] - s;
+      }
+    *done_out = 1;
+  }
+  return MALIO_OK;
+}
+
+// esekfom.hpp:621-637 on the reduced normal equations: P_inv = (P^-1 + blk(HtRinvH))^-1,
+// K_h = P_inv[:, 0:C] HtRinvh, K_x[:, 0:C] = P_inv[:, 0:C] HtRinvH
+static GainFn normal_eq_gain(int L, const double *HtRinvH, const double *HtRinvh) {
+  return [=](const std::vector<double> &P_, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
+    const int n = 17 + 6 * L, C = 6 * (L + 1);
+    Mat Pt(P_);
+    if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+    for (int a = 0; a < C; a++)
+      for (int b = 0; b < C; b++) Pt[a * n + b] += HtRinvH[a * C + b];
+    if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+    for (int a = 0; a < n; a++) {
+      double s = 0;
+      for (int b = 0; b < C; b++) s += Pt[a * n + b] * HtRinvh[b];
+      K_h[a] = s;
+      for (int b = 0; b < C; b++) {
+        double s2 = 0;
+        for (int k = 0; k < C; k++) s2 += Pt[a * n + k] * HtRinvH[k * C + b];
+        K_x[a * n + b] = s2;
+      }
+    }
+    return MALIO_OK;
+  };
+}
+
+int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+               const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
+               int *done_out, double *P_out) {
+  return step_core(L, maximum_iter, i, x, x_propagated, P_prop, normal_eq_gain(L, HtRinvH, HtRinvh), t_io,
+                   converge_out, done_out, P_out);
+}
+
+int ieskf_update(Ctx *c, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
+  const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
+  malio_state_t x_ = *xio;
+  const malio_state_t x_propagated = x_;
+  const Mat P_prop(Pio, Pio + (size_t)n * n);
+  int converge = 1, t = 0, passes = 0, searches = 0, lastM = 0;
+  double solve = 0;
   malio_measure_out_t mo;
   std::vector<double> rows_hx, rows_h, rows_R;
-
   for (int i = -1; i < maximum_iter; i++) {  // esekfom.hpp:509
     memset(&mo, 0, sizeof(mo));
     searches += converge ? 1 : 0;
-    int rc = malio_measure((malio_handle_t)c, &x_, converge ? 1 : 0, &mo);
+    int rc = malio_measure((malio_handle_t)c, &x_, converge, &mo);
     passes++;
     if (rc < 0) return rc;
     if (!mo.valid) continue;  // :514-517
     lastM = mo.M;
     auto t0 = std::chrono::steady_clock::now();
-    state_boxminus(x_, x_propagated, L, dx.data());  // :526
-    dx_new = dx;
-    P_ = P_prop;
-    for (int idx : so3_idx) {  // :534-549
-      double B[9];
-      A_matrix_T(&dx[idx], B);
-      double tmp[3];
-      for (int a = 0; a < 3; a++) tmp[a] = B[a * 3] * dx_new[idx] + B[a * 3 + 1] * dx_new[idx + 1] + B[a * 3 + 2] * dx_new[idx + 2];
-      for (int a = 0; a < 3; a++) dx_new[idx + a] = tmp[a];
-      rows_apply(P_, P_, n, idx, 3, B, n);
-      cols_applyT(P_, n, idx, 3, B);
-    }
-    {  // :551-572
-      double B[4];
-      s2_NxMx(x_.grav, x_propagated.grav, dx[s2_idx], dx[s2_idx + 1], B);
-      double a0 = B[0] * dx_new[s2_idx] + B[1] * dx_new[s2_idx + 1], a1 = B[2] * dx_new[s2_idx] + B[3] * dx_new[s2_idx + 1];
-      dx_new[s2_idx] = a0, dx_new[s2_idx + 1] = a1;
-      rows_apply(P_, P_, n, s2_idx, 2, B, n);
-      cols_applyT(P_, n, s2_idx, 2, B);
-    }
-    std::fill(K_x.begin(), K_x.end(), 0.0);
+    GainFn gain;
     if (n > mo.M) {
-      // :574-582 small-M fallback: K = P H^T (H P H^T / R + I)^-1 / R with scalar R, needs the rows
+      // :574-582 small-M fallback: K = P H^T (H P H^T / R + I)^-1 / R with the scalar R, needs the rows.
+      // Same state, converge = 0: the accept flags of the pass above stand, so these are its rows.
       const int M = mo.M;
       rows_hx.assign((size_t)c->N * C, 0.0), rows_h.assign(c->N, 0.0), rows_R.assign(c->N, 0.0);
       malio_measure_out_t mr;
       memset(&mr, 0, sizeof(mr));
       mr.h_x = rows_hx.data(), mr.h = rows_h.data(), mr.R = rows_R.data();
-      // same state, neighbours reused; the accept flags of the pass above stand, so the rows are
-      // those of that pass (reuse pass on an unchanged state is idempotent)
       rc = malio_measure((malio_handle_t)c, &x_, 0, &mr);
       if (rc < 0) return rc;
-      Mat S((size_t)M * M, 0.0), PHt((size_t)n * M, 0.0);
-      for (int a = 0; a < n; a++)
-        for (int m = 0; m < M; m++) {
+      gain = [&, M](const std::vector<double> &P_, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
+        Mat S((size_t)M * M, 0.0), PHt((size_t)n * M, 0.0);
+        for (int a = 0; a < n; a++)
+          for (int m = 0; m < M; m++) {
+            double s = 0;
+            for (int b = 0; b < C; b++) s += P_[a * n + b] * rows_hx[(size_t)m * C + b];
+            PHt[a * M + m] = s;
+          }
+        for (int m = 0; m < M; m++)
+          for (int k = 0; k < M; k++) {
+            double s = 0;
+            for (int b = 0; b < C; b++) s += rows_hx[(size_t)m * C + b] * PHt[b * M + k];
+            S[m * M + k] = s / R + (m == k ? 1.0 : 0.0);
+          }
+        if (!invert(S, M)) return MALIO_ERR_BAD_ARG;
+        Mat K((size_t)n * M, 0.0);
+        for (int a = 0; a < n; a++)
+          for (int k = 0; k < M; k++) {
+            double s = 0;
+            for (int m = 0; m < M; m++) s += PHt[a * M + m] * S[m * M + k];
+            K[a * M + k] = s / R;
+          }
+        for (int a = 0; a < n; a++) {
           double s = 0;
-          for (int b = 0; b < C; b++) s += P_[a * n + b] * rows_hx[(size_t)m * C + b];
-          PHt[a * M + m] = s;
+          for (int m = 0; m < M; m++) s += K[a * M + m] * rows_h[m];
+          K_h[a] = s;
+          for (int b = 0; b < C; b++) {
+            double s2 = 0;
+            for (int m = 0; m < M; m++) s2 += K[a * M + m] * rows_hx[(size_t)m * C + b];
+            K_x[a * n + b] = s2;
+          }
         }
-      for (int m = 0; m < M; m++)
-        for (int k = 0; k < M; k++) {
-          double s = 0;
-          for (int b = 0; b < C; b++) s += rows_hx[(size_t)m * C + b] * PHt[b * M + k];
-          S[m * M + k] = s / R + (m == k ? 1.0 : 0.0);
-        }
-      if (!invert(S, M)) return MALIO_ERR_BAD_ARG;
-      Mat K((size_t)n * M, 0.0);
-      for (int a = 0; a < n; a++)
-        for (int k = 0; k < M; k++) {
-          double s = 0;
-          for (int m = 0; m < M; m++) s += PHt[a * M + m] * S[m * M + k];
-          K[a * M + k] = s / R;
-        }
-      for (int a = 0; a < n; a++) {
-        double s = 0;
-        for (int m = 0; m < M; m++) s += K[a * M + m] * rows_h[m];
-        K_h[a] = s;
-        for (int b = 0; b < C; b++) {
-          double s2 = 0;
-          for (int m = 0; m < M; m++) s2 += K[a * M + m] * rows_hx[(size_t)m * C + b];
-          K_x[a * n + b] = s2;
-        }
-      }
+        return MALIO_OK;
+      };
     } else {
-      // :621-637 with the reduced normal equations: P_inv = (P^-1 + blk(HtRinvH))^-1,
-      // K_h = P_inv[:, 0:C] HtRinvh, K_x[:, 0:C] = P_inv[:, 0:C] HtRinvH
-      Mat Pt(P_);
-      if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
-      for (int a = 0; a < C; a++)
-        for (int b = 0; b < C; b++) Pt[a * n + b] += mo.HtRinvH[a * C + b];
-      if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
-      for (int a = 0; a < n; a++) {
-        double s = 0;
-        for (int b = 0; b < C; b++) s += Pt[a * n + b] * mo.HtRinvh[b];
-        K_h[a] = s;
-        for (int b = 0; b < C; b++) {
-          double s2 = 0;
-          for (int k = 0; k < C; k++) s2 += Pt[a * n + k] * mo.HtRinvH[k * C + b];
-          K_x[a * n + b] = s2;
-        }
-      }
+      gain = normal_eq_gain(L, mo.HtRinvH, mo.HtRinvh);
     }
-    for (int a = 0; a < n; a++) {  // :642
-      double s = K_h[a];
-      for (int b = 0; b < n; b++) s += (K_x[a * n + b] - (a == b ? 1.0 : 0.0)) * dx_new[b];
-      dx_[a] = s;
-    }
-    state_boxplus(x_, L, dx_.data());  // :646
-    converge = true;                   // :649-657
-    for (int a = 0; a < n; a++)
-      if (std::fabs(dx_[a]) > 0.001) {
-        converge = false;
-        break;
-      }
-    if (converge) t++;
-    if (!t && i == maximum_iter - 2) converge = true;  // :660-663
-    if (t > 1 || i == maximum_iter - 1) {               // :665-718
-      Mat L_(P_);
-      for (int idx : so3_idx) {
-        double B[9];
-        A_matrix_T(&dx_[idx], B);
-        rows_apply(L_, P_, n, idx, 3, B, n);
-        rows_apply(K_x, K_x, n, idx, 3, B, C);
-        cols_applyT(L_, n, idx, 3, B);
-        cols_applyT(P_, n, idx, 3, B);
-      }
-      {
-        double B[4];
-        s2_NxMx(x_.grav, x_propagated.grav, dx_[s2_idx], dx_[s2_idx + 1], B);
-        rows_apply(L_, P_, n, s2_idx, 2, B, n);
-        rows_apply(K_x, K_x, n, s2_idx, 2, B, C);
-        cols_applyT(L_, n, s2_idx, 2, B);
-        cols_applyT(P_, n, s2_idx, 2, B);
-      }
-      for (int a = 0; a < n; a++)  // :714
-        for (int b = 0; b < n; b++) {
-          double s = 0;
-          for (int k = 0; k < C; k++) s += K_x[a * n + k] * P_[k * n + b];
-          Pio[a * n + b] = L_[a * n + b] - s;
-        }
-      solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      *xio = x_;
-      if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
-      if (solve_time) *solve_time += solve;
-      return MALIO_OK;
-    }
+    int done = 0;
+    rc = step_core(L, maximum_iter, i, &x_, &x_propagated, P_prop.data(), gain, &t, &converge, &done, Pio);
     solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != MALIO_OK) return rc;
+    if (done) break;
   }
-  // every pass was invalid (no effective points): the reference leaves x_ and P_ as propagated
+  // (when every pass was invalid the reference leaves x_ and P_ as propagated: Pio untouched)
   *xio = x_;
   if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
   if (solve_time) *solve_time += solve;

@@ -124,6 +124,15 @@ class Oracle:
         return dict(valid=bool(valid.value), M=M, h_x=hx[:M].copy(), h=hv[:M].copy(), R=Rv[:M].copy(),
                     weight=w.value)
 
+    def last_minmax(self):
+        out = np.zeros(4, np.float64)
+        lib().orc_last_minmax(self.h, _p(out, C.c_double))
+        return out
+
+    def set_override(self, mm4=None, skip_loc_weight=False):
+        mm = _f64(mm4) if mm4 is not None else None
+        lib().orc_set_override(self.h, _p(mm, C.c_double) if mm is not None else None, int(bool(skip_loc_weight)))
+
     def scan_get(self):
         n = self.N
         out = dict(normal_y=np.zeros(n, np.float32), nearest=np.zeros((n, 5, 12), np.float32),

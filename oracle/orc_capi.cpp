@@ -152,6 +152,15 @@ int orc_h_share_model(void *hh, const double *state, int converge, int *valid, d
   return M;
 }
 
+// Multi-GPU test support: local extrema of the last pass; override with all-reduced values (null = off).
+void orc_last_minmax(void *hh, double *out4) { std::memcpy(out4, ((Handle *)hh)->sc.last_minmax, sizeof(double) * 4); }
+void orc_set_override(void *hh, const double *mm4, int skip_loc_weight) {
+  Scene &sc = ((Handle *)hh)->sc;
+  sc.use_override = mm4 != nullptr;
+  if (mm4) std::memcpy(sc.override_minmax, mm4, sizeof(double) * 4);
+  sc.skip_loc_weight = skip_loc_weight != 0;
+}
+
 // Side effects later code relies on. Any pointer may be null.
 void orc_scan_get(void *hh, float *normal_y, float *nearest12, int *nearest_cnt, unsigned char *selected,
                   float *res_last, float *world_xyz, float *normvec4) {

@@ -104,6 +104,12 @@ struct Scene {
   std::vector<Pose> temporal_comp;          // kf.temporal_comp, IMU_Processing.hpp:510-522
   int effct_feat_num = 0;
   double last_weight = 0;  // localization weight actually applied (laserMapping.cpp:749-756)
+  // Multi-GPU test support: the four scan-global extrema of :615-616,646-647 as this shard
+  // computed them, and an optional override holding the all-reduced values. Not part of the reference.
+  double last_minmax[4] = {0, 1000, 0, 9999};  // max_unit_cov, min_unit_cov, max_cov, min_cov (local)
+  bool use_override = false;
+  double override_minmax[4] = {0, 0, 0, 0};
+  bool skip_loc_weight = false;  // leave h_x / h un-weighted by the localization weight (it is global too)
   void set_scan(const std::vector<Pt> &body);
   // laserMapping.cpp:552-760
   void h_share_model(const State &s, DynShare &ekfom_data);

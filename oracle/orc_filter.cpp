@@ -122,6 +122,9 @@ void Scene::h_share_model(const State &s, DynShare &ekfom_data) {
       effct_feat_num++;
     }
   }
+  last_minmax[0] = max_unit_cov, last_minmax[1] = min_unit_cov;
+  last_minmax[2] = 0, last_minmax[3] = 9999;
+  if (use_override) max_unit_cov = override_minmax[0], min_unit_cov = override_minmax[1];
   if (effct_feat_num < 1) {  // :635-639
     ekfom_data.valid = false;
     return;
@@ -187,6 +190,8 @@ void Scene::h_share_model(const State &s, DynShare &ekfom_data) {
     ekfom_data.h[i] = (-1) * norm_p.intensity;  // :707
   }
 
+  last_minmax[2] = max_cov, last_minmax[3] = min_cov;
+  if (use_override) max_cov = override_minmax[2], min_cov = override_minmax[3];
   for (int i = 0; i < effct_feat_num; i++) {  // :711-722 (FIC)
     for (int j = 0; j < C; j++) ekfom_data.h_x(i, j) = ekfom_data.h_x(i, j) * cov_plane[i];
     ekfom_data.h[i] = ekfom_data.h[i] * cov_plane[i];
@@ -234,6 +239,7 @@ void Scene::h_share_model(const State &s, DynShare &ekfom_data) {
                  (prm.localize_thresh_max - prm.localize_thresh_min) +
              prm.localize_cov_min;
   last_weight = weight;
+  if (skip_loc_weight) return;
   for (auto &v : ekfom_data.h_x.a) v *= weight;  // :758
   for (auto &v : ekfom_data.h) v *= weight;      // :759
 }

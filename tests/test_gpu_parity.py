@@ -197,3 +197,49 @@ def test_full_size_configs(capi, orc, scenes, cfg):
     got = scenes.unpack_state(u["state"], sc["L"])
     if cfg != 5:
         assert np.linalg.norm(got["pos"] - gt["pos"]) < 0.02
+
+
+def test_staged_path_equals_fused_call(capi, scenes):
+    """malio_measure_stage1/stage2 + dist.assemble (the multi-GPU path, world size 1) == malio_measure."""
+    import torch
+    from malio_amd import dist as mdist
+    sc = scenes.make_scene(seed=221, N=3000, Nmap=40000, L=3)
+    eng = capi.Engine(sc["params"], device=0)
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ref = eng.measure(sc["state0"], True)
+    be = mdist.HipBackend(eng)
+    out = mdist.sharded_measure(be, sc["state0"], True)
+    torch.cuda.synchronize()
+    assert out["M"] == ref["M"] and out["w_loc"] == pytest.approx(ref["w_loc"], rel=1e-12)
+    assert np.allclose(out["HtRinvH"], ref["HtRinvH"], rtol=1e-12, atol=1e-12 * np.abs(ref["HtRinvH"]).max())
+    assert np.allclose(out["HtRinvh"], ref["HtRinvh"], rtol=1e-12, atol=1e-12 * np.abs(ref["HtRinvh"]).max())
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    u = mdist.sharded_update_iterated(be, sc["state0"], sc["P0"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    eng.set_stream(0)
+    v = eng.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    assert np.abs(u["state"] - v["state"]).max() < 1e-10
+
+
+def test_bench_contract_single_rank_rccl():
+    """bench.py under torch.distributed.run with one rank: the RCCL code path and the JSON contract."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5",
+           "--warmup", "2", "--config", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    js = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in js
+    assert js["n_gpus"] == 1 and js["steps"] == 5 and js["value"] > 0 and js["scaling"] == "weak"
+    assert js["roofline"]["bound"] == "hbm" and 0 < js["roofline"]["frac"] < 1
