@@ -124,8 +124,10 @@ int malio_create(const malio_params_t *params, int device, malio_handle_t *out);
 int malio_destroy(malio_handle_t h);
 const char *malio_version(void);
 const char *malio_last_error(malio_handle_t h);
-/* Use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own one. */
-int malio_set_stream(malio_handle_t h, void *hip_stream);
+/* external != 0: run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream; the value 0 /
+ * NULL then means the legacy default stream, which is what PyTorch uses unless told otherwise).
+ * external == 0: go back to the handle's own non-blocking stream. */
+int malio_set_stream(malio_handle_t h, void *hip_stream, int external);
 
 /* ---- map: KD_TREE<PointType> call sites ------------------------------------------------------ */
 /* ikdtree.Build(feats_down_world->points)            laserMapping.cpp:1007 / ikd_Tree.cpp:369-397 */

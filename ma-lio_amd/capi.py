@@ -153,8 +153,9 @@ class Engine:
         except Exception:
             pass
 
-    def set_stream(self, stream_ptr):
-        self._chk(lib().malio_set_stream(self.h, C.c_void_p(stream_ptr)), "malio_set_stream")
+    def set_stream(self, stream_ptr, external=True):
+        """external=True: run on the caller's stream (0 = legacy default stream, PyTorch's default)."""
+        self._chk(lib().malio_set_stream(self.h, C.c_void_p(stream_ptr), int(bool(external))), "malio_set_stream")
 
     def set_profiling(self, on=True):
         self._chk(lib().malio_set_profiling(self.h, int(on)), "malio_set_profiling")

@@ -128,9 +128,10 @@ int malio_destroy(malio_handle_t h) {
   return MALIO_OK;
 }
 
-int malio_set_stream(malio_handle_t h, void *hip_stream) {
+int malio_set_stream(malio_handle_t h, void *hip_stream, int external) {
   if (check(h)) return MALIO_ERR_BAD_ARG;
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  (void)hipStreamSynchronize(h->stream);
+  h->stream = external ? (hipStream_t)hip_stream : h->own_stream;
   return MALIO_OK;
 }
 

@@ -217,7 +217,7 @@ def test_staged_path_equals_fused_call(capi, scenes):
     eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     u = mdist.sharded_update_iterated(be, sc["state0"], sc["P0"])
     eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-    eng.set_stream(0)
+    eng.set_stream(0, external=False)
     v = eng.update_iterated(sc["state0"], sc["P0"])
     assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
     assert np.abs(u["state"] - v["state"]).max() < 1e-10
