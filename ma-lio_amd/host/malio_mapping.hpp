@@ -1,0 +1,168 @@
+// Header-only C++ mirror of the reference's interface for the hot path, on top of the C ABI (include/malio.h).
+// Same names, argument meaning and error behaviour as the reference so that laserMapping.cpp changes by a few
+// lines. It deliberately depends on neither Eigen nor PCL: the caller's own types are
+// layout-compatible (pcl::PointXYZINormal == malio_point_t, Pose == malio_pose_t up to Eigen's storage).
+//
+//   KD_TREE<PointType> ikdtree                    -> malio::KdTreeGpu            (laserMapping.cpp:95)
+//   h_share_model(state_ikfom&, dyn_share&)       -> malio::Mapping::h_share_model (laserMapping.cpp:552)
+//   kf.update_iterated_dyn_share_modified(R, t)   -> malio::Mapping::update_iterated_dyn_share_modified
+//                                                                             (esekfom.hpp:495)
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/malio.h"
+
+namespace malio {
+
+using PointType = malio_point_t;            // common_lib.h:31
+using PointVector = std::vector<PointType>;  // common_lib.h:33
+using BoxPointType = malio_box_t;           // ikd_Tree.h:25-29
+using Pose = malio_pose_t;                  // common_lib.h:57-63
+
+// esekfom::dyn_share_datastruct<double> (esekfom.hpp:80-90) without Eigen: row-major h_x (M x C).
+struct dyn_share_datastruct {
+  bool valid = true;
+  bool converge = true;
+  int rows = 0, cols = 0;
+  std::vector<double> h_x, h, R;
+  // fused form (fast path): what esekfom.hpp:621-635 computes from h_x / h / R
+  std::vector<double> HtRinvH, HtRinvh;
+  double w_loc = 0;
+};
+
+class Handle {
+ public:
+  Handle(const malio_params_t &prm, int device = 0) : prm_(prm) {
+    int rc = malio_create(&prm, device, &h_);
+    if (rc != MALIO_OK) throw std::runtime_error("malio_create failed (" + std::to_string(rc) + "): no gfx950 device?");
+  }
+  ~Handle() {
+    if (h_) malio_destroy(h_);
+  }
+  Handle(const Handle &) = delete;
+  Handle &operator=(const Handle &) = delete;
+  malio_handle_t get() const { return h_; }
+  const malio_params_t &params() const { return prm_; }
+  void check(int rc, const char *what) const {
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + malio_last_error(h_));
+  }
+
+ private:
+  malio_handle_t h_ = nullptr;
+  malio_params_t prm_;
+};
+
+// The ikd-Tree call sites of laserMapping.cpp, same member names (ikd_Tree.h:308-340).
+class KdTreeGpu {
+ public:
+  explicit KdTreeGpu(Handle &h) : h_(h) {}
+  void set_downsample_param(float) {}                                  // laserMapping.cpp:999 (kept in params)
+  void Build(const PointVector &pts) {                                 // :1007
+    h_.check(malio_map_build(h_.get(), pts.data(), (int)pts.size()), "Build");
+    built_ = true;
+  }
+  bool empty() const { return !built_; }                               // `Root_Node == nullptr` test, :995
+  int size() const {                                                   // :824
+    int n = 0;
+    malio_map_size(h_.get(), &n);
+    return n;
+  }
+  // Batched form of Nearest_Search (:586): all queries of a scan in one call.
+  void Nearest_Search(const PointVector &queries, int k, std::vector<PointVector> &Nearest_Points,
+                      std::vector<std::vector<float>> &Point_Distance) const {
+    const int n = (int)queries.size();
+    std::vector<PointType> out((size_t)n * k);
+    std::vector<float> d2((size_t)n * k);
+    std::vector<int> cnt(n);
+    h_.check(malio_nearest_search(h_.get(), queries.data(), n, k, out.data(), d2.data(), cnt.data()), "Nearest_Search");
+    Nearest_Points.assign(n, PointVector());
+    Point_Distance.assign(n, std::vector<float>());
+    for (int i = 0; i < n; i++) {
+      Nearest_Points[i].assign(out.begin() + (size_t)i * k, out.begin() + (size_t)i * k + cnt[i]);
+      Point_Distance[i].assign(d2.begin() + (size_t)i * k, d2.begin() + (size_t)i * k + cnt[i]);
+    }
+  }
+  int Add_Points(PointVector &PointToAdd, bool downsample_on) {         // :443-444
+    int added = 0;
+    h_.check(malio_map_add(h_.get(), PointToAdd.data(), (int)PointToAdd.size(), downsample_on ? 1 : 0, &added), "Add_Points");
+    return added;
+  }
+  int Delete_Point_Boxes(std::vector<BoxPointType> &BoxPoints) {        // :223
+    int del = 0;
+    h_.check(malio_map_delete_boxes(h_.get(), BoxPoints.data(), (int)BoxPoints.size(), &del), "Delete_Point_Boxes");
+    return del;
+  }
+
+ private:
+  Handle &h_;
+  bool built_ = false;
+};
+
+// The per-scan globals + the two calls on the hot path.
+class Mapping {
+ public:
+  explicit Mapping(Handle &h) : h_(h) {}
+  // feats_down_body (laserMapping.cpp:86,982), pose_unc (:1028-1048), kf.temporal_comp (IMU_Processing.hpp:510-522)
+  void set_scan(const PointVector &feats_down_body, const std::vector<std::vector<Pose>> &pose_unc,
+                const std::vector<Pose> &temporal_comp) {
+    const int L = h_.params().lid_num;
+    std::vector<const Pose *> ptr(L);
+    std::vector<int> len(L);
+    for (int l = 0; l < L; l++) ptr[l] = pose_unc[l].data(), len[l] = (int)pose_unc[l].size();
+    feats_down_size_ = (int)feats_down_body.size();
+    h_.check(malio_scan_set(h_.get(), feats_down_body.data(), feats_down_size_, ptr.data(), len.data(),
+                            L > 1 ? temporal_comp.data() : nullptr), "set_scan");
+  }
+  // void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> &ekfom_data), laserMapping.cpp:552.
+  // want_rows = true reproduces h_x / h / R exactly as the reference fills them (:642-644); false hands the
+  // filter the reduced normal equations instead.
+  void h_share_model(const malio_state_t &s, dyn_share_datastruct &ekfom_data, bool want_rows = false) {
+    const int C = 6 * (1 + h_.params().lid_num);
+    malio_measure_out_t out;
+    std::memset(&out, 0, sizeof(out));
+    if (want_rows) {
+      ekfom_data.h_x.assign((size_t)feats_down_size_ * C, 0.0);
+      ekfom_data.h.assign(feats_down_size_, 0.0);
+      ekfom_data.R.assign(feats_down_size_, 0.0);
+      out.h_x = ekfom_data.h_x.data(), out.h = ekfom_data.h.data(), out.R = ekfom_data.R.data();
+    }
+    int rc = malio_measure(h_.get(), &s, ekfom_data.converge ? 1 : 0, &out);
+    h_.check(rc, "h_share_model");
+    if (!out.valid) {  // laserMapping.cpp:635-639: ekfom_data.valid = false; ROS_WARN("No Effective Points!")
+      ekfom_data.valid = false;
+      return;
+    }
+    ekfom_data.rows = out.M, ekfom_data.cols = C, ekfom_data.w_loc = out.w_loc;
+    ekfom_data.HtRinvH.assign(out.HtRinvH, out.HtRinvH + C * C);
+    ekfom_data.HtRinvh.assign(out.HtRinvh, out.HtRinvh + C);
+    if (want_rows) {
+      ekfom_data.h_x.resize((size_t)out.M * C);
+      ekfom_data.h.resize(out.M);
+      ekfom_data.R.resize(out.M);
+    }
+  }
+  // kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time), laserMapping.cpp:1052.
+  // P: n x n row-major, n = 17 + 6 lid_num.
+  void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {
+    h_.check(malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
+  }
+  // side effects map_incremental reads (laserMapping.cpp:406,411-435)
+  void get_side_effects(std::vector<float> &normal_y, std::vector<PointType> &Nearest_Points_flat,
+                        std::vector<int> &nearest_count, std::vector<uint8_t> &point_selected_surf) {
+    normal_y.resize(feats_down_size_);
+    Nearest_Points_flat.resize((size_t)feats_down_size_ * 5);
+    nearest_count.resize(feats_down_size_);
+    point_selected_surf.resize(feats_down_size_);
+    h_.check(malio_scan_get(h_.get(), normal_y.data(), Nearest_Points_flat.data(), nearest_count.data(),
+                            point_selected_surf.data(), nullptr, nullptr, nullptr), "scan_get");
+  }
+
+ private:
+  Handle &h_;
+  int feats_down_size_ = 0;
+};
+
+}  // namespace malio
