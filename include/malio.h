@@ -211,6 +211,9 @@ int malio_last_kernel_times(malio_handle_t h, const char **names, float *ms, int
 /* Enable/disable per-kernel event timing (off by default: events add launch latency). */
 int malio_set_profiling(malio_handle_t h, int on);
 
+/* Diagnostics: out3 = {reserved, reserved, occupied map cells}. */
+int malio_debug_counters(malio_handle_t h, int *out3);
+
 #ifdef __cplusplus
 }
 #endif

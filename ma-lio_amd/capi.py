@@ -21,7 +21,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step",
+    "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters",
 ]
 
 
@@ -166,6 +166,11 @@ class Engine:
         n = C.c_int(0)
         lib().malio_last_kernel_times(self.h, names, ms, 16, C.byref(n))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def debug_counters(self):
+        out = (C.c_int * 3)()
+        lib().malio_debug_counters(self.h, out)
+        return dict(items=out[0], fallback=out[1], map_cells=out[2])
 
     def map_build(self, pts12):
         pts12 = np.ascontiguousarray(pts12, np.float32)

@@ -457,6 +457,14 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
   return ieskf_update(h, x, P, R, stats, solve_time);
 }
 
+// Diagnostics (not part of the reference interface): out[2] = occupied map cells (out[0], out[1] reserved).
+int malio_debug_counters(malio_handle_t h, int *out3) {
+  if (check(h) || !out3) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  out3[0] = 0, out3[1] = 0, out3[2] = (int)c->map.ncells;
+  return MALIO_OK;
+}
+
 int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state_t *x, const malio_state_t *x_propagated,
                      const double *P_propagated, const double *HtRinvH, const double *HtRinvh, int *t_io,
                      int *converge_out, int *done_out, double *P_out) {

@@ -27,6 +27,11 @@ struct alignas(16) Cell {
 struct CellGrid {
   Cell *table = nullptr;  // [tsize]
   u32 tmask = 0;          // tsize - 1
+  // Occupancy filter: one 64-byte line (8 u64 = 8 z-layers of 8x8 xy bits) per hashed 8x8x8-cell brick.
+  // A clear bit proves the cell is empty (no table probe); colliding bricks only add false positives.
+  u64 *occ = nullptr;     // [(omask + 1) * 8]
+  u32 omask = 0;
+  size_t cap_occ = 0;
   u32 ncells = 0;
   float4 *pts = nullptr;  // [n] sorted by cell: x, y, z, bits(original index)
   u32 *orig = nullptr;    // [n] original index of each sorted point

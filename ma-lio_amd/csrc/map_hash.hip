@@ -13,13 +13,13 @@ __device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
   return ((u64)(ix + (long long)B) & 0x1FFFFF) | (((u64)(iy + (long long)B) & 0x1FFFFF) << 21) |
          (((u64)(iz + (long long)B) & 0x1FFFFF) << 42);
 }
-__device__ __forceinline__ u32 hash_key(u64 k) {  // murmur3 fmix64
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ull;
-  k ^= k >> 33;
-  return (u32)k;
+__device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (7 VALU ops); == hash_key_d()
+  u32 lo = (u32)k, hi = (u32)(k >> 32);
+  u32 h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 13;
+  return h;
 }
 
 // Pass 1: insert every point's cell key into a big scratch table, take a rank inside the cell.
@@ -136,6 +136,26 @@ __global__ void __launch_bounds__(BLK) k_gbc_compact(const u64 *__restrict__ key
   table[d].count = cnt[s];
 }
 
+__device__ __forceinline__ u32 brick_hash(int bx, int by, int bz) {  // == brick_hash_d() in measure.hip
+  u32 h = (u32)bx * 0x9E3779B1u ^ (u32)by * 0x85EBCA77u ^ (u32)bz * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x27D4EB2Fu;
+  h ^= h >> 13;
+  return h;
+}
+__global__ void __launch_bounds__(BLK) k_gbc_occ(const Cell *__restrict__ table, u32 tsize, u64 *occ, u32 omask) {
+  u32 s = blockIdx.x * BLK + threadIdx.x;
+  if (s >= tsize) return;
+  Cell c = table[s];
+  if (c.key == EMPTY_KEY || c.count == 0) return;
+  const long long B = 1ll << 20;
+  int ix = (int)((long long)(c.key & 0x1FFFFF) - B);
+  int iy = (int)((long long)((c.key >> 21) & 0x1FFFFF) - B);
+  int iz = (int)((long long)((c.key >> 42) & 0x1FFFFF) - B);
+  u32 line = brick_hash(ix >> 3, iy >> 3, iz >> 3) & omask;
+  atomicOr(&occ[(size_t)line * 8 + (iz & 7)], 1ull << ((ix & 7) + 8 * (iy & 7)));
+}
+
 __global__ void __launch_bounds__(BLK) k_fill_u64(u64 *p, u64 v, size_t n) {
   size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
   if (i < n) p[i] = v;
@@ -157,6 +177,7 @@ static u32 next_pow2(u32 v) {
 
 void free_grid(CellGrid &g) {
   if (g.table) (void)hipFree(g.table);
+  if (g.occ) (void)hipFree(g.occ);
   if (g.pts) (void)hipFree(g.pts);
   if (g.orig) (void)hipFree(g.orig);
   g = CellGrid();
@@ -216,6 +237,18 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize);
   hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
                      g.table, tsize - 1);
+  // occupancy filter: >= 8 lines per occupied brick-equivalent keeps false positives rare; 2 MB at 1M points
+  u32 olines = next_pow2(std::max(1024u, h_ncells / 4));
+  if ((size_t)olines * 8 > g.cap_occ) {
+    if (g.occ) (void)hipFree(g.occ);
+    g.occ = nullptr;
+    g.cap_occ = (size_t)olines * 8;
+    MALIO_HIP(hipMalloc(&g.occ, sizeof(u64) * g.cap_occ));
+  }
+  MALIO_HIP(hipMemsetAsync(g.occ, 0, sizeof(u64) * (size_t)olines * 8, c->stream));
+  hipLaunchKernelGGL(k_gbc_occ, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize, g.occ,
+                     olines - 1);
+  g.omask = olines - 1;
   MALIO_HIP(hipStreamSynchronize(c->stream));
   g.tmask = tsize - 1;
   g.ncells = h_ncells;

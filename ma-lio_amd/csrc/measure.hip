@@ -6,10 +6,12 @@
 // Compiled with -ffp-contract=off: the float stages (distances, QR plane fit, gates) and the double
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
+#include <cstdlib>
 #include "malio_internal.hpp"
 
 namespace malio {
 
+__constant__ int g_dbg = 0;  // timing-experiment bits (MALIO_DBG); 0 in production
 constexpr int NSUM = 97;  // 78 (12x12 upper) + 12 (rhs) + 6 (c^2 n n^T) + 1 (count)
 constexpr u32 INVALID = 0xFFFFFFFFu;
 
@@ -60,6 +62,8 @@ struct Pass1Args {
   const float4 *map_pts;  // sorted by cell: x y z bits(original index)
   const Cell *table;
   u32 tmask;
+  const u64 *occ;  // occupancy filter (CellGrid::occ)
+  u32 omask;
   float cell, inv_cell;
   // tables
   const UncEntry *unc;
@@ -110,13 +114,13 @@ __device__ __forceinline__ u64 cell_key_d(int ix, int iy, int iz) {
   const long long B = 1ll << 20;
   return ((u64)(ix + B) & 0x1FFFFF) | (((u64)(iy + B) & 0x1FFFFF) << 21) | (((u64)(iz + B) & 0x1FFFFF) << 42);
 }
-__device__ __forceinline__ u32 hash_key_d(u64 k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ull;
-  k ^= k >> 33;
-  return (u32)k;
+__device__ __forceinline__ u32 hash_key_d(u64 k) {  // must equal hash_key() in map_hash.hip
+  u32 lo = (u32)k, hi = (u32)(k >> 32);
+  u32 h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 13;
+  return h;
 }
 
 // Sorted (ascending) 5-slot candidate list with the total order (d2, original map index).
@@ -138,6 +142,20 @@ __device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 og) {
     t.og[k] = sw ? ik1 : ik;
     t.og[k - 1] = sw ? ik : ik1;
   }
+}
+
+__device__ __forceinline__ u32 brick_hash_d(int bx, int by, int bz) {  // == brick_hash() in map_hash.hip
+  u32 h = (u32)bx * 0x9E3779B1u ^ (u32)by * 0x85EBCA77u ^ (u32)bz * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x27D4EB2Fu;
+  h ^= h >> 13;
+  return h;
+}
+// address of the occupancy word of cell (ix,iy,iz) and its bit
+__device__ __forceinline__ const u64 *occ_word(const u64 *__restrict__ occ, u32 omask, int ix, int iy, int iz, u64 &bit) {
+  u32 line = brick_hash_d(ix >> 3, iy >> 3, iz >> 3) & omask;
+  bit = 1ull << ((ix & 7) + 8 * (iy & 7));
+  return occ + (size_t)line * 8 + (iz & 7);
 }
 
 // One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
@@ -209,8 +227,8 @@ __device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
 // `pointSearchSqDis[4] > 5`); map_pts[j] = (x, y, z, bits(original index)).
 template <int G>
 __device__ __forceinline__ void knn5_group(float wx, float wy, float wz, int sub, const float4 *__restrict__ map_pts,
-                                           const Cell *__restrict__ table, u32 tmask, float cell, float inv_cell,
-                                           float limit2, Top5 &t) {
+                                           const Cell *__restrict__ table, u32 tmask, const u64 *__restrict__ occ,
+                                           u32 omask, float cell, float inv_cell, float limit2, Top5 &t) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
   for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.og[k] = INVALID;
@@ -224,30 +242,65 @@ __device__ __forceinline__ void knn5_group(float wx, float wy, float wz, int sub
   float lo_y = fmaxf(fy * cell - margin, 0.f), hi_y = fmaxf((1.f - fy) * cell - margin, 0.f);
   float lo_z = fmaxf(fz * cell - margin, 0.f), hi_z = fmaxf((1.f - fz) * cell - margin, 0.f);
 
-  // ---- ring 1: 27 cells, ceil(27/G) per lane, probes issued together ----
+  // ---- ring 1: 27 cells, ceil(27/G) per lane; probes issued together, then the first 4 points of the next
+  //      cell are in flight while the current cell's are processed ----
   constexpr int CPL = (27 + G - 1) / G;
   {
-    u64 key[CPL];
-    u32 slot[CPL];
-    Cell rec[CPL];
+    // occupancy filter first (2 MB, L2-resident): most of the 27 cells are air and never reach the table
+    u64 ow[CPL], ob[CPL];
+    int cx[CPL], cy[CPL], cz[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       int o = sub + k * G;
       int oo = o < 27 ? o : 0;
-      key[k] = cell_key_d(kx + c_off[oo][0], ky + c_off[oo][1], kz + c_off[oo][2]);
-      slot[k] = hash_key_d(key[k]) & tmask;
-      rec[k] = table[slot[k]];
+      cx[k] = kx + c_off[oo][0], cy[k] = ky + c_off[oo][1], cz[k] = kz + c_off[oo][2];
+      ow[k] = *occ_word(occ, omask, cx[k], cy[k], cz[k], ob[k]);
     }
+    u64 key[CPL];
+    u32 slot[CPL];
+    Cell rec[CPL];
+    bool occd[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-      if (sub + k * G < 27) {
-        u32 start, count;
-        cell_lookup(table, tmask, key[k], rec[k], slot[k], start, count);
-        scan_cell(map_pts, start, count, wx, wy, wz, limit2, t);
+      occd[k] = (sub + k * G < 27) && (ow[k] & ob[k]) != 0;
+      key[k] = cell_key_d(cx[k], cy[k], cz[k]);
+      slot[k] = hash_key_d(key[k]) & tmask;
+      if (occd[k]) rec[k] = table[slot[k]];
+    }
+    u32 cs[CPL], cc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      cs[k] = 0, cc[k] = 0;
+      if (occd[k]) cell_lookup(table, tmask, key[k], rec[k], slot[k], cs[k], cc[k]);
+    }
+    if (g_dbg & 1) {
+#pragma unroll
+      for (int k = 0; k < CPL; k++) cc[k] = 0, cs[k] = 0;  // experiment: no point scanning
+    }
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) cur[u] = map_pts[cs[0] + min((u32)u, cc[0] > 0 ? cc[0] - 1 : 0u)];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      if (k + 1 < CPL) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) nxt[u] = map_pts[cs[k + 1] + min((u32)u, cc[k + 1] > 0 ? cc[k + 1] - 1 : 0u)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float ddx = wx - cur[u].x, ddy = wy - cur[u].y, ddz = wz - cur[u].z;
+        float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+        if ((u32)u < cc[k] && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(cur[u].w));
+      }
+      if (cc[k] > 4) scan_cell(map_pts, cs[k] + 4, cc[k] - 4, wx, wy, wz, limit2, t);
+      if (k + 1 < CPL) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) cur[u] = nxt[u];
       }
     }
   }
-  merge_group<G>(t, sentinel);
+  if (!(g_dbg & 2)) merge_group<G>(t, sentinel);
+  if (g_dbg & 4) return;
   // radius ring 1 guarantees: one cell edge plus the distance to the nearest face of the own cell
   float g1 = cell + fminf(fminf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
   bool done = (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
@@ -269,6 +322,8 @@ __device__ __forceinline__ void knn5_group(float wx, float wy, float wz, int sub
     float az = dz == 0 ? 0.f : (dz < 0 ? lo_z + (float)(-dz - 1) * cell : hi_z + (float)(dz - 1) * cell);
     float bd2 = (ax * ax + ay * ay + az * az) * 0.99999f;
     if (bd2 > bound) continue;
+    u64 obit;
+    if (!(*occ_word(occ, omask, kx + dx, ky + dy, kz + dz, obit) & obit)) continue;
     u64 key = cell_key_d(kx + dx, ky + dy, kz + dz);
     u32 slot = hash_key_d(key) & tmask;
     u32 start, count;
@@ -539,7 +594,7 @@ __global__ void __launch_bounds__(BLK) k_knn(Pass1Args a) {
   const bool active = qi < a.N;
   const float4 w = a.world4[active ? qi : a.N - 1];
   Top5 t;
-  knn5_group<G>(w.x, w.y, w.z, sub, a.map_pts, a.table, a.tmask, a.cell, a.inv_cell, 5.0f, t);
+  knn5_group<G>(w.x, w.y, w.z, sub, a.map_pts, a.table, a.tmask, a.occ, a.omask, a.cell, a.inv_cell, 5.0f, t);
   if (!active) return;
   if (sub < 5) {
     u32 v = sub == 0 ? t.og[0] : sub == 1 ? t.og[1] : sub == 2 ? t.og[2] : sub == 3 ? t.og[3] : t.og[4];
@@ -848,19 +903,19 @@ __global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict_
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
-constexpr int KNN_G = 8;  // lanes per query (measured 4/8/16)
+constexpr int KNN_G = 16;  // lanes per query (measured 8 / 16)
 
 __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, int n, int k,
                                                  const float4 *__restrict__ map_pts, const Cell *__restrict__ table,
-                                                 u32 tmask, float cell, float inv_cell, u32 *out_idx, float *out_d2,
-                                                 int *out_cnt) {
+                                                 u32 tmask, const u64 *__restrict__ occ, u32 omask, float cell,
+                                                 float inv_cell, u32 *out_idx, float *out_d2, int *out_cnt) {
   const int tid = blockIdx.x * BLK + threadIdx.x;
   const int qi = tid / KNN_G, sub = tid % KNN_G;
   const bool active = qi < n;
   float4 p = q[active ? qi : n - 1];
   Top5 t;
   // radius limit = a hair under two cell edges (>= sqrt 5): everything inside it is in the 5x5x5 block
-  knn5_group<KNN_G>(p.x, p.y, p.z, sub, map_pts, table, tmask, cell, inv_cell, 4.f * cell * cell * 0.999f, t);
+  knn5_group<KNN_G>(p.x, p.y, p.z, sub, map_pts, table, tmask, occ, omask, cell, inv_cell, 4.f * cell * cell * 0.999f, t);
   if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {
@@ -877,7 +932,7 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
   long long threads = (long long)n * KNN_G;
   hipLaunchKernelGGL(k_nearest, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_q, n, k,
-                     c->map.pts, c->map.table, c->map.tmask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
+                     c->map.pts, c->map.table, c->map.tmask, c->map.occ, c->map.omask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -1031,6 +1086,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   a.N = c->N;
   a.scan = c->d_scan;
   a.map_pts = c->map.pts, a.table = c->map.table, a.tmask = c->map.tmask, a.map_in = c->d_map_in;
+  a.occ = c->map.occ, a.omask = c->map.omask;
   a.cell = c->cell, a.inv_cell = c->inv_cell;
   a.unc = c->d_unc;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
@@ -1044,8 +1100,22 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   if (converge) {
     hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_transform");
-    long long threads = (long long)c->N * KNN_G;
-    hipLaunchKernelGGL(k_knn<KNN_G>, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, a);
+    static const int dbg_sel = getenv("MALIO_DBG") ? atoi(getenv("MALIO_DBG")) : 0;
+    static bool dbg_set = false;
+    if (!dbg_set) {
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg_sel, sizeof(int));
+      dbg_set = true;
+    }
+    static const int g_sel = getenv("MALIO_KNN_G") ? atoi(getenv("MALIO_KNN_G")) : KNN_G;  // tuning experiments
+    const int G = (g_sel == 8 || g_sel == 32) ? g_sel : 16;
+    long long threads = (long long)c->N * G;
+    dim3 kgrid((unsigned)((threads + BLK - 1) / BLK));
+    if (G == 32)
+      hipLaunchKernelGGL(k_knn<32>, kgrid, dim3(BLK), 0, c->stream, a);
+    else if (G == 16)
+      hipLaunchKernelGGL(k_knn<16>, kgrid, dim3(BLK), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(k_knn<8>, kgrid, dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_knn");
     hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_plane");

@@ -44,6 +44,7 @@ def run(N, Nmap, L, seed=7, kind="city", map_unc=False):
     print("update: passes", u["passes"], v["passes"], "searches", u["searches"], v["searches"], "M", u["M"], v["M"])
     print("state max|d|", np.abs(u["state"] - v["state"]).max(), "P max|d|", np.abs(u["P"] - v["P"]).max(), "gpu %.4fs oracle %.3fs" % (tg, to))
     # timing of passes
+    print("counters", eng.debug_counters())
     eng.set_profiling(True)
     for k in range(3):
         eng.measure(sc["state0"], True)
