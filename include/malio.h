@@ -83,7 +83,7 @@ typedef struct malio_params {
   double localize_cov_max, localize_cov_min;
   double localize_thresh_max, localize_thresh_min;
   double filter_size_map; /* filter_size_map_min: ikdtree.set_downsample_param, laserMapping.cpp:999 */
-  float cell_size;        /* spatial-hash cell edge [m]; 0 = default (1.125 m >= sqrt(5)/2) */
+  float cell_size;        /* level-1 neighbour-list cell edge [m]; 0 = default 1.125 (>= sqrt(5)/2; level 2 uses twice this) */
   int32_t reserved[3];
 } malio_params_t;
 
@@ -211,7 +211,7 @@ int malio_last_kernel_times(malio_handle_t h, const char **names, float *ms, int
 /* Enable/disable per-kernel event timing (off by default: events add launch latency). */
 int malio_set_profiling(malio_handle_t h, int on);
 
-/* Diagnostics: out3 = {reserved, reserved, occupied map cells}. */
+/* Diagnostics: out3 = {level-1 directory cells, map points, level-2 directory cells}. */
 int malio_debug_counters(malio_handle_t h, int *out3);
 
 #ifdef __cplusplus

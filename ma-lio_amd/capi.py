@@ -170,7 +170,7 @@ class Engine:
     def debug_counters(self):
         out = (C.c_int * 3)()
         lib().malio_debug_counters(self.h, out)
-        return dict(items=out[0], fallback=out[1], map_cells=out[2])
+        return dict(nl1_cells=out[0], map_points=out[1], nl2_cells=out[2])
 
     def map_build(self, pts12):
         pts12 = np.ascontiguousarray(pts12, np.float32)

@@ -96,7 +96,7 @@ int malio_create(const malio_params_t *params, int device, malio_handle_t *out) 
   c->prm = *params;
   c->device = device;
   c->cell = params->cell_size > 0.f ? params->cell_size : 1.125f;
-  if (c->cell < 1.1180341f) c->cell = 1.1180341f;  // two cell edges must cover the sqrt(5) m acceptance radius
+  if (c->cell < 1.1180341f) c->cell = 1.1180341f;  // level 2 (2 * cell) must cover the sqrt(5) m acceptance radius
   c->inv_cell = 1.0f / c->cell;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -115,7 +115,8 @@ int malio_destroy(malio_handle_t h) {
   auto fr = [](void *p) {
     if (p) (void)hipFree(p);
   };
-  free_grid(c->map);
+  free_nlist(c->nl1);
+  free_nlist(c->nl2);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm), fr(c->d_ny);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
@@ -167,7 +168,8 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
     MALIO_HIP(hipMalloc(&c->d_map_in, sizeof(float4) * c->cap_map_in));
   }
   MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  int rc = group_by_cell(c, c->d_map_in, n, c->inv_cell, c->map);
+  int rc = build_nlist(c, c->d_map_in, n, c->cell, c->nl1);
+  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, n, 2.0f * std::max(c->cell, 1.1180341f), c->nl2);
   (void)hipStreamSynchronize(c->stream);
   (void)hipHostFree(stage);
   if (rc != MALIO_OK) return rc;
@@ -185,7 +187,7 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
                          float *out_d2, int *out_count) {
   if (check(h) || !queries || n <= 0 || k < 1 || k > 5) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
-  if (c->map.n <= 0) return MALIO_ERR_NO_MAP;
+  if (c->map_n <= 0) return MALIO_ERR_NO_MAP;
   MALIO_HIP(hipSetDevice(c->device));
   std::vector<float4> hq(n);
   for (int i = 0; i < n; i++) hq[i] = make_float4(queries[i].x, queries[i].y, queries[i].z, 0.f);
@@ -206,7 +208,7 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
   MALIO_HIP(hipMemcpyAsync(idx.data(), d_idx, sizeof(u32) * idx.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(d2.data(), d_d2, sizeof(float) * d2.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
-  std::vector<float4> mp(c->map.n);  // original order
+  std::vector<float4> mp(c->map_n);  // original order
   MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) {
@@ -457,11 +459,11 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
   return ieskf_update(h, x, P, R, stats, solve_time);
 }
 
-// Diagnostics (not part of the reference interface): out[2] = occupied map cells (out[0], out[1] reserved).
+// Diagnostics (not part of the reference interface): {level-1 directory cells, map points, level-2 directory cells}.
 int malio_debug_counters(malio_handle_t h, int *out3) {
   if (check(h) || !out3) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
-  out3[0] = 0, out3[1] = 0, out3[2] = (int)c->map.ncells;
+  out3[0] = (int)c->nl1.ncells, out3[1] = (int)(c->nl1.total / 27), out3[2] = (int)c->nl2.ncells;
   return MALIO_OK;
 }
 

@@ -27,16 +27,25 @@ struct alignas(16) Cell {
 struct CellGrid {
   Cell *table = nullptr;  // [tsize]
   u32 tmask = 0;          // tsize - 1
-  // Occupancy filter: one 64-byte line (8 u64 = 8 z-layers of 8x8 xy bits) per hashed 8x8x8-cell brick.
-  // A clear bit proves the cell is empty (no table probe); colliding bricks only add false positives.
-  u64 *occ = nullptr;     // [(omask + 1) * 8]
-  u32 omask = 0;
-  size_t cap_occ = 0;
   u32 ncells = 0;
   float4 *pts = nullptr;  // [n] sorted by cell: x, y, z, bits(original index)
   u32 *orig = nullptr;    // [n] original index of each sorted point
   int n = 0;
   size_t cap_pts = 0, cap_table = 0;
+};
+
+// Neighbour lists (fast path of the 5-NN): for every fine cell (edge cf = cell / 1.5) that has a map point in
+// its 3x3x3 block, the points of that block stored CONTIGUOUSLY (each map point is replicated 27 times -
+// 432 MB at 1M points: this is what the 288 GB of HBM are for). A query then needs ONE directory probe and one
+// streaming read of ~20 points instead of 27 probes and 9 scattered runs.
+struct NList {
+  Cell *table = nullptr;  // fine cell -> (start, count) of its neighbourhood list
+  u32 tmask = 0;
+  u32 ncells = 0;
+  float4 *pts = nullptr;  // [total] x, y, z, bits(original index)
+  size_t total = 0;
+  size_t cap_pts = 0, cap_table = 0;
+  float cf = 0.75f, inv_cf = 1.f / 0.75f;
 };
 
 // Per-LiDAR constants of one pass (all double; rotation matrices row-major).
@@ -73,7 +82,7 @@ struct Ctx {
   float cell = 1.125f, inv_cell = 1.f / 1.125f;
 
   // map
-  CellGrid map;
+  NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
   size_t cap_map_in = 0;
   int map_n = 0;
@@ -144,6 +153,8 @@ struct Ctx {
 // group `n` device points (float4, xyz used) by spatial-hash cell into `g` (allocates/grows g's buffers)
 int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig = nullptr);
 void free_grid(CellGrid &g);
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
+void free_nlist(NList &nl);
 
 // measure.hip
 int measure_alloc(Ctx *c);

@@ -1,5 +1,7 @@
-// GPU-resident spatial hash that replaces the ikd-Tree as the 5-NN search structure
-// (reference: KD_TREE<PointType>, include/ikd-Tree/ikd_Tree.{h,cpp}; Build :369-397).
+// GPU-resident map that replaces the ikd-Tree as the 5-NN search structure
+// (reference: KD_TREE<PointType>, include/ikd-Tree/ikd_Tree.{h,cpp}; Build :369-397): hashed cell directories
+// over NEIGHBOUR LISTS (every point replicated into the lists of the 27 cells whose 3x3x3 block contains it), at
+// two cell sizes; plus the counting-sort "group by cell" used to order the scan for locality.
 // Layout in HBM: points sorted by cell as float4 (x,y,z,bits(original index)) + the original-order
 // float4 (x,y,z,normal_y) array the plane fit gathers from + a compact open-addressing table
 // of 16-byte {key,start,count} entries. Cell edge c >= sqrt(5) m so the 27 cells around a query
@@ -136,26 +138,6 @@ __global__ void __launch_bounds__(BLK) k_gbc_compact(const u64 *__restrict__ key
   table[d].count = cnt[s];
 }
 
-__device__ __forceinline__ u32 brick_hash(int bx, int by, int bz) {  // == brick_hash_d() in measure.hip
-  u32 h = (u32)bx * 0x9E3779B1u ^ (u32)by * 0x85EBCA77u ^ (u32)bz * 0xC2B2AE3Du;
-  h ^= h >> 15;
-  h *= 0x27D4EB2Fu;
-  h ^= h >> 13;
-  return h;
-}
-__global__ void __launch_bounds__(BLK) k_gbc_occ(const Cell *__restrict__ table, u32 tsize, u64 *occ, u32 omask) {
-  u32 s = blockIdx.x * BLK + threadIdx.x;
-  if (s >= tsize) return;
-  Cell c = table[s];
-  if (c.key == EMPTY_KEY || c.count == 0) return;
-  const long long B = 1ll << 20;
-  int ix = (int)((long long)(c.key & 0x1FFFFF) - B);
-  int iy = (int)((long long)((c.key >> 21) & 0x1FFFFF) - B);
-  int iz = (int)((long long)((c.key >> 42) & 0x1FFFFF) - B);
-  u32 line = brick_hash(ix >> 3, iy >> 3, iz >> 3) & omask;
-  atomicOr(&occ[(size_t)line * 8 + (iz & 7)], 1ull << ((ix & 7) + 8 * (iy & 7)));
-}
-
 __global__ void __launch_bounds__(BLK) k_fill_u64(u64 *p, u64 v, size_t n) {
   size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
   if (i < n) p[i] = v;
@@ -177,7 +159,6 @@ static u32 next_pow2(u32 v) {
 
 void free_grid(CellGrid &g) {
   if (g.table) (void)hipFree(g.table);
-  if (g.occ) (void)hipFree(g.occ);
   if (g.pts) (void)hipFree(g.pts);
   if (g.orig) (void)hipFree(g.orig);
   g = CellGrid();
@@ -237,18 +218,6 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize);
   hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
                      g.table, tsize - 1);
-  // occupancy filter: >= 8 lines per occupied brick-equivalent keeps false positives rare; 2 MB at 1M points
-  u32 olines = next_pow2(std::max(1024u, h_ncells / 4));
-  if ((size_t)olines * 8 > g.cap_occ) {
-    if (g.occ) (void)hipFree(g.occ);
-    g.occ = nullptr;
-    g.cap_occ = (size_t)olines * 8;
-    MALIO_HIP(hipMalloc(&g.occ, sizeof(u64) * g.cap_occ));
-  }
-  MALIO_HIP(hipMemsetAsync(g.occ, 0, sizeof(u64) * (size_t)olines * 8, c->stream));
-  hipLaunchKernelGGL(k_gbc_occ, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize, g.occ,
-                     olines - 1);
-  g.omask = olines - 1;
   MALIO_HIP(hipStreamSynchronize(c->stream));
   g.tmask = tsize - 1;
   g.ncells = h_ncells;
@@ -260,6 +229,116 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   (void)hipFree(rank_of);
   (void)hipFree(tiles);
   (void)hipFree(ncells);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+// ---- neighbour lists -----------------------------------------------------------------------------------------
+// pass A: every point bumps the counters of the 27 fine cells whose 3x3x3 block contains it
+__global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts, int n, float inv_cf, u64 *keys, u32 *cnt,
+                                                  u32 mask, u32 *ncells, u32 *overflow) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  int ix = (int)floorf(p.x * inv_cf), iy = (int)floorf(p.y * inv_cf), iz = (int)floorf(p.z * inv_cf);
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+        u32 s = hash_key(key) & mask;
+        int probes = 0;
+        while (true) {
+          u64 old = atomicCAS(&keys[s], EMPTY_KEY, key);
+          if (old == EMPTY_KEY) {
+            atomicAdd(ncells, 1u);
+            break;
+          }
+          if (old == key) break;
+          s = (s + 1) & mask;
+          if (++probes > 4096) {
+            atomicAdd(overflow, 1u);
+            return;
+          }
+        }
+        atomicAdd(&cnt[s], 1u);
+      }
+}
+// pass B: place every point into the 27 lists (cursor = running fill count of the list)
+__global__ void __launch_bounds__(BLK) k_nl_fill(const float4 *__restrict__ pts, int n, float inv_cf,
+                                                 const u64 *__restrict__ keys, const u32 *__restrict__ start, u32 *cursor,
+                                                 u32 mask, float4 *out) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  float4 rec = make_float4(p.x, p.y, p.z, __uint_as_float((u32)i));
+  int ix = (int)floorf(p.x * inv_cf), iy = (int)floorf(p.y * inv_cf), iz = (int)floorf(p.z * inv_cf);
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+        u32 s = hash_key(key) & mask;
+        while (keys[s] != key) s = (s + 1) & mask;
+        out[(size_t)start[s] + atomicAdd(&cursor[s], 1u)] = rec;
+      }
+}
+
+void free_nlist(NList &nl) {
+  if (nl.table) (void)hipFree(nl.table);
+  if (nl.pts) (void)hipFree(nl.pts);
+  nl = NList();
+}
+
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
+  nl.cf = cf;
+  nl.inv_cf = 1.0f / nl.cf;
+  // scratch table: halo cells are a few times the occupied ones; 8 slots per point keeps the load low
+  u32 tbig = next_pow2((u32)std::max(4096, 8 * n));
+  u64 *keys = nullptr;
+  u32 *cnt = nullptr, *start = nullptr, *tiles = nullptr, *counters = nullptr;
+  int ntiles = (tbig + 1023) / 1024;
+  MALIO_HIP(hipMalloc(&keys, sizeof(u64) * tbig));
+  MALIO_HIP(hipMalloc(&cnt, sizeof(u32) * tbig));
+  MALIO_HIP(hipMalloc(&start, sizeof(u32) * tbig));
+  MALIO_HIP(hipMalloc(&tiles, sizeof(u32) * (ntiles + 1)));
+  MALIO_HIP(hipMalloc(&counters, sizeof(u32) * 2));
+  hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
+  MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
+  MALIO_HIP(hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream));
+  int nb = (n + BLK - 1) / BLK;
+  hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, cnt, tbig - 1, counters,
+                     counters + 1);
+  exclusive_scan_u32(c, cnt, start, tiles, (int)tbig);
+  u32 h_cnt[2] = {0, 0};
+  MALIO_HIP(hipMemcpyAsync(h_cnt, counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  if (h_cnt[1] != 0) {
+    c->err = "neighbour-list directory overflow";
+    return MALIO_ERR_ALLOC;
+  }
+  size_t total = (size_t)27 * (size_t)n;
+  if (total > nl.cap_pts) {
+    if (nl.pts) (void)hipFree(nl.pts);
+    nl.pts = nullptr;
+    nl.cap_pts = total + total / 16 + 1024;
+    MALIO_HIP(hipMalloc(&nl.pts, sizeof(float4) * nl.cap_pts));
+  }
+  MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));  // reuse as the fill cursor
+  hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,
+                     nl.pts);
+  // compact directory: the fill cursors now equal the list lengths
+  u32 tsize = next_pow2(std::max(1024u, 2u * h_cnt[0]));
+  if ((size_t)tsize > nl.cap_table) {
+    if (nl.table) (void)hipFree(nl.table);
+    nl.table = nullptr;
+    nl.cap_table = tsize;
+    MALIO_HIP(hipMalloc(&nl.table, sizeof(Cell) * nl.cap_table));
+  }
+  hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
+  hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
+                     nl.table, tsize - 1);
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  nl.tmask = tsize - 1, nl.ncells = h_cnt[0], nl.total = total;
+  (void)hipFree(keys), (void)hipFree(cnt), (void)hipFree(start), (void)hipFree(tiles), (void)hipFree(counters);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }

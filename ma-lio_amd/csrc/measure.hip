@@ -6,12 +6,10 @@
 // Compiled with -ffp-contract=off: the float stages (distances, QR plane fit, gates) and the double
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
-#include <cstdlib>
 #include "malio_internal.hpp"
 
 namespace malio {
 
-__constant__ int g_dbg = 0;  // timing-experiment bits (MALIO_DBG); 0 in production
 constexpr int NSUM = 97;  // 78 (12x12 upper) + 12 (rhs) + 6 (c^2 n n^T) + 1 (count)
 constexpr u32 INVALID = 0xFFFFFFFFu;
 
@@ -59,12 +57,6 @@ struct Pass1Args {
   int N;
   const float4 *scan;
   // map
-  const float4 *map_pts;  // sorted by cell: x y z bits(original index)
-  const Cell *table;
-  u32 tmask;
-  const u64 *occ;  // occupancy filter (CellGrid::occ)
-  u32 omask;
-  float cell, inv_cell;
   // tables
   const UncEntry *unc;
   int unc_off[MALIO_MAX_LIDAR], unc_len[MALIO_MAX_LIDAR];
@@ -88,26 +80,6 @@ struct Pass1Args {
   unsigned char *nfound;
   float *ny;        // [N] feats_down_body[i].normal_y as the reference would hold it (committed lazily)
   int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
-};
-
-// generated: 27 ring-1 offsets (|d|_inf <= 1) then the 98 cells of the 5x5x5 shell, each sorted by |d|_2
-__constant__ signed char c_off[125][3] = {
-    {0, 0, 0}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}, {-1, -1, 0},
-    {-1, 0, -1}, {-1, 0, 1}, {-1, 1, 0}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1}, {1, -1, 0},
-    {1, 0, -1}, {1, 0, 1}, {1, 1, 0}, {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1},
-    {1, -1, 1}, {1, 1, -1}, {1, 1, 1}, {-2, 0, 0}, {0, -2, 0}, {0, 0, -2}, {0, 0, 2}, {0, 2, 0},
-    {2, 0, 0}, {-2, -1, 0}, {-2, 0, -1}, {-2, 0, 1}, {-2, 1, 0}, {-1, -2, 0}, {-1, 0, -2}, {-1, 0, 2},
-    {-1, 2, 0}, {0, -2, -1}, {0, -2, 1}, {0, -1, -2}, {0, -1, 2}, {0, 1, -2}, {0, 1, 2}, {0, 2, -1},
-    {0, 2, 1}, {1, -2, 0}, {1, 0, -2}, {1, 0, 2}, {1, 2, 0}, {2, -1, 0}, {2, 0, -1}, {2, 0, 1},
-    {2, 1, 0}, {-2, -1, -1}, {-2, -1, 1}, {-2, 1, -1}, {-2, 1, 1}, {-1, -2, -1}, {-1, -2, 1}, {-1, -1, -2},
-    {-1, -1, 2}, {-1, 1, -2}, {-1, 1, 2}, {-1, 2, -1}, {-1, 2, 1}, {1, -2, -1}, {1, -2, 1}, {1, -1, -2},
-    {1, -1, 2}, {1, 1, -2}, {1, 1, 2}, {1, 2, -1}, {1, 2, 1}, {2, -1, -1}, {2, -1, 1}, {2, 1, -1},
-    {2, 1, 1}, {-2, -2, 0}, {-2, 0, -2}, {-2, 0, 2}, {-2, 2, 0}, {0, -2, -2}, {0, -2, 2}, {0, 2, -2},
-    {0, 2, 2}, {2, -2, 0}, {2, 0, -2}, {2, 0, 2}, {2, 2, 0}, {-2, -2, -1}, {-2, -2, 1}, {-2, -1, -2},
-    {-2, -1, 2}, {-2, 1, -2}, {-2, 1, 2}, {-2, 2, -1}, {-2, 2, 1}, {-1, -2, -2}, {-1, -2, 2}, {-1, 2, -2},
-    {-1, 2, 2}, {1, -2, -2}, {1, -2, 2}, {1, 2, -2}, {1, 2, 2}, {2, -2, -1}, {2, -2, 1}, {2, -1, -2},
-    {2, -1, 2}, {2, 1, -2}, {2, 1, 2}, {2, 2, -1}, {2, 2, 1}, {-2, -2, -2}, {-2, -2, 2}, {-2, 2, -2},
-    {-2, 2, 2}, {2, -2, -2}, {2, -2, 2}, {2, 2, -2}, {2, 2, 2},
 };
 
 __device__ __forceinline__ u64 cell_key_d(int ix, int iy, int iz) {
@@ -144,20 +116,6 @@ __device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 og) {
   }
 }
 
-__device__ __forceinline__ u32 brick_hash_d(int bx, int by, int bz) {  // == brick_hash() in map_hash.hip
-  u32 h = (u32)bx * 0x9E3779B1u ^ (u32)by * 0x85EBCA77u ^ (u32)bz * 0xC2B2AE3Du;
-  h ^= h >> 15;
-  h *= 0x27D4EB2Fu;
-  h ^= h >> 13;
-  return h;
-}
-// address of the occupancy word of cell (ix,iy,iz) and its bit
-__device__ __forceinline__ const u64 *occ_word(const u64 *__restrict__ occ, u32 omask, int ix, int iy, int iz, u64 &bit) {
-  u32 line = brick_hash_d(ix >> 3, iy >> 3, iz >> 3) & omask;
-  bit = 1ull << ((ix & 7) + 8 * (iy & 7));
-  return occ + (size_t)line * 8 + (iz & 7);
-}
-
 // One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
 __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 tmask, u64 key, Cell first, u32 slot,
                                             u32 &start, u32 &count) {
@@ -173,23 +131,6 @@ __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 
     }
     slot = (slot + 1) & tmask;
     c = table[slot];
-  }
-}
-
-// Scan one cell's points (4 independent 16-byte loads in flight), keep those with d2 <= limit2.
-__device__ __forceinline__ void scan_cell(const float4 *__restrict__ map_pts, u32 start, u32 count, float wx, float wy,
-                                          float wz, float limit2, Top5 &t) {
-  const u32 end = start + count;
-  for (u32 j = start; j < end; j += 4) {
-    float4 m[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) m[u] = map_pts[min(j + u, end - 1)];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
-      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-      if (j + u < end && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(m[u].w));
-    }
   }
 }
 
@@ -216,122 +157,6 @@ __device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
     }
   }
   t = out;
-}
-
-// Exact radius-limited 5-NN in the hash grid, G lanes of a wave per query. Cell edge c >= sqrt(5)/2,
-// so the 5x5x5 block around the query's cell holds every map point within the acceptance radius
-// (laserMapping.cpp:587). Ring 1 (27 cells) is split over the G lanes: each lane issues its probes
-// together, scans its cells, then the lists are merged; the query is finished when the 5th distance is
-// inside the radius ring 1 guarantees. Otherwise the 98 shell cells are searched the same way, pruned
-// by the current 5th distance. Keeps candidates with d2 <= limit2 (float compare, as
-// `pointSearchSqDis[4] > 5`); map_pts[j] = (x, y, z, bits(original index)).
-template <int G>
-__device__ __forceinline__ void knn5_group(float wx, float wy, float wz, int sub, const float4 *__restrict__ map_pts,
-                                           const Cell *__restrict__ table, u32 tmask, const u64 *__restrict__ occ,
-                                           u32 omask, float cell, float inv_cell, float limit2, Top5 &t) {
-  const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
-#pragma unroll
-  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.og[k] = INVALID;
-  float gx = wx * inv_cell, gy = wy * inv_cell, gz = wz * inv_cell;
-  float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
-  int kx = (int)kxf, ky = (int)kyf, kz = (int)kzf;
-  float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
-  // conservative allowance for the float rounding of the cell coordinates (k_knn)
-  float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * cell;
-  float lo_x = fmaxf(fx * cell - margin, 0.f), hi_x = fmaxf((1.f - fx) * cell - margin, 0.f);
-  float lo_y = fmaxf(fy * cell - margin, 0.f), hi_y = fmaxf((1.f - fy) * cell - margin, 0.f);
-  float lo_z = fmaxf(fz * cell - margin, 0.f), hi_z = fmaxf((1.f - fz) * cell - margin, 0.f);
-
-  // ---- ring 1: 27 cells, ceil(27/G) per lane; probes issued together, then the first 4 points of the next
-  //      cell are in flight while the current cell's are processed ----
-  constexpr int CPL = (27 + G - 1) / G;
-  {
-    // occupancy filter first (2 MB, L2-resident): most of the 27 cells are air and never reach the table
-    u64 ow[CPL], ob[CPL];
-    int cx[CPL], cy[CPL], cz[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) {
-      int o = sub + k * G;
-      int oo = o < 27 ? o : 0;
-      cx[k] = kx + c_off[oo][0], cy[k] = ky + c_off[oo][1], cz[k] = kz + c_off[oo][2];
-      ow[k] = *occ_word(occ, omask, cx[k], cy[k], cz[k], ob[k]);
-    }
-    u64 key[CPL];
-    u32 slot[CPL];
-    Cell rec[CPL];
-    bool occd[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) {
-      occd[k] = (sub + k * G < 27) && (ow[k] & ob[k]) != 0;
-      key[k] = cell_key_d(cx[k], cy[k], cz[k]);
-      slot[k] = hash_key_d(key[k]) & tmask;
-      if (occd[k]) rec[k] = table[slot[k]];
-    }
-    u32 cs[CPL], cc[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) {
-      cs[k] = 0, cc[k] = 0;
-      if (occd[k]) cell_lookup(table, tmask, key[k], rec[k], slot[k], cs[k], cc[k]);
-    }
-    if (g_dbg & 1) {
-#pragma unroll
-      for (int k = 0; k < CPL; k++) cc[k] = 0, cs[k] = 0;  // experiment: no point scanning
-    }
-    float4 cur[4], nxt[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) cur[u] = map_pts[cs[0] + min((u32)u, cc[0] > 0 ? cc[0] - 1 : 0u)];
-#pragma unroll
-    for (int k = 0; k < CPL; k++) {
-      if (k + 1 < CPL) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) nxt[u] = map_pts[cs[k + 1] + min((u32)u, cc[k + 1] > 0 ? cc[k + 1] - 1 : 0u)];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        float ddx = wx - cur[u].x, ddy = wy - cur[u].y, ddz = wz - cur[u].z;
-        float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-        if ((u32)u < cc[k] && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(cur[u].w));
-      }
-      if (cc[k] > 4) scan_cell(map_pts, cs[k] + 4, cc[k] - 4, wx, wy, wz, limit2, t);
-      if (k + 1 < CPL) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) cur[u] = nxt[u];
-      }
-    }
-  }
-  if (!(g_dbg & 2)) merge_group<G>(t, sentinel);
-  if (g_dbg & 4) return;
-  // radius ring 1 guarantees: one cell edge plus the distance to the nearest face of the own cell
-  float g1 = cell + fminf(fminf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
-  bool done = (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
-  if (done) return;  // group-uniform: every lane holds the same merged list
-
-  // ---- ring 2: the 98 cells of the 5x5x5 shell, pruned by the current 5th distance ----
-  const float bound = t.d[4];  // <= sentinel
-  Top5 loc;
-  if (sub == 0) {
-    loc = t;  // lane 0 carries the ring-1 result into the merge
-  } else {
-#pragma unroll
-    for (int k = 0; k < 5; k++) loc.d[k] = sentinel, loc.og[k] = INVALID;
-  }
-  for (int o = 27 + sub; o < 125; o += G) {
-    int dx = c_off[o][0], dy = c_off[o][1], dz = c_off[o][2];
-    float ax = dx == 0 ? 0.f : (dx < 0 ? lo_x + (float)(-dx - 1) * cell : hi_x + (float)(dx - 1) * cell);
-    float ay = dy == 0 ? 0.f : (dy < 0 ? lo_y + (float)(-dy - 1) * cell : hi_y + (float)(dy - 1) * cell);
-    float az = dz == 0 ? 0.f : (dz < 0 ? lo_z + (float)(-dz - 1) * cell : hi_z + (float)(dz - 1) * cell);
-    float bd2 = (ax * ax + ay * ay + az * az) * 0.99999f;
-    if (bd2 > bound) continue;
-    u64 obit;
-    if (!(*occ_word(occ, omask, kx + dx, ky + dy, kz + dz, obit) & obit)) continue;
-    u64 key = cell_key_d(kx + dx, ky + dy, kz + dz);
-    u32 slot = hash_key_d(key) & tmask;
-    u32 start, count;
-    cell_lookup(table, tmask, key, table[slot], slot, start, count);
-    scan_cell(map_pts, start, count, wx, wy, wz, limit2, loc);
-  }
-  t = loc;
-  merge_group<G>(t, sentinel);
 }
 
 // Eigen ColPivHouseholderQR<Matrix<float,5,3>>::solve(b = -1) restated with static register indexing
@@ -586,24 +411,98 @@ __global__ void __launch_bounds__(BLK) k_transform(Pass1Args a) {
   a.pbnorm[i] = nb;
 }
 
-// a2: ikdtree.Nearest_Search (laserMapping.cpp:586), G lanes per query.
+// a2: ikdtree.Nearest_Search (laserMapping.cpp:586) on neighbour lists. ONE directory probe + one contiguous
+// list per query; G lanes stride over the list with 8 independent 16-byte loads in flight each, keep a sorted
+// top-5 under the total order (d2, map index) and merge it with 64-bit min-reductions over xor-shuffles.
+// The list holds every map point of the 3x3x3 block of cells (edge cf) around the query's cell, so the result is
+// exact whenever the 5th distance lies inside the radius that block guarantees at the query's position.
+//   level 1 (FINAL = false, cf1 small): queries that cannot be certified are marked NF_PENDING;
+//   level 2 (FINAL = true, cf2 >= sqrt 5): guaranteed radius >= cf2 covers the reference's acceptance radius
+//   (`pointSearchSqDis[4] > 5` rejects, :587), so whatever it finds inside d2 <= 5 is final.
+// Squared distances are computed as ikd_Tree.cpp:1697 without FMA; candidates with d2 > limit2 are dropped.
+constexpr unsigned char NF_PENDING = 0xFF;
+struct NlView {
+  const Cell *table;
+  u32 tmask;
+  const float4 *pts;
+  float cf, inv_cf;
+};
 template <int G>
-__global__ void __launch_bounds__(BLK) k_knn(Pass1Args a) {
+__device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
+                                          Top5 &t) {
+  const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
+#pragma unroll
+  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.og[k] = INVALID;
+  float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
+  float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
+  u64 key = cell_key_d((int)kxf, (int)kyf, (int)kzf);
+  u32 slot = hash_key_d(key) & nl.tmask;
+  u32 start, count;
+  cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
+  for (u32 j = (u32)sub; j < count; j += 8 * G) {
+    float4 m[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+      if (j + (u32)(u * G) < count && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(m[u].w));
+    }
+  }
+  if (G > 1) merge_group<G>(t, sentinel);
+  // radius the block guarantees: one cell edge plus the distance to the nearest face of the own cell, minus a
+  // conservative allowance for the float rounding of the cell coordinates
+  float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
+  float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
+  float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
+  float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
+  return (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
+}
+
+template <int G>
+__global__ void __launch_bounds__(BLK) k_knn_nl(Pass1Args a, NlView nl) {
   const int tid = blockIdx.x * BLK + threadIdx.x;
   const int qi = tid / G, sub = tid % G;
   const bool active = qi < a.N;
   const float4 w = a.world4[active ? qi : a.N - 1];
   Top5 t;
-  knn5_group<G>(w.x, w.y, w.z, sub, a.map_pts, a.table, a.tmask, a.occ, a.omask, a.cell, a.inv_cell, 5.0f, t);
-  if (!active) return;
-  if (sub < 5) {
-    u32 v = sub == 0 ? t.og[0] : sub == 1 ? t.og[1] : sub == 2 ? t.og[2] : sub == 3 ? t.og[3] : t.og[4];
-    a.nbr[(size_t)sub * a.N + qi] = v;
-  } else if (sub == 5) {
-    int nf = 0;
+  const bool certified = nl_search<G>(nl, w.x, w.y, w.z, sub, 5.0f, t);
+  if (!active || sub != 0) return;
+  if (certified) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
-    a.nfound[qi] = (unsigned char)nf;
+    for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + qi] = t.og[k];
+    a.nfound[qi] = 5;
+  } else {
+    a.nfound[qi] = NF_PENDING;
+  }
+}
+
+// Level 2: one lane per query looks at the flag; every wave then serves ITS pending queries one at a time with
+// all 64 lanes striding over the (~180-point) level-2 list. Nothing pending (the common case) costs one byte
+// load per query; a pending query costs one probe, one or two rounds of loads and a 6-step merge.
+__global__ void __launch_bounds__(BLK) k_knn_l2(Pass1Args a, NlView nl) {
+  const int qi0 = blockIdx.x * BLK + (threadIdx.x & ~63);  // first query of this wave
+  const int lane = threadIdx.x & 63;
+  const int myq = qi0 + lane;
+  const bool pending = myq < a.N && a.nfound[myq] == NF_PENDING;
+  unsigned long long todo = __ballot(pending);
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int qi = qi0 + l;
+    const float4 w = a.world4[qi];
+    Top5 t;
+    nl_search<64>(nl, w.x, w.y, w.z, lane, 5.0f, t);
+    if (lane < 5) {
+      u32 v = lane == 0 ? t.og[0] : lane == 1 ? t.og[1] : lane == 2 ? t.og[2] : lane == 3 ? t.og[3] : t.og[4];
+      a.nbr[(size_t)lane * a.N + qi] = v;
+    } else if (lane == 5) {
+      int nf = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+      a.nfound[qi] = (unsigned char)nf;
+    }
   }
 }
 
@@ -903,19 +802,18 @@ __global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict_
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
-constexpr int KNN_G = 16;  // lanes per query (measured 8 / 16)
+constexpr int NL1_G = 4;   // lanes per query on the level-1 lists (~45 candidates; measured 1: 30, 2: 24, 4: 20 us)
+constexpr int NL2_G = 16;  // lanes per query on the level-2 lists (~180 candidates), batched API
 
-__global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, int n, int k,
-                                                 const float4 *__restrict__ map_pts, const Cell *__restrict__ table,
-                                                 u32 tmask, const u64 *__restrict__ occ, u32 omask, float cell,
-                                                 float inv_cell, u32 *out_idx, float *out_d2, int *out_cnt) {
+// Batched Nearest_Search API: level-2 lists, radius limit just under cf2 (what the block always guarantees).
+__global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, int n, int k, NlView nl, u32 *out_idx,
+                                                 float *out_d2, int *out_cnt) {
   const int tid = blockIdx.x * BLK + threadIdx.x;
-  const int qi = tid / KNN_G, sub = tid % KNN_G;
+  const int qi = tid / NL2_G, sub = tid % NL2_G;
   const bool active = qi < n;
   float4 p = q[active ? qi : n - 1];
   Top5 t;
-  // radius limit = a hair under two cell edges (>= sqrt 5): everything inside it is in the 5x5x5 block
-  knn5_group<KNN_G>(p.x, p.y, p.z, sub, map_pts, table, tmask, occ, omask, cell, inv_cell, 4.f * cell * cell * 0.999f, t);
+  nl_search<NL2_G>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t);
   if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {
@@ -929,10 +827,16 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   out_cnt[qi] = c;
 }
 
+static NlView view_of(const NList &nl) {
+  NlView v;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
+  return v;
+}
+
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
-  long long threads = (long long)n * KNN_G;
+  long long threads = (long long)n * NL2_G;
   hipLaunchKernelGGL(k_nearest, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_q, n, k,
-                     c->map.pts, c->map.table, c->map.tmask, c->map.occ, c->map.omask, c->cell, c->inv_cell, d_idx, d_d2, d_cnt);
+                     view_of(c->nl2), d_idx, d_d2, d_cnt);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -1059,7 +963,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   for (int l = 0; l < L; l++) {
     int n = c->seg_start[l + 1] - c->seg_start[l];
     if (n <= 0) continue;
-    int rc = group_by_cell(c, d_w + c->seg_start[l], n, c->inv_cell, g);
+    int rc = group_by_cell(c, d_w + c->seg_start[l], n, c->nl1.inv_cf, g);
     if (rc != MALIO_OK) return rc;
     hipLaunchKernelGGL(k_gather_scan, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
                        c->d_scan_in + c->seg_start[l], g.orig, n, c->seg_start[l], c->d_scan, c->d_perm,
@@ -1075,7 +979,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
 }
 
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
-  if (c->map.n <= 0) return MALIO_ERR_NO_MAP;
+  if (c->map_n <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
@@ -1085,9 +989,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   }
   a.N = c->N;
   a.scan = c->d_scan;
-  a.map_pts = c->map.pts, a.table = c->map.table, a.tmask = c->map.tmask, a.map_in = c->d_map_in;
-  a.occ = c->map.occ, a.omask = c->map.omask;
-  a.cell = c->cell, a.inv_cell = c->inv_cell;
+  a.map_in = c->d_map_in;
   a.unc = c->d_unc;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
@@ -1100,23 +1002,14 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   if (converge) {
     hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_transform");
-    static const int dbg_sel = getenv("MALIO_DBG") ? atoi(getenv("MALIO_DBG")) : 0;
-    static bool dbg_set = false;
-    if (!dbg_set) {
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg_sel, sizeof(int));
-      dbg_set = true;
+    {
+      long long th = (long long)c->N * NL1_G;
+      hipLaunchKernelGGL(k_knn_nl<NL1_G>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, a,
+                         view_of(c->nl1));
+      prof_mark(c, "k_knn");
+      hipLaunchKernelGGL(k_knn_l2, dim3(nb), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
+      prof_mark(c, "k_knn_l2");
     }
-    static const int g_sel = getenv("MALIO_KNN_G") ? atoi(getenv("MALIO_KNN_G")) : KNN_G;  // tuning experiments
-    const int G = (g_sel == 8 || g_sel == 32) ? g_sel : 16;
-    long long threads = (long long)c->N * G;
-    dim3 kgrid((unsigned)((threads + BLK - 1) / BLK));
-    if (G == 32)
-      hipLaunchKernelGGL(k_knn<32>, kgrid, dim3(BLK), 0, c->stream, a);
-    else if (G == 16)
-      hipLaunchKernelGGL(k_knn<16>, kgrid, dim3(BLK), 0, c->stream, a);
-    else
-      hipLaunchKernelGGL(k_knn<8>, kgrid, dim3(BLK), 0, c->stream, a);
-    prof_mark(c, "k_knn");
     hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_plane");
   } else {
