@@ -114,8 +114,12 @@ def main():
         def step():
             return mdist.sharded_measure(be, state, True)
     else:
+        fast, fast_out = eng.measure_fn(state, True)  # ctypes call with pre-built structs: no Python in the loop
+
         def step():
-            return eng.measure(state, True)
+            rc = fast()
+            assert rc >= 0
+            return fast_out
 
     out = None
     for _ in range(args.warmup):
@@ -187,7 +191,7 @@ def main():
             "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step%s" % (
                 cfg["name"], N, L, sc["Nmap"], "" if not distributed else
                 "; scan sharded %d x %d pts, map replicated, 2 RCCL all-reduces per pass" % (world, N)),
-                "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"]),
+                "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"] if isinstance(out, dict) else out.M),
                 "seed": sc["seed"]},
             "eskf": eskf, "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -220,6 +220,20 @@ class Engine:
             res.update(h_x=hx[:M].copy(), h=hv[:M].copy(), R=Rv[:M].copy())
         return res
 
+    def measure_fn(self, state_flat, converge=True):
+        """Pre-bound call for timing loops: returns (fn, out_struct); fn() runs one malio_measure pass with no
+        Python-side conversions (state struct and output struct are built once)."""
+        s = state_from_flat(state_flat, self.L)
+        out = MeasureOut()
+        f = lib().malio_measure
+        h, sp, op, cv = self.h, C.byref(s), C.byref(out), int(bool(converge))
+        keep = (s, out)
+
+        def fn():
+            return f(h, sp, cv, op)
+        fn._keep = keep
+        return fn, out
+
     def scan_get(self):
         n = self.N
         out = dict(normal_y=np.zeros(n, np.float32), nearest=np.zeros((n, 5, 12), np.float32),
