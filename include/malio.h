@@ -186,12 +186,22 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
  * pts (in/out, sorted by curvature as :229-233): x,y,z rewritten, intensity <- uncertainty-interval
  * index; the first point is left untouched like the reference's loop bounds (:475-476).
  * knot_times[n_knots] / knot_poses[n_knots*16]: the spline's control poses (BsplineSE3.cpp:59-77),
- * absolute seconds. imu_stamps[n_imu]: imu_cov[k].first.first; cov_pointer0: value after :453-467.
- * out_cross_index[n] (optional): idx after each point, for building the uncertainty tables on host. */
+ * absolute seconds. imu_stamps[n_imu]: imu_cov[k].first.first (ascending); cov_pointer0: value after :453-467.
+ * out_entry_point[<= n_imu] (optional): indices of the points at which the reference pushes an uncertainty
+ * entry (:484-494), in processing order (descending index); out_n_entries: how many. */
 int malio_undistort(malio_handle_t h, malio_point_t *pts, int n, double lidar_beg_time, const double *knot_times,
                     const double *knot_poses, int n_knots, const double ext_q[4], const double ext_t[3],
                     const double end_q[4], const double end_t[3], const double *imu_stamps, int n_imu,
                     int cov_pointer0, int *out_entry_point, int *out_n_entries);
+/* Host side of the trajectory spline (pure host, no handle):
+ * ov_core::BsplineSE3::feed_trajectory (src/BsplineSE3.cpp:26-82): traj8[n][8] = t, p(3), q(x,y,z,w) ->
+ * uniform 10 ms control poses (times + row-major 4x4). Returns MALIO_ERR_ALLOC when cap is too small. */
+int malio_spline_feed(const double *traj8, int n, double *out_times, double *out_poses16, int cap, int *out_n);
+/* ov_core::BsplineSE3::get_pose (src/BsplineSE3.cpp:84-118): 1 = success, 0 = the spline cannot bound
+ * `timestamp` (p zeroed, like the reference). Needed on the host for the scan-end poses
+ * (IMU_Processing.hpp:430,470) and the uncertainty-table entries (:488-492). */
+int malio_spline_get_pose(const double *times, const double *poses16, int n, double timestamp, double q[4],
+                          double p[3]);
 
 /* ---- multi-GPU staging: scan points sharded, map replicated -------------------- */
 /* Stage 1: search/plane/gates + local [max_unit_cov, -min_unit_cov, max_R, -min_R] into d_minmax4

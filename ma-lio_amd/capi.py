@@ -21,7 +21,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters",
+    "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
 ]
 
 
@@ -256,6 +256,22 @@ class Engine:
         return dict(state=state_to_flat(s, self.L), P=P, passes=stats[0], searches=stats[1], M=stats[2],
                     t=stats[3], solve_time=st.value)
 
+    def undistort(self, pts12, lidar_beg_time, knot_times, knot_poses, ext_q, ext_t, end_q, end_t, imu_stamps,
+                  cov_pointer0):
+        """malio_undistort: returns (points [n,12] copy, entry point indices)."""
+        pts = np.ascontiguousarray(pts12, np.float32).copy()
+        kt = np.ascontiguousarray(knot_times, np.float64)
+        kp = np.ascontiguousarray(knot_poses, np.float64).reshape(-1, 16)
+        imu = np.ascontiguousarray(imu_stamps, np.float64)
+        v = lambda a: _p(np.ascontiguousarray(a, np.float64), C.c_double)
+        ent = np.zeros(max(len(imu), 1) + 4, np.int32)
+        ne = C.c_int(0)
+        self._chk(lib().malio_undistort(self.h, _p(pts, Point), pts.shape[0], C.c_double(lidar_beg_time),
+                                        _p(kt, C.c_double), _p(kp, C.c_double), len(kt), v(ext_q), v(ext_t), v(end_q),
+                                        v(end_t), _p(imu, C.c_double), len(imu), int(cov_pointer0), _p(ent, C.c_int),
+                                        C.byref(ne)), "malio_undistort")
+        return pts, ent[:ne.value].copy()
+
     # ---- multi-GPU staging (device pointers are plain ints, e.g. torch.Tensor.data_ptr()) ----
     def sums_len(self):
         return lib().malio_sums_len(self.h)
@@ -296,3 +312,26 @@ def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh
     if rc != OK:
         raise MalioError(f"malio_ieskf_step rc={rc}")
     return state_to_flat(x, L), t_io.value, bool(conv.value), bool(done.value), P_out
+
+
+def spline_feed(traj8, cap=4096):
+    """malio_spline_feed (pure host): control-point times [K] and poses [K,4,4]."""
+    traj8 = np.ascontiguousarray(traj8, np.float64)
+    t = np.zeros(cap, np.float64)
+    T = np.zeros((cap, 16), np.float64)
+    n = C.c_int(0)
+    rc = lib().malio_spline_feed(_p(traj8, C.c_double), traj8.shape[0], _p(t, C.c_double), _p(T, C.c_double), cap,
+                                 C.byref(n))
+    if rc != OK:
+        raise MalioError(f"malio_spline_feed rc={rc}")
+    return t[:n.value].copy(), T[:n.value].reshape(-1, 4, 4).copy()
+
+
+def spline_get_pose(times, poses, ts):
+    times = np.ascontiguousarray(times, np.float64)
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+    q = np.zeros(4, np.float64)
+    p = np.zeros(3, np.float64)
+    ok = lib().malio_spline_get_pose(_p(times, C.c_double), _p(poses, C.c_double), len(times), C.c_double(ts),
+                                     _p(q, C.c_double), _p(p, C.c_double))
+    return ok == 1, q, p

@@ -477,11 +477,4 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
                     converge_out, done_out, P_out);
 }
 
-int malio_undistort(malio_handle_t h, malio_point_t *, int, double, const double *, const double *, int, const double *,
-                    const double *, const double *, const double *, const double *, int, int, int *, int *) {
-  if (check(h)) return MALIO_ERR_BAD_ARG;
-  h->err = "malio_undistort: not built yet";
-  return MALIO_ERR_BAD_ARG;
-}
-
 }  // extern "C"

@@ -1,2 +1,257 @@
-// placeholder translation unit: the undistortion kernel (IMU_Processing.hpp:475-507) lands here.
+// a13/a14: per-raw-point undistortion (ImuProcess::UndistortPcl, /root/reference/MA_LIO/src/IMU_Processing.hpp:475-507)
+// on the SE(3) cubic B-spline (BsplineSE3::get_pose, src/BsplineSE3.cpp:84-118; quat_ops.h:190-221).
+// One thread per raw point: knot interval by binary search on absolute double timestamps (the reference's
+// std::map lookups), the three log_se3 of that interval read from a per-scan table (they only depend on the
+// interval; the reference recomputes them per point), three exp_se3 + three 3x4 products in double, Eigen's
+// matrix->quaternion conversion, then the rigid compensation of :498-503 in Eigen's quaternion-vector order.
+// Also emits, per point, how many IMU stamps lie strictly above its time (D_i): the host turns that into the
+// reference's single-step `if` counter (:484-494, the uncertainty-interval index written to `intensity`).
+// Algorithmic bytes: 16 B read + 16 B written per raw point.
+#include <algorithm>
 #include "malio_internal.hpp"
+
+namespace malio {
+
+struct UndArgs {
+  int n;
+  const float4 *in;  // x y z curvature[ms]
+  float4 *out;       // x y z (w: 1 if compensated, 0 if the spline could not bound the point's time)
+  int *D;            // [n] IMU stamps above the point's time (counted down from cov_pointer0)
+  double lidar_beg_time;
+  const double *knot_t;   // [K]
+  const double *knot_T;   // [K][12] rows of R|t
+  const double *knot_log; // [K-1][6] log_se3(T_k^-1 T_{k+1})
+  int K;
+  const double *imu_t;  // [n_imu]
+  int n_imu, cov_pointer0;
+  double eq[4], et[3];  // extrinsic of this LiDAR (q: x,y,z,w)
+  double lq[4], lt[3];  // IMU pose at this LiDAR's scan end
+};
+
+struct D3u {
+  double x, y, z;
+};
+__device__ __forceinline__ D3u cross_u(D3u a, D3u b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Eigen::QuaternionBase::_transformVector
+__device__ __forceinline__ D3u qrot_u(const double q[4], D3u v) {
+  D3u qv{q[0], q[1], q[2]};
+  D3u uv = cross_u(qv, v);
+  uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+  D3u c2 = cross_u(qv, uv);
+  return {(v.x + q[3] * uv.x) + c2.x, (v.y + q[3] * uv.y) + c2.y, (v.z + q[3] * uv.z) + c2.z};
+}
+
+// exp_se3 (quat_ops.h:190-221) as R (row-major 3x3) and t
+__device__ __forceinline__ void exp_se3_d(const double v[6], double R[9], double t[3]) {
+  const double wx = v[0], wy = v[1], wz = v[2];
+  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  double A, B, C;
+  if (theta < 1e-7) {
+    A = 1, B = 0.5, C = 1.0 / 6.0;
+  } else {
+    A = sin(theta) / theta;
+    B = (1 - cos(theta)) / (theta * theta);
+    C = (1 - A) / (theta * theta);
+  }
+  const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double K2[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) K2[i * 3 + j] = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+  double V[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const double I = (i % 4 == 0) ? 1.0 : 0.0;
+    R[i] = I + A * K[i] + B * K2[i];
+    V[i] = I + B * K[i] + C * K2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) t[i] = V[i * 3] * v[3] + V[i * 3 + 1] * v[4] + V[i * 3 + 2] * v[5];
+}
+// (R,t) <- (R,t) * (Rb,tb)
+__device__ __forceinline__ void se3_mul_d(double R[9], double t[3], const double Rb[9], const double tb[3]) {
+  double Rn[9], tn[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) Rn[i * 3 + j] = R[i * 3] * Rb[j] + R[i * 3 + 1] * Rb[3 + j] + R[i * 3 + 2] * Rb[6 + j];
+    tn[i] = R[i * 3] * tb[0] + R[i * 3 + 1] * tb[1] + R[i * 3 + 2] * tb[2] + t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) R[i] = Rn[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) t[i] = tn[i];
+}
+
+__global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.n) return;
+  const float4 p = a.in[i];
+  const double point_t = (double)p.w / 1000.0 + a.lidar_beg_time;  // :482
+  // D_i: stamps imu_t[k], k <= cov_pointer0, that are > point_t (imu_t ascending)
+  {
+    int lo = 0, hi = a.cov_pointer0 + 1;  // first index in [0, c0] with imu_t > point_t
+    if (hi > a.n_imu) hi = a.n_imu;
+    int top = hi;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (a.imu_t[mid] > point_t)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    a.D[i] = top - lo;
+  }
+  // knot interval: i1 = (number of knots <= t) - 1; needs i1-1 and i1+2 (BsplineSE3.cpp:173-230)
+  int lo = 0, hi = a.K;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a.knot_t[mid] <= point_t)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int i1 = lo - 1;
+  if (i1 < 1 || i1 + 2 >= a.K || i == 0) {  // i == 0: the reference's loop stops before begin() (:475-476)
+    a.out[i] = make_float4(p.x, p.y, p.z, 0.f);
+    return;
+  }
+  const double t1 = a.knot_t[i1], t2 = a.knot_t[i1 + 1];
+  const double DT = t2 - t1;
+  const double u = (point_t - t1) / DT;
+  const double b0 = 1.0 / 6.0 * (5 + 3 * u - 3 * u * u + u * u * u);
+  const double b1 = 1.0 / 6.0 * (1 + 3 * u + 3 * u * u - 2 * u * u * u);
+  const double b2 = 1.0 / 6.0 * (u * u * u);
+  double R[9], t[3];
+  {
+    const double *T0 = a.knot_T + (size_t)(i1 - 1) * 12;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      R[r * 3] = T0[r * 4], R[r * 3 + 1] = T0[r * 4 + 1], R[r * 3 + 2] = T0[r * 4 + 2];
+      t[r] = T0[r * 4 + 3];
+    }
+  }
+  const double bb[3] = {b0, b1, b2};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double *lg = a.knot_log + (size_t)(i1 - 1 + k) * 6;
+    double v[6], Rk[9], tk[3];
+#pragma unroll
+    for (int c = 0; c < 6; c++) v[c] = bb[k] * lg[c];
+    exp_se3_d(v, Rk, tk);
+    se3_mul_d(R, t, Rk, tk);  // pose0 * A0 * A1 * A2 (:111)
+  }
+  // Eigen quaternion-from-matrix (q_GtoI = R_GtoI, :113)
+  double q[4];
+  {
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+      double s = sqrt(tr + 1.0);
+      q[3] = 0.5 * s;
+      s = 0.5 / s;
+      q[0] = (R[7] - R[5]) * s, q[1] = (R[2] - R[6]) * s, q[2] = (R[3] - R[1]) * s;
+    } else {
+      int ii = 0;
+      if (R[4] > R[0]) ii = 1;
+      if (R[8] > (ii == 0 ? R[0] : R[4])) ii = 2;
+      const int jj = (ii + 1) % 3, kk = (jj + 1) % 3;
+      double s = sqrt(R[ii * 4] - R[jj * 4] - R[kk * 4] + 1.0);
+      double qi = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (R[kk * 3 + jj] - R[jj * 3 + kk]) * s;
+      double qj = (R[jj * 3 + ii] + R[ii * 3 + jj]) * s, qk = (R[kk * 3 + ii] + R[ii * 3 + kk]) * s;
+      q[0] = ii == 0 ? qi : (jj == 0 ? qj : qk);
+      q[1] = ii == 1 ? qi : (jj == 1 ? qj : qk);
+      q[2] = ii == 2 ? qi : (jj == 2 ? qj : qk);
+    }
+  }
+  // :498-503
+  const D3u P_i{(double)p.x, (double)p.y, (double)p.z};
+  const D3u T_ei{t[0] - a.lt[0], t[1] - a.lt[1], t[2] - a.lt[2]};
+  const double eqc[4] = {-a.eq[0], -a.eq[1], -a.eq[2], a.eq[3]};
+  const double lqc[4] = {-a.lq[0], -a.lq[1], -a.lq[2], a.lq[3]};
+  D3u x = qrot_u(a.eq, P_i);
+  x = {x.x + a.et[0], x.y + a.et[1], x.z + a.et[2]};
+  x = qrot_u(q, x);
+  x = {x.x + T_ei.x, x.y + T_ei.y, x.z + T_ei.z};
+  x = qrot_u(lqc, x);
+  x = {x.x - a.et[0], x.y - a.et[1], x.z - a.et[2]};
+  x = qrot_u(eqc, x);
+  a.out[i] = make_float4((float)x.x, (float)x.y, (float)x.z, 1.f);
+}
+
+int spline_interval(const double *times, int n, double ts);
+void spline_interval_logs(const double *poses16, int n, double *logs6);
+
+}  // namespace malio
+
+using namespace malio;
+
+extern "C" int malio_undistort(malio_handle_t h, malio_point_t *pts, int n, double lidar_beg_time,
+                               const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
+                               const double ext_t[3], const double end_q[4], const double end_t[3],
+                               const double *imu_stamps, int n_imu, int cov_pointer0, int *out_entry_point,
+                               int *out_n_entries) {
+  if (!h || !pts || n <= 0 || !knot_times || !knot_poses || n_knots < 4 || !ext_q || !ext_t || !end_q || !end_t ||
+      !imu_stamps || n_imu <= 0)
+    return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  // per-scan tables: rows of the control poses and the per-interval log twists
+  std::vector<double> T12((size_t)n_knots * 12), logs((size_t)(n_knots - 1) * 6);
+  for (int k = 0; k < n_knots; k++)
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 4; cc++) T12[(size_t)k * 12 + r * 4 + cc] = knot_poses[(size_t)k * 16 + r * 4 + cc];
+  spline_interval_logs(knot_poses, n_knots, logs.data());
+  std::vector<float4> hin(n);
+  for (int i = 0; i < n; i++) hin[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].curvature);
+  float4 *d_in = nullptr, *d_out = nullptr;
+  int *d_D = nullptr;
+  double *d_tab = nullptr;
+  const size_t ntab = (size_t)n_knots + T12.size() + logs.size() + (size_t)n_imu;
+  MALIO_HIP(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
+  MALIO_HIP(hipMalloc(&d_out, sizeof(float4) * (size_t)n));
+  MALIO_HIP(hipMalloc(&d_D, sizeof(int) * (size_t)n));
+  MALIO_HIP(hipMalloc(&d_tab, sizeof(double) * ntab));
+  std::vector<double> tab;
+  tab.insert(tab.end(), knot_times, knot_times + n_knots);
+  tab.insert(tab.end(), T12.begin(), T12.end());
+  tab.insert(tab.end(), logs.begin(), logs.end());
+  tab.insert(tab.end(), imu_stamps, imu_stamps + n_imu);
+  MALIO_HIP(hipMemcpyAsync(d_tab, tab.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemcpyAsync(d_in, hin.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  UndArgs a;
+  a.n = n, a.in = d_in, a.out = d_out, a.D = d_D, a.lidar_beg_time = lidar_beg_time;
+  a.knot_t = d_tab, a.knot_T = d_tab + n_knots, a.knot_log = d_tab + n_knots + T12.size(), a.K = n_knots;
+  a.imu_t = d_tab + n_knots + T12.size() + logs.size(), a.n_imu = n_imu, a.cov_pointer0 = cov_pointer0;
+  for (int k = 0; k < 4; k++) a.eq[k] = ext_q[k], a.lq[k] = end_q[k];
+  for (int k = 0; k < 3; k++) a.et[k] = ext_t[k], a.lt[k] = end_t[k];
+  prof_begin(c);
+  hipLaunchKernelGGL(k_undistort, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, a);
+  prof_mark(c, "k_undistort");
+  std::vector<float4> hout(n);
+  std::vector<int> D(n);
+  MALIO_HIP(hipMemcpyAsync(hout.data(), d_out, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(D.data(), d_D, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  prof_end(c);
+  (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_D), (void)hipFree(d_tab);
+  // The reference's pointer walk (:484-494): going from the last point to the second, cov_pointer steps down by
+  // at most ONE per point, so the interval count is A_i = min(D_i, A_{i+1} + 1); intensity <- A_i - 1 (:504).
+  int A = 0, ne = 0;
+  for (int i = n - 1; i >= 1; i--) {
+    int An = std::min(D[i], A + 1);
+    if (An > A && out_entry_point) out_entry_point[ne] = i;
+    if (An > A) ne++;
+    A = An;
+    if (hout[i].w != 0.f) {
+      pts[i].x = hout[i].x, pts[i].y = hout[i].y, pts[i].z = hout[i].z;
+      pts[i].intensity = (float)(A - 1);
+    }
+  }
+  if (out_n_entries) *out_n_entries = ne;
+  return MALIO_OK;
+}
