@@ -203,6 +203,15 @@ int malio_spline_feed(const double *traj8, int n, double *out_times, double *out
 int malio_spline_get_pose(const double *times, const double *poses16, int n, double timestamp, double q[4],
                           double p[3]);
 
+/* ---- uncertainty tables on the host (a15; include/associate_uct.hpp) -------------------------------- */
+/* compoundPoseWithCov(pose_1, cov_1, pose_2, cov_2, pose_cp, cov_cp, 2) (:85-142); the covariances travel inside
+ * the poses; pose_cp may alias pose_2 (laserMapping.cpp:1043), with the reference's read/write order. */
+int malio_compound_pose_cov(const malio_pose_t *pose_1, const malio_pose_t *pose_2, malio_pose_t *pose_cp);
+/* compoundInvPoseWithCov(...) (:29-83): pose_cp = pose_1^-1 * pose_2 */
+int malio_compound_inv_pose_cov(const malio_pose_t *pose_1, const malio_pose_t *pose_2, malio_pose_t *pose_cp);
+/* evalPointUncertainty(pi, cov_point, pose) (:153-175): full 3x3 (row-major); the hot path only needs its trace. */
+int malio_eval_point_uncertainty(const malio_point_t *pi, const malio_pose_t *pose, double cov_point[9]);
+
 /* ---- multi-GPU staging: scan points sharded, map replicated -------------------- */
 /* Stage 1: search/plane/gates + local [max_unit_cov, -min_unit_cov, max_R, -min_R] into d_minmax4
  * (device, 4 doubles) -> caller all-reduces with MAX. Stage 2: rows + local sums into d_sums (device,

@@ -22,6 +22,7 @@ EXPORTS = [
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
 
@@ -335,3 +336,23 @@ def spline_get_pose(times, poses, ts):
     ok = lib().malio_spline_get_pose(_p(times, C.c_double), _p(poses, C.c_double), len(times), C.c_double(ts),
                                      _p(q, C.c_double), _p(p, C.c_double))
     return ok == 1, q, p
+
+
+def compound(pose1_59, pose2_59, inverse=False, alias=False):
+    """malio_compound_pose_cov / malio_compound_inv_pose_cov on flat 59-double poses (pure host)."""
+    p1 = np.ascontiguousarray(pose1_59, np.float64).copy()
+    p2 = np.ascontiguousarray(pose2_59, np.float64).copy()
+    out = p2 if alias else np.zeros(59, np.float64)
+    f = lib().malio_compound_inv_pose_cov if inverse else lib().malio_compound_pose_cov
+    rc = f(_p(p1, Pose), _p(p2, Pose), _p(out, Pose))
+    if rc != OK:
+        raise MalioError(f"compound rc={rc}")
+    return out
+
+
+def eval_point_uncertainty(p12, pose59):
+    p = np.ascontiguousarray(p12, np.float32)
+    ps = np.ascontiguousarray(pose59, np.float64)
+    cov = np.zeros(9, np.float64)
+    lib().malio_eval_point_uncertainty(_p(p, Point), _p(ps, Pose), _p(cov, C.c_double))
+    return cov.reshape(3, 3)
