@@ -324,7 +324,7 @@ int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge,
 }
 int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_sums) {
   if (check(h) || !d_minmax4 || !d_sums) return MALIO_ERR_BAD_ARG;
-  int rc = pass_stage2(h, d_minmax4, d_sums, false);
+  int rc = pass_stage2(h, d_minmax4, nullptr, d_sums, false);
   return rc;
 }
 int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax4_host,
@@ -343,17 +343,16 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   const bool want_rows = out->h_x || out->h || out->R;
   prof_begin(c);
-  double *d_mm = c->d_sums + MALIO_MAX_LIDAR * 97;  // 8 doubles after the sums
-  int rc = pass_stage1(c, s, converge, d_mm);
-  if (rc != MALIO_OK) return rc;
-  rc = pass_stage2(c, d_mm, c->d_sums, want_rows);
-  if (rc != MALIO_OK) return rc;
   const int ns = sums_len(c);
-  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * ns, hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(c->h_minmax, d_mm, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+  double *d_mm = c->d_sums + ns;  // 5 doubles right after the sums: one D2H copy brings both
+  int rc = pass_stage1(c, s, converge, nullptr);
+  if (rc != MALIO_OK) return rc;
+  rc = pass_stage2(c, nullptr, d_mm, c->d_sums, want_rows);
+  if (rc != MALIO_OK) return rc;
+  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * (ns + 5), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   prof_end(c);
-  rc = finish_host(c, c->h_sums, c->h_minmax, out);
+  rc = finish_host(c, c->h_sums, c->h_sums + ns, out);
   c->last_M = out->M;
   if (want_rows && out->valid) {
     // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to

@@ -478,10 +478,11 @@ __global__ void __launch_bounds__(BLK) k_knn_nl(Pass1Args a, NlView nl) {
   }
 }
 
-// Level 2: one lane per query looks at the flag; every wave then serves ITS pending queries one at a time with
-// all 64 lanes striding over the (~180-point) level-2 list. Nothing pending (the common case) costs one byte
-// load per query; a pending query costs one probe, one or two rounds of loads and a 6-step merge.
-__global__ void __launch_bounds__(BLK) k_knn_l2(Pass1Args a, NlView nl) {
+// Level 2 (device function, first thing k_plane does): one lane per query looks at the flag; every wave then
+// serves ITS pending queries one at a time with all 64 lanes striding over the (~180-point) level-2 list.
+// Nothing pending (the common case: 8 of 100 k at config 2) costs one ballot; a pending query costs one probe,
+// one or two rounds of loads and a 6-step merge.
+__device__ __forceinline__ void serve_pending(const Pass1Args &a, const NlView &nl) {
   const int qi0 = blockIdx.x * BLK + (threadIdx.x & ~63);  // first query of this wave
   const int lane = threadIdx.x & 63;
   const int myq = qi0 + lane;
@@ -504,10 +505,15 @@ __global__ void __launch_bounds__(BLK) k_knn_l2(Pass1Args a, NlView nl) {
       a.nfound[qi] = (unsigned char)nf;
     }
   }
+  // the lanes that own those queries read nbr/nfound right after: same wave, program order + this fence
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // a3 + gates + a6 of a SEARCH pass: thread per query.
-__global__ void __launch_bounds__(BLK) k_plane(Pass1Args a) {
+__global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
+  serve_pending(a, nl2);
   const int i = blockIdx.x * BLK + threadIdx.x;
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
@@ -637,16 +643,20 @@ struct Pass2Args {
   int seg_start[MALIO_MAX_LIDAR + 1];   // first sorted point of each LiDAR segment
   PassConst pc;
   WeightConst wc;
-  const double *minmax4;  // decoded doubles: max_ucov, -min_ucov, max_R, -min_R
+  const double *minmax4;  // [max_ucov, -min_ucov, max_R, -min_R] when the caller reduced them (multi-GPU), else null
+  const double *blockmm;  // per-workgroup extrema of pass 1 [nb_mm][5] (single-GPU path: folded here)
+  int nb_mm;
+  double *mm_out;         // where workgroup 0 publishes the folded extrema + M for the host
   double *partials;       // [nblocks][NSUM]
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
 };
 
 // a5 + a7: weights and the 12 non-zero entries of the (c_i-scaled) Jacobian row of one accepted point
-__device__ __forceinline__ void point_row(const Pass2Args &a, int i, int lid, double u[12], double &hs, double &r) {
+__device__ __forceinline__ void point_row(const Pass2Args &a, const double mm[4], int i, int lid, double u[12],
+                                          double &hs, double &r) {
   const float4 q = a.scan[i];
   const float4 pl = a.plane[i];
-  const double max_u = a.minmax4[0], min_u = -a.minmax4[1], max_c = a.minmax4[2], min_c = -a.minmax4[3];
+  const double max_u = mm[0], min_u = -mm[1], max_c = mm[2], min_c = -mm[3];
   // plane weight c_i (laserMapping.cpp:651-656)
   double cp = a.ucov[i];
   if (cp == 0)
@@ -705,6 +715,42 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __shared__ double X[BLK][13];  // u[0..11], hs
   __shared__ double Y[BLK][12];  // u / r (r clamped as esekfom.hpp:624-626)
   __shared__ double half1[NSUM];
+  __shared__ double smm[BLK / 64][5];
+  __shared__ double mm_s[5];
+  // ---- a4 fold: every workgroup reduces the per-workgroup extrema of pass 1 itself (<= N/256 rows of 5
+  //      doubles from L2) instead of waiting for a separate 1-workgroup kernel ----
+  if (a.minmax4) {
+    if (threadIdx.x < 4) mm_s[threadIdx.x] = a.minmax4[threadIdx.x];
+  } else {
+    double r0 = -INFINITY, r1 = INFINITY, r2 = -INFINITY, r3 = INFINITY, r4 = 0;
+    for (int b = threadIdx.x; b < a.nb_mm; b += BLK) {
+      const double *v = a.blockmm + (size_t)b * 5;
+      r0 = fmax(r0, v[0]), r1 = fmin(r1, v[1]), r2 = fmax(r2, v[2]), r3 = fmin(r3, v[3]), r4 += v[4];
+    }
+    r0 = wave_max(r0), r1 = wave_min(r1), r2 = wave_max(r2), r3 = wave_min(r3);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) r4 += __shfl_xor(r4, d);
+    if ((threadIdx.x & 63) == 0) {
+      int w = threadIdx.x >> 6;
+      smm[w][0] = r0, smm[w][1] = r1, smm[w][2] = r2, smm[w][3] = r3, smm[w][4] = r4;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // initial values of laserMapping.cpp:615-616,646-647
+      double m0 = 0.0, m1 = 1000.0, m2 = 0.0, m3 = 9999.0, cnt = 0;
+      for (int w = 0; w < BLK / 64; w++) {
+        m0 = fmax(m0, smm[w][0]), m1 = fmin(m1, smm[w][1]);
+        if (a.extrinsic_est_en) m2 = fmax(m2, smm[w][2]), m3 = fmin(m3, smm[w][3]);
+        cnt += smm[w][4];
+      }
+      mm_s[0] = m0, mm_s[1] = -m1, mm_s[2] = m2, mm_s[3] = -m3, mm_s[4] = cnt;
+      if (blockIdx.x == 0 && a.mm_out) {
+        a.mm_out[0] = m0, a.mm_out[1] = -m1, a.mm_out[2] = m2, a.mm_out[3] = -m3, a.mm_out[4] = cnt;
+      }
+    }
+  }
+  __syncthreads();
+  const double mm[4] = {mm_s[0], mm_s[1], mm_s[2], mm_s[3]};
   int lid = 0;
 #pragma unroll
   for (int l = 1; l < MALIO_MAX_LIDAR; l++)
@@ -715,7 +761,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   double u[12], hs = 0, r = 1;
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
-  if (selected) point_row(a, i, lid, u, hs, r);
+  if (selected) point_row(a, mm, i, lid, u, hs, r);
   if (a.rows && in) {
     double *row = a.rows + (size_t)i * 14;
 #pragma unroll
@@ -1007,18 +1053,18 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
       hipLaunchKernelGGL(k_knn_nl<NL1_G>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, a,
                          view_of(c->nl1));
       prof_mark(c, "k_knn");
-      hipLaunchKernelGGL(k_knn_l2, dim3(nb), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
-      prof_mark(c, "k_knn_l2");
     }
-    hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a);
+    hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
     prof_mark(c, "k_plane");
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_reuse");
   }
-  hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, c->stream, c->d_blockmm, nb, c->prm.extrinsic_est_en,
-                     d_minmax4_out);
-  prof_mark(c, "k_minmax_reduce");
+  if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
+    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, c->stream, c->d_blockmm, nb, c->prm.extrinsic_est_en,
+                       d_minmax4_out);
+    prof_mark(c, "k_minmax_reduce");
+  }
   MALIO_HIP(hipGetLastError());
   // matrix form of the same state for stage 2
   PassConst &pc = c->pc;
@@ -1043,7 +1089,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   return MALIO_OK;
 }
 
-int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_sums_out, bool want_rows) {
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows) {
   Pass2Args a;
   a.N = c->N, a.L = c->prm.lid_num, a.extrinsic_est_en = c->prm.extrinsic_est_en;
   a.scan = c->d_scan, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.ucov = c->d_ucov, a.trace = c->d_trace, a.sel = c->d_sel;
@@ -1054,6 +1100,7 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_sums_out, bool wan
   a.wc.point_cov_max = c->prm.point_cov_max, a.wc.point_cov_min = c->prm.point_cov_min;
   a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
   a.minmax4 = d_minmax4_in;
+  a.blockmm = c->d_blockmm, a.nb_mm = (c->N + BLK - 1) / BLK, a.mm_out = d_mm_out;
   a.partials = c->d_partials;
   a.rows = nullptr;
   if (want_rows) {
