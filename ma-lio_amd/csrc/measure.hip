@@ -771,11 +771,12 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   }
   double rc = r;
   if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
-  double rinv = 1.0 / rc;
+  // one reciprocal instead of 12 f64 divisions (the reference divides, esekfom.hpp:627; the difference is one
+  // rounding per entry, far below the summation-order noise of the 1e5-term sums)
+  const double rinv = selected ? 1.0 / rc : 0.0;
 #pragma unroll
-  for (int k = 0; k < 12; k++) X[threadIdx.x][k] = u[k], Y[threadIdx.x][k] = selected ? u[k] / rc : 0.0;
+  for (int k = 0; k < 12; k++) X[threadIdx.x][k] = u[k], Y[threadIdx.x][k] = u[k] * rinv;
   X[threadIdx.x][12] = hs;
-  (void)rinv;
   unsigned long long bal = __ballot(selected);
   __shared__ int wcnt[BLK / 64];
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
@@ -798,13 +799,23 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       ra = m6[e - 90][0], cb = m6[e - 90][1], xx = true;
     }
     const int p0 = half * 128;
+    // 4 independent accumulators: a single f64 FMA chain of 128 would serialise on the FMA latency.
+    // (fixed association, so the result is still deterministic run to run)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (xx) {
-#pragma unroll 8
-      for (int p = p0; p < p0 + 128; p++) acc += X[p][ra] * X[p][cb];
+#pragma unroll 4
+      for (int p = p0; p < p0 + 128; p += 4) {
+        a0 += X[p][ra] * X[p][cb], a1 += X[p + 1][ra] * X[p + 1][cb];
+        a2 += X[p + 2][ra] * X[p + 2][cb], a3 += X[p + 3][ra] * X[p + 3][cb];
+      }
     } else {
-#pragma unroll 8
-      for (int p = p0; p < p0 + 128; p++) acc += Y[p][ra] * X[p][cb];
+#pragma unroll 4
+      for (int p = p0; p < p0 + 128; p += 4) {
+        a0 += Y[p][ra] * X[p][cb], a1 += Y[p + 1][ra] * X[p + 1][cb];
+        a2 += Y[p + 2][ra] * X[p + 2][cb], a3 += Y[p + 3][ra] * X[p + 3][cb];
+      }
     }
+    acc = (a0 + a1) + (a2 + a3);
   } else if (e == NSUM - 1) {
     acc = half == 0 ? (double)(wcnt[0] + wcnt[1]) : (double)(wcnt[2] + wcnt[3]);
   }
