@@ -171,8 +171,12 @@ def main():
         kt = {k: float(np.mean(v)) for k, v in per.items()}
         dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
         achieved = ALG_BYTES_SEARCH_PASS * N / (dom_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC run of this same workload, if any
+        tj = os.path.join(ROOT, "profiles", "round1", "r01c_pmc_traffic.json")
+        if args.config == 2 and os.path.exists(tj):
+            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * N, "kernel_ms": dom_ms,
                     "kernel_event_ms": kt}
     if distributed:
