@@ -140,10 +140,20 @@ int malio_map_size(malio_handle_t h, int *out_size);
  * out_pts [n*k], out_d2 [n*k] (INFINITY-padded), out_count [n]. */
 int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,
                          float *out_d2, int *out_count);
-/* ikdtree.Add_Points(PointToAdd, downsample_on)      laserMapping.cpp:443-444 / ikd_Tree.cpp:478-584 */
+/* ikdtree.Add_Points(PointToAdd, downsample_on)      laserMapping.cpp:443-444 / ikd_Tree.cpp:478-584.
+ * downsample_on != 0: per voxel of edge params.filter_size_map (set_downsample_param, laserMapping.cpp:1005) the
+ * reference's keeper rule is replayed in input order (one GPU thread per voxel, all voxels in parallel);
+ * *out_added = the reference's return value (number of insertions performed; 0 on the no-downsample branch).
+ * Map point indices change: read Nearest_Points (malio_scan_get) BEFORE calling this, as map_incremental does.
+ * Only x, y, z, normal_y of a map point are stored (the fields the hot path and Add_Points read). */
 int malio_map_add(malio_handle_t h, const malio_point_t *pts, int n, int downsample_on, int *out_added);
-/* ikdtree.Delete_Point_Boxes(cub_needrm)             laserMapping.cpp:223 / ikd_Tree.cpp:643-669 */
+/* ikdtree.Delete_Point_Boxes(cub_needrm)             laserMapping.cpp:223 / ikd_Tree.cpp:643-669.
+ * A point is inside a box iff vertex_min <= p < vertex_max on every axis (ikd_Tree.cpp:807,1263-1274).
+ * *out_deleted = number of points removed. */
 int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, int *out_deleted);
+/* ikdtree.flatten(Root_Node, PCL_Storage, NOT_RECORD) laserMapping.cpp:1018-1019 (map publishing / saving).
+ * Copies min(cap, size) valid points in map order, *out_n = size. Order differs from the tree's traversal. */
+int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);
 
 /* ---- per scan ------------------------------------------------------------------------------- */
 /* replaces the per-scan globals h_share_model reads: feats_down_body (laserMapping.cpp:86,982),

@@ -18,7 +18,7 @@ ERR_NO_DEVICE = -1
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -61,12 +61,33 @@ class MeasureOut(C.Structure):  # malio_measure_out_t
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7,
+    looked up by FILE name `libamdhip64.so`); if /opt/rocm's copy is mapped first, torch later maps its own next
+    to it and its device init fails ("No HIP GPUs are available"). Mapping torch's copy first makes the loader
+    satisfy our DT_NEEDED libamdhip64.so.7 with it, in whichever order the two are used. No torch -> system HIP."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         _lib = C.CDLL(LIB_PATH)
         _lib.malio_version.restype = C.c_char_p
         _lib.malio_last_error.restype = C.c_char_p
@@ -176,6 +197,30 @@ class Engine:
     def map_build(self, pts12):
         pts12 = np.ascontiguousarray(pts12, np.float32)
         self._chk(lib().malio_map_build(self.h, _p(pts12, Point), pts12.shape[0]), "malio_map_build")
+
+    def map_add(self, pts12, downsample_on=True):
+        """ikdtree.Add_Points: returns the reference's return value (insertions performed)."""
+        pts12 = np.ascontiguousarray(pts12, np.float32).reshape(-1, 12)
+        added = C.c_int(0)
+        self._chk(lib().malio_map_add(self.h, _p(pts12, Point), pts12.shape[0], int(bool(downsample_on)),
+                                      C.byref(added)), "malio_map_add")
+        return added.value
+
+    def map_delete_boxes(self, boxes6):
+        """ikdtree.Delete_Point_Boxes: boxes6 [nb, 6] = vertex_min xyz, vertex_max xyz. Returns #deleted."""
+        boxes6 = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+        deleted = C.c_int(0)
+        self._chk(lib().malio_map_delete_boxes(self.h, boxes6.ctypes.data_as(C.c_void_p), boxes6.shape[0],
+                                               C.byref(deleted)), "malio_map_delete_boxes")
+        return deleted.value
+
+    def map_get(self):
+        """ikdtree.flatten: [n, 12] valid map points (x, y, z, normal_y populated)."""
+        n = self.map_size()
+        out = np.zeros((max(n, 1), 12), np.float32)
+        got = C.c_int(0)
+        self._chk(lib().malio_map_get(self.h, _p(out, Point), n, C.byref(got)), "malio_map_get")
+        return out[:n]
 
     def map_size(self):
         n = C.c_int(0)

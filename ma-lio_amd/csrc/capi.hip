@@ -118,6 +118,7 @@ int malio_destroy(malio_handle_t h) {
   free_nlist(c->nl1);
   free_nlist(c->nl2);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm), fr(c->d_ny);
+  fr(c->d_map_alt), free_grid(c->vox);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
@@ -168,13 +169,13 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
     MALIO_HIP(hipMalloc(&c->d_map_in, sizeof(float4) * c->cap_map_in));
   }
   MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  int rc = build_nlist(c, c->d_map_in, n, c->cell, c->nl1);
-  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, n, 2.0f * std::max(c->cell, 1.1180341f), c->nl2);
+  c->map_n = n;
+  c->vox_valid = false;
+  int rc = map_rebuild_search(c);
   (void)hipStreamSynchronize(c->stream);
   (void)hipHostFree(stage);
-  if (rc != MALIO_OK) return rc;
-  c->map_n = n;
-  return MALIO_OK;
+  if (rc != MALIO_OK) c->map_n = 0;
+  return rc;
 }
 
 int malio_map_size(malio_handle_t h, int *out_size) {
@@ -231,15 +232,35 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
   return MALIO_OK;
 }
 
-int malio_map_add(malio_handle_t h, const malio_point_t *, int, int, int *) {
-  if (check(h)) return MALIO_ERR_BAD_ARG;
-  h->err = "malio_map_add: not implemented in this round (SURVEY.md §8 f-1)";
-  return MALIO_ERR_BAD_ARG;
+int malio_map_add(malio_handle_t h, const malio_point_t *pts, int n, int downsample_on, int *out_added) {
+  if (check(h) || n < 0 || (n > 0 && !pts)) return MALIO_ERR_BAD_ARG;
+  std::vector<float4> stage((size_t)n);
+  for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+  return map_add(h, stage.data(), n, downsample_on, out_added);
 }
-int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *, int, int *) {
-  if (check(h)) return MALIO_ERR_BAD_ARG;
-  h->err = "malio_map_delete_boxes: not implemented in this round (SURVEY.md §8 f-1)";
-  return MALIO_ERR_BAD_ARG;
+
+int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, int *out_deleted) {
+  if (check(h) || nb < 0 || (nb > 0 && !boxes)) return MALIO_ERR_BAD_ARG;
+  return map_delete_boxes(h, boxes, nb, out_deleted);
+}
+
+int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
+  if (check(h) || !out_n || cap < 0 || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  *out_n = c->map_n;
+  int n = std::min(cap, c->map_n);
+  if (n <= 0) return MALIO_OK;
+  MALIO_HIP(hipSetDevice(c->device));
+  std::vector<float4> mp((size_t)n);
+  MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    malio_point_t p;
+    memset(&p, 0, sizeof(p));
+    p.x = mp[i].x, p.y = mp[i].y, p.z = mp[i].z, p._pad0 = 1.f, p.normal_y = mp[i].w;
+    out[i] = p;
+  }
+  return MALIO_OK;
 }
 
 // ---- scan -----------------------------------------------------------------------------------------
@@ -305,6 +326,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   MALIO_HIP(hipMemsetAsync(c->d_sel, 0, (size_t)n, c->stream));
   MALIO_HIP(hipMemsetAsync(c->d_nfound, 0, (size_t)n, c->stream));
   MALIO_HIP(hipMemsetAsync(c->d_nbr, 0xFF, sizeof(u32) * 5 * (size_t)n, c->stream));
+  c->nbr_epoch = c->map_epoch;
   MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
   MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
@@ -413,6 +435,10 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(plane.data(), c->d_plane, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
   std::vector<float4> near;
+  if (nearest && c->nbr_epoch != c->map_epoch) {
+    c->err = "malio_scan_get: the map changed after the last search pass; read Nearest_Points before map_add/delete";
+    return MALIO_ERR_BAD_ARG;
+  }
   if (nearest) {
     float4 *d_near = nullptr;
     MALIO_HIP(hipMalloc(&d_near, sizeof(float4) * 5 * (size_t)N));

@@ -48,6 +48,23 @@ struct NList {
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
 };
 
+#if defined(__HIP__)
+// cell directory hashing shared by every .hip file (measure.hip keeps identical _d copies next to its hot loops)
+__device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
+  const u64 B = 1ull << 20;
+  return ((u64)(ix + (long long)B) & 0x1FFFFF) | (((u64)(iy + (long long)B) & 0x1FFFFF) << 21) |
+         (((u64)(iz + (long long)B) & 0x1FFFFF) << 42);
+}
+__device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (7 VALU ops); == hash_key_d()
+  u32 lo = (u32)k, hi = (u32)(k >> 32);
+  u32 h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 13;
+  return h;
+}
+#endif
+
 // Per-LiDAR constants of one pass (all double; rotation matrices row-major).
 struct LidarConst {
   double Rl[9], tl[3];    // extrinsic of this LiDAR (iterated)   q_l, t_l
@@ -84,7 +101,12 @@ struct Ctx {
   // map
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
-  size_t cap_map_in = 0;
+  float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
+  size_t cap_map_in = 0, cap_map_alt = 0;
+  CellGrid vox;  // map grouped by downsample voxel (edge filter_size_map), rebuilt by map_add when stale
+  bool vox_valid = false;
+  int map_epoch = 0;   // bumped by every change of the map array (indices in d_nbr refer to one epoch)
+  int nbr_epoch = 0;   // epoch d_nbr was filled in
   int map_n = 0;
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
@@ -151,10 +173,17 @@ struct Ctx {
   } while (0)
 
 // group `n` device points (float4, xyz used) by spatial-hash cell into `g` (allocates/grows g's buffers)
-int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig = nullptr);
+int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig = nullptr,
+                  float div_cell = 0.f);  // div_cell > 0: cell index = floor(x / div_cell) (ikd-Tree voxel rule)
+int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n);  // d_tiles: [(n+1023)/1024 + 1]
 void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);
+
+// map_update.hip
+int map_add(Ctx *c, const float4 *h_pts, int n, int downsample_on, int *out_added);
+int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
+int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n]
 
 // measure.hip
 int measure_alloc(Ctx *c);

@@ -10,27 +10,19 @@
 
 namespace malio {
 
-__device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
-  const u64 B = 1ull << 20;
-  return ((u64)(ix + (long long)B) & 0x1FFFFF) | (((u64)(iy + (long long)B) & 0x1FFFFF) << 21) |
-         (((u64)(iz + (long long)B) & 0x1FFFFF) << 42);
-}
-__device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (7 VALU ops); == hash_key_d()
-  u32 lo = (u32)k, hi = (u32)(k >> 32);
-  u32 h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
-  h ^= h >> 15;
-  h *= 0xC2B2AE3Du;
-  h ^= h >> 13;
-  return h;
-}
-
 // Pass 1: insert every point's cell key into a big scratch table, take a rank inside the cell.
-__global__ void __launch_bounds__(BLK) k_gbc_insert(const float4 *__restrict__ pts, int n, float inv_c, u64 *keys,
-                                                    u32 *cnt, u32 mask, u32 *slot_of, u32 *rank_of, u32 *ncells) {
+__global__ void __launch_bounds__(BLK) k_gbc_insert(const float4 *__restrict__ pts, int n, float inv_c, float div_c,
+                                                    u64 *keys, u32 *cnt, u32 mask, u32 *slot_of, u32 *rank_of,
+                                                    u32 *ncells) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  int ix = (int)floorf(p.x * inv_c), iy = (int)floorf(p.y * inv_c), iz = (int)floorf(p.z * inv_c);
+  int ix, iy, iz;
+  if (div_c > 0.f) {  // voxel index exactly as ikd_Tree.cpp:494-499 forms it: floor(x / downsample_size)
+    ix = (int)floorf(p.x / div_c), iy = (int)floorf(p.y / div_c), iz = (int)floorf(p.z / div_c);
+  } else {
+    ix = (int)floorf(p.x * inv_c), iy = (int)floorf(p.y * inv_c), iz = (int)floorf(p.z * inv_c);
+  }
   u64 key = cell_key(ix, iy, iz);
   u32 s = hash_key(key) & mask;
   while (true) {
@@ -164,7 +156,7 @@ void free_grid(CellGrid &g) {
   g = CellGrid();
 }
 
-static int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n) {
+int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n) {
   int ntiles = (n + 1023) / 1024;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(BLK), 0, c->stream, d_in, d_out, d_tiles, n);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, c->stream, d_tiles, ntiles);
@@ -172,7 +164,8 @@ static int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles,
   return MALIO_OK;
 }
 
-int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig) {
+int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig,
+                  float div_cell) {
   if (n <= 0) {
     g.n = 0;
     return MALIO_OK;
@@ -192,8 +185,8 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
   MALIO_HIP(hipMemsetAsync(ncells, 0, sizeof(u32), c->stream));
   int nb = (n + BLK - 1) / BLK;
-  hipLaunchKernelGGL(k_gbc_insert, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, inv_cell, keys, cnt, tbig - 1, slot_of,
-                     rank_of, ncells);
+  hipLaunchKernelGGL(k_gbc_insert, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, inv_cell, div_cell, keys, cnt, tbig - 1,
+                     slot_of, rank_of, ncells);
   exclusive_scan_u32(c, cnt, start, tiles, (int)tbig);
   if ((size_t)n > g.cap_pts) {
     if (g.pts) (void)hipFree(g.pts);

@@ -1,0 +1,349 @@
+// Map maintenance on the GPU: the two ikd-Tree mutators the mapping loop calls once per scan.
+//   Add_Points(PointToAdd, downsample_on)   ikd_Tree.cpp:478-584  (laserMapping.cpp:443-444)
+//   Delete_Point_Boxes(cub_needrm)          ikd_Tree.cpp:643-669  (laserMapping.cpp:223)
+//
+// The reference walks the new points ONE BY ONE; each step reads the tree state the previous steps left.
+// That dependency only exists between points of the same downsample voxel, so the work is sharded by voxel:
+// one thread replays, in input order, the steps of the new points that fall into its voxel against the stored
+// points of that voxel, and every voxel runs in parallel. Outputs are two flag arrays (stored point deleted /
+// new point kept); a prefix-sum compaction then writes the next map array (survivors in their old order, then
+// the kept new points in input order) and the neighbour lists of both search levels are rebuilt from it.
+//
+// Keeper rule of one step (ikd_Tree.cpp:504-528), restated order-free. With p the new point, S the stored
+// points inside the voxel box, "near" meaning calc_dist(q, mid) < downsample_size/8 (a SQUARED distance compared
+// with a length: the reference's quirk, kept):
+//   - some point of {p} + S is near  ->  the near point of lowest normal_y wins
+//   - otherwise                      ->  the point closest to the voxel centre wins
+// The reference's loop resolves exact ties by visiting order (p first, then S in tree-traversal order, which is
+// not reproducible outside the tree); here ties go to p, then to the lowest map index. Then
+// (ikd_Tree.cpp:529-537): if |S| > 1 or the winner coincides with p (same_point, 1e-6 per axis), the box is
+// emptied and the winner inserted; otherwise nothing changes.
+#include "malio_internal.hpp"
+
+namespace malio {
+
+namespace {
+
+__device__ __forceinline__ bool vox_find(const Cell *__restrict__ table, u32 tmask, u64 key, u32 &start, u32 &count) {
+  u32 s = hash_key(key) & tmask;
+  while (true) {
+    Cell e = table[s];
+    if (e.key == key) {
+      start = e.start, count = e.count;
+      return true;
+    }
+    if (e.key == EMPTY_KEY) return false;
+    s = (s + 1) & tmask;
+  }
+}
+
+// ikd_Tree.cpp:1694-1699 (float, left to right; the build has -ffp-contract=off)
+__device__ __forceinline__ float calc_dist3(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+struct Winner {
+  float x, y, z, cov, dist;
+  u32 rank;  // 0 = the new point, 1 + map index = stored point, 0xFFFFFFFF = the new point kept earlier in this call
+  bool near;
+};
+
+// does candidate b displace the current winner a?
+__device__ __forceinline__ bool displaces(const Winner &a, const Winner &b) {
+  if (a.near != b.near) return b.near;
+  if (a.near) return b.cov < a.cov || (b.cov == a.cov && b.rank < a.rank);
+  return b.dist < a.dist || (b.dist == a.dist && b.rank < a.rank);
+}
+
+// One thread per occupied voxel of the NEW points.
+__global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable, u32 ntsize,
+                                                 const u32 *__restrict__ norig, const float4 *__restrict__ newp,
+                                                 const Cell *__restrict__ mtable, u32 mtmask,
+                                                 const u32 *__restrict__ morig, const float4 *__restrict__ mapp,
+                                                 int map_n, float ds, unsigned char *del, u32 *addf, u32 *counter) {
+  u32 slot = blockIdx.x * BLK + threadIdx.x;
+  if (slot >= ntsize) return;
+  Cell nc = ntable[slot];
+  if (nc.key == EMPTY_KEY || nc.count == 0) return;
+  u32 es = 0, ec = 0;
+  if (map_n > 0) vox_find(mtable, mtmask, nc.key, es, ec);
+  const float near_th = ds / 8;  // ikd_Tree.cpp:510
+  const u32 NONE = 0xFFFFFFFFu;
+  u32 alive = NONE;  // new point of this voxel currently in the map
+  u32 last = 0, adds = 0;
+  for (u32 step = 0; step < nc.count; step++) {
+    u32 cur = NONE;  // next new point in input order
+    for (u32 j = 0; j < nc.count; j++) {
+      u32 o = norig[nc.start + j];
+      if ((step == 0 || o > last) && o < cur) cur = o;
+    }
+    last = cur;
+    float4 p = newp[cur];
+    // ikd_Tree.cpp:494-502: box and centre of the voxel, with the reference's float/double mix
+    float bmin[3], bmax[3], mid[3];
+    const float pv[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      bmin[a] = (float)(floor((double)(pv[a] / ds)) * (double)ds);
+      bmax[a] = bmin[a] + ds;
+      mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+    }
+    Winner w;
+    w.x = p.x, w.y = p.y, w.z = p.z, w.cov = p.w, w.rank = 0;
+    w.dist = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+    w.near = w.dist < near_th;
+    u32 inbox = 0;
+    for (u32 j = 0; j < ec; j++) {
+      u32 mi = morig[es + j];
+      if (del[mi]) continue;
+      float4 q = mapp[mi];
+      // Search_by_range / Delete_by_range leaf test (ikd_Tree.cpp:1263-1274, :807): min <= q < max
+      if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
+        continue;
+      inbox++;
+      Winner b;
+      b.x = q.x, b.y = q.y, b.z = q.z, b.cov = q.w, b.rank = 1u + mi;
+      b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+      b.near = b.dist < near_th;
+      if (displaces(w, b)) w = b;
+    }
+    if (alive != NONE) {
+      float4 q = newp[alive];
+      if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+        inbox++;
+        Winner b;
+        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = q.w, b.rank = NONE;
+        b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+        b.near = b.dist < near_th;
+        if (displaces(w, b)) w = b;
+      }
+    }
+    // ikd_Tree.cpp:1688-1691
+    bool same = fabs((double)(p.x - w.x)) < 1e-6 && fabs((double)(p.y - w.y)) < 1e-6 && fabs((double)(p.z - w.z)) < 1e-6;
+    if (inbox > 1 || same) {
+      for (u32 j = 0; j < ec; j++) {
+        u32 mi = morig[es + j];
+        if (del[mi] || w.rank == 1u + mi) continue;
+        float4 q = mapp[mi];
+        if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
+          del[mi] = 1;
+      }
+      if (alive != NONE && w.rank != NONE) {
+        float4 q = newp[alive];
+        if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+          addf[alive] = 0;
+          alive = NONE;
+        }
+      }
+      if (w.rank == 0) {
+        addf[cur] = 1;
+        alive = cur;
+      }
+      adds++;
+    }
+  }
+  if (adds) atomicAdd(counter, adds);
+}
+
+__global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ mapp, int n,
+                                                    const malio_box_t *__restrict__ boxes, int nb, unsigned char *del,
+                                                    u32 *counter) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  bool hit = false;
+  if (i < n) {
+    float4 q = mapp[i];
+    for (int b = 0; b < nb; b++) {
+      const malio_box_t bx = boxes[b];
+      hit = hit || (bx.vertex_min[0] <= q.x && bx.vertex_max[0] > q.x && bx.vertex_min[1] <= q.y &&
+                    bx.vertex_max[1] > q.y && bx.vertex_min[2] <= q.z && bx.vertex_max[2] > q.z);
+    }
+    del[i] = hit ? 1 : 0;
+  }
+  unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (u32)__popcll(m));
+}
+
+__global__ void __launch_bounds__(BLK) k_keep_flags(const unsigned char *__restrict__ del, int n, u32 *keep) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i <= n) keep[i] = (i < n && !del[i]) ? 1u : 0u;  // keep[n] = 0: the scan then leaves the total at [n]
+}
+
+__global__ void __launch_bounds__(BLK) k_compact(const float4 *__restrict__ src, const u32 *__restrict__ flag,
+                                                 const u32 *__restrict__ pos, int n, const u32 *__restrict__ base,
+                                                 float4 *dst) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && flag[i]) dst[(base ? *base : 0u) + pos[i]] = src[i];
+}
+
+int ensure_alt(Ctx *c, size_t need) {
+  if (need > c->cap_map_alt) {
+    if (c->d_map_alt) (void)hipFree(c->d_map_alt);
+    c->d_map_alt = nullptr;
+    c->cap_map_alt = need + need / 8 + 1024;
+    MALIO_HIP(hipMalloc(&c->d_map_alt, sizeof(float4) * c->cap_map_alt));
+  }
+  return MALIO_OK;
+}
+
+void swap_maps(Ctx *c) {
+  std::swap(c->d_map_in, c->d_map_alt);
+  std::swap(c->cap_map_in, c->cap_map_alt);
+}
+
+struct Scratch {  // freed on every exit path
+  std::vector<void *> p;
+  ~Scratch() {
+    for (void *q : p) (void)hipFree(q);
+  }
+  template <class T>
+  hipError_t get(T **out, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
+    if (e == hipSuccess) p.push_back(q);
+    *out = (T *)q;
+    return e;
+  }
+};
+
+}  // namespace
+
+int map_rebuild_search(Ctx *c) {
+  c->map_epoch++;
+  if (c->map_n <= 0) return MALIO_OK;
+  int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1);
+  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, 2.0f * std::max(c->cell, 1.1180341f), c->nl2);
+  return rc;
+}
+
+int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_added) {
+  MALIO_HIP(hipSetDevice(c->device));
+  if (out_added) *out_added = 0;
+  if (m <= 0) return MALIO_OK;
+  const float ds = (float)c->prm.filter_size_map;
+  Scratch sc;
+  float4 *d_new = nullptr;
+  MALIO_HIP(sc.get(&d_new, (size_t)m));
+  MALIO_HIP(hipMemcpyAsync(d_new, h_pts, sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+  const int n0 = c->map_n;
+  // set_downsample_param(filter_size_map_min) is what arms DOWNSAMPLE_SWITCH (ikd_Tree.cpp:486); a non-positive
+  // size means it was never armed
+  if (!downsample_on || !(ds > 0.f)) {
+    int rc = ensure_alt(c, (size_t)n0 + m);
+    if (rc != MALIO_OK) return rc;
+    if (n0 > 0)
+      MALIO_HIP(hipMemcpyAsync(c->d_map_alt, c->d_map_in, sizeof(float4) * (size_t)n0, hipMemcpyDeviceToDevice, c->stream));
+    MALIO_HIP(hipMemcpyAsync(c->d_map_alt + n0, d_new, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    swap_maps(c);
+    c->map_n = n0 + m;
+    c->vox_valid = false;
+    return map_rebuild_search(c);  // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
+  }
+  int rc;
+  if (!c->vox_valid && n0 > 0) {
+    rc = group_by_cell(c, c->d_map_in, n0, 1.f / ds, c->vox, nullptr, ds);
+    if (rc != MALIO_OK) return rc;
+    c->vox_valid = true;
+  }
+  CellGrid gnew;
+  rc = group_by_cell(c, d_new, m, 1.f / ds, gnew, nullptr, ds);
+  if (rc != MALIO_OK) {
+    free_grid(gnew);
+    return rc;
+  }
+  unsigned char *del = nullptr;
+  u32 *addf = nullptr, *keep = nullptr, *kpos = nullptr, *apos = nullptr, *tiles = nullptr, *counter = nullptr;
+  const int nt = std::max(n0, m) + 1;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = sc.get(&del, (size_t)n0 + 1);
+  if (e == hipSuccess) e = sc.get(&addf, (size_t)m + 1);
+  if (e == hipSuccess) e = sc.get(&keep, (size_t)n0 + 1);
+  if (e == hipSuccess) e = sc.get(&kpos, (size_t)n0 + 1);
+  if (e == hipSuccess) e = sc.get(&apos, (size_t)m + 1);
+  if (e == hipSuccess) e = sc.get(&tiles, (size_t)(nt + 1023) / 1024 + 2);
+  if (e == hipSuccess) e = sc.get(&counter, 1);
+  if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)n0 + 1, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1), c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(counter, 0, sizeof(u32), c->stream);
+  if (e != hipSuccess) {
+    free_grid(gnew);
+    MALIO_HIP(e);
+  }
+  const u32 ntsize = gnew.tmask + 1;
+  hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
+                     d_new, c->vox.table, c->vox.tmask, c->vox.orig, c->d_map_in, n0, ds, del, addf, counter);
+  hipLaunchKernelGGL(k_keep_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, del, n0, keep);
+  exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
+  exclusive_scan_u32(c, addf, apos, tiles, m + 1);
+  u32 h_tot[3] = {0, 0, 0};
+  e = hipMemcpyAsync(&h_tot[0], kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[2], counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    free_grid(gnew);
+    MALIO_HIP(e);
+  }
+  const int n1 = (int)(h_tot[0] + h_tot[1]);
+  rc = ensure_alt(c, (size_t)n1);
+  if (rc != MALIO_OK) {
+    free_grid(gnew);
+    return rc;
+  }
+  if (n0 > 0)
+    hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
+                       (const u32 *)nullptr, c->d_map_alt);
+  hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, addf, apos, m, kpos + n0,
+                     c->d_map_alt);
+  e = hipStreamSynchronize(c->stream);
+  free_grid(gnew);
+  MALIO_HIP(e);
+  swap_maps(c);
+  c->map_n = n1;
+  c->vox_valid = false;
+  if (out_added) *out_added = (int)h_tot[2];
+  return map_rebuild_search(c);
+}
+
+int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted) {
+  MALIO_HIP(hipSetDevice(c->device));
+  if (out_deleted) *out_deleted = 0;
+  const int n0 = c->map_n;
+  if (nb <= 0 || n0 <= 0) return MALIO_OK;
+  Scratch sc;
+  malio_box_t *d_boxes = nullptr;
+  unsigned char *del = nullptr;
+  u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr, *counter = nullptr;
+  MALIO_HIP(sc.get(&d_boxes, (size_t)nb));
+  MALIO_HIP(sc.get(&del, (size_t)n0 + 1));
+  MALIO_HIP(sc.get(&keep, (size_t)n0 + 1));
+  MALIO_HIP(sc.get(&kpos, (size_t)n0 + 1));
+  MALIO_HIP(sc.get(&tiles, (size_t)(n0 + 1 + 1023) / 1024 + 2));
+  MALIO_HIP(sc.get(&counter, 1));
+  MALIO_HIP(hipMemcpyAsync(d_boxes, boxes, sizeof(malio_box_t) * (size_t)nb, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemsetAsync(counter, 0, sizeof(u32), c->stream));
+  hipLaunchKernelGGL(k_box_delete, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, d_boxes, nb, del,
+                     counter);
+  hipLaunchKernelGGL(k_keep_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, del, n0, keep);
+  exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
+  u32 h_tot[2] = {0, 0};
+  MALIO_HIP(hipMemcpyAsync(&h_tot[0], kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(&h_tot[1], counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  MALIO_HIP(hipGetLastError());
+  if (out_deleted) *out_deleted = (int)h_tot[1];
+  if (h_tot[1] == 0) return MALIO_OK;
+  int rc = ensure_alt(c, (size_t)h_tot[0]);
+  if (rc != MALIO_OK) return rc;
+  hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
+                     (const u32 *)nullptr, c->d_map_alt);
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  swap_maps(c);
+  c->map_n = (int)h_tot[0];
+  c->vox_valid = false;
+  return map_rebuild_search(c);
+}
+
+}  // namespace malio

@@ -1057,6 +1057,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
   const int nb = (c->N + BLK - 1) / BLK;
   if (converge) {
+    c->nbr_epoch = c->map_epoch;
     hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_transform");
     {

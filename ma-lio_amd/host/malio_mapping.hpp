@@ -95,6 +95,12 @@ class KdTreeGpu {
     h_.check(malio_map_delete_boxes(h_.get(), BoxPoints.data(), (int)BoxPoints.size(), &del), "Delete_Point_Boxes");
     return del;
   }
+  // ikdtree.flatten(ikdtree.Root_Node, ikdtree.PCL_Storage, NOT_RECORD)  :1018-1019 (valid points, map order)
+  void flatten(PointVector &Storage) const {
+    int n = size();
+    Storage.resize((size_t)n);
+    h_.check(malio_map_get(h_.get(), Storage.data(), n, &n), "flatten");
+  }
 
  private:
   Handle &h_;

@@ -229,3 +229,61 @@ class Spline:
                                 _p(imu_t, C.c_double), _p(imu_cov, C.c_double), imu_t.shape[0],
                                 _p(_f64(ext59), C.c_double), _p(_f64(lt59), C.c_double), _p(unc, C.c_double), cap)
         return pts, unc[:n].copy()
+
+
+class VoxMap:
+    """Flat-list restatement of Add_Points / Delete_Point_Boxes (oracle/orc_map.cpp)."""
+
+    def __init__(self, downsample):
+        lib().orc_vmap_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_vmap_create(C.c_float(downsample)))
+        self._pfx = "orc_vmap_"
+        self._l = lib()
+
+    def _f(self, name):
+        return getattr(self._l, self._pfx + name)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._f("destroy")(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def build(self, pts12):
+        pts12 = _f32(pts12)
+        self._f("build")(self.h, _p(pts12, C.c_float), pts12.shape[0])
+
+    def size(self):
+        return self._f("size")(self.h)
+
+    def add(self, pts12, downsample_on=True):
+        pts12 = _f32(pts12).reshape(-1, 12)
+        return self._f("add")(self.h, _p(pts12, C.c_float), pts12.shape[0], int(bool(downsample_on)))
+
+    def delete_boxes(self, boxes6):
+        boxes6 = _f32(boxes6).reshape(-1, 6)
+        return self._f("delete_boxes")(self.h, _p(boxes6, C.c_float), boxes6.shape[0])
+
+    def flatten(self):
+        n = self.size()
+        out = np.zeros((max(n, 1), 12), np.float32)
+        got = self._f("flatten")(self.h, _p(out, C.c_float), n)
+        assert got == n
+        return out[:n]
+
+
+class RefTree(VoxMap):
+    """The REFERENCE's own ikd-Tree (oracle/_ref/libikd_ref.so, compiled from /root/reference in place)."""
+
+    def __init__(self, downsample):
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libikd_ref.so not built")
+        self._l = C.CDLL(REF_SO)
+        self._l.refikd_create.restype = C.c_void_p
+        self._pfx = "refikd_"
+        self.h = C.c_void_p(self._l.refikd_create(C.c_float(downsample)))
+
+    def size(self):
+        return self._l.refikd_validnum(self.h)

@@ -1,0 +1,195 @@
+"""Map maintenance: Add_Points / Delete_Point_Boxes.
+
+CPU part: the flat-list restatement (oracle/orc_map.cpp) against the reference's own ikd-Tree compiled from
+source (oracle/_ref). GPU part: the HIP map (malio_map_add / malio_map_delete_boxes / malio_map_get) against both,
+as SETS of valid points (the map order is an implementation detail on either side), followed by a k-NN check so
+the rebuilt search structure is covered too.
+"""
+import numpy as np
+import pytest
+
+
+def _pts(rng, n, lo, hi, cov_scale=0.01):
+    p = np.zeros((n, 12), np.float32)
+    p[:, :3] = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    p[:, 3] = 1.0
+    p[:, 5] = (rng.uniform(0.0, 1.0, n) * cov_scale).astype(np.float32)  # normal_y: the stored uncertainty
+    p[:, 8] = rng.uniform(0, 255, n).astype(np.float32)
+    return p
+
+
+def _as_set(p12):
+    """Sorted [n,4] view (x, y, z, normal_y) - the fields every implementation stores."""
+    a = np.ascontiguousarray(p12[:, [0, 1, 2, 5]], np.float32)
+    order = np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))
+    return a[order]
+
+
+def _script(seed, n0=4000, nadd=1500, rounds=4, ds=0.5, extent=12.0, faces=True):
+    """A mapping-loop-like call sequence: build, then per round add(downsample), add(no downsample), and
+    sometimes a box delete - with duplicates, near-centre points and voxel-boundary coordinates mixed in."""
+    rng = np.random.default_rng(seed)
+    ops = [("build", _pts(rng, n0, -extent, extent))]
+    for r in range(rounds):
+        a = _pts(rng, nadd, -extent - 2, extent + 2)
+        k = nadd // 10
+        # exact duplicates of stored/new points, points at voxel centres (near rule), points on voxel faces
+        a[:k, :3] = ops[0][1][rng.integers(0, n0, k), :3]
+        cen = (np.floor(a[k:2 * k, :3] / ds) * ds + ds / 2).astype(np.float32)
+        a[k:2 * k, :3] = cen + rng.uniform(-0.05, 0.05, size=(k, 3)).astype(np.float32)
+        if faces:
+            a[2 * k:3 * k, 0] = (np.floor(a[2 * k:3 * k, 0] / ds) * ds).astype(np.float32)
+        a[3 * k:4 * k] = a[4 * k:5 * k]  # repeated inside the same call
+        ops.append(("add", a, True))
+        ops.append(("add", _pts(rng, nadd // 5, -extent, extent), False))
+        if r % 2 == 1:
+            c = rng.uniform(-extent, extent, size=(2, 3)).astype(np.float32)
+            boxes = np.concatenate([c - 3.0, c + 3.0], axis=1).astype(np.float32)
+            boxes[0, :3] = np.floor(boxes[0, :3] / ds) * ds  # faces on the voxel lattice: the < / <= edges matter
+            ops.append(("del", boxes))
+    return ops
+
+
+def _run(target, ops):
+    rets = []
+    for op in ops:
+        if op[0] == "build":
+            target.build(op[1])
+        elif op[0] == "add":
+            rets.append(int(target.add(op[1], op[2])))
+        else:
+            rets.append(int(target.delete_boxes(op[1])))
+        rets.append(int(target.size()))
+    return rets
+
+
+@pytest.mark.parametrize("seed,ds", [(1, 0.5), (2, 0.5), (3, 0.3), (4, 0.25)])
+def test_restatement_matches_reference_tree(orc, seed, ds):
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built")
+    ops = _script(seed, ds=ds)
+    ref, port = orc.RefTree(ds), orc.VoxMap(ds)
+    r_ref, r_port = _run(ref, ops), _run(port, ops)
+    assert r_ref == r_port
+    np.testing.assert_array_equal(_as_set(ref.flatten()), _as_set(port.flatten()))
+
+
+def test_restatement_keeper_rule_units(orc):
+    """Hand-built voxel [0,0.5)^3: the near-centre / closest rules and the 'nothing happens' branch."""
+    ds = 0.5
+
+    def P(x, y, z, cov):
+        p = np.zeros((1, 12), np.float32)
+        p[0, :3] = (x, y, z)
+        p[0, 5] = cov
+        return p
+
+    # neither near: d^2(stored) = 3*0.04 = 0.12, d^2(new) = 3*0.0225 = 0.0675 -> the new one is closer and replaces
+    m = orc.VoxMap(ds)
+    m.build(P(0.05, 0.05, 0.05, 0.5))        # voxel centre is (0.25, 0.25, 0.25)
+    assert m.add(P(0.40, 0.40, 0.40, 0.1), True) == 1
+    assert m.size() == 1 and np.allclose(m.flatten()[0, :3], 0.40)
+    # both near (d^2 < ds/8 = 0.0625): lower normal_y wins even when farther
+    m = orc.VoxMap(ds)
+    m.build(P(0.30, 0.30, 0.30, 0.9))
+    assert m.add(P(0.25, 0.25, 0.25, 0.95), True) == 0 and np.allclose(m.flatten()[0, :3], 0.30)
+    assert m.add(P(0.20, 0.20, 0.35, 0.1), True) == 1 and np.allclose(m.flatten()[0, :3], (0.20, 0.20, 0.35))
+    # two stored points: the box is always rewritten, even when a stored point wins
+    m = orc.VoxMap(ds)
+    m.build(np.concatenate([P(0.26, 0.25, 0.25, 0.2), P(0.05, 0.4, 0.1, 0.1)]))
+    assert m.add(P(0.45, 0.45, 0.45, 0.0), True) == 1
+    assert m.size() == 1 and np.allclose(m.flatten()[0, :3], (0.26, 0.25, 0.25))
+    # no-downsample branch returns 0 and appends
+    assert m.add(P(0.26, 0.25, 0.25, 0.2), False) == 0 and m.size() == 2
+    # box delete: min inclusive, max exclusive
+    assert m.delete_boxes(np.array([[0.26, 0.0, 0.0, 0.5, 0.5, 0.5]], np.float32)) == 2
+    m.build(P(0.26, 0.25, 0.25, 0.2))
+    assert m.delete_boxes(np.array([[0.0, 0.0, 0.0, 0.26, 0.5, 0.5]], np.float32)) == 0
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+class _GpuMap:
+    def __init__(self, capi, scenes, ds):
+        prm = dict(scenes.make_scene(cfg=1)["params"])
+        prm["filter_size_map"] = ds
+        self.e = capi.Engine(prm)
+
+    def build(self, p):
+        self.e.map_build(p)
+
+    def add(self, p, on):
+        return self.e.map_add(p, on)
+
+    def delete_boxes(self, b):
+        return self.e.map_delete_boxes(b)
+
+    def size(self):
+        return self.e.map_size()
+
+    def flatten(self):
+        return self.e.map_get()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,ds", [(1, 0.5), (2, 0.5), (3, 0.3), (5, 0.25)])
+def test_gpu_map_update_matches_oracle_and_reference(orc, capi, scenes, seed, ds):
+    # points exactly ON a voxel face: exact on the GPU for power-of-two lattices (the shipped 0.5 m); for other
+    # sizes a point within one ulp of a face may be attributed to the neighbouring voxel
+    ops = _script(seed, ds=ds, faces=float(np.log2(ds)).is_integer())
+    gpu, port = _GpuMap(capi, scenes, ds), orc.VoxMap(ds)
+    r_gpu, r_port = _run(gpu, ops), _run(port, ops)
+    assert r_gpu == r_port
+    got = _as_set(gpu.flatten())
+    np.testing.assert_array_equal(got, _as_set(port.flatten()))
+    if orc.have_ref():
+        ref = orc.RefTree(ds)
+        assert _run(ref, ops) == r_gpu
+        np.testing.assert_array_equal(got, _as_set(ref.flatten()))
+        # the rebuilt search structure answers like the reference tree after the same history
+        rng = np.random.default_rng(seed + 100)
+        q = _pts(rng, 2000, -10, 10)
+        _, d2_g, cnt_g = gpu.e.nearest_search(q, 5)
+        near = np.zeros((q.shape[0], 5, 12), np.float32)
+        d2_r = np.zeros((q.shape[0], 5), np.float32)
+        cnt_r = np.zeros(q.shape[0], np.int32)
+        import ctypes as C
+        ref._l.refikd_knn(ref.h, q.ctypes.data_as(C.POINTER(C.c_float)), q.shape[0], 5,
+                          near.ctypes.data_as(C.POINTER(C.c_float)), d2_r.ctypes.data_as(C.POINTER(C.c_float)),
+                          cnt_r.ctypes.data_as(C.POINTER(C.c_int)), 4)
+        # the GPU search is exact inside radius 2*cell (>= sqrt(5)); compare there
+        inside = d2_r < 5.0
+        np.testing.assert_array_equal(d2_g[inside], d2_r[inside])
+
+
+@pytest.mark.gpu
+def test_gpu_map_update_mapping_loop_scale(orc, capi, scenes):
+    """configs[0]-sized map, one scan's worth of additions: the measurement update keeps matching the oracle
+    after the map changed under it."""
+    sc = scenes.make_scene(cfg=1)
+    ds = float(sc["params"]["filter_size_map"])
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    port = orc.VoxMap(ds)
+    port.build(sc["map"])
+    rng = np.random.default_rng(7)
+    new = sc["map"][rng.integers(0, sc["map"].shape[0], 20000)].copy()
+    new[:, :3] += rng.normal(0, 0.2, size=(new.shape[0], 3)).astype(np.float32)
+    new[:, 5] = (rng.uniform(0, 1, new.shape[0]) * 0.01).astype(np.float32)
+    assert eng.map_add(new, True) == port.add(new, True)
+    assert eng.map_size() == port.size()
+    m_gpu, m_port = eng.map_get(), port.flatten()
+    np.testing.assert_array_equal(_as_set(m_gpu), _as_set(m_port))
+    # same measurement update on the updated map, both sides
+    o = orc.Oracle(sc["params"], threads=4, use_ref=True)
+    o.map_build(m_port)
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ro = o.h_share_model(sc["state0"], True)
+    rg = eng.measure(sc["state0"], True)
+    assert rg["M"] == ro["M"] and rg["valid"] == ro["valid"]
+    so, sg = o.scan_get(), eng.scan_get()
+    np.testing.assert_array_equal(sg["selected"], so["selected"])
+    np.testing.assert_array_equal(sg["res_last"][so["selected"] > 0], so["res_last"][so["selected"] > 0])
+    with pytest.raises(RuntimeError):
+        eng.map_add(new[:10], True)
+        eng.scan_get()  # Nearest_Points now refer to a map that no longer exists
