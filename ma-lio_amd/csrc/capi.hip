@@ -117,6 +117,7 @@ int malio_destroy(malio_handle_t h) {
   };
   free_nlist(c->nl1);
   free_nlist(c->nl2);
+  free_nl_scratch(c->nl_scratch);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm), fr(c->d_ny);
   fr(c->d_map_alt), free_grid(c->vox);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
@@ -171,6 +172,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   c->map_n = n;
   c->vox_valid = false;
+  c->map_epoch++;
   int rc = map_rebuild_search(c);
   (void)hipStreamSynchronize(c->stream);
   (void)hipHostFree(stage);

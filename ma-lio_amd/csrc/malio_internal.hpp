@@ -48,6 +48,13 @@ struct NList {
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
 };
 
+// scratch of build_nlist (open-addressing directory under construction), kept between rebuilds
+struct NlScratch {
+  u64 *keys = nullptr;
+  u32 *cnt = nullptr, *start = nullptr, *tiles = nullptr, *counters = nullptr;
+  u32 cap = 0;
+};
+
 #if defined(__HIP__)
 // cell directory hashing shared by every .hip file (measure.hip keeps identical _d copies next to its hot loops)
 __device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
@@ -99,6 +106,8 @@ struct Ctx {
   float cell = 1.125f, inv_cell = 1.f / 1.125f;
 
   // map
+  NlScratch nl_scratch;
+  bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
   float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
@@ -179,11 +188,13 @@ int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n)
 void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);
+void free_nl_scratch(NlScratch &s);
 
 // map_update.hip
 int map_add(Ctx *c, const float4 *h_pts, int n, int downsample_on, int *out_added);
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
-int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n]
+int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
+int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
 
 // measure.hip
 int measure_alloc(Ctx *c);

@@ -25,15 +25,21 @@ __global__ void __launch_bounds__(BLK) k_gbc_insert(const float4 *__restrict__ p
   }
   u64 key = cell_key(ix, iy, iz);
   u32 s = hash_key(key) & mask;
+  bool fresh = false;
   while (true) {
-    u64 old = atomicCAS(&keys[s], EMPTY_KEY, key);
+    u64 old = __builtin_nontemporal_load(&keys[s]);
     if (old == EMPTY_KEY) {
-      atomicAdd(ncells, 1u);
-      break;
+      old = atomicCAS(&keys[s], EMPTY_KEY, key);
+      if (old == EMPTY_KEY) {
+        fresh = true;
+        break;
+      }
     }
     if (old == key) break;
     s = (s + 1) & mask;
   }
+  unsigned long long m = __ballot(fresh);
+  if (fresh && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(ncells, (u32)__popcll(m));
   slot_of[i] = s;
   rank_of[i] = atomicAdd(&cnt[s], 1u);
 }
@@ -240,11 +246,17 @@ __global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts
         u64 key = cell_key(ix + dx, iy + dy, iz + dz);
         u32 s = hash_key(key) & mask;
         int probes = 0;
+        bool fresh = false;
         while (true) {
-          u64 old = atomicCAS(&keys[s], EMPTY_KEY, key);
+          // plain load first: most probes hit a slot that already holds the key (27 points-per-cell hits per
+          // slot), and a 64-bit CAS there is a wasted read-modify-write at L2
+          u64 old = __builtin_nontemporal_load(&keys[s]);
           if (old == EMPTY_KEY) {
-            atomicAdd(ncells, 1u);
-            break;
+            old = atomicCAS(&keys[s], EMPTY_KEY, key);
+            if (old == EMPTY_KEY) {
+              fresh = true;
+              break;
+            }
           }
           if (old == key) break;
           s = (s + 1) & mask;
@@ -254,6 +266,9 @@ __global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts
           }
         }
         atomicAdd(&cnt[s], 1u);
+        // one counter bump per wave instead of one per new cell (same-address atomics serialise)
+        unsigned long long m = __ballot(fresh);
+        if (fresh && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(ncells, (u32)__popcll(m));
       }
 }
 // pass B: place every point into the 27 lists (cursor = running fill count of the list)
@@ -275,6 +290,15 @@ __global__ void __launch_bounds__(BLK) k_nl_fill(const float4 *__restrict__ pts,
       }
 }
 
+void free_nl_scratch(NlScratch &s) {
+  if (s.keys) (void)hipFree(s.keys);
+  if (s.cnt) (void)hipFree(s.cnt);
+  if (s.start) (void)hipFree(s.start);
+  if (s.tiles) (void)hipFree(s.tiles);
+  if (s.counters) (void)hipFree(s.counters);
+  s = NlScratch();
+}
+
 void free_nlist(NList &nl) {
   if (nl.table) (void)hipFree(nl.table);
   if (nl.pts) (void)hipFree(nl.pts);
@@ -286,14 +310,19 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
   nl.inv_cf = 1.0f / nl.cf;
   // scratch table: halo cells are a few times the occupied ones; 8 slots per point keeps the load low
   u32 tbig = next_pow2((u32)std::max(4096, 8 * n));
-  u64 *keys = nullptr;
-  u32 *cnt = nullptr, *start = nullptr, *tiles = nullptr, *counters = nullptr;
   int ntiles = (tbig + 1023) / 1024;
-  MALIO_HIP(hipMalloc(&keys, sizeof(u64) * tbig));
-  MALIO_HIP(hipMalloc(&cnt, sizeof(u32) * tbig));
-  MALIO_HIP(hipMalloc(&start, sizeof(u32) * tbig));
-  MALIO_HIP(hipMalloc(&tiles, sizeof(u32) * (ntiles + 1)));
-  MALIO_HIP(hipMalloc(&counters, sizeof(u32) * 2));
+  NlScratch &sc = c->nl_scratch;  // kept across rebuilds: the map is rebuilt after every Add_Points
+  if (tbig > sc.cap) {
+    free_nl_scratch(sc);
+    MALIO_HIP(hipMalloc(&sc.keys, sizeof(u64) * tbig));
+    MALIO_HIP(hipMalloc(&sc.cnt, sizeof(u32) * tbig));
+    MALIO_HIP(hipMalloc(&sc.start, sizeof(u32) * tbig));
+    MALIO_HIP(hipMalloc(&sc.tiles, sizeof(u32) * (ntiles + 1)));
+    MALIO_HIP(hipMalloc(&sc.counters, sizeof(u32) * 2));
+    sc.cap = tbig;
+  }
+  u64 *keys = sc.keys;
+  u32 *cnt = sc.cnt, *start = sc.start, *tiles = sc.tiles, *counters = sc.counters;
   hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
   MALIO_HIP(hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream));
@@ -331,7 +360,6 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
                      nl.table, tsize - 1);
   MALIO_HIP(hipStreamSynchronize(c->stream));
   nl.tmask = tsize - 1, nl.ncells = h_cnt[0], nl.total = total;
-  (void)hipFree(keys), (void)hipFree(cnt), (void)hipFree(start), (void)hipFree(tiles), (void)hipFree(counters);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }

@@ -208,8 +208,13 @@ struct Scratch {  // freed on every exit path
 
 }  // namespace
 
+int map_sync_search(Ctx *c) {
+  if (!c->search_dirty) return MALIO_OK;
+  return map_rebuild_search(c);
+}
+
 int map_rebuild_search(Ctx *c) {
-  c->map_epoch++;
+  c->search_dirty = false;
   if (c->map_n <= 0) return MALIO_OK;
   int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1);
   if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, 2.0f * std::max(c->cell, 1.1180341f), c->nl2);
@@ -238,7 +243,8 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
     swap_maps(c);
     c->map_n = n0 + m;
     c->vox_valid = false;
-    return map_rebuild_search(c);  // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
+    c->map_epoch++, c->search_dirty = true;
+    return MALIO_OK;  // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
   }
   int rc;
   if (!c->vox_valid && n0 > 0) {
@@ -304,7 +310,10 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
   c->map_n = n1;
   c->vox_valid = false;
   if (out_added) *out_added = (int)h_tot[2];
-  return map_rebuild_search(c);
+  // the mapping loop calls Add_Points twice per scan (laserMapping.cpp:443-444): the neighbour lists are rebuilt
+  // once, by whichever search comes next
+  c->map_epoch++, c->search_dirty = true;
+  return MALIO_OK;
 }
 
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted) {
@@ -343,7 +352,8 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   swap_maps(c);
   c->map_n = (int)h_tot[0];
   c->vox_valid = false;
-  return map_rebuild_search(c);
+  c->map_epoch++, c->search_dirty = true;
+  return MALIO_OK;
 }
 
 }  // namespace malio

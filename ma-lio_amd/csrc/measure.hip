@@ -891,6 +891,7 @@ static NlView view_of(const NList &nl) {
 }
 
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
+  if (int rc = map_sync_search(c)) return rc;
   long long threads = (long long)n * NL2_G;
   hipLaunchKernelGGL(k_nearest, dim3((unsigned)((threads + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_q, n, k,
                      view_of(c->nl2), d_idx, d_d2, d_cnt);
@@ -1038,6 +1039,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
   if (c->map_n <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  if (int rc = map_sync_search(c)) return rc;
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
   if (!c->scan_sorted) {

@@ -19,6 +19,12 @@ for n in (10000, 10000, 50000):
     print("map_add(ds) %d pts -> %d insertions, size %d: %.2f ms" % (n, a, e.map_size(), dt * 1e3))
     t = time.perf_counter(); e.map_add(new[:n // 10], False); dt = time.perf_counter() - t
     print("map_add(no ds) %d pts, size %d: %.2f ms" % (n // 10, e.map_size(), dt * 1e3))
+    t = time.perf_counter(); e.nearest_search(new[:8], 5); dt = time.perf_counter() - t
+    print("   next search (rebuilds both neighbour-list levels): %.2f ms" % (dt * 1e3))
+    t = time.perf_counter(); e.nearest_search(new[:8], 5); dt = time.perf_counter() - t
+    print("   search again: %.2f ms" % (dt * 1e3))
 box = np.array([[0, 0, -5, 30, 30, 5]], np.float32)
 t = time.perf_counter(); d = e.map_delete_boxes(box); dt = time.perf_counter() - t
 print("delete_boxes -> %d deleted, size %d: %.2f ms" % (d, e.map_size(), dt * 1e3))
+t = time.perf_counter(); e.nearest_search(sc["map"][:8], 5); dt = time.perf_counter() - t
+print("   next search: %.2f ms" % (dt * 1e3))
