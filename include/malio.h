@@ -151,6 +151,16 @@ int malio_map_add(malio_handle_t h, const malio_point_t *pts, int n, int downsam
  * A point is inside a box iff vertex_min <= p < vertex_max on every axis (ikd_Tree.cpp:807,1263-1274).
  * *out_deleted = number of points removed. */
 int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, int *out_deleted);
+/* map_incremental()                                   laserMapping.cpp:398-446, on the resident scan, no host copy
+ * of Nearest_Points: skips points whose normal_y exceeds cov_threshold (:406), recomputes the world point with
+ * `state_point` (the posterior; pointBodyToWorld :134-147), sorts every remaining point into PointToAdd or
+ * PointNoNeedDownsample from the neighbours of the last search pass (:411-440), then performs
+ * Add_Points(PointToAdd, true) and Add_Points(PointNoNeedDownsample, false) (:443-444).
+ * world_normal_y: [N] in scan order, the value feats_down_world->points[i].normal_y holds on the caller's side (the
+ * reference never writes it on this path; it is what ends up stored in the map), or NULL for zeros.
+ * out_counts3 (may be NULL): |PointToAdd|, |PointNoNeedDownsample|, return value of the first Add_Points. */
+int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
+                          const float *world_normal_y, int *out_counts3);
 /* ikdtree.flatten(Root_Node, PCL_Storage, NOT_RECORD) laserMapping.cpp:1018-1019 (map publishing / saving).
  * Copies min(cap, size) valid points in map order, *out_n = size. Order differs from the tree's traversal. */
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);

@@ -18,7 +18,7 @@ ERR_NO_DEVICE = -1
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -213,6 +213,19 @@ class Engine:
         self._chk(lib().malio_map_delete_boxes(self.h, boxes6.ctypes.data_as(C.c_void_p), boxes6.shape[0],
                                                C.byref(deleted)), "malio_map_delete_boxes")
         return deleted.value
+
+    def map_incremental(self, state_flat, flg_EKF_inited=True, world_normal_y=None):
+        """laserMapping.cpp:398-446 on the resident scan. Returns (|PointToAdd|, |PointNoNeedDownsample|,
+        Add_Points(PointToAdd, true) return value)."""
+        s = state_from_flat(state_flat, self.L)
+        cnt = (C.c_int * 3)()
+        wny = None
+        if world_normal_y is not None:
+            wny = np.ascontiguousarray(world_normal_y, np.float32)
+            assert wny.shape[0] == self.N
+        self._chk(lib().malio_map_incremental(self.h, C.byref(s), int(bool(flg_EKF_inited)), _p(wny, C.c_float),
+                                              cnt), "malio_map_incremental")
+        return cnt[0], cnt[1], cnt[2]
 
     def map_get(self):
         """ikdtree.flatten: [n, 12] valid map points (x, y, z, normal_y populated)."""

@@ -246,6 +246,12 @@ int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, i
   return map_delete_boxes(h, boxes, nb, out_deleted);
 }
 
+int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
+                          const float *world_normal_y, int *out_counts3) {
+  if (check(h) || !state_point) return MALIO_ERR_BAD_ARG;
+  return map_incremental(h, state_point, flg_EKF_inited, world_normal_y, out_counts3);
+}
+
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   if (check(h) || !out_n || cap < 0 || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;

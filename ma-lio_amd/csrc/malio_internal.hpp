@@ -192,6 +192,12 @@ void free_nl_scratch(NlScratch &s);
 
 // map_update.hip
 int map_add(Ctx *c, const float4 *h_pts, int n, int downsample_on, int *out_added);
+int map_add_dev(Ctx *c, const float4 *d_pts, int n, int downsample_on, int *out_added);  // d_pts: device memory
+int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
+                    int *out_counts);
+// measure.hip: PointToAdd / PointNoNeedDownsample membership + world points, all in ORIGINAL scan order
+int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
+                    u32 *d_nonf, float4 *d_wp);
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)

@@ -225,11 +225,19 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
   MALIO_HIP(hipSetDevice(c->device));
   if (out_added) *out_added = 0;
   if (m <= 0) return MALIO_OK;
+  Scratch up;
+  float4 *d_new = nullptr;
+  MALIO_HIP(up.get(&d_new, (size_t)m));
+  MALIO_HIP(hipMemcpyAsync(d_new, h_pts, sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, c->stream));
+  return map_add_dev(c, d_new, m, downsample_on, out_added);
+}
+
+int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_added) {
+  MALIO_HIP(hipSetDevice(c->device));
+  if (out_added) *out_added = 0;
+  if (m <= 0) return MALIO_OK;
   const float ds = (float)c->prm.filter_size_map;
   Scratch sc;
-  float4 *d_new = nullptr;
-  MALIO_HIP(sc.get(&d_new, (size_t)m));
-  MALIO_HIP(hipMemcpyAsync(d_new, h_pts, sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, c->stream));
   const int n0 = c->map_n;
   // set_downsample_param(filter_size_map_min) is what arms DOWNSAMPLE_SWITCH (ikd_Tree.cpp:486); a non-positive
   // size means it was never armed
@@ -356,4 +364,51 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   return MALIO_OK;
 }
 
+}  // namespace malio
+
+// map_incremental(), laserMapping.cpp:398-446, entirely on the device: selection (measure.hip), stable compaction
+// of the two lists in scan order, then the two Add_Points calls of :443-444.
+namespace malio {
+int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
+                    int *out_counts) {
+  MALIO_HIP(hipSetDevice(c->device));
+  const int N = c->N;
+  if (N <= 0) return MALIO_ERR_NO_SCAN;
+  Scratch sc;
+  float *d_wny = nullptr;
+  u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr;
+  float4 *wp = nullptr, *d_add = nullptr, *d_non = nullptr;
+  MALIO_HIP(sc.get(&addf, (size_t)N + 1));
+  MALIO_HIP(sc.get(&nonf, (size_t)N + 1));
+  MALIO_HIP(sc.get(&apos, (size_t)N + 1));
+  MALIO_HIP(sc.get(&npos, (size_t)N + 1));
+  MALIO_HIP(sc.get(&tiles, (size_t)(N + 1 + 1023) / 1024 + 2));
+  MALIO_HIP(sc.get(&wp, (size_t)N));
+  if (h_world_normal_y) {
+    MALIO_HIP(sc.get(&d_wny, (size_t)N));
+    MALIO_HIP(hipMemcpyAsync(d_wny, h_world_normal_y, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+  }
+  MALIO_HIP(hipMemsetAsync(addf + N, 0, sizeof(u32), c->stream));
+  MALIO_HIP(hipMemsetAsync(nonf + N, 0, sizeof(u32), c->stream));
+  int rc = mapinc_classify(c, state_point, flg_EKF_inited, d_wny, addf, nonf, wp);
+  if (rc != MALIO_OK) return rc;
+  exclusive_scan_u32(c, addf, apos, tiles, N + 1);
+  exclusive_scan_u32(c, nonf, npos, tiles, N + 1);
+  u32 h_tot[2] = {0, 0};
+  MALIO_HIP(hipMemcpyAsync(&h_tot[0], apos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(&h_tot[1], npos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  const int na = (int)h_tot[0], nn = (int)h_tot[1];
+  MALIO_HIP(sc.get(&d_add, (size_t)na));
+  MALIO_HIP(sc.get(&d_non, (size_t)nn));
+  hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, addf, apos, N,
+                     (const u32 *)nullptr, d_add);
+  hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, nonf, npos, N,
+                     (const u32 *)nullptr, d_non);
+  int added = 0;
+  rc = map_add_dev(c, d_add, na, 1, &added);                 // ikdtree.Add_Points(PointToAdd, true)           :443
+  if (rc == MALIO_OK) rc = map_add_dev(c, d_non, nn, 0, nullptr);  // ikdtree.Add_Points(PointNoNeedDownsample, false) :444
+  if (out_counts) out_counts[0] = na, out_counts[1] = nn, out_counts[2] = added;
+  return rc;
+}
 }  // namespace malio

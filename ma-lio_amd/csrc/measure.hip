@@ -899,6 +899,189 @@ int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d
   return MALIO_OK;
 }
 
+// ---- map_incremental() selection (laserMapping.cpp:398-442) ------------------------------------------------
+// The reference's Nearest_Points[i] holds the 5 nearest map points at ANY distance (ikd_Tree Nearest_Search has no
+// radius), the search pass only kept those with d2 <= 5. That is enough for the re-add test below (a neighbour
+// farther than sqrt(5) m can never be closer to the voxel centre than the point itself, which sits inside its
+// 0.5 m voxel), but :421-425 also looks at points_near[0] when it is far away. k_far_nearest finds that one
+// exactly for the queries whose search ball was empty: shells of 3x3x3-cell blocks of the level-2 lists around
+// the query cell, until the best distance is inside the covered cube; then (rare) a scan of the whole map.
+constexpr int FAR_RMAX = 6;
+static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
+__global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__restrict__ world4,
+                                                     const unsigned char *__restrict__ nfound, NlView nl,
+                                                     const float4 *__restrict__ map_in, int map_n, u32 *far_idx) {
+  const int qi = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (qi >= N) return;
+  if (nfound[qi] != 0) {
+    if (lane == 0) far_idx[qi] = INVALID;
+    return;
+  }
+  const float4 w = world4[qi];
+  const float gx = w.x * nl.inv_cf, gy = w.y * nl.inv_cf, gz = w.z * nl.inv_cf;
+  const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
+  const float margin = 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
+  float bd = INFINITY;
+  u32 bo = INVALID;
+  bool done = false;
+  for (int r = 0; r <= FAR_RMAX && !done; r++) {
+    const int side = 2 * r + 1, nblk = side * side * side;
+    for (int base = 0; base < nblk; base += 64) {
+      const int bi = base + lane;
+      u32 start = 0, count = 0;
+      if (bi < nblk) {
+        const int a = bi % side - r, b = (bi / side) % side - r, c = bi / (side * side) - r;
+        if (max(max(abs(a), abs(b)), abs(c)) == r) {  // only the new shell
+          u64 key = cell_key_d(cx + 3 * a, cy + 3 * b, cz + 3 * c);
+          u32 slot = hash_key_d(key) & nl.tmask;
+          cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
+        }
+      }
+      unsigned long long m = __ballot(count > 0);
+      while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const u32 s0 = __shfl(start, src), cn = __shfl(count, src);
+        for (u32 j = (u32)lane; j < cn; j += 64) {
+          const float4 p = nl.pts[(size_t)s0 + j];
+          float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
+          float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+          u32 og = __float_as_uint(p.w);
+          if (d2 < bd || (d2 == bd && og < bo)) bd = d2, bo = og;
+        }
+      }
+    }
+    // best over the wave, (d2, index) order
+    unsigned long long kk = ((unsigned long long)__float_as_uint(bd) << 32) | bo;  // d2 >= 0: bit order == value order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      unsigned long long other = __shfl_xor(kk, o);
+      kk = other < kk ? other : kk;
+    }
+    const float wd = __uint_as_float((u32)(kk >> 32));
+    const u32 wo = (u32)kk;
+    // everything within (3r+1) cell edges of the query's cell has been seen
+    const float reach = (float)(3 * r + 1) * nl.cf - margin;
+    if (wo != INVALID && wd <= reach * reach * 0.99999f) {
+      bd = wd, bo = wo;
+      done = true;
+    }
+  }
+  if (!done) {  // farther than ~40 m from every map point: scan the map
+    bd = INFINITY, bo = INVALID;
+    for (int j = lane; j < map_n; j += 64) {
+      const float4 p = map_in[j];
+      float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+      if (d2 < bd || (d2 == bd && (u32)j < bo)) bd = d2, bo = (u32)j;
+    }
+    unsigned long long kk = ((unsigned long long)__float_as_uint(bd) << 32) | bo;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      unsigned long long other = __shfl_xor(kk, o);
+      kk = other < kk ? other : kk;
+    }
+    bo = (u32)kk;
+  }
+  if (lane == 0) far_idx[qi] = bo;
+}
+
+struct MapIncArgs {
+  int N, map_n, flg_EKF_inited, extrinsic_est_en, commit_prev;
+  const float4 *scan;  // sorted
+  const u32 *perm;     // sorted -> original
+  QuatConst qc;        // state_point (posterior) + temporal compensation
+  const unsigned char *nfound, *sel;
+  const u32 *nbr, *far_idx;
+  const float4 *map_in;
+  const float *ny;
+  const double *trace;
+  const float *wny;  // [N] original order: feats_down_world[i].normal_y as the caller holds it
+  double cov_threshold, fs;
+  u32 *addf, *nonf;  // [N + 1] original order: PointToAdd / PointNoNeedDownsample membership
+  float4 *wp;        // [N] original order: the world point that would be pushed
+};
+
+__global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.N) return;
+  const u32 o = a.perm[i];
+  const float4 q = a.scan[i];
+  const int lid = (int)(__float_as_uint(q.w) & 0xFF);
+  // feats_down_body[i].normal_y with the last pass' rewrite folded in (see commit_normal_y)
+  const bool untouched = !a.commit_prev || (a.sel[i] && !a.extrinsic_est_en);
+  const float nyv = untouched ? a.ny[i] : (float)a.trace[i];
+  u32 cls = 0;
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  if (!((double)nyv > a.cov_threshold)) {  // :406
+    // pointBodyToWorld(PointType*, PointType*), :134-147
+    const D3 p{(double)q.x, (double)q.y, (double)q.z};
+    const D3 X = (lid == 0) ? qrot(a.qc.ql[0], p) + a.qc.tl[0]
+                            : qrot(a.qc.qtc[lid], qrot(a.qc.ql[lid], p) + a.qc.tl[lid]) + a.qc.ttc[lid];
+    const D3 pg = qrot(a.qc.rot, X) + a.qc.pos;
+    wx = (float)pg.x, wy = (float)pg.y, wz = (float)pg.z;
+    cls = 1;
+    if (a.map_n > 0 && a.flg_EKF_inited) {  // :411 (Nearest_Search on a non-empty tree never returns nothing)
+      const float mx = (float)(floor((double)wx / a.fs) * a.fs + 0.5 * a.fs);
+      const float my = (float)(floor((double)wy / a.fs) * a.fs + 0.5 * a.fs);
+      const float mz = (float)(floor((double)wz / a.fs) * a.fs + 0.5 * a.fs);
+      const float dist = ((wx - mx) * (wx - mx) + (wy - my) * (wy - my)) + (wz - mz) * (wz - mz);
+      const int nf = a.nfound[i];
+      const u32 n0 = nf > 0 ? a.nbr[i] : a.far_idx[i];
+      const float4 m0 = a.map_in[n0];
+      if ((double)fabsf(m0.x - mx) > 0.5 * a.fs && (double)fabsf(m0.y - my) > 0.5 * a.fs &&
+          (double)fabsf(m0.z - mz) > 0.5 * a.fs) {  // :421-425
+        cls = 2;
+      } else if (a.map_n >= 5) {  // :426-435 (points_near.size() == 5 whenever the tree holds 5 points)
+        for (int k = 0; k < nf; k++) {
+          const float4 m = a.map_in[a.nbr[(size_t)k * a.N + i]];
+          const float d = ((m.x - mx) * (m.x - mx) + (m.y - my) * (m.y - my)) + (m.z - mz) * (m.z - mz);
+          if (d < dist) {
+            cls = 0;
+            break;
+          }
+        }
+      }
+    }
+  }
+  a.addf[o] = cls == 1 ? 1u : 0u;
+  a.nonf[o] = cls == 2 ? 1u : 0u;
+  a.wp[o] = make_float4(wx, wy, wz, a.wny ? a.wny[o] : 0.f);
+}
+
+int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
+                    u32 *d_nonf, float4 *d_wp) {
+  if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
+  if (c->map_n > 0 && c->nbr_epoch != c->map_epoch) {
+    c->err = "map_incremental: the map changed after the last search pass of this scan";
+    return MALIO_ERR_BAD_ARG;
+  }
+  if (int rc = map_sync_search(c)) return rc;
+  const int N = c->N;
+  u32 *d_far = nullptr;
+  MALIO_HIP(hipMalloc(&d_far, sizeof(u32) * (size_t)N));
+  if (c->map_n > 0 && flg_EKF_inited) {
+    long long th = (long long)N * 64;
+    hipLaunchKernelGGL(k_far_nearest, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
+                       c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
+  }
+  MapIncArgs a;
+  a.N = N, a.map_n = c->map_n, a.flg_EKF_inited = flg_EKF_inited, a.extrinsic_est_en = c->prm.extrinsic_est_en;
+  a.commit_prev = c->last_M > 0 ? 1 : 0;
+  a.scan = c->d_scan, a.perm = c->d_perm;
+  fill_quat_const(c, state_point, a.qc);
+  a.nfound = c->d_nfound, a.sel = c->d_sel, a.nbr = c->d_nbr, a.far_idx = d_far, a.map_in = c->d_map_in;
+  a.ny = c->d_ny, a.trace = c->d_trace, a.wny = d_wny;
+  a.cov_threshold = c->prm.cov_threshold, a.fs = c->prm.filter_size_map;
+  a.addf = d_addf, a.nonf = d_nonf, a.wp = d_wp;
+  hipLaunchKernelGGL(k_mapinc_classify, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, a);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_far);
+  MALIO_HIP(e);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
 // ---- host side of a pass -------------------------------------------------------------------------
 static void q_to_R(const double q[4], double R[9]) {  // (x,y,z,w) -> row-major, Eigen toRotationMatrix
   double x = q[0], y = q[1], z = q[2], w = q[3];

@@ -145,6 +145,18 @@ class Oracle:
                            _p(out["normvec"], C.c_float))
         return out
 
+    def map_incremental(self, state, flg_EKF_inited=True, world_normal_y=None):
+        """laserMapping.cpp:398-442: returns (PointToAdd [na,12], PointNoNeedDownsample [nn,12])."""
+        state = _f64(state)
+        a = np.zeros((max(self.N, 1), 12), np.float32)
+        b = np.zeros((max(self.N, 1), 12), np.float32)
+        cnt = np.zeros(2, np.int32)
+        wny = _f32(world_normal_y) if world_normal_y is not None else None
+        lib().orc_map_incremental(self.h, _p(state, C.c_double), int(bool(flg_EKF_inited)),
+                                  _p(wny, C.c_float) if wny is not None else None, _p(a, C.c_float), _p(b, C.c_float),
+                                  _p(cnt, C.c_int))
+        return a[:cnt[0]].copy(), b[:cnt[1]].copy()
+
     def update_iterated(self, state, P, R=0.001):
         state = _f64(state).copy()
         P = _f64(P).copy()

@@ -133,6 +133,23 @@ int orc_scan_set(void *hh, const float *pts12, int n, const int *table_len, cons
   return 0;
 }
 
+// map_incremental selection (laserMapping.cpp:398-442). world_normal_y [N] or null: feats_down_world[i].normal_y as the
+// caller's cloud holds it. out_add12 / out_non12 need capacity N*12 floats; counts[0] = |PointToAdd|, counts[1] =
+// |PointNoNeedDownsample|.
+int orc_map_incremental(void *hh, const double *state, int flg_EKF_inited, const float *world_normal_y, float *out_add12,
+                        float *out_non12, int *counts) {
+  Handle *h = (Handle *)hh;
+  State s = state_from(state, h->sc.prm.lid_num);
+  const size_t n = h->sc.feats_down_body.size();
+  for (size_t i = 0; i < n; i++) h->sc.feats_down_world[i].normal_y = world_normal_y ? world_normal_y[i] : 0.f;
+  std::vector<Pt> a, b;
+  h->sc.map_incremental(s, flg_EKF_inited != 0, a, b);
+  if (!a.empty()) std::memcpy(out_add12, (void *)a.data(), sizeof(Pt) * a.size());
+  if (!b.empty()) std::memcpy(out_non12, (void *)b.data(), sizeof(Pt) * b.size());
+  counts[0] = (int)a.size(), counts[1] = (int)b.size();
+  return 0;
+}
+
 // One h_share_model pass. hx/h/R need capacity N*C / N / N. Returns M (0 when !valid).
 int orc_h_share_model(void *hh, const double *state, int converge, int *valid, double *hx, double *hv, double *Rv,
                       double *weight) {

@@ -113,6 +113,9 @@ struct Scene {
   void set_scan(const std::vector<Pt> &body);
   // laserMapping.cpp:552-760
   void h_share_model(const State &s, DynShare &ekfom_data);
+  // laserMapping.cpp:398-446 (selection only; the two Add_Points calls are the caller's)
+  void map_incremental(const State &state_point, bool flg_EKF_inited, std::vector<Pt> &PointToAdd,
+                       std::vector<Pt> &PointNoNeedDownsample);
 };
 
 // State manifold ops (build_manifold.hpp:193-201 -> vect.hpp, SOn.hpp:241-247, S2.hpp:136-167)

@@ -523,3 +523,65 @@ void update_iterated(Scene &sc, State &x_, Mat &P_, double R, UpdateStats &st, s
 }
 
 }  // namespace orc
+
+// ---------------------------------------------------------------------------------------------------------
+// map_incremental(), laserMapping.cpp:398-446: which points of the scan go into the map, and through which
+// Add_Points branch. Runs after the filter update: `state_point` is the posterior, Nearest_Points are those of
+// the last search pass. feats_down_world[i].normal_y is whatever the caller's cloud held at index i (the
+// reference never writes it on this path: 0.001 below the first scan's size, :1004, else PCL's default 0).
+namespace orc {
+static float calc_dist_pt(const Pt &a, const Pt &b) {  // ikd_Tree.cpp:1694-1699 via common_lib.h
+  float dist = (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z);
+  return dist;
+}
+
+void Scene::map_incremental(const State &state_point, bool flg_EKF_inited, std::vector<Pt> &PointToAdd,
+                            std::vector<Pt> &PointNoNeedDownsample) {
+  const int feats_down_size = (int)feats_down_body.size();
+  const double filter_size_map_min = prm.filter_size_map;
+  PointToAdd.clear(), PointNoNeedDownsample.clear();
+  for (int i = 0; i < feats_down_size; i++) {
+    if (feats_down_body[i].normal_y > prm.cov_threshold) continue;  // :406
+    {  // pointBodyToWorld, :134-147
+      const Pt *pi = &feats_down_body[i];
+      Pt *po = &feats_down_world[i];
+      V3 p_body{pi->x, pi->y, pi->z};
+      V3 p_global;
+      int lid_idx = (int)pi->intensity;
+      if (lid_idx == 0)
+        p_global = state_point.rot * (state_point.offset_R[lid_idx] * p_body + state_point.offset_T[lid_idx]) + state_point.pos;
+      else
+        p_global = state_point.rot * (temporal_comp[lid_idx - 1].q_ * (state_point.offset_R[lid_idx] * p_body + state_point.offset_T[lid_idx]) +
+                                      temporal_comp[lid_idx - 1].t_) +
+                   state_point.pos;
+      po->x = (float)p_global.x, po->y = (float)p_global.y, po->z = (float)p_global.z;
+      po->intensity = pi->intensity;
+    }
+    if (!Nearest_Points[i].empty() && flg_EKF_inited) {  // :411
+      const std::vector<Pt> &points_near = Nearest_Points[i];
+      bool need_add = true;
+      Pt mid_point;
+      mid_point.x = (float)(std::floor(feats_down_world[i].x / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+      mid_point.y = (float)(std::floor(feats_down_world[i].y / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+      mid_point.z = (float)(std::floor(feats_down_world[i].z / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+      float dist = calc_dist_pt(feats_down_world[i], mid_point);
+      if (std::fabs(points_near[0].x - mid_point.x) > 0.5 * filter_size_map_min &&
+          std::fabs(points_near[0].y - mid_point.y) > 0.5 * filter_size_map_min &&
+          std::fabs(points_near[0].z - mid_point.z) > 0.5 * filter_size_map_min) {  // :421-425
+        PointNoNeedDownsample.push_back(feats_down_world[i]);
+        continue;
+      }
+      for (int readd_i = 0; readd_i < NUM_MATCH_POINTS; readd_i++) {  // :426-435
+        if ((int)points_near.size() < NUM_MATCH_POINTS) break;
+        if (calc_dist_pt(points_near[readd_i], mid_point) < dist) {
+          need_add = false;
+          break;
+        }
+      }
+      if (need_add) PointToAdd.push_back(feats_down_world[i]);
+    } else {
+      PointToAdd.push_back(feats_down_world[i]);
+    }
+  }
+}
+}  // namespace orc

@@ -193,3 +193,63 @@ def test_gpu_map_update_mapping_loop_scale(orc, capi, scenes):
     with pytest.raises(RuntimeError):
         eng.map_add(new[:10], True)
         eng.scan_get()  # Nearest_Points now refer to a map that no longer exists
+
+
+# ------------------------------------------------------------------------------ map_incremental (laserMapping.cpp:398-446)
+def _mapinc_case(orc, capi, scenes, cfg, map_filter=None, iterate=False, seed=0, flg=True):
+    sc = scenes.make_scene(cfg=cfg)
+    ds = float(sc["params"]["filter_size_map"])
+    mp = sc["map"] if map_filter is None else sc["map"][map_filter(sc["map"])]
+    assert mp.shape[0] > 0
+    rng = np.random.default_rng(seed)
+    o = orc.Oracle(sc["params"], threads=4, use_ref=True)
+    o.map_build(mp)
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    eng = capi.Engine(sc["params"])
+    eng.map_build(mp)
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    if iterate:   # the real sequence: iterated update, then the map takes the scan at the posterior
+        uo = o.update_iterated(sc["state0"], sc["P0"])
+        eng.update_iterated(sc["state0"], sc["P0"])
+        post = uo["state"]
+    else:         # one search pass, then a posterior that differs from the search-pass state
+        o.h_share_model(sc["state0"], True)
+        eng.measure(sc["state0"], True)
+        post = np.array(sc["state0"], np.float64).copy()
+        post[:3] += (0.03, -0.02, 0.01)
+    wny = np.where(np.arange(sc["N"]) < sc["N"] // 3, 0.001, 0.0).astype(np.float32)
+    wny[rng.integers(0, sc["N"], 50)] = 0.004
+    A, B = o.map_incremental(post, flg, wny)
+    na, nn, ret = eng.map_incremental(post, flg, wny)
+    assert (na, nn) == (A.shape[0], B.shape[0])
+    port = orc.VoxMap(ds)
+    port.build(mp)
+    assert port.add(A, True) == ret
+    port.add(B, False)
+    assert eng.map_size() == port.size()
+    np.testing.assert_array_equal(_as_set(eng.map_get()), _as_set(port.flatten()))
+    return dict(na=na, nn=nn, ret=ret, N=sc["N"], size=port.size())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,iterate", [(1, False), (1, True), (3, True)])
+def test_gpu_map_incremental_matches_oracle(orc, capi, scenes, cfg, iterate):
+    r = _mapinc_case(orc, capi, scenes, cfg, iterate=iterate)
+    assert r["na"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_map_incremental_frontier_and_far_map(orc, capi, scenes):
+    """Scan points with no map point within sqrt(5) m: points_near[0] of the reference is then far away and
+    still steers :421-425 (k_far_nearest: shell search, then the whole-map scan)."""
+    cx = scenes.SURFACE_SHIFT[0]
+    r1 = _mapinc_case(orc, capi, scenes, 1, map_filter=lambda m: m[:, 0] < cx + 4.0)   # half the scene unmapped
+    assert r1["nn"] > 0
+    _mapinc_case(orc, capi, scenes, 1, map_filter=lambda m: m[:, 0] > cx + 30.0)       # map tens of metres away
+    _mapinc_case(orc, capi, scenes, 1, map_filter=lambda m: np.arange(m.shape[0]) < 3)  # fewer than 5 map points
+
+
+@pytest.mark.gpu
+def test_gpu_map_incremental_before_ekf_init(orc, capi, scenes):
+    r = _mapinc_case(orc, capi, scenes, 1, flg=False)   # :411 false -> everything goes through PointToAdd
+    assert r["nn"] == 0
