@@ -7,6 +7,7 @@
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
 #include "malio_internal.hpp"
+#include <hipcub/hipcub.hpp>
 
 namespace malio {
 
@@ -1157,6 +1158,14 @@ __global__ void __launch_bounds__(BLK) k_scan_world(const float4 *__restrict__ i
   D3 pg = qrot(qc.rot, X) + qc.pos;
   out[i] = make_float4((float)pg.x, (float)pg.y, (float)pg.z, 0.f);
 }
+// sort key of a scan point: its level-1 cell (row-major cell order; ties keep the upload order - radix sort is stable)
+__global__ void __launch_bounds__(BLK) k_scan_keys(const float4 *__restrict__ w, int n, float inv_cf, u64 *keys, u32 *vals) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float4 p = w[i];
+  keys[i] = cell_key_d((int)floorf(p.x * inv_cf), (int)floorf(p.y * inv_cf), (int)floorf(p.z * inv_cf));
+  vals[i] = (u32)i;
+}
 __global__ void __launch_bounds__(BLK) k_gather_scan(const float4 *__restrict__ in, const u32 *__restrict__ src, int n,
                                                      int dst0, float4 *out_scan, u32 *out_perm,
                                                      const u32 *__restrict__ part_orig,
@@ -1200,18 +1209,31 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(hipMalloc(&d_ny_in, sizeof(float) * (size_t)c->N));
   MALIO_HIP(hipMemcpyAsync(d_ny_in, ny_part.data(), sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_scan_world, dim3((c->N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_scan_in, c->N, qc, d_w);
-  CellGrid g;
+  // Group every LiDAR segment by level-1 cell with a stable radix sort: unlike a counting sort on atomic ranks, the
+  // resulting order - and with it every fixed-order reduction over the sorted scan - is identical in every run.
+  u64 *d_keys = nullptr, *d_keys2 = nullptr;
+  u32 *d_vals = nullptr, *d_vals2 = nullptr;
+  void *d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  MALIO_HIP(hipMalloc(&d_keys, sizeof(u64) * (size_t)c->N));
+  MALIO_HIP(hipMalloc(&d_keys2, sizeof(u64) * (size_t)c->N));
+  MALIO_HIP(hipMalloc(&d_vals, sizeof(u32) * (size_t)c->N));
+  MALIO_HIP(hipMalloc(&d_vals2, sizeof(u32) * (size_t)c->N));
+  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, c->N, 0, 63, c->stream));
+  MALIO_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
   for (int l = 0; l < L; l++) {
     int n = c->seg_start[l + 1] - c->seg_start[l];
     if (n <= 0) continue;
-    int rc = group_by_cell(c, d_w + c->seg_start[l], n, c->nl1.inv_cf, g);
-    if (rc != MALIO_OK) return rc;
+    hipLaunchKernelGGL(k_scan_keys, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_w + c->seg_start[l], n,
+                       c->nl1.inv_cf, d_keys, d_vals);
+    size_t tb = tmp_bytes;
+    MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 63, c->stream));
     hipLaunchKernelGGL(k_gather_scan, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                       c->d_scan_in + c->seg_start[l], g.orig, n, c->seg_start[l], c->d_scan, c->d_perm,
+                       c->d_scan_in + c->seg_start[l], d_vals2, n, c->seg_start[l], c->d_scan, c->d_perm,
                        d_part_orig + c->seg_start[l], d_ny_in + c->seg_start[l], c->d_ny);
   }
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  free_grid(g);
+  (void)hipFree(d_keys), (void)hipFree(d_keys2), (void)hipFree(d_vals), (void)hipFree(d_vals2), (void)hipFree(d_tmp);
   (void)hipFree(d_w);
   (void)hipFree(d_part_orig);
   (void)hipFree(d_ny_in);

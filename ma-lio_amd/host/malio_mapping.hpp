@@ -155,7 +155,18 @@ class Mapping {
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {
     h_.check(malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
   }
-  // side effects map_incremental reads (laserMapping.cpp:406,411-435)
+  // void map_incremental(), laserMapping.cpp:398-446, without bringing Nearest_Points to the host.
+  // state_point = kf.get_x() after the update (:1053); feats_down_world is the caller's cloud: only its normal_y
+  // is read (the value the reference would store with each added point). Returns add_point_size (:445).
+  int map_incremental(const malio_state_t &state_point, bool flg_EKF_inited, const PointVector &feats_down_world) {
+    std::vector<float> wny(feats_down_size_, 0.f);
+    for (int i = 0; i < feats_down_size_ && i < (int)feats_down_world.size(); i++) wny[i] = feats_down_world[i].normal_y;
+    int counts[3] = {0, 0, 0};
+    h_.check(malio_map_incremental(h_.get(), &state_point, flg_EKF_inited ? 1 : 0, wny.data(), counts), "map_incremental");
+    return counts[0] + counts[1];
+  }
+  // the same side effects on the host, for a caller that keeps its own map_incremental (laserMapping.cpp:406,411-435).
+  // Note: Nearest_Points here are the neighbours with d2 <= 5 (the plane-fit gate, :587), not the unbounded 5-NN.
   void get_side_effects(std::vector<float> &normal_y, std::vector<PointType> &Nearest_Points_flat,
                         std::vector<int> &nearest_count, std::vector<uint8_t> &point_selected_surf) {
     normal_y.resize(feats_down_size_);

@@ -1,0 +1,113 @@
+// Host-side check of the C++ mirror (ma-lio_amd/host/malio_mapping.hpp): one turn of the reference's mapping loop
+// (laserMapping.cpp:995-1060) written against the mirror's classes, the way a patched laserMapping.cpp would use
+// them. Reads a scene dumped by tests/test_cpp_mirror.py, prints results the test compares with the Python path.
+//   usage: mapping_loop <scene.bin> [--syntax-only]
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include "malio_mapping.hpp"
+
+namespace {
+struct Reader {
+  FILE *f;
+  template <class T>
+  void get(T *p, size_t n) {
+    if (n && fread(p, sizeof(T), n, f) != n) {
+      fprintf(stderr, "short read\n");
+      exit(2);
+    }
+  }
+};
+
+malio_state_t state_from_flat(const std::vector<double> &v, int L) {
+  malio_state_t s;
+  std::memset(&s, 0, sizeof(s));
+  const double *p = v.data();
+  std::memcpy(s.pos, p, 24), p += 3;
+  std::memcpy(s.rot, p, 32), p += 4;
+  for (int l = 0; l < L; l++) std::memcpy(s.offset_R[l], p, 32), p += 4;
+  for (int l = 0; l < L; l++) std::memcpy(s.offset_T[l], p, 24), p += 3;
+  std::memcpy(s.vel, p, 24), p += 3;
+  std::memcpy(s.bg, p, 24), p += 3;
+  std::memcpy(s.ba, p, 24), p += 3;
+  std::memcpy(s.grav, p, 24);
+  for (int l = L; l < MALIO_MAX_LIDAR; l++) s.offset_R[l][3] = 1.0;
+  return s;
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 1;
+  Reader r{fopen(argv[1], "rb")};
+  if (!r.f) return 1;
+  int32_t hdr[3];
+  r.get(hdr, 3);
+  const int L = hdr[0], N = hdr[1], Nmap = hdr[2];
+  double prm16[16];
+  r.get(prm16, 16);
+  malio_params_t prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.lid_num = (int)prm16[0], prm.max_iteration = (int)prm16[1], prm.extrinsic_est_en = (int)prm16[2];
+  prm.plane_th = (float)prm16[3], prm.cov_threshold = prm16[4], prm.range_min = prm16[5], prm.range_max = prm16[6];
+  prm.point_cov_max = prm16[7], prm.point_cov_min = prm16[8], prm.plane_cov_max = prm16[9], prm.plane_cov_min = prm16[10];
+  prm.localize_cov_max = prm16[11], prm.localize_cov_min = prm16[12], prm.localize_thresh_max = prm16[13];
+  prm.localize_thresh_min = prm16[14], prm.filter_size_map = prm16[15];
+  const int n = 17 + 6 * L;
+  std::vector<double> flat(19 + 7 * L), P((size_t)n * n);
+  r.get(flat.data(), flat.size());
+  r.get(P.data(), P.size());
+  malio::PointVector map_pts(Nmap), feats_down_body(N), feats_down_world(N);
+  r.get(map_pts.data(), (size_t)Nmap);
+  r.get(feats_down_body.data(), (size_t)N);
+  std::vector<int32_t> len(L);
+  r.get(len.data(), (size_t)L);
+  std::vector<std::vector<malio::Pose>> pose_unc(L);
+  for (int l = 0; l < L; l++) pose_unc[l].resize(len[l]), r.get(pose_unc[l].data(), (size_t)len[l]);
+  std::vector<malio::Pose> temporal_comp(L > 1 ? L - 1 : 0);
+  r.get(temporal_comp.data(), temporal_comp.size());
+  std::vector<float> wny(N);
+  r.get(wny.data(), (size_t)N);
+  for (int i = 0; i < N; i++) feats_down_world[i].normal_y = wny[i];
+  fclose(r.f);
+
+  try {
+    malio::Handle handle(prm);
+    malio::KdTreeGpu ikdtree(handle);
+    malio::Mapping mapping(handle);
+    ikdtree.set_downsample_param((float)prm.filter_size_map);  // :999
+    ikdtree.Build(map_pts);                                    // :1007
+    printf("size0 %d\n", ikdtree.size());
+    mapping.set_scan(feats_down_body, pose_unc, temporal_comp);
+    // one explicit pass through the hook, as esekfom.hpp:512 would
+    malio_state_t x = state_from_flat(flat, L);
+    malio::dyn_share_datastruct d;
+    d.converge = true;
+    mapping.h_share_model(x, d, /*want_rows=*/true);
+    printf("pass valid %d rows %d cols %d h0 %a R0 %a HtH00 %a\n", (int)d.valid, d.rows, d.cols, d.rows ? d.h[0] : 0.0,
+           d.rows ? d.R[0] : 0.0, d.HtRinvH.empty() ? 0.0 : d.HtRinvH[0]);
+    double solve_time = 0;
+    mapping.update_iterated_dyn_share_modified(x, P, 0.001, solve_time);  // :1052
+    printf("pos %a %a %a rot %a %a %a %a P00 %a\n", x.pos[0], x.pos[1], x.pos[2], x.rot[0], x.rot[1], x.rot[2], x.rot[3], P[0]);
+    int add_point_size = mapping.map_incremental(x, true, feats_down_world);  // :1058
+    printf("add_point_size %d size1 %d\n", add_point_size, ikdtree.size());
+    std::vector<malio::BoxPointType> cub_needrm(1);
+    for (int a = 0; a < 3; a++) cub_needrm[0].vertex_min[a] = (float)x.pos[a] - 4.f, cub_needrm[0].vertex_max[a] = (float)x.pos[a] + 4.f;
+    int del = ikdtree.Delete_Point_Boxes(cub_needrm);  // :223
+    printf("deleted %d size2 %d\n", del, ikdtree.size());
+    malio::PointVector storage;
+    ikdtree.flatten(storage);
+    double cs = 0;
+    for (auto &p : storage) cs += (double)p.x + 2.0 * (double)p.y + 3.0 * (double)p.z + 1000.0 * (double)p.normal_y;
+    printf("flatten %zu checksum %a\n", storage.size(), cs);
+    malio::PointVector q(feats_down_world.begin(), feats_down_world.begin() + 4);
+    for (auto &p : q) p.x = (float)x.pos[0] + 6.f, p.y = (float)x.pos[1], p.z = (float)x.pos[2];
+    std::vector<malio::PointVector> near;
+    std::vector<std::vector<float>> d2;
+    ikdtree.Nearest_Search(q, 5, near, d2);
+    printf("knn %zu d2 %a\n", near[0].size(), near[0].empty() ? 0.0 : (double)d2[0][0]);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}
