@@ -13,6 +13,19 @@ namespace malio {
 
 constexpr int NSUM = 97;  // 78 (12x12 upper) + 12 (rhs) + 6 (c^2 n n^T) + 1 (count)
 constexpr u32 INVALID = 0xFFFFFFFFu;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Developer aid (make PHASE=1): shader-clock stamps of one mid-grid workgroup at phase boundaries of the
+// latency-bound kernels; read back with malio_debug_phase(). Compiled out of the shipped library.
+#ifdef MALIO_PHASE_CLOCK
+__device__ long long g_phase[4][16];
+#define PH(kid, k)                                                                     \
+  do {                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_phase[kid][k] = wall_clock64(); \
+  } while (0)
+#else
+#define PH(kid, k)
+#endif
 
 struct D3 {
   double x, y, z;
@@ -514,7 +527,9 @@ __device__ __forceinline__ void serve_pending(const Pass1Args &a, const NlView &
 
 // a3 + gates + a6 of a SEARCH pass: thread per query.
 __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
+  PH(0, 0);
   serve_pending(a, nl2);
+  PH(0, 1);
   const int i = blockIdx.x * BLK + threadIdx.x;
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
@@ -534,6 +549,7 @@ __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
         A[k][0] = P[k][0] = m.x, A[k][1] = P[k][1] = m.y, A[k][2] = P[k][2] = m.z, W[k] = m.w;
       }
       double cov_sum = 0;
+      PH(0, 2);
 #pragma unroll
       for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
       if ((double)W[0] > 0.00001) {
@@ -544,7 +560,9 @@ __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
         }
       }
       float nv[3], pabcd[4];
+      PH(0, 3);
       qr_solve_5x3(A, nv);
+      PH(0, 4);
       float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
       pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
       pabcd[3] = (float)(1.0 / (double)n);
@@ -564,10 +582,13 @@ __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
       }
     }
     a.sel[i] = selected ? 1 : 0;
+    PH(0, 5);
     tr = trace_for(a, q, lid, tidx, selected);
     a.trace[i] = tr;
   }
+  PH(0, 6);
   block_minmax(a, selected, ucov, tr);
+  PH(0, 7);
 }
 
 // REUSE pass (ekfom_data.converge == false, :583-595): neighbours, plane and flag are kept; the
@@ -710,14 +731,15 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const double mm[4]
   r = R;
 }
 
-// One workgroup = 256 consecutive sorted points of ONE LiDAR. Rows go to LDS, then the 97 sums of
-// the workgroup are formed by 2 x 97 threads reading LDS with wave-uniform (broadcast) addresses.
+// One workgroup = 256 consecutive sorted points of ONE LiDAR. Rows go to LDS, each wave turns its 64 rows into a
+// 16x16 block of sums with 16 f64 MFMAs, the 4 wave blocks are added in a fixed order.
 __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
-  __shared__ double X[BLK][13];  // u[0..11], hs
-  __shared__ double Y[BLK][12];  // u / r (r clamped as esekfom.hpp:624-626)
-  __shared__ double half1[NSUM];
+  __shared__ double SA[BLK][17];  // a_p: u / r (r clamped as esekfom.hpp:624-626), u[0..2], 0   (+1 pad)
+  __shared__ double SB[BLK][17];  // b_p: u, hs, 0 0 0                                           (+1 pad)
+  __shared__ double DW[BLK / 64][16][16];
   __shared__ double smm[BLK / 64][5];
   __shared__ double mm_s[5];
+  PH(1, 0);
   // ---- a4 fold: every workgroup reduces the per-workgroup extrema of pass 1 itself (<= N/256 rows of 5
   //      doubles from L2) instead of waiting for a separate 1-workgroup kernel ----
   if (a.minmax4) {
@@ -751,6 +773,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
     }
   }
   __syncthreads();
+  PH(1, 1);
   const double mm[4] = {mm_s[0], mm_s[1], mm_s[2], mm_s[3]};
   int lid = 0;
 #pragma unroll
@@ -763,6 +786,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
   if (selected) point_row(a, mm, i, lid, u, hs, r);
+  PH(1, 2);
   if (a.rows && in) {
     double *row = a.rows + (size_t)i * 14;
 #pragma unroll
@@ -775,55 +799,66 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   // one reciprocal instead of 12 f64 divisions (the reference divides, esekfom.hpp:627; the difference is one
   // rounding per entry, far below the summation-order noise of the 1e5-term sums)
   const double rinv = selected ? 1.0 / rc : 0.0;
+  // ---- a10: the 97 sums of this workgroup as ONE 16x16 f64 outer-product accumulation on the matrix cores.
+  // Per point p:  a_p = [ u/r (12) | u[0..2] (3) | 0 ],  b_p = [ u (12) | hs | 0 0 0 ];  D = sum_p a_p b_p^T holds
+  // H^T R^-1 H (rows 0..11 x cols 0..11), H^T R^-1 h (col 12) and N^T N (rows 12..14 x cols 0..2).
+  // v_mfma_f64_16x16x4_f64 wants A[i = lane & 15][k = lane >> 4] and B[k = lane >> 4][j = lane & 15]: the rows are
+  // transposed through LDS (stride 17 doubles: conflict-free b64 writes, contiguous reads); each wave accumulates
+  // its own 64 points in 16 dependent MFMAs (~0.2 us) instead of a 128-step FMA chain per entry fed by 400 KB of
+  // LDS reads. The accumulation order is fixed by the hardware, so the result is still reproducible run to run.
 #pragma unroll
-  for (int k = 0; k < 12; k++) X[threadIdx.x][k] = u[k], Y[threadIdx.x][k] = u[k] * rinv;
-  X[threadIdx.x][12] = hs;
+  for (int k = 0; k < 12; k++) SA[threadIdx.x][k] = u[k] * rinv, SB[threadIdx.x][k] = u[k];
+  SA[threadIdx.x][12] = u[0], SA[threadIdx.x][13] = u[1], SA[threadIdx.x][14] = u[2], SA[threadIdx.x][15] = 0.0;
+  SB[threadIdx.x][12] = hs, SB[threadIdx.x][13] = 0.0, SB[threadIdx.x][14] = 0.0, SB[threadIdx.x][15] = 0.0;
   unsigned long long bal = __ballot(selected);
   __shared__ int wcnt[BLK / 64];
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
   __syncthreads();
-  // entry e: 0..77 -> (ra, cb) upper triangle of Y^T X ; 78..89 -> rhs Y^T hs ; 90..95 -> X^T X (3x3) ; 96 count
-  const int e = threadIdx.x & 127, half = threadIdx.x >> 7;
-  double acc = 0;
-  if (e < NSUM - 1) {
-    int ra, cb;
-    bool xx = false;
-    if (e < 78) {
-      int rem = e;
-      ra = 0;
-      while (rem >= 12 - ra) rem -= 12 - ra, ra++;
-      cb = ra + rem;
-    } else if (e < 90) {
-      ra = e - 78, cb = 12;
-    } else {
-      const int m6[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
-      ra = m6[e - 90][0], cb = m6[e - 90][1], xx = true;
-    }
-    const int p0 = half * 128;
-    // 4 independent accumulators: a single f64 FMA chain of 128 would serialise on the FMA latency.
-    // (fixed association, so the result is still deterministic run to run)
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    if (xx) {
-#pragma unroll 4
-      for (int p = p0; p < p0 + 128; p += 4) {
-        a0 += X[p][ra] * X[p][cb], a1 += X[p + 1][ra] * X[p + 1][cb];
-        a2 += X[p + 2][ra] * X[p + 2][cb], a3 += X[p + 3][ra] * X[p + 3][cb];
-      }
-    } else {
-#pragma unroll 4
-      for (int p = p0; p < p0 + 128; p += 4) {
-        a0 += Y[p][ra] * X[p][cb], a1 += Y[p + 1][ra] * X[p + 1][cb];
-        a2 += Y[p + 2][ra] * X[p + 2][cb], a3 += Y[p + 3][ra] * X[p + 3][cb];
-      }
-    }
-    acc = (a0 + a1) + (a2 + a3);
-  } else if (e == NSUM - 1) {
-    acc = half == 0 ? (double)(wcnt[0] + wcnt[1]) : (double)(wcnt[2] + wcnt[3]);
+  PH(1, 3);
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int prow = (threadIdx.x & ~63) + (lane >> 4), col = lane & 15;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 16; g++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[prow + 4 * g][col], SB[prow + 4 * g][col], acc, 0, 0, 0);
+    // C/D map of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) DW[wave][(lane >> 4) + 4 * rg][col] = acc[rg];
   }
-  if (half == 1 && e < NSUM) half1[e] = acc;
+  PH(1, 4);
   __syncthreads();
-  if (half == 0 && e < NSUM) a.partials[(size_t)blockIdx.x * NSUM + e] = acc + half1[e];
+  // entry e: 0..77 -> (ra, cb) upper triangle of Y^T X ; 78..89 -> rhs Y^T hs ; 90..95 -> X^T X (3x3) ; 96 count
+  const int e = threadIdx.x;
+  if (e < NSUM) {
+    double v;
+    if (e == NSUM - 1) {
+      v = (double)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
+    } else {
+      int ra, cb;
+      if (e < 78) {
+        int rem = e;
+        ra = 0;
+        while (rem >= 12 - ra) rem -= 12 - ra, ra++;
+        cb = ra + rem;
+      } else if (e < 90) {
+        ra = e - 78, cb = 12;
+      } else {
+        const int m6[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+        ra = 12 + m6[e - 90][0], cb = m6[e - 90][1];
+      }
+      v = (DW[0][ra][cb] + DW[1][ra][cb]) + (DW[2][ra][cb] + DW[3][ra][cb]);
+    }
+    a.partials[(size_t)blockIdx.x * NSUM + e] = v;
+  }
+  PH(1, 5);
 }
+
+#ifdef MALIO_PHASE_CLOCK
+extern "C" int malio_debug_phase(long long *out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Fixed-order final sum: one workgroup per LiDAR, 8 groups of 128 lanes stride over that LiDAR's
 // workgroups, then the 8 group sums are added in order. out: [L][NSUM].

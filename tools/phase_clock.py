@@ -1,0 +1,22 @@
+"""Developer aid: per-phase time of one mid-grid workgroup of k_plane / k_rows_reduce (needs `make PHASE=1`)."""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, "/root/repo")
+import __graft_entry__ as ge
+ge.load_package()
+from malio_amd import capi, scenes
+sc = scenes.make_scene(cfg=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+e = capi.Engine(sc["params"]); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+for _ in range(20):
+    e.measure(sc["state0"], True)
+out = (C.c_longlong * 64)()
+assert capi.lib().malio_debug_phase(out) == 0
+ph = np.array(out[:]).reshape(4, 16)
+names = {0: ["enter", "serve_pending", "neighbours gathered (+world, commit)", "plane_cov", "QR", "normalise+gates", "trace", "block_minmax"],
+         1: ["enter", "extrema fold", "point_row", "LDS stage + sync", "97 sums", "write partials"]}
+for k, nm in names.items():
+    t = ph[k][:len(nm)]
+    print("kernel", "k_plane" if k == 0 else "k_rows_reduce", "(100 MHz ticks -> us)")
+    for j in range(1, len(nm)):
+        print("   %-40s %6.2f us" % (nm[j], (t[j] - t[j - 1]) / 100.0))
+    print("   %-40s %6.2f us" % ("total", (t[len(nm) - 1] - t[0]) / 100.0))
