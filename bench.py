@@ -30,7 +30,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 ALG_BYTES_SEARCH_PASS = 120.0  # algorithmic bytes per scan point of a search pass
-DOMINANT_KERNEL = "k_knn"
+DOMINANT_KERNEL = "k_search"
 
 
 def cpu_baseline(sc, budget_s=20.0):

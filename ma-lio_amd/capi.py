@@ -84,11 +84,12 @@ def _share_hip_runtime_with_torch():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+        path = os.environ.get("MALIO_LIB", LIB_PATH)  # developer override: A/B runs of kernel variants
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with __graft_entry__.build() "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         _share_hip_runtime_with_torch()
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(path)
         _lib.malio_version.restype = C.c_char_p
         _lib.malio_last_error.restype = C.c_char_p
         _lib.malio_last_error.argtypes = [C.c_void_p]

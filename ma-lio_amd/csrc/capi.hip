@@ -96,7 +96,7 @@ int malio_create(const malio_params_t *params, int device, malio_handle_t *out) 
   c->prm = *params;
   c->device = device;
   c->cell = params->cell_size > 0.f ? params->cell_size : 1.125f;
-  if (c->cell < 1.1180341f) c->cell = 1.1180341f;  // level 2 (2 * cell) must cover the sqrt(5) m acceptance radius
+  if (c->cell < 0.25f) c->cell = 0.25f;  // level 2 is max(2 * cell, 2.25 m): it alone must cover the sqrt(5) m radius
   c->inv_cell = 1.0f / c->cell;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -118,7 +118,7 @@ int malio_destroy(malio_handle_t h) {
   free_nlist(c->nl1);
   free_nlist(c->nl2);
   free_nl_scratch(c->nl_scratch);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_blockmm), fr(c->d_ny);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_ny);
   fr(c->d_map_alt), free_grid(c->vox);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);

@@ -146,7 +146,8 @@ struct Ctx {
   unsigned char *d_sel = nullptr;  // [N]
   unsigned char *d_nfound = nullptr;  // [N]
   // reductions
-  double *d_blockmm = nullptr;  // [nblocks][5] per-workgroup max_u, min_u, max_R, min_R, count
+  u64 *d_mmslots = nullptr;  // [2 parities][64 slots][5]: max_u, min_u, max_R, min_R (order-encoded doubles), count
+  int mm_parity = 0;
   double *d_partials = nullptr;  // [nblocks][NSUM]
   double *d_sums = nullptr;      // [NSUM_OUT]
   double *h_sums = nullptr;      // pinned

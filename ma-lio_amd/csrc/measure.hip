@@ -83,7 +83,8 @@ struct Pass1Args {
   // per-point outputs (sorted order)
   float4 *world4;  // [N] world point of the search pass
   double *pbnorm;  // [N] |p'| (double), range gate :599
-  double *blockmm; // [nblocks][5]
+  u64 *mm_cur;     // extrema slots this pass accumulates into (MmSlots)
+  u64 *mm_next;    // the other parity: reset here for the next pass
   u32 *nbr;  // [5][N] ORIGINAL map indices (INVALID when fewer than 5 inside the radius)
   float4 *plane;
   float *pd2;
@@ -389,7 +390,49 @@ __device__ __forceinline__ void commit_normal_y(const Pass1Args &a, int i) {
   a.ny[i] = (float)a.trace[i];
 }
 
-// a4: per-workgroup min/max of unit_cov and R over accepted points, and their count
+// a4: min/max of unit_cov and R over the accepted points, and their count (laserMapping.cpp:614-632,646-647).
+// Extrema and an integer count are order-independent, so they are combined with atomics - spread over MM_SLOTS
+// addresses so that no address sees more than a few dozen (same-address atomics serialise at ~12 ns each) - and
+// folded by one wave of the consumer. Slot layout: [MM_SLOTS][5] u64 = max_u, min_u, max_R, min_R (doubles under
+// an order-preserving encoding), count. Two parities alternate between passes; a stage-1 kernel accumulates into
+// one and resets the other, so no separate clearing launch is needed.
+constexpr int MM_SLOTS = 64;
+__device__ __forceinline__ u64 mm_enc(double x) {
+  u64 b = (u64)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mm_dec(u64 k) {
+  u64 b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ void mm_reset_slot(u64 *slots, int sl) {
+  u64 *o = slots + (size_t)sl * 5;
+  o[0] = mm_enc(-INFINITY), o[1] = mm_enc(INFINITY), o[2] = mm_enc(-INFINITY), o[3] = mm_enc(INFINITY), o[4] = 0;
+}
+// one lane publishes what its wave / workgroup reduced
+__device__ __forceinline__ void mm_publish(u64 *slots, double mxu, double mnu, double mxr, double mnr, u64 count) {
+  if (count == 0) return;  // nothing accepted here: the identities would not change anything
+  u64 *o = slots + (size_t)(blockIdx.x & (MM_SLOTS - 1)) * 5;
+  atomicMax(&o[0], mm_enc(mxu)), atomicMin(&o[1], mm_enc(mnu));
+  atomicMax(&o[2], mm_enc(mxr)), atomicMin(&o[3], mm_enc(mnr));
+  atomicAdd(&o[4], count);
+}
+// Called by the first wave (64 lanes) of a consumer: folds the slots with the reference's initial values
+// (laserMapping.cpp:615-616,646-647). Lane 0 returns [max_u, -min_u, max_R, -min_R, M] in out5.
+__device__ __forceinline__ void mm_fold_wave(const u64 *slots, int extrinsic_est_en, double out5[5]) {
+  const int lane = threadIdx.x & 63;
+  const u64 *o = slots + (size_t)lane * 5;
+  double r0 = mm_dec(o[0]), r1 = mm_dec(o[1]), r2 = mm_dec(o[2]), r3 = mm_dec(o[3]);
+  u64 cnt = o[4];
+  r0 = wave_max(r0), r1 = wave_min(r1), r2 = wave_max(r2), r3 = wave_min(r3);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+  double m0 = fmax(0.0, r0), m1 = fmin(1000.0, r1), m2 = 0.0, m3 = 9999.0;
+  if (extrinsic_est_en) m2 = fmax(m2, r2), m3 = fmin(m3, r3);
+  out5[0] = m0, out5[1] = -m1, out5[2] = m2, out5[3] = -m3, out5[4] = (double)cnt;
+}
+
+// workgroup-wide version for the thread-per-point kernels (k_reuse)
 __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, double ucov, double tr) {
   __shared__ double sm[BLK / 64][5];
   double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
@@ -409,20 +452,9 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, 
       r0 = fmax(r0, sm[w][0]), r1 = fmin(r1, sm[w][1]), r2 = fmax(r2, sm[w][2]), r3 = fmin(r3, sm[w][3]);
       r4 += sm[w][4];
     }
-    double *o = a.blockmm + (size_t)blockIdx.x * 5;
-    o[0] = r0, o[1] = r1, o[2] = r2, o[3] = r3, o[4] = r4;
+    mm_publish(a.mm_cur, r0, r1, r2, r3, (u64)r4);
   }
-}
-
-__global__ void __launch_bounds__(BLK) k_transform(Pass1Args a) {
-  const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= a.N) return;
-  const float4 q = a.scan[i];
-  float wx, wy, wz;
-  double nb;
-  world_point(a.qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
-  a.world4[i] = make_float4(wx, wy, wz, 0.f);
-  a.pbnorm[i] = nb;
+  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(a.mm_next, threadIdx.x);
 }
 
 // a2: ikdtree.Nearest_Search (laserMapping.cpp:586) on neighbour lists. ONE directory probe + one contiguous
@@ -474,82 +506,98 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   return (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
 }
 
-template <int G>
-__global__ void __launch_bounds__(BLK) k_knn_nl(Pass1Args a, NlView nl) {
-  const int tid = blockIdx.x * BLK + threadIdx.x;
-  const int qi = tid / G, sub = tid % G;
-  const bool active = qi < a.N;
-  const float4 w = a.world4[active ? qi : a.N - 1];
-  Top5 t;
-  const bool certified = nl_search<G>(nl, w.x, w.y, w.z, sub, 5.0f, t);
-  if (!active || sub != 0) return;
-  if (certified) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + qi] = t.og[k];
-    a.nfound[qi] = 5;
-  } else {
-    a.nfound[qi] = NF_PENDING;
+// ---- SEARCH pass, one kernel (laserMapping.cpp:563-612 + the rejected-point trace of :725-743) ----------------
+// A workgroup owns SQ = 64 consecutive sorted queries and runs three phases:
+//   A  wave 0, lane = query: a1 world transform (double, Eigen's operation order) -> LDS, world4, |p'|
+//   B  all 4 waves, G = 4 lanes per query: a2 level-1 neighbour-list search (8 x 16-byte loads in flight per lane),
+//      result (5 map ids or "not certified") -> LDS; waves 1-3 retire
+//   C  wave 0, lane = query: level-2 search for the few uncertified queries (all 64 lanes per query), a3 plane fit,
+//      gates, a6/a8 trace, extrema -> slots
+// One kernel instead of three saves two kernel boundaries (each costs a few us of drain + cache writeback at
+// this size) and lets the latency-bound plane fit of one workgroup overlap with the memory-bound search of the
+// others on the same CU.
+constexpr int NL1_G = 4;   // lanes per query on the level-1 lists (~45 candidates; measured 1: 30, 2: 24, 4: 20 us)
+constexpr int SQ = BLK / NL1_G;
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
+  __shared__ float4 s_w[SQ];
+  __shared__ u32 s_og[5][SQ];
+  __shared__ unsigned char s_nf[SQ];
+  __shared__ double s_nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
+  const int q0 = blockIdx.x * SQ;
+  // ---- phase A ----
+  const int i = q0 + (int)threadIdx.x;  // meaningful for wave 0 only
+  const bool mine = threadIdx.x < SQ && i < a.N;
+  PH(0, 0);
+  if (threadIdx.x < SQ) {
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+      const float4 q = a.scan[i];
+      double nb;
+      world_point(a.qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
+      a.world4[i] = w;
+      s_nb[threadIdx.x] = nb;
+    }
+    s_w[threadIdx.x] = w;
   }
-}
-
-// Level 2 (device function, first thing k_plane does): one lane per query looks at the flag; every wave then
-// serves ITS pending queries one at a time with all 64 lanes striding over the (~180-point) level-2 list.
-// Nothing pending (the common case: 8 of 100 k at config 2) costs one ballot; a pending query costs one probe,
-// one or two rounds of loads and a 6-step merge.
-__device__ __forceinline__ void serve_pending(const Pass1Args &a, const NlView &nl) {
-  const int qi0 = blockIdx.x * BLK + (threadIdx.x & ~63);  // first query of this wave
-  const int lane = threadIdx.x & 63;
-  const int myq = qi0 + lane;
-  const bool pending = myq < a.N && a.nfound[myq] == NF_PENDING;
-  unsigned long long todo = __ballot(pending);
-  while (todo) {
-    const int l = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const int qi = qi0 + l;
-    const float4 w = a.world4[qi];
+  __syncthreads();
+  PH(0, 1);
+  // ---- phase B ----
+  {
+    const int ql = threadIdx.x / NL1_G, sub = threadIdx.x % NL1_G;
+    const float4 ww = s_w[ql];
     Top5 t;
-    nl_search<64>(nl, w.x, w.y, w.z, lane, 5.0f, t);
-    if (lane < 5) {
-      u32 v = lane == 0 ? t.og[0] : lane == 1 ? t.og[1] : lane == 2 ? t.og[2] : lane == 3 ? t.og[3] : t.og[4];
-      a.nbr[(size_t)lane * a.N + qi] = v;
-    } else if (lane == 5) {
-      int nf = 0;
+    const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t);
+    if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
-      a.nfound[qi] = (unsigned char)nf;
+      for (int k = 0; k < 5; k++) s_og[k][ql] = t.og[k];
+      s_nf[ql] = certified ? 5 : NF_PENDING;
     }
   }
-  // the lanes that own those queries read nbr/nfound right after: same wave, program order + this fence
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// a3 + gates + a6 of a SEARCH pass: thread per query.
-__global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
-  PH(0, 0);
-  serve_pending(a, nl2);
-  PH(0, 1);
-  const int i = blockIdx.x * BLK + threadIdx.x;
+  __syncthreads();
+  if (threadIdx.x >= SQ) return;
+  PH(0, 2);
+  // ---- phase C (wave 0) ----
+  const int lane = threadIdx.x;
+  u32 og[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) og[k] = s_og[k][lane];
+  int nf = s_nf[lane];
+  {  // level 2: the wave serves its uncertified queries one at a time, 64 lanes striding over the level-2 list
+    unsigned long long todo = __ballot(mine && nf == NF_PENDING);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const float4 ww = s_w[l];
+      Top5 t;
+      nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
+      if (lane == l) {
+        nf = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) og[k] = t.og[k], nf += (t.og[k] != INVALID);
+      }
+    }
+  }
+  PH(0, 3);
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
-  if (i < a.N) {
-    const float4 q = a.scan[i];
-    const int packed = __float_as_int(q.w);
-    const int lid = packed & 0xFF, tidx = packed >> 8;
-    const float4 w = a.world4[i];
+  if (mine) {
+    const float4 w = s_w[lane];
+#pragma unroll
+    for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
+    a.nfound[i] = (unsigned char)nf;
     a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+    a.pbnorm[i] = s_nb[lane];
     commit_normal_y(a, i);
-    if (a.nfound[i] == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
+    if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
       // ---- esti_plane<float> (common_lib.h:144-190) ----
-      float A[5][3], P[5][3], W[5];
+      float A[5][3], W[5];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        float4 m = a.map_in[a.nbr[(size_t)k * a.N + i]];
-        A[k][0] = P[k][0] = m.x, A[k][1] = P[k][1] = m.y, A[k][2] = P[k][2] = m.z, W[k] = m.w;
+        float4 m = a.map_in[og[k]];
+        A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
       }
+      PH(0, 4);
       double cov_sum = 0;
-      PH(0, 2);
 #pragma unroll
       for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
       if ((double)W[0] > 0.00001) {
@@ -560,35 +608,46 @@ __global__ void __launch_bounds__(BLK) k_plane(Pass1Args a, NlView nl2) {
         }
       }
       float nv[3], pabcd[4];
-      PH(0, 3);
+      PH(0, 5);
       qr_solve_5x3(A, nv);
-      PH(0, 4);
+      PH(0, 6);
       float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
       pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
       pabcd[3] = (float)(1.0 / (double)n);
       bool plane_ok = true;
 #pragma unroll
-      for (int k = 0; k < 5; k++)
-        if (fabsf(pabcd[0] * P[k][0] + pabcd[1] * P[k][1] + pabcd[2] * P[k][2] + pabcd[3]) > a.plane_th)
-          plane_ok = false;
+      for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from L1/L2 (one live copy
+        const float4 m = a.map_in[og[k]];  // instead of two keeps the kernel at 6 waves per SIMD)
+        if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
+      }
       a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
       a.ucov[i] = ucov;
       if (plane_ok) {
         float pd2;
-        if (residual_gate(pabcd, w.x, w.y, w.z, a.pbnorm[i], pd2)) {
+        if (residual_gate(pabcd, w.x, w.y, w.z, s_nb[lane], pd2)) {
           selected = true;
           a.pd2[i] = pd2;
         }
       }
     }
     a.sel[i] = selected ? 1 : 0;
-    PH(0, 5);
-    tr = trace_for(a, q, lid, tidx, selected);
+    PH(0, 7);
+    const float4 q = a.scan[i];
+    const int packed = __float_as_int(q.w);
+    tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
     a.trace[i] = tr;
   }
-  PH(0, 6);
-  block_minmax(a, selected, ucov, tr);
-  PH(0, 7);
+  PH(0, 8);
+  {  // a4 over this wave's 64 queries
+    double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
+    const bool rsel = selected && a.extrinsic_est_en;
+    double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
+    mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
+    const unsigned long long bal = __ballot(selected);
+    if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, (u64)__popcll(bal));
+    if (blockIdx.x == 0) mm_reset_slot(a.mm_next, lane);  // MM_SLOTS == 64 lanes
+  }
+  PH(0, 9);
 }
 
 // REUSE pass (ekfom_data.converge == false, :583-595): neighbours, plane and flag are kept; the
@@ -623,32 +682,15 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
   block_minmax(a, selected, ucov, tr);
 }
 
-// One workgroup folds the per-workgroup (max_u, min_u, max_R, min_R, M) rows with the reference's
-// initial values (laserMapping.cpp:615-616,646-647) into [max_u, -min_u, max_R, -min_R, M].
-__global__ void __launch_bounds__(1024) k_minmax_reduce(const double *__restrict__ blockmm, int nb, int extrinsic_est_en,
-                                                        double *out) {
-  __shared__ double sm[16][5];
-  double r0 = -INFINITY, r1 = INFINITY, r2 = -INFINITY, r3 = INFINITY, r4 = 0;
-  for (int b = threadIdx.x; b < nb; b += 1024) {
-    const double *v = blockmm + (size_t)b * 5;
-    r0 = fmax(r0, v[0]), r1 = fmin(r1, v[1]), r2 = fmax(r2, v[2]), r3 = fmin(r3, v[3]), r4 += v[4];
-  }
-  r0 = wave_max(r0), r1 = wave_min(r1), r2 = wave_max(r2), r3 = wave_min(r3);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) r4 += __shfl_xor(r4, d);
-  if ((threadIdx.x & 63) == 0) {
-    int w = threadIdx.x >> 6;
-    sm[w][0] = r0, sm[w][1] = r1, sm[w][2] = r2, sm[w][3] = r3, sm[w][4] = r4;
-  }
-  __syncthreads();
+__global__ void k_mm_init(u64 *slots) { mm_reset_slot(slots, threadIdx.x); }
+
+// Staged (multi-GPU) path: one wave folds the slots into [max_u, -min_u, max_R, -min_R, M] for the all-reduce.
+__global__ void __launch_bounds__(64) k_minmax_reduce(const u64 *__restrict__ slots, int extrinsic_est_en, double *out) {
+  double o5[5];
+  mm_fold_wave(slots, extrinsic_est_en, o5);
   if (threadIdx.x == 0) {
-    double m0 = 0.0, m1 = 1000.0, m2 = 0.0, m3 = 9999.0, cnt = 0;
-    for (int w = 0; w < 16; w++) {
-      m0 = fmax(m0, sm[w][0]), m1 = fmin(m1, sm[w][1]);
-      if (extrinsic_est_en) m2 = fmax(m2, sm[w][2]), m3 = fmin(m3, sm[w][3]);
-      cnt += sm[w][4];
-    }
-    out[0] = m0, out[1] = -m1, out[2] = m2, out[3] = -m3, out[4] = cnt;
+#pragma unroll
+    for (int k = 0; k < 5; k++) out[k] = o5[k];
   }
 }
 
@@ -666,8 +708,7 @@ struct Pass2Args {
   PassConst pc;
   WeightConst wc;
   const double *minmax4;  // [max_ucov, -min_ucov, max_R, -min_R] when the caller reduced them (multi-GPU), else null
-  const double *blockmm;  // per-workgroup extrema of pass 1 [nb_mm][5] (single-GPU path: folded here)
-  int nb_mm;
+  const u64 *mmslots;  // extrema slots of stage 1 (single-GPU path: folded here by the first wave)
   double *mm_out;         // where workgroup 0 publishes the folded extrema + M for the host
   double *partials;       // [nblocks][NSUM]
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
@@ -737,38 +778,20 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __shared__ double SA[BLK][17];  // a_p: u / r (r clamped as esekfom.hpp:624-626), u[0..2], 0   (+1 pad)
   __shared__ double SB[BLK][17];  // b_p: u, hs, 0 0 0                                           (+1 pad)
   __shared__ double DW[BLK / 64][16][16];
-  __shared__ double smm[BLK / 64][5];
   __shared__ double mm_s[5];
   PH(1, 0);
-  // ---- a4 fold: every workgroup reduces the per-workgroup extrema of pass 1 itself (<= N/256 rows of 5
-  //      doubles from L2) instead of waiting for a separate 1-workgroup kernel ----
+  // ---- a4 fold: the first wave of every workgroup folds the 64 extrema slots of stage 1 (2.5 KB from L2) ----
   if (a.minmax4) {
     if (threadIdx.x < 4) mm_s[threadIdx.x] = a.minmax4[threadIdx.x];
-  } else {
-    double r0 = -INFINITY, r1 = INFINITY, r2 = -INFINITY, r3 = INFINITY, r4 = 0;
-    for (int b = threadIdx.x; b < a.nb_mm; b += BLK) {
-      const double *v = a.blockmm + (size_t)b * 5;
-      r0 = fmax(r0, v[0]), r1 = fmin(r1, v[1]), r2 = fmax(r2, v[2]), r3 = fmin(r3, v[3]), r4 += v[4];
-    }
-    r0 = wave_max(r0), r1 = wave_min(r1), r2 = wave_max(r2), r3 = wave_min(r3);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) r4 += __shfl_xor(r4, d);
-    if ((threadIdx.x & 63) == 0) {
-      int w = threadIdx.x >> 6;
-      smm[w][0] = r0, smm[w][1] = r1, smm[w][2] = r2, smm[w][3] = r3, smm[w][4] = r4;
-    }
-    __syncthreads();
+  } else if (threadIdx.x < 64) {
+    double o5[5];
+    mm_fold_wave(a.mmslots, a.extrinsic_est_en, o5);
     if (threadIdx.x == 0) {
-      // initial values of laserMapping.cpp:615-616,646-647
-      double m0 = 0.0, m1 = 1000.0, m2 = 0.0, m3 = 9999.0, cnt = 0;
-      for (int w = 0; w < BLK / 64; w++) {
-        m0 = fmax(m0, smm[w][0]), m1 = fmin(m1, smm[w][1]);
-        if (a.extrinsic_est_en) m2 = fmax(m2, smm[w][2]), m3 = fmin(m3, smm[w][3]);
-        cnt += smm[w][4];
-      }
-      mm_s[0] = m0, mm_s[1] = -m1, mm_s[2] = m2, mm_s[3] = -m3, mm_s[4] = cnt;
+#pragma unroll
+      for (int k = 0; k < 5; k++) mm_s[k] = o5[k];
       if (blockIdx.x == 0 && a.mm_out) {
-        a.mm_out[0] = m0, a.mm_out[1] = -m1, a.mm_out[2] = m2, a.mm_out[3] = -m3, a.mm_out[4] = cnt;
+#pragma unroll
+        for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
       }
     }
   }
@@ -895,7 +918,6 @@ __global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict_
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
-constexpr int NL1_G = 4;   // lanes per query on the level-1 lists (~45 candidates; measured 1: 30, 2: 24, 4: 20 us)
 constexpr int NL2_G = 16;  // lanes per query on the level-2 lists (~180 candidates), batched API
 
 // Batched Nearest_Search API: level-2 lists, radius limit just under cf2 (what the block always guarantees).
@@ -1171,8 +1193,11 @@ int measure_alloc(Ctx *c) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     c->cap_partials = nb + nb / 8 + 16;
     MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));
-    if (c->d_blockmm) (void)hipFree(c->d_blockmm);
-    MALIO_HIP(hipMalloc(&c->d_blockmm, sizeof(double) * 5 * c->cap_partials));
+  }
+  if (!c->d_mmslots) {
+    MALIO_HIP(hipMalloc(&c->d_mmslots, sizeof(u64) * 2 * MM_SLOTS * 5));
+    hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
+    c->mm_parity = 0;
   }
   if (!c->d_sums) {
     MALIO_HIP(hipMalloc(&c->d_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8 + 16)));
@@ -1292,7 +1317,10 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   a.unc = c->d_unc;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
-  a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm, a.blockmm = c->d_blockmm;
+  a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm;
+  c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
+  a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
+  a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;
@@ -1300,22 +1328,15 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   const int nb = (c->N + BLK - 1) / BLK;
   if (converge) {
     c->nbr_epoch = c->map_epoch;
-    hipLaunchKernelGGL(k_transform, dim3(nb), dim3(BLK), 0, c->stream, a);
-    prof_mark(c, "k_transform");
-    {
-      long long th = (long long)c->N * NL1_G;
-      hipLaunchKernelGGL(k_knn_nl<NL1_G>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, a,
-                         view_of(c->nl1));
-      prof_mark(c, "k_knn");
-    }
-    hipLaunchKernelGGL(k_plane, dim3(nb), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
-    prof_mark(c, "k_plane");
+    hipLaunchKernelGGL(k_search, dim3((c->N + SQ - 1) / SQ), dim3(BLK), 0, c->stream, a, view_of(c->nl1),
+                       view_of(c->nl2));
+    prof_mark(c, "k_search");
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_reuse");
   }
   if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
-    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, c->stream, c->d_blockmm, nb, c->prm.extrinsic_est_en,
+    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en,
                        d_minmax4_out);
     prof_mark(c, "k_minmax_reduce");
   }
@@ -1354,7 +1375,7 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   a.wc.point_cov_max = c->prm.point_cov_max, a.wc.point_cov_min = c->prm.point_cov_min;
   a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
   a.minmax4 = d_minmax4_in;
-  a.blockmm = c->d_blockmm, a.nb_mm = (c->N + BLK - 1) / BLK, a.mm_out = d_mm_out;
+  a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
   a.partials = c->d_partials;
   a.rows = nullptr;
   if (want_rows) {

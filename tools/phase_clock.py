@@ -12,11 +12,11 @@ for _ in range(20):
 out = (C.c_longlong * 64)()
 assert capi.lib().malio_debug_phase(out) == 0
 ph = np.array(out[:]).reshape(4, 16)
-names = {0: ["enter", "serve_pending", "neighbours gathered (+world, commit)", "plane_cov", "QR", "normalise+gates", "trace", "block_minmax"],
+names = {0: ["enter", "A: transform + sync", "B: level-1 search + sync", "C: level-2 for pending", "neighbours gathered", "plane_cov", "QR", "normalise+gates", "trace", "extrema"],
          1: ["enter", "extrema fold", "point_row", "LDS stage + sync", "97 sums", "write partials"]}
 for k, nm in names.items():
     t = ph[k][:len(nm)]
-    print("kernel", "k_plane" if k == 0 else "k_rows_reduce", "(100 MHz ticks -> us)")
+    print("kernel", "k_search" if k == 0 else "k_rows_reduce", "(100 MHz ticks -> us)")
     for j in range(1, len(nm)):
         print("   %-40s %6.2f us" % (nm[j], (t[j] - t[j - 1]) / 100.0))
     print("   %-40s %6.2f us" % ("total", (t[len(nm) - 1] - t[0]) / 100.0))

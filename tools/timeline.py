@@ -3,7 +3,7 @@ mean gap before it (end of the previous kernel of the same pass -> its start), p
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-names = ["k_transform", "k_knn_nl", "k_plane", "k_rows_reduce", "k_final_reduce"]
+names = ["k_search", "k_rows_reduce", "k_final_reduce"]
 def short(n):
     for s in names:
         if s in n:
@@ -13,13 +13,13 @@ seq = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp
 seq = [s for s in seq if s[0]]
 passes, cur = [], []
 for s in seq:
-    if s[0] == "k_transform":
-        if len(cur) == 5:
+    if s[0] == names[0]:
+        if len(cur) == len(names):
             passes.append(cur)
         cur = [s]
     elif cur:
         cur.append(s)
-if len(cur) == 5:
+if len(cur) == len(names):
     passes.append(cur)
 passes = passes[len(passes) // 4:]  # steady state
 dur = collections.defaultdict(list); gap = collections.defaultdict(list); period = []
@@ -27,7 +27,7 @@ for i, p in enumerate(passes):
     for j, (n, s, e) in enumerate(p):
         dur[n].append(e - s)
         if j: gap[n].append(s - p[j - 1][2])
-    if i: period.append(p[0][1] - passes[i - 1][0][1]); gap["k_transform"].append(p[0][1] - passes[i - 1][-1][2])
+    if i: period.append(p[0][1] - passes[i - 1][0][1]); gap[names[0]].append(p[0][1] - passes[i - 1][-1][2])
 import statistics as st
 print("passes analysed:", len(passes))
 for n in names:
