@@ -1,0 +1,16 @@
+#!/bin/bash
+# One GPU call that produces everything profiles/ keeps for a tag: tools/profile_round.sh r01d
+# (run via gpurun from the repo root; outputs under gpurun_out/<tag>/)
+set -u
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+python bench.py > $OUT/${TAG}_bench_stdout.txt 2> $OUT/bench_stderr.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_stdout.txt 2> $OUT/rocprof_stderr.txt
+bash $ROOT/tools/pmc_run.sh $TAG/pmc > $OUT/pmc_run_stdout.txt 2>&1
+python $ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/${TAG}_pmc_summary.txt 2>&1
+ls $OUT
+tail -c 600 $OUT/${TAG}_bench_stdout.txt
