@@ -70,6 +70,46 @@ class HipBackend:
         self.eng.stage2(self.d_mm.data_ptr(), self.d_sums.data_ptr())
         return self.d_sums
 
+    def pass_fn(self, state, converge, group=None):
+        """Pre-bound sharded pass for loops that repeat the same (state, converge): no Python-side conversions,
+        one D2H copy of [sums | extrema] into pinned memory, finish in C (malio_measure_finish). Returns
+        (fn, out_struct); fn() -> rc like malio_measure. Same sequence as sharded_measure()."""
+        import ctypes as C
+        from . import capi
+        eng = self.eng
+        ns = eng.sums_len()
+        buf = torch.zeros(ns + 8, dtype=torch.float64, device="cuda")          # [sums | mm(5) + pad]
+        host = torch.zeros(ns + 8, dtype=torch.float64).pin_memory()
+        sums, mm4 = buf[:ns], buf[ns:ns + 4]
+        p_sums, p_mm = buf.data_ptr(), buf.data_ptr() + 8 * ns
+        s = capi.state_from_flat(state, eng.L)
+        out = capi.MeasureOut()
+        lib = capi.lib()
+        f1, f2, f3 = lib.malio_measure_stage1, lib.malio_measure_stage2, lib.malio_measure_finish
+        h, sp, op, cv = eng.h, C.byref(s), C.byref(out), int(bool(converge))
+        vp_mm, vp_sums = C.c_void_p(p_mm), C.c_void_p(p_sums)
+        hp_sums = C.cast(host.data_ptr(), C.POINTER(C.c_double))
+        hp_mm = C.cast(host.data_ptr() + 8 * ns, C.POINTER(C.c_double))
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        stream = torch.cuda.current_stream()
+
+        def fn():
+            rc = f1(h, sp, cv, vp_mm)
+            if rc < 0:
+                return rc
+            if multi:
+                dist.all_reduce(mm4, op=dist.ReduceOp.MAX, group=group)
+            rc = f2(h, vp_mm, vp_sums)
+            if rc < 0:
+                return rc
+            if multi:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            host.copy_(buf, non_blocking=True)
+            stream.synchronize()
+            return f3(h, hp_sums, hp_mm, op)
+        fn._keep = (s, out, buf, host)
+        return fn, out
+
 
 def sharded_measure(backend, state, converge, group=None):
     """One measurement pass over a scan sharded across the ranks of `group`."""

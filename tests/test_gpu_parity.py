@@ -261,3 +261,24 @@ def test_results_are_bitwise_reproducible_across_engines(capi, scenes):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.gpu
+def test_prebound_sharded_pass_equals_fused_call(capi, scenes):
+    """dist.HipBackend.pass_fn (what bench.py times for N > 1) on one rank == malio_measure."""
+    import torch
+    from malio_amd import dist as mdist
+    sc = scenes.make_scene(cfg=3)
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ref = eng.measure(sc["state0"], True)
+    be = mdist.HipBackend(eng)
+    fn, out = be.pass_fn(sc["state0"], True)
+    for _ in range(3):
+        assert fn() >= 0
+    torch.cuda.synchronize()
+    Cc = eng.C
+    assert out.M == ref["M"] and bool(out.valid) == ref["valid"] and out.w_loc == ref["w_loc"]
+    np.testing.assert_array_equal(np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), ref["HtRinvH"])
+    np.testing.assert_array_equal(np.array(out.HtRinvh[:Cc]), ref["HtRinvh"])
