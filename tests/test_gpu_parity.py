@@ -282,3 +282,21 @@ def test_prebound_sharded_pass_equals_fused_call(capi, scenes):
     assert out.M == ref["M"] and bool(out.valid) == ref["valid"] and out.w_loc == ref["w_loc"]
     np.testing.assert_array_equal(np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), ref["HtRinvH"])
     np.testing.assert_array_equal(np.array(out.HtRinvh[:Cc]), ref["HtRinvh"])
+
+
+@pytest.mark.gpu
+def test_config4_on_one_gpu(capi, orc, scenes):
+    """BASELINE.json configs[3] (200 k-point scan vs 8 M-point map; quoted on 8 GPUs) fits one MI355X: the 8 M-point
+    map costs 2 x 3.5 GB of neighbour lists. Direct parity of one search pass with the oracle (reference ikd-Tree
+    over the same 8 M points) and the whole iterated update."""
+    sc = scenes.make_scene(cfg=4)
+    eng, o = make_pair(capi, orc, sc, threads=16)
+    g, r = compare_pass(eng, o, sc["state0"], True)
+    assert g["M"] > 0.8 * sc["N"]
+    c = eng.measure(sc["state0"], True)
+    assert np.array_equal(c["HtRinvH"], g["HtRinvH"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    assert np.abs(u["state"] - v["state"]).max() < 1e-7
