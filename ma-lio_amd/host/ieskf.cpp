@@ -217,17 +217,29 @@ bool invert(Mat &A, int n) {
         for (int j = k + 1; j < n; j++) A[i * n + j] -= l * A[k * n + j];
     }
   }
-  Mat X((size_t)n * n);
-  std::vector<double> y(n);
-  for (int col = 0; col < n; col++) {
-    for (int i = 0; i < n; i++) y[i] = piv[i] == col ? 1.0 : 0.0;
-    for (int i = 0; i < n; i++)
-      for (int j = 0; j < i; j++) y[i] -= A[i * n + j] * y[j];
-    for (int i = n - 1; i >= 0; i--) {
-      for (int j = i + 1; j < n; j++) y[i] -= A[i * n + j] * y[j];
-      y[i] /= A[i * n + i];
+  // A^-1 = U^-1 L^-1 P with ALL right-hand sides advanced together, one row operation at a time (row-major, so the
+  // inner loops run over contiguous columns and vectorise without reassociation). Every entry sees exactly the
+  // operations, in exactly the order, of a column-by-column forward/back substitution: same bits, ~5x faster -
+  // at 60 us per GPU pass the 35 x 35 algebra between passes is no longer negligible.
+  Mat X((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) X[(size_t)i * n + piv[i]] = 1.0;
+  for (int i = 0; i < n; i++) {
+    double *xi = &X[(size_t)i * n];
+    for (int j = 0; j < i; j++) {
+      const double l = A[i * n + j];
+      const double *xj = &X[(size_t)j * n];
+      for (int c = 0; c < n; c++) xi[c] -= l * xj[c];
     }
-    for (int i = 0; i < n; i++) X[i * n + col] = y[i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double *xi = &X[(size_t)i * n];
+    for (int j = i + 1; j < n; j++) {
+      const double u = A[i * n + j];
+      const double *xj = &X[(size_t)j * n];
+      for (int c = 0; c < n; c++) xi[c] -= u * xj[c];
+    }
+    const double d = A[i * n + i];
+    for (int c = 0; c < n; c++) xi[c] /= d;
   }
   A.swap(X);
   return true;
@@ -340,12 +352,16 @@ static int step_core(int L, int maximum_iter, int i, malio_state_t *x, const mal
       cols_applyT(L_, n, s2_idx, 2, B);
       cols_applyT(P_, n, s2_idx, 2, B);
     }
-    for (int a = 0; a < n; a++)  // :714
-      for (int b = 0; b < n; b++) {
-        double s = 0;
-        for (int k = 0; k < C; k++) s += K_x[a * n + k] * P_[k * n + b];
-        P_out[a * n + b] = L_[a * n + b] - s;
+    std::vector<double> acc(n);
+    for (int a = 0; a < n; a++) {  // :714, P = L - K_x[:, 0:C] P[0:C, :]  (k ascending per entry, row-wise axpy)
+      for (int b = 0; b < n; b++) acc[b] = 0.0;
+      for (int k = 0; k < C; k++) {
+        const double kx = K_x[a * n + k];
+        const double *pk = &P_[(size_t)k * n];
+        for (int b = 0; b < n; b++) acc[b] += kx * pk[b];
       }
+      for (int b = 0; b < n; b++) P_out[a * n + b] = L_[a * n + b] - acc[b];
+    }
     *done_out = 1;
   }
   return MALIO_OK;
@@ -365,10 +381,12 @@ static GainFn normal_eq_gain(int L, const double *HtRinvH, const double *HtRinvh
       double s = 0;
       for (int b = 0; b < C; b++) s += Pt[a * n + b] * HtRinvh[b];
       K_h[a] = s;
-      for (int b = 0; b < C; b++) {
-        double s2 = 0;
-        for (int k = 0; k < C; k++) s2 += Pt[a * n + k] * HtRinvH[k * C + b];
-        K_x[a * n + b] = s2;
+      double *kx = &K_x[(size_t)a * n];
+      for (int b = 0; b < C; b++) kx[b] = 0.0;
+      for (int k = 0; k < C; k++) {  // k ascending per entry, as a dot product would; contiguous in b
+        const double p = Pt[a * n + k];
+        const double *hk = &HtRinvH[(size_t)k * C];
+        for (int b = 0; b < C; b++) kx[b] += p * hk[b];
       }
     }
     return MALIO_OK;
