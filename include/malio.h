@@ -250,8 +250,10 @@ int malio_last_kernel_times(malio_handle_t h, const char **names, float *ms, int
 /* Enable/disable per-kernel event timing (off by default: events add launch latency). */
 int malio_set_profiling(malio_handle_t h, int on);
 
-/* Diagnostics: out3 = {level-1 directory cells, map points, level-2 directory cells}. */
-int malio_debug_counters(malio_handle_t h, int *out3);
+/* Diagnostics: out8 = {level-1 directory cells, map points at the last list build, level-2 directory cells,
+ * full list rebuilds so far, map changes applied to the lists in place so far, deleted slots awaiting compaction,
+ * tombstoned points in the lists, map slots in use}. */
+int malio_debug_counters(malio_handle_t h, int *out8);
 
 #ifdef __cplusplus
 }

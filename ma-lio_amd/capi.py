@@ -191,9 +191,10 @@ class Engine:
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
 
     def debug_counters(self):
-        out = (C.c_int * 3)()
+        out = (C.c_int * 8)()
         lib().malio_debug_counters(self.h, out)
-        return dict(nl1_cells=out[0], map_points=out[1], nl2_cells=out[2])
+        return dict(nl1_cells=out[0], map_points=out[1], nl2_cells=out[2], rebuilds=out[3], inplace=out[4],
+                    dead_slots=out[5], tombstones=out[6], slots=out[7])
 
     def map_build(self, pts12):
         pts12 = np.ascontiguousarray(pts12, np.float32)

@@ -125,7 +125,7 @@ int malio_destroy(malio_handle_t h) {
   free_nlist(c->nl2);
   free_nl_scratch(c->nl_scratch);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_ny);
-  fr(c->d_map_alt), free_grid(c->vox);
+  fr(c->d_map_alt);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
@@ -177,7 +177,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   }
   MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   c->map_n = n;
-  c->vox_valid = false;
+  c->map_dead = 0;
   c->map_epoch++;
   int rc = map_rebuild_search(c);
   (void)hipStreamSynchronize(c->stream);
@@ -188,7 +188,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
 
 int malio_map_size(malio_handle_t h, int *out_size) {
   if (check(h) || !out_size) return MALIO_ERR_BAD_ARG;
-  *out_size = h->map_n;
+  *out_size = h->map_n - h->map_dead;
   return MALIO_OK;
 }
 
@@ -196,7 +196,7 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
                          float *out_d2, int *out_count) {
   if (check(h) || !queries || n <= 0 || k < 1 || k > 5) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
-  if (c->map_n <= 0) return MALIO_ERR_NO_MAP;
+  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   MALIO_HIP(hipSetDevice(c->device));
   std::vector<float4> hq(n);
   for (int i = 0; i < n; i++) hq[i] = make_float4(queries[i].x, queries[i].y, queries[i].z, 0.f);
@@ -261,18 +261,19 @@ int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, in
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   if (check(h) || !out_n || cap < 0 || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
-  *out_n = c->map_n;
-  int n = std::min(cap, c->map_n);
-  if (n <= 0) return MALIO_OK;
+  *out_n = c->map_n - c->map_dead;
+  if (cap <= 0 || c->map_n <= 0) return MALIO_OK;
   MALIO_HIP(hipSetDevice(c->device));
-  std::vector<float4> mp((size_t)n);
-  MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  std::vector<float4> mp((size_t)c->map_n);
+  MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < n; i++) {
+  int k = 0;
+  for (size_t i = 0; i < mp.size() && k < cap; i++) {
+    if (std::isinf(mp[i].x)) continue;  // deleted slot
     malio_point_t p;
     memset(&p, 0, sizeof(p));
     p.x = mp[i].x, p.y = mp[i].y, p.z = mp[i].z, p._pad0 = 1.f, p.normal_y = mp[i].w;
-    out[i] = p;
+    out[k++] = p;
   }
   return MALIO_OK;
 }
@@ -499,10 +500,11 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
 }
 
 // Diagnostics (not part of the reference interface): {level-1 directory cells, map points, level-2 directory cells}.
-int malio_debug_counters(malio_handle_t h, int *out3) {
-  if (check(h) || !out3) return MALIO_ERR_BAD_ARG;
+int malio_debug_counters(malio_handle_t h, int *out8) {
+  if (check(h) || !out8) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
-  out3[0] = (int)c->nl1.ncells, out3[1] = (int)(c->nl1.total / 27), out3[2] = (int)c->nl2.ncells;
+  out8[0] = (int)c->nl1.ncells, out8[1] = (int)(c->nl1.entries / 27), out8[2] = (int)c->nl2.ncells;
+  out8[3] = c->n_rebuilds, out8[4] = c->n_inplace, out8[5] = c->map_dead, out8[6] = c->nl_tomb, out8[7] = c->map_n;
   return MALIO_OK;
 }
 

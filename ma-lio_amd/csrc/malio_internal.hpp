@@ -42,8 +42,11 @@ struct NList {
   Cell *table = nullptr;  // fine cell -> (start, count) of its neighbourhood list
   u32 tmask = 0;
   u32 ncells = 0;
-  float4 *pts = nullptr;  // [total] x, y, z, bits(original index)
-  size_t total = 0;
+  float4 *pts = nullptr;  // [cap_pts] x, y, z, bits(map index); a deleted point's entries carry x = +inf
+  u32 *cap = nullptr;     // [table size] capacity of every list (count + slack): room for incremental inserts
+  u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells
+  size_t total = 0;       // entries reserved by the lists built last (capacities)
+  size_t entries = 0;     // live entries at build time (27 per point)
   size_t cap_pts = 0, cap_table = 0;
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
 };
@@ -51,8 +54,18 @@ struct NList {
 // scratch of build_nlist (open-addressing directory under construction), kept between rebuilds
 struct NlScratch {
   u64 *keys = nullptr;
-  u32 *cnt = nullptr, *start = nullptr, *tiles = nullptr, *counters = nullptr;
+  u32 *cnt = nullptr, *start = nullptr, *capv = nullptr, *tiles = nullptr, *counters = nullptr;
   u32 cap = 0;
+};
+
+// device-side view of a neighbour-list level for the incremental kernels
+struct NlDev {
+  Cell *table;
+  u32 tmask;
+  float4 *pts;
+  u32 *cap, *state;
+  u32 bump_end;
+  float inv_cf;
 };
 
 #if defined(__HIP__)
@@ -112,11 +125,12 @@ struct Ctx {
   float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
   float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
   size_t cap_map_in = 0, cap_map_alt = 0;
-  CellGrid vox;  // map grouped by downsample voxel (edge filter_size_map), rebuilt by map_add when stale
-  bool vox_valid = false;
+  int map_dead = 0;  // slots of d_map_in[0, map_n) that hold a deleted point (x = +inf)
+  int nl_tomb = 0;   // tombstoned points in the lists since the last full build
+  int n_rebuilds = 0, n_inplace = 0;  // diagnostics: full list builds / map changes applied to the lists in place
   int map_epoch = 0;   // bumped by every change of the map array (indices in d_nbr refer to one epoch)
   int nbr_epoch = 0;   // epoch d_nbr was filled in
-  int map_n = 0;
+  int map_n = 0;  // slots in use (live + dead); the number of valid points is map_n - map_dead
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
   bool scan_sorted = false;
@@ -189,6 +203,10 @@ int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n)
 void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);
+// incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
+void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m);
+void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
+void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const unsigned char *del, int hw);
 void free_nl_scratch(NlScratch &s);
 
 // map_update.hip

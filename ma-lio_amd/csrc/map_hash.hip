@@ -294,6 +294,7 @@ void free_nl_scratch(NlScratch &s) {
   if (s.keys) (void)hipFree(s.keys);
   if (s.cnt) (void)hipFree(s.cnt);
   if (s.start) (void)hipFree(s.start);
+  if (s.capv) (void)hipFree(s.capv);
   if (s.tiles) (void)hipFree(s.tiles);
   if (s.counters) (void)hipFree(s.counters);
   s = NlScratch();
@@ -302,7 +303,37 @@ void free_nl_scratch(NlScratch &s) {
 void free_nlist(NList &nl) {
   if (nl.table) (void)hipFree(nl.table);
   if (nl.pts) (void)hipFree(nl.pts);
+  if (nl.cap) (void)hipFree(nl.cap);
+  if (nl.state) (void)hipFree(nl.state);
   nl = NList();
+}
+
+// capacity of a list built with `cnt` entries: room for a quarter more, at least NL_MIN_SLACK
+constexpr u32 NL_MIN_SLACK = 8;
+constexpr u32 NL_NEW_CAP = 12;  // capacity handed to a list that is created by an incremental insert
+__global__ void __launch_bounds__(BLK) k_nl_caps(const u32 *__restrict__ cnt, u32 *capv, u32 n) {
+  u32 i = blockIdx.x * BLK + threadIdx.x;
+  if (i > n) return;  // capv[n] = 0: the exclusive scan then leaves the total there
+  u32 c = i < n ? cnt[i] : 0u;
+  capv[i] = c ? c + max(NL_MIN_SLACK, c / 4) : 0u;
+}
+// scratch slots -> compact directory, with the capacity of every list next to it
+__global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys, const u32 *__restrict__ cnt,
+                                                    const u32 *__restrict__ start, const u32 *__restrict__ capv, u32 tbig,
+                                                    Cell *table, u32 *cap, u32 tmask) {
+  u32 s = blockIdx.x * BLK + threadIdx.x;
+  if (s >= tbig) return;
+  u64 key = keys[s];
+  if (key == EMPTY_KEY) return;
+  u32 d = hash_key(key) & tmask;
+  while (true) {
+    u64 old = atomicCAS(&table[d].key, EMPTY_KEY, key);
+    if (old == EMPTY_KEY) break;
+    d = (d + 1) & tmask;
+  }
+  table[d].start = start[s];
+  table[d].count = cnt[s];
+  cap[d] = capv[s];
 }
 
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
@@ -310,58 +341,181 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
   nl.inv_cf = 1.0f / nl.cf;
   // scratch table: halo cells are a few times the occupied ones; 8 slots per point keeps the load low
   u32 tbig = next_pow2((u32)std::max(4096, 8 * n));
-  int ntiles = (tbig + 1023) / 1024;
-  NlScratch &sc = c->nl_scratch;  // kept across rebuilds: the map is rebuilt after every Add_Points
+  int ntiles = (tbig + 1 + 1023) / 1024;
+  NlScratch &sc = c->nl_scratch;  // kept across rebuilds
   if (tbig > sc.cap) {
     free_nl_scratch(sc);
     MALIO_HIP(hipMalloc(&sc.keys, sizeof(u64) * tbig));
-    MALIO_HIP(hipMalloc(&sc.cnt, sizeof(u32) * tbig));
-    MALIO_HIP(hipMalloc(&sc.start, sizeof(u32) * tbig));
-    MALIO_HIP(hipMalloc(&sc.tiles, sizeof(u32) * (ntiles + 1)));
+    MALIO_HIP(hipMalloc(&sc.cnt, sizeof(u32) * (tbig + 1)));
+    MALIO_HIP(hipMalloc(&sc.start, sizeof(u32) * (tbig + 1)));
+    MALIO_HIP(hipMalloc(&sc.capv, sizeof(u32) * (tbig + 1)));
+    MALIO_HIP(hipMalloc(&sc.tiles, sizeof(u32) * (ntiles + 2)));
     MALIO_HIP(hipMalloc(&sc.counters, sizeof(u32) * 2));
     sc.cap = tbig;
   }
   u64 *keys = sc.keys;
-  u32 *cnt = sc.cnt, *start = sc.start, *tiles = sc.tiles, *counters = sc.counters;
+  u32 *cnt = sc.cnt, *start = sc.start, *capv = sc.capv, *tiles = sc.tiles, *counters = sc.counters;
   hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
   MALIO_HIP(hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream));
   int nb = (n + BLK - 1) / BLK;
   hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, cnt, tbig - 1, counters,
                      counters + 1);
-  exclusive_scan_u32(c, cnt, start, tiles, (int)tbig);
-  u32 h_cnt[2] = {0, 0};
+  // every list gets slack for incremental inserts (map_update.hip); starts = exclusive scan of the capacities
+  hipLaunchKernelGGL(k_nl_caps, dim3((tbig + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, cnt, capv, tbig);
+  exclusive_scan_u32(c, capv, start, tiles, (int)tbig + 1);
+  u32 h_cnt[3] = {0, 0, 0};
   MALIO_HIP(hipMemcpyAsync(h_cnt, counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(&h_cnt[2], start + tbig, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   if (h_cnt[1] != 0) {
     c->err = "neighbour-list directory overflow";
     return MALIO_ERR_ALLOC;
   }
-  size_t total = (size_t)27 * (size_t)n;
-  if (total > nl.cap_pts) {
+  const size_t used = h_cnt[2];
+  // tail of the array: lists of cells that do not exist yet are carved from here by incremental inserts
+  const size_t want = used + used / 4 + ((size_t)1 << 20);
+  if (want > nl.cap_pts || !nl.pts) {
     if (nl.pts) (void)hipFree(nl.pts);
     nl.pts = nullptr;
-    nl.cap_pts = total + total / 16 + 1024;
+    nl.cap_pts = want + want / 16;
+    if (nl.cap_pts > 0xFFFFFF00ull) {
+      c->err = "neighbour lists exceed 2^32 entries";
+      return MALIO_ERR_ALLOC;
+    }
     MALIO_HIP(hipMalloc(&nl.pts, sizeof(float4) * nl.cap_pts));
   }
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));  // reuse as the fill cursor
   hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,
                      nl.pts);
-  // compact directory: the fill cursors now equal the list lengths
-  u32 tsize = next_pow2(std::max(1024u, 2u * h_cnt[0]));
-  if ((size_t)tsize > nl.cap_table) {
+  // compact directory (the fill cursors now equal the list lengths); sized for growth to load 0.7
+  u32 tsize = next_pow2(std::max(1024u, 3u * h_cnt[0]));
+  if ((size_t)tsize > nl.cap_table || !nl.table) {
     if (nl.table) (void)hipFree(nl.table);
-    nl.table = nullptr;
+    if (nl.cap) (void)hipFree(nl.cap);
+    nl.table = nullptr, nl.cap = nullptr;
     nl.cap_table = tsize;
     MALIO_HIP(hipMalloc(&nl.table, sizeof(Cell) * nl.cap_table));
+    MALIO_HIP(hipMalloc(&nl.cap, sizeof(u32) * nl.cap_table));
   }
+  if (!nl.state) MALIO_HIP(hipMalloc(&nl.state, sizeof(u32) * 4));
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
-  hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
-                     nl.table, tsize - 1);
+  MALIO_HIP(hipMemsetAsync(nl.cap, 0, sizeof(u32) * tsize, c->stream));
+  hipLaunchKernelGGL(k_nl_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, capv, tbig,
+                     nl.table, nl.cap, tsize - 1);
+  const u32 h_state[4] = {(u32)used, 0u, h_cnt[0], 0u};  // bump cursor, overflow flag, cells, -
+  MALIO_HIP(hipMemcpyAsync(nl.state, h_state, sizeof(h_state), hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  nl.tmask = tsize - 1, nl.ncells = h_cnt[0], nl.total = total;
+  nl.tmask = tsize - 1, nl.ncells = h_cnt[0], nl.total = used, nl.entries = (size_t)27 * (size_t)n;
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
+}
+
+// ---- incremental maintenance (called by map_update.hip; same stream, never concurrent with a search) -----------
+// (1) make sure the 27 cells around every kept new point have a directory entry and a list to append to
+__global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
+                                                   NlDev nl) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= m || !keep[i]) return;
+  float4 p = newp[i];
+  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+        u32 s = hash_key(key) & nl.tmask;
+        while (true) {
+          u64 old = __builtin_nontemporal_load(&nl.table[s].key);
+          if (old == EMPTY_KEY) {
+            old = atomicCAS(&nl.table[s].key, EMPTY_KEY, key);
+            if (old == EMPTY_KEY) {  // this thread created the cell: carve its list from the tail
+              u32 st = atomicAdd(&nl.state[0], NL_NEW_CAP);
+              if (st + NL_NEW_CAP > nl.bump_end) {
+                atomicExch(&nl.state[1], 1u);
+                st = 0;  // never written to: capacity 0
+                nl.cap[s] = 0;
+              } else {
+                nl.cap[s] = NL_NEW_CAP;
+              }
+              nl.table[s].start = st;
+              nl.table[s].count = 0;
+              atomicAdd(&nl.state[2], 1u);
+              break;
+            }
+          }
+          if (old == key) break;
+          s = (s + 1) & nl.tmask;
+        }
+      }
+}
+// (2) append every kept new point (map index og_base + rank) to its 27 lists
+__global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ newp, const u32 *__restrict__ keep,
+                                                   const u32 *__restrict__ rank, u32 og_base, int m, NlDev nl) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= m || !keep[i]) return;
+  float4 p = newp[i];
+  float4 rec = make_float4(p.x, p.y, p.z, __uint_as_float(og_base + rank[i]));
+  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+        u32 s = hash_key(key) & nl.tmask;
+        while (nl.table[s].key != key) s = (s + 1) & nl.tmask;
+        u32 pos = atomicAdd(&nl.table[s].count, 1u);
+        if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
+          atomicSub(&nl.table[s].count, 1u);
+          atomicExch(&nl.state[1], 1u);
+        } else {
+          nl.pts[(size_t)nl.table[s].start + pos] = rec;
+        }
+      }
+}
+// (3) a deleted map point leaves its 27 lists: the entry stays but can never be a neighbour again (x = +inf makes
+//     every distance +inf, which the search drops); tombstones are swept by the next full rebuild
+__global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const unsigned char *__restrict__ del,
+                                                      int hw, NlDev nl) {
+  // 32 lanes per map slot, one of its 27 lists each (a level-2 list has ~180 entries to look through)
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const int i = (int)(t >> 5), cidx = (int)(t & 31);
+  if (i >= hw || cidx >= 27 || !del[i]) return;
+  float4 p = mapp[i];
+  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  const int dx = cidx % 3 - 1, dy = (cidx / 3) % 3 - 1, dz = cidx / 9 - 1;
+  u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+  u32 s = hash_key(key) & nl.tmask;
+  while (true) {
+    u64 k = nl.table[s].key;
+    if (k == key) break;
+    if (k == EMPTY_KEY) return;  // cannot happen for a point that was inserted
+    s = (s + 1) & nl.tmask;
+  }
+  const u32 st = nl.table[s].start, cn = nl.table[s].count;
+  for (u32 j = 0; j < cn; j++)
+    if (__float_as_uint(nl.pts[(size_t)st + j].w) == (u32)i) {
+      nl.pts[(size_t)st + j].x = INFINITY;
+      break;
+    }
+}
+
+NlDev nl_dev(const NList &nl) {
+  NlDev v;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.state = nl.state;
+  v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf;
+  return v;
+}
+
+void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m) {
+  hipLaunchKernelGGL(k_nl_ensure, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl));
+}
+void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m) {
+  hipLaunchKernelGGL(k_nl_append, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, rank, og_base, m,
+                     nl_dev(nl));
+}
+void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const unsigned char *del, int hw) {
+  const long long th = (long long)hw * 32;
+  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_map, del, hw,
+                     nl_dev(nl));
 }
 
 }  // namespace malio

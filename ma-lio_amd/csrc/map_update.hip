@@ -6,8 +6,12 @@
 // That dependency only exists between points of the same downsample voxel, so the work is sharded by voxel:
 // one thread replays, in input order, the steps of the new points that fall into its voxel against the stored
 // points of that voxel, and every voxel runs in parallel. Outputs are two flag arrays (stored point deleted /
-// new point kept); a prefix-sum compaction then writes the next map array (survivors in their old order, then
-// the kept new points in input order) and the neighbour lists of both search levels are rebuilt from it.
+// new point kept). They are applied IN PLACE: a deleted point's slot in the map array and its 27 entries per
+// neighbour-list level become tombstones (x = +inf: at infinite distance from everything), kept new points are
+// appended to the array and to the slack every list was built with (new cells get a list carved from the tail).
+// Map indices therefore stay stable between full rebuilds; a rebuild (compaction + both list levels from scratch)
+// happens lazily, at the next search, only when a list, the tail or the directory runs out of room or a fifth of
+// the entries are tombstones.
 //
 // Keeper rule of one step (ikd_Tree.cpp:504-528), restated order-free. With p the new point, S the stored
 // points inside the voxel box, "near" meaning calc_dist(q, mid) < downsample_size/8 (a SQUARED distance compared
@@ -56,22 +60,23 @@ __device__ __forceinline__ bool displaces(const Winner &a, const Winner &b) {
   return b.dist < a.dist || (b.dist == a.dist && b.rank < a.rank);
 }
 
-// One thread per occupied voxel of the NEW points.
+// One thread per occupied voxel of the NEW points. The stored points of the voxel are found in the level-1
+// neighbour list of the new point's cell: the list holds every map point of the 3x3x3 block of cells (edge cf >=
+// downsample size) around it, so the whole voxel box is covered; the literal box test decides.
 __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable, u32 ntsize,
                                                  const u32 *__restrict__ norig, const float4 *__restrict__ newp,
-                                                 const Cell *__restrict__ mtable, u32 mtmask,
-                                                 const u32 *__restrict__ morig, const float4 *__restrict__ mapp,
-                                                 int map_n, float ds, unsigned char *del, u32 *addf, u32 *counter) {
+                                                 const Cell *__restrict__ ltable, u32 ltmask,
+                                                 const float4 *__restrict__ lpts, float linv_cf,
+                                                 const float4 *__restrict__ mapp, int have_map, float ds,
+                                                 unsigned char *del, u32 *addf, u32 *counters /*[0] adds [1] deletions*/) {
   u32 slot = blockIdx.x * BLK + threadIdx.x;
   if (slot >= ntsize) return;
   Cell nc = ntable[slot];
   if (nc.key == EMPTY_KEY || nc.count == 0) return;
-  u32 es = 0, ec = 0;
-  if (map_n > 0) vox_find(mtable, mtmask, nc.key, es, ec);
   const float near_th = ds / 8;  // ikd_Tree.cpp:510
   const u32 NONE = 0xFFFFFFFFu;
   u32 alive = NONE;  // new point of this voxel currently in the map
-  u32 last = 0, adds = 0;
+  u32 last = 0, adds = 0, dels = 0;
   for (u32 step = 0; step < nc.count; step++) {
     u32 cur = NONE;  // next new point in input order
     for (u32 j = 0; j < nc.count; j++) {
@@ -89,21 +94,27 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
       bmax[a] = bmin[a] + ds;
       mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
     }
+    // stored candidates: the level-1 list of the cell of the voxel centre (any point of the box would do)
+    u32 es = 0, ec = 0;
+    if (have_map) {
+      u64 key = cell_key((int)floorf(mid[0] * linv_cf), (int)floorf(mid[1] * linv_cf), (int)floorf(mid[2] * linv_cf));
+      vox_find(ltable, ltmask, key, es, ec);
+    }
     Winner w;
     w.x = p.x, w.y = p.y, w.z = p.z, w.cov = p.w, w.rank = 0;
     w.dist = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
     w.near = w.dist < near_th;
     u32 inbox = 0;
     for (u32 j = 0; j < ec; j++) {
-      u32 mi = morig[es + j];
-      if (del[mi]) continue;
-      float4 q = mapp[mi];
+      const float4 q = lpts[(size_t)es + j];  // x = +inf for a tombstone: fails the box test
       // Search_by_range / Delete_by_range leaf test (ikd_Tree.cpp:1263-1274, :807): min <= q < max
       if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
         continue;
+      const u32 mi = __float_as_uint(q.w);
+      if (del[mi]) continue;
       inbox++;
       Winner b;
-      b.x = q.x, b.y = q.y, b.z = q.z, b.cov = q.w, b.rank = 1u + mi;
+      b.x = q.x, b.y = q.y, b.z = q.z, b.cov = mapp[mi].w, b.rank = 1u + mi;
       b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
       b.near = b.dist < near_th;
       if (displaces(w, b)) w = b;
@@ -123,11 +134,13 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
     bool same = fabs((double)(p.x - w.x)) < 1e-6 && fabs((double)(p.y - w.y)) < 1e-6 && fabs((double)(p.z - w.z)) < 1e-6;
     if (inbox > 1 || same) {
       for (u32 j = 0; j < ec; j++) {
-        u32 mi = morig[es + j];
+        const float4 q = lpts[(size_t)es + j];
+        if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
+          continue;
+        const u32 mi = __float_as_uint(q.w);
         if (del[mi] || w.rank == 1u + mi) continue;
-        float4 q = mapp[mi];
-        if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
-          del[mi] = 1;
+        del[mi] = 1;
+        dels++;
       }
       if (alive != NONE && w.rank != NONE) {
         float4 q = newp[alive];
@@ -143,7 +156,8 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
       adds++;
     }
   }
-  if (adds) atomicAdd(counter, adds);
+  if (adds) atomicAdd(&counters[0], adds);
+  if (dels) atomicAdd(&counters[1], dels);
 }
 
 __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ mapp, int n,
@@ -152,7 +166,7 @@ __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ m
   int i = blockIdx.x * BLK + threadIdx.x;
   bool hit = false;
   if (i < n) {
-    float4 q = mapp[i];
+    float4 q = mapp[i];  // a deleted slot has x = +inf: inside no box
     for (int b = 0; b < nb; b++) {
       const malio_box_t bx = boxes[b];
       hit = hit || (bx.vertex_min[0] <= q.x && bx.vertex_max[0] > q.x && bx.vertex_min[1] <= q.y &&
@@ -162,11 +176,6 @@ __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ m
   }
   unsigned long long m = __ballot(hit);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (u32)__popcll(m));
-}
-
-__global__ void __launch_bounds__(BLK) k_keep_flags(const unsigned char *__restrict__ del, int n, u32 *keep) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i <= n) keep[i] = (i < n && !del[i]) ? 1u : 0u;  // keep[n] = 0: the scan then leaves the total at [n]
 }
 
 __global__ void __launch_bounds__(BLK) k_compact(const float4 *__restrict__ src, const u32 *__restrict__ flag,
@@ -206,6 +215,23 @@ struct Scratch {  // freed on every exit path
   }
 };
 
+__global__ void __launch_bounds__(BLK) k_alive_flags(const float4 *__restrict__ mapp, int n, u32 *keep) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i <= n) keep[i] = (i < n && !isinf(mapp[i].x)) ? 1u : 0u;  // keep[n] = 0: the scan leaves the total at [n]
+}
+__global__ void __launch_bounds__(BLK) k_map_kill(float4 *mapp, const unsigned char *__restrict__ del, int n) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && del[i]) mapp[i].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
+}
+__global__ void __launch_bounds__(BLK) k_fill_u32(u32 *p, u32 v, int n) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void __launch_bounds__(BLK) k_iota_u32(u32 *p, int n) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) p[i] = (u32)i;
+}
+
 }  // namespace
 
 int map_sync_search(Ctx *c) {
@@ -213,12 +239,106 @@ int map_sync_search(Ctx *c) {
   return map_rebuild_search(c);
 }
 
+// Full rebuild: sweep the deleted slots out of the map array (indices change), then both list levels from scratch.
 int map_rebuild_search(Ctx *c) {
   c->search_dirty = false;
+  if (c->map_dead > 0 && c->map_n > 0) {
+    Scratch sc;
+    u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr;
+    const int n0 = c->map_n;
+    MALIO_HIP(sc.get(&keep, (size_t)n0 + 1));
+    MALIO_HIP(sc.get(&kpos, (size_t)n0 + 1));
+    MALIO_HIP(sc.get(&tiles, (size_t)(n0 + 1 + 1023) / 1024 + 2));
+    hipLaunchKernelGGL(k_alive_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, keep);
+    exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
+    u32 alive = 0;
+    MALIO_HIP(hipMemcpyAsync(&alive, kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    int rc = ensure_alt(c, (size_t)alive + (size_t)alive / 4 + 4096);
+    if (rc != MALIO_OK) return rc;
+    hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
+                       (const u32 *)nullptr, c->d_map_alt);
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    swap_maps(c);
+    c->map_n = (int)alive;
+    c->map_dead = 0;
+    c->map_epoch++;
+  }
+  c->nl_tomb = 0;
   if (c->map_n <= 0) return MALIO_OK;
+  c->n_rebuilds++;
   int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1);
-  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, 2.0f * std::max(c->cell, 1.1180341f), c->nl2);
+  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;
+}
+
+// room for `extra` more slots at the end of the map array
+static int map_reserve(Ctx *c, size_t extra) {
+  const size_t need = (size_t)c->map_n + extra;
+  if (need <= c->cap_map_in) return MALIO_OK;
+  int rc = ensure_alt(c, need + need / 4 + 4096);
+  if (rc != MALIO_OK) return rc;
+  if (c->map_n > 0)
+    MALIO_HIP(hipMemcpyAsync(c->d_map_alt, c->d_map_in, sizeof(float4) * (size_t)c->map_n, hipMemcpyDeviceToDevice, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  swap_maps(c);
+  return MALIO_OK;
+}
+
+// Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
+//   del[map_n] != 0 -> slot dies (x = +inf), its 27 entries per level become tombstones
+//   keep[m] != 0    -> d_new[i] is appended as slot map_n + rank[i] and inserted into 27 lists per level
+// Falls back to "lists are stale" (rebuilt by the next search) when a list or the directory runs out of room or
+// too many tombstones have piled up.
+static int map_apply(Ctx *c, const unsigned char *del, u32 ndel, const float4 *d_new, const u32 *keep, const u32 *rank,
+                     int m, u32 nadd) {
+  const int hw = c->map_n;
+  bool in_place = !c->search_dirty && hw > 0;
+  // the directory must not fill up while cells are being created (27 new cells per new point at the very worst);
+  // tombstones stay below a fifth of the live points
+  if (in_place) {
+    const size_t worst1 = (size_t)c->nl1.ncells + 27 * (size_t)nadd, worst2 = (size_t)c->nl2.ncells + 27 * (size_t)nadd;
+    if (worst1 * 10 > (size_t)(c->nl1.tmask + 1) * 9 || worst2 * 10 > (size_t)(c->nl2.tmask + 1) * 9) in_place = false;
+    if ((size_t)(c->nl_tomb + ndel) * 5 > (size_t)(hw - c->map_dead)) in_place = false;
+  }
+  if (ndel) {
+    if (in_place) {
+      nl_tombstone(c, c->nl1, c->d_map_in, del, hw);
+      nl_tombstone(c, c->nl2, c->d_map_in, del, hw);
+    }
+    hipLaunchKernelGGL(k_map_kill, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, del, hw);
+    c->map_dead += (int)ndel, c->nl_tomb += (int)ndel;
+  }
+  if (nadd) {
+    int rc = map_reserve(c, nadd);
+    if (rc != MALIO_OK) return rc;
+    hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, rank, m,
+                       (const u32 *)nullptr, c->d_map_in + hw);
+    if (in_place) {
+      nl_ensure(c, c->nl1, d_new, keep, m);
+      nl_ensure(c, c->nl2, d_new, keep, m);
+      nl_append(c, c->nl1, d_new, keep, rank, (u32)hw, m);
+      nl_append(c, c->nl2, d_new, keep, rank, (u32)hw, m);
+      u32 st1[4], st2[4];
+      MALIO_HIP(hipMemcpyAsync(st1, c->nl1.state, sizeof(st1), hipMemcpyDeviceToHost, c->stream));
+      MALIO_HIP(hipMemcpyAsync(st2, c->nl2.state, sizeof(st2), hipMemcpyDeviceToHost, c->stream));
+      MALIO_HIP(hipStreamSynchronize(c->stream));
+      c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
+      if (st1[1] || st2[1]) in_place = false;  // a list or the tail region overflowed
+      // probing stays short below load 0.7; past it the next search rebuilds with a larger directory
+      if ((size_t)st1[2] * 10 > (size_t)(c->nl1.tmask + 1) * 7 || (size_t)st2[2] * 10 > (size_t)(c->nl2.tmask + 1) * 7)
+        in_place = false;
+    }
+    c->map_n = hw + (int)nadd;
+  }
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  MALIO_HIP(hipGetLastError());
+  if ((ndel || nadd)) {
+    c->map_epoch++;  // neighbour ids handed out before this call may now name a dead slot
+    if (!in_place) c->search_dirty = true;
+    else c->n_inplace++;
+  }
+  return MALIO_OK;
 }
 
 int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_added) {
@@ -238,28 +358,24 @@ int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_
   if (m <= 0) return MALIO_OK;
   const float ds = (float)c->prm.filter_size_map;
   Scratch sc;
-  const int n0 = c->map_n;
+  u32 *addf = nullptr, *apos = nullptr, *tiles = nullptr, *counters = nullptr;
+  MALIO_HIP(sc.get(&addf, (size_t)m + 1));
+  MALIO_HIP(sc.get(&apos, (size_t)m + 1));
   // set_downsample_param(filter_size_map_min) is what arms DOWNSAMPLE_SWITCH (ikd_Tree.cpp:486); a non-positive
   // size means it was never armed
   if (!downsample_on || !(ds > 0.f)) {
-    int rc = ensure_alt(c, (size_t)n0 + m);
-    if (rc != MALIO_OK) return rc;
-    if (n0 > 0)
-      MALIO_HIP(hipMemcpyAsync(c->d_map_alt, c->d_map_in, sizeof(float4) * (size_t)n0, hipMemcpyDeviceToDevice, c->stream));
-    MALIO_HIP(hipMemcpyAsync(c->d_map_alt + n0, d_new, sizeof(float4) * (size_t)m, hipMemcpyDeviceToDevice, c->stream));
-    MALIO_HIP(hipStreamSynchronize(c->stream));
-    swap_maps(c);
-    c->map_n = n0 + m;
-    c->vox_valid = false;
-    c->map_epoch++, c->search_dirty = true;
-    return MALIO_OK;  // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
+    hipLaunchKernelGGL(k_fill_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf, 1u, m);
+    hipLaunchKernelGGL(k_iota_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, apos, m);
+    // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
+    return map_apply(c, nullptr, 0, d_new, addf, apos, m, (u32)m);
   }
-  int rc;
-  if (!c->vox_valid && n0 > 0) {
-    rc = group_by_cell(c, c->d_map_in, n0, 1.f / ds, c->vox, nullptr, ds);
-    if (rc != MALIO_OK) return rc;
-    c->vox_valid = true;
+  if (ds > 2.0f * c->cell) {
+    c->err = "malio_map_add: filter_size_map larger than twice the level-1 cell edge is not supported";
+    return MALIO_ERR_BAD_ARG;
   }
+  int rc = map_sync_search(c);  // the voxel lookups below read the level-1 lists
+  if (rc != MALIO_OK) return rc;
+  const int hw = c->map_n;
   CellGrid gnew;
   rc = group_by_cell(c, d_new, m, 1.f / ds, gnew, nullptr, ds);
   if (rc != MALIO_OK) {
@@ -267,101 +383,55 @@ int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_
     return rc;
   }
   unsigned char *del = nullptr;
-  u32 *addf = nullptr, *keep = nullptr, *kpos = nullptr, *apos = nullptr, *tiles = nullptr, *counter = nullptr;
-  const int nt = std::max(n0, m) + 1;
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = sc.get(&del, (size_t)n0 + 1);
-  if (e == hipSuccess) e = sc.get(&addf, (size_t)m + 1);
-  if (e == hipSuccess) e = sc.get(&keep, (size_t)n0 + 1);
-  if (e == hipSuccess) e = sc.get(&kpos, (size_t)n0 + 1);
-  if (e == hipSuccess) e = sc.get(&apos, (size_t)m + 1);
-  if (e == hipSuccess) e = sc.get(&tiles, (size_t)(nt + 1023) / 1024 + 2);
-  if (e == hipSuccess) e = sc.get(&counter, 1);
-  if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)n0 + 1, c->stream);
+  hipError_t e = sc.get(&del, (size_t)hw + 1);
+  if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
+  if (e == hipSuccess) e = sc.get(&counters, 2);
+  if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)hw + 1, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1), c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(counter, 0, sizeof(u32), c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream);
   if (e != hipSuccess) {
     free_grid(gnew);
     MALIO_HIP(e);
   }
   const u32 ntsize = gnew.tmask + 1;
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
-                     d_new, c->vox.table, c->vox.tmask, c->vox.orig, c->d_map_in, n0, ds, del, addf, counter);
-  hipLaunchKernelGGL(k_keep_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, del, n0, keep);
-  exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
+                     d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
+                     addf, counters);
   exclusive_scan_u32(c, addf, apos, tiles, m + 1);
   u32 h_tot[3] = {0, 0, 0};
-  e = hipMemcpyAsync(&h_tot[0], kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[2], counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  e = hipMemcpyAsync(&h_tot[0], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) {
-    free_grid(gnew);
-    MALIO_HIP(e);
-  }
-  const int n1 = (int)(h_tot[0] + h_tot[1]);
-  rc = ensure_alt(c, (size_t)n1);
-  if (rc != MALIO_OK) {
-    free_grid(gnew);
-    return rc;
-  }
-  if (n0 > 0)
-    hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
-                       (const u32 *)nullptr, c->d_map_alt);
-  hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, addf, apos, m, kpos + n0,
-                     c->d_map_alt);
-  e = hipStreamSynchronize(c->stream);
   free_grid(gnew);
   MALIO_HIP(e);
-  swap_maps(c);
-  c->map_n = n1;
-  c->vox_valid = false;
-  if (out_added) *out_added = (int)h_tot[2];
-  // the mapping loop calls Add_Points twice per scan (laserMapping.cpp:443-444): the neighbour lists are rebuilt
-  // once, by whichever search comes next
-  c->map_epoch++, c->search_dirty = true;
-  return MALIO_OK;
+  if (out_added) *out_added = (int)h_tot[1];
+  return map_apply(c, del, h_tot[2], d_new, addf, apos, m, h_tot[0]);
 }
 
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted) {
   MALIO_HIP(hipSetDevice(c->device));
   if (out_deleted) *out_deleted = 0;
-  const int n0 = c->map_n;
-  if (nb <= 0 || n0 <= 0) return MALIO_OK;
+  const int hw = c->map_n;
+  if (nb <= 0 || hw <= 0) return MALIO_OK;
   Scratch sc;
   malio_box_t *d_boxes = nullptr;
   unsigned char *del = nullptr;
-  u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr, *counter = nullptr;
+  u32 *counter = nullptr;
   MALIO_HIP(sc.get(&d_boxes, (size_t)nb));
-  MALIO_HIP(sc.get(&del, (size_t)n0 + 1));
-  MALIO_HIP(sc.get(&keep, (size_t)n0 + 1));
-  MALIO_HIP(sc.get(&kpos, (size_t)n0 + 1));
-  MALIO_HIP(sc.get(&tiles, (size_t)(n0 + 1 + 1023) / 1024 + 2));
+  MALIO_HIP(sc.get(&del, (size_t)hw + 1));
   MALIO_HIP(sc.get(&counter, 1));
   MALIO_HIP(hipMemcpyAsync(d_boxes, boxes, sizeof(malio_box_t) * (size_t)nb, hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipMemsetAsync(counter, 0, sizeof(u32), c->stream));
-  hipLaunchKernelGGL(k_box_delete, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, d_boxes, nb, del,
+  hipLaunchKernelGGL(k_box_delete, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, hw, d_boxes, nb, del,
                      counter);
-  hipLaunchKernelGGL(k_keep_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, del, n0, keep);
-  exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
-  u32 h_tot[2] = {0, 0};
-  MALIO_HIP(hipMemcpyAsync(&h_tot[0], kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(&h_tot[1], counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  u32 ndel = 0;
+  MALIO_HIP(hipMemcpyAsync(&ndel, counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   MALIO_HIP(hipGetLastError());
-  if (out_deleted) *out_deleted = (int)h_tot[1];
-  if (h_tot[1] == 0) return MALIO_OK;
-  int rc = ensure_alt(c, (size_t)h_tot[0]);
-  if (rc != MALIO_OK) return rc;
-  hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
-                     (const u32 *)nullptr, c->d_map_alt);
-  MALIO_HIP(hipStreamSynchronize(c->stream));
-  swap_maps(c);
-  c->map_n = (int)h_tot[0];
-  c->vox_valid = false;
-  c->map_epoch++, c->search_dirty = true;
-  return MALIO_OK;
+  if (out_deleted) *out_deleted = (int)ndel;
+  if (ndel == 0) return MALIO_OK;
+  return map_apply(c, del, ndel, nullptr, nullptr, nullptr, 0, 0);
 }
 
 }  // namespace malio

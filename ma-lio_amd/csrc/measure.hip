@@ -1118,13 +1118,13 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   const int N = c->N;
   u32 *d_far = nullptr;
   MALIO_HIP(hipMalloc(&d_far, sizeof(u32) * (size_t)N));
-  if (c->map_n > 0 && flg_EKF_inited) {
+  if (c->map_n - c->map_dead > 0 && flg_EKF_inited) {
     long long th = (long long)N * 64;
     hipLaunchKernelGGL(k_far_nearest, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
                        c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
   }
   MapIncArgs a;
-  a.N = N, a.map_n = c->map_n, a.flg_EKF_inited = flg_EKF_inited, a.extrinsic_est_en = c->prm.extrinsic_est_en;
+  a.N = N, a.map_n = c->map_n - c->map_dead, a.flg_EKF_inited = flg_EKF_inited, a.extrinsic_est_en = c->prm.extrinsic_est_en;
   a.commit_prev = c->last_M > 0 ? 1 : 0;
   a.scan = c->d_scan, a.perm = c->d_perm;
   fill_quat_const(c, state_point, a.qc);
@@ -1302,7 +1302,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
 }
 
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
-  if (c->map_n <= 0) return MALIO_ERR_NO_MAP;
+  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   if (int rc = map_sync_search(c)) return rc;
   Pass1Args a;

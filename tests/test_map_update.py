@@ -253,3 +253,60 @@ def test_gpu_map_incremental_frontier_and_far_map(orc, capi, scenes):
 def test_gpu_map_incremental_before_ekf_init(orc, capi, scenes):
     r = _mapinc_case(orc, capi, scenes, 1, flg=False)   # :411 false -> everything goes through PointToAdd
     assert r["nn"] == 0
+
+
+@pytest.mark.gpu
+def test_gpu_in_place_list_updates_equal_a_full_rebuild(orc, capi, scenes):
+    """Mapping-loop regime: a large map, a few thousand changes per call. The changes must reach the neighbour lists
+    IN PLACE (slack / tail / tombstones, no rebuild), and every search afterwards must answer exactly like an
+    engine whose lists were built from scratch on the resulting map - and like the reference tree."""
+    sc = scenes.make_scene(cfg=3)
+    ds = float(sc["params"]["filter_size_map"])
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    port = orc.VoxMap(ds)
+    port.build(sc["map"])
+    rng = np.random.default_rng(11)
+    q = sc["map"][rng.integers(0, sc["Nmap"], 4000)].copy()
+    q[:, :3] += rng.normal(0, 0.4, size=(4000, 3)).astype(np.float32)
+    before = eng.debug_counters()
+    for r in range(4):
+        new = sc["map"][rng.integers(0, sc["Nmap"], 3000)].copy()
+        new[:, :3] += rng.normal(0, 0.3, size=(3000, 3)).astype(np.float32)
+        new[:, 5] = (rng.uniform(0, 1, 3000) * 0.002).astype(np.float32)
+        assert eng.map_add(new, True) == port.add(new, True)
+        far = new[:300].copy()
+        far[:, :3] += np.float32(400.0)                       # cells that do not exist yet: lists from the tail
+        assert eng.map_add(far, False) == port.add(far, False)
+        c = (sc["map"][rng.integers(0, sc["Nmap"]), :3] + 0).astype(np.float32)
+        box = np.concatenate([c - 2.0, c + 2.0]).astype(np.float32)[None]
+        assert eng.map_delete_boxes(box) == port.delete_boxes(box)
+        assert eng.map_size() == port.size()
+        _, d2_inc, cnt_inc = eng.nearest_search(q, 5)
+        fresh = capi.Engine(sc["params"])
+        fresh.map_build(port.flatten())
+        _, d2_new, cnt_new = fresh.nearest_search(q, 5)
+        np.testing.assert_array_equal(d2_inc, d2_new)
+        np.testing.assert_array_equal(cnt_inc, cnt_new)
+    after = eng.debug_counters()
+    assert after["rebuilds"] == before["rebuilds"], "the changes were meant to fit in place"
+    assert after["inplace"] >= before["inplace"] + 12 and after["tombstones"] > 0
+    np.testing.assert_array_equal(_as_set(eng.map_get()), _as_set(port.flatten()))
+    # the measurement update on the incrementally maintained map == on a freshly built one
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    fresh.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    a, b = eng.measure(sc["state0"], True), fresh.measure(sc["state0"], True)
+    assert a["M"] == b["M"]
+    sa, sb = eng.scan_get(), fresh.scan_get()
+    np.testing.assert_array_equal(sa["selected"], sb["selected"])
+    np.testing.assert_array_equal(sa["res_last"], sb["res_last"])
+    np.testing.assert_allclose(a["HtRinvH"], b["HtRinvH"], rtol=1e-12, atol=1e-9 * np.abs(b["HtRinvH"]).max())
+    # many deletions: tombstones pile up past a fifth of the map -> compaction + rebuild, still the same answers
+    big = np.array([[-1e4, -1e4, -1e4, 1e4, 1e4, sc["map"][:, 2].mean()]], np.float32)
+    assert eng.map_delete_boxes(big) == port.delete_boxes(big)
+    _, d2_inc, _ = eng.nearest_search(q, 5)
+    fresh = capi.Engine(sc["params"])
+    fresh.map_build(port.flatten())
+    _, d2_new, _ = fresh.nearest_search(q, 5)
+    np.testing.assert_array_equal(d2_inc, d2_new)
+    assert eng.debug_counters()["rebuilds"] > after["rebuilds"]
