@@ -128,11 +128,9 @@ def secondary_figures(eng, sc, scenes, capi):
     t = time.perf_counter()
     na, nn, _ = eng.map_incremental(u["state"], True, wny)
     t_inc = time.perf_counter() - t
-    t = time.perf_counter()
-    eng.nearest_search(sc["scan"][:8], 5)
-    t_reb = time.perf_counter() - t
+    dbg = eng.debug_counters()
     out["map_update"] = {"map_points": eng.map_size(), "added": int(na + nn), "map_incremental_ms": t_inc * 1e3,
-                         "rebuild_ms": t_reb * 1e3}
+                         "lists_updated_in_place": bool(dbg["inplace"] > 0 and dbg["rebuilds"] <= 1)}
     return out
 
 
