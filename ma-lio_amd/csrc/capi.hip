@@ -124,6 +124,8 @@ int malio_destroy(malio_handle_t h) {
   free_nlist(c->nl1);
   free_nlist(c->nl2);
   free_nl_scratch(c->nl_scratch);
+  free_grid(c->gnew);
+  c->arena.release_all();
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_ny);
   fr(c->d_map_alt);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);

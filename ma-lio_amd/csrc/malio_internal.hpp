@@ -111,6 +111,58 @@ struct alignas(16) UncEntry {
   double Q[6];  // xx yy zz xy xz yz
 };
 
+// Per-call device scratch: one block that grows to the largest call seen, handed out by a bump pointer and released
+// in stack order (hipMalloc/hipFree cost ~0.1 ms each and a map update needs a dozen temporaries).
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, off = 0, want = 0;
+  int depth = 0;
+  std::vector<void *> extra;  // overflow blocks of the current outermost scope
+  hipError_t take_bytes(void **out, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    want += bytes;
+    if (off + bytes <= cap) {
+      *out = base + off;
+      off += bytes;
+      return hipSuccess;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipSuccess) extra.push_back(q);
+    *out = q;
+    return e;
+  }
+  void release_all() {
+    for (void *q : extra) (void)hipFree(q);
+    extra.clear();
+    if (base) (void)hipFree(base);
+    base = nullptr, cap = 0, off = 0;
+  }
+};
+struct ArenaScope {  // allocations made through a scope die with it
+  Arena &a;
+  size_t mark, want_mark;
+  explicit ArenaScope(Arena &ar) : a(ar), mark(ar.off), want_mark(ar.want) { a.depth++; }
+  ~ArenaScope() {
+    a.off = mark;
+    if (--a.depth == 0) {
+      if (!a.extra.empty()) {  // the block was too small: grow it for the next call
+        const size_t need = a.want + a.want / 2;
+        a.release_all();
+        if (hipMalloc((void **)&a.base, need) == hipSuccess) a.cap = need;
+      }
+      a.want = 0;
+    } else {
+      (void)want_mark;  // inner scopes keep counting towards the outermost call's demand
+    }
+  }
+  template <class T>
+  hipError_t get(T **out, size_t count) {
+    return a.take_bytes((void **)out, sizeof(T) * (count ? count : 1));
+  }
+};
+
 struct Ctx {
   malio_params_t prm{};
   int device = 0;
@@ -120,6 +172,8 @@ struct Ctx {
 
   // map
   NlScratch nl_scratch;
+  Arena arena;       // per-call temporaries of the map update paths
+  CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
@@ -206,7 +260,7 @@ void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
 void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m);
 void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
-void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const unsigned char *del, int hw);
+void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
 void free_nl_scratch(NlScratch &s);
 
 // map_update.hip

@@ -177,16 +177,17 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
     return MALIO_OK;
   }
   u32 tbig = next_pow2((u32)std::max(1024, 2 * n));
+  ArenaScope sc(c->arena);
   u64 *keys = nullptr;
   u32 *cnt = nullptr, *start = nullptr, *slot_of = nullptr, *rank_of = nullptr, *tiles = nullptr, *ncells = nullptr;
   int ntiles = (tbig + 1023) / 1024;
-  MALIO_HIP(hipMalloc(&keys, sizeof(u64) * tbig));
-  MALIO_HIP(hipMalloc(&cnt, sizeof(u32) * tbig));
-  MALIO_HIP(hipMalloc(&start, sizeof(u32) * tbig));
-  MALIO_HIP(hipMalloc(&slot_of, sizeof(u32) * n));
-  MALIO_HIP(hipMalloc(&rank_of, sizeof(u32) * n));
-  MALIO_HIP(hipMalloc(&tiles, sizeof(u32) * (ntiles + 1)));
-  MALIO_HIP(hipMalloc(&ncells, sizeof(u32)));
+  MALIO_HIP(sc.get(&keys, (size_t)tbig));
+  MALIO_HIP(sc.get(&cnt, (size_t)tbig));
+  MALIO_HIP(sc.get(&start, (size_t)tbig));
+  MALIO_HIP(sc.get(&slot_of, (size_t)n));
+  MALIO_HIP(sc.get(&rank_of, (size_t)n));
+  MALIO_HIP(sc.get(&tiles, (size_t)ntiles + 1));
+  MALIO_HIP(sc.get(&ncells, 1));
   hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
   MALIO_HIP(hipMemsetAsync(ncells, 0, sizeof(u32), c->stream));
@@ -221,13 +222,6 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   g.tmask = tsize - 1;
   g.ncells = h_ncells;
   g.n = n;
-  (void)hipFree(keys);
-  (void)hipFree(cnt);
-  (void)hipFree(start);
-  (void)hipFree(slot_of);
-  (void)hipFree(rank_of);
-  (void)hipFree(tiles);
-  (void)hipFree(ncells);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -415,74 +409,69 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
 // (1) make sure the 27 cells around every kept new point have a directory entry and a list to append to
 __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
                                                    NlDev nl) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= m || !keep[i]) return;
+  // 32 lanes per point, one of its 27 cells each
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const int i = (int)(t >> 5), cidx = (int)(t & 31);
+  if (i >= m || cidx >= 27 || !keep[i]) return;
   float4 p = newp[i];
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
-  for (int dz = -1; dz <= 1; dz++)
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
-        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
-        u32 s = hash_key(key) & nl.tmask;
-        while (true) {
-          u64 old = __builtin_nontemporal_load(&nl.table[s].key);
-          if (old == EMPTY_KEY) {
-            old = atomicCAS(&nl.table[s].key, EMPTY_KEY, key);
-            if (old == EMPTY_KEY) {  // this thread created the cell: carve its list from the tail
-              u32 st = atomicAdd(&nl.state[0], NL_NEW_CAP);
-              if (st + NL_NEW_CAP > nl.bump_end) {
-                atomicExch(&nl.state[1], 1u);
-                st = 0;  // never written to: capacity 0
-                nl.cap[s] = 0;
-              } else {
-                nl.cap[s] = NL_NEW_CAP;
-              }
-              nl.table[s].start = st;
-              nl.table[s].count = 0;
-              atomicAdd(&nl.state[2], 1u);
-              break;
-            }
-          }
-          if (old == key) break;
-          s = (s + 1) & nl.tmask;
+  u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
+  u32 s = hash_key(key) & nl.tmask;
+  while (true) {
+    u64 old = __builtin_nontemporal_load(&nl.table[s].key);
+    if (old == EMPTY_KEY) {
+      old = atomicCAS(&nl.table[s].key, EMPTY_KEY, key);
+      if (old == EMPTY_KEY) {  // this thread created the cell: carve its list from the tail
+        u32 st = atomicAdd(&nl.state[0], NL_NEW_CAP);
+        if (st + NL_NEW_CAP > nl.bump_end) {
+          atomicExch(&nl.state[1], 1u);
+          st = 0;  // never written to: capacity 0
+          nl.cap[s] = 0;
+        } else {
+          nl.cap[s] = NL_NEW_CAP;
         }
+        nl.table[s].start = st;
+        nl.table[s].count = 0;
+        atomicAdd(&nl.state[2], 1u);
+        return;
       }
+    }
+    if (old == key) return;
+    s = (s + 1) & nl.tmask;
+  }
 }
 // (2) append every kept new point (map index og_base + rank) to its 27 lists
 __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ newp, const u32 *__restrict__ keep,
                                                    const u32 *__restrict__ rank, u32 og_base, int m, NlDev nl) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= m || !keep[i]) return;
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const int i = (int)(t >> 5), cidx = (int)(t & 31);
+  if (i >= m || cidx >= 27 || !keep[i]) return;
   float4 p = newp[i];
   float4 rec = make_float4(p.x, p.y, p.z, __uint_as_float(og_base + rank[i]));
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
-  for (int dz = -1; dz <= 1; dz++)
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
-        u64 key = cell_key(ix + dx, iy + dy, iz + dz);
-        u32 s = hash_key(key) & nl.tmask;
-        while (nl.table[s].key != key) s = (s + 1) & nl.tmask;
-        u32 pos = atomicAdd(&nl.table[s].count, 1u);
-        if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
-          atomicSub(&nl.table[s].count, 1u);
-          atomicExch(&nl.state[1], 1u);
-        } else {
-          nl.pts[(size_t)nl.table[s].start + pos] = rec;
-        }
-      }
+  u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
+  u32 s = hash_key(key) & nl.tmask;
+  while (nl.table[s].key != key) s = (s + 1) & nl.tmask;
+  u32 pos = atomicAdd(&nl.table[s].count, 1u);
+  if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
+    atomicSub(&nl.table[s].count, 1u);
+    atomicExch(&nl.state[1], 1u);
+  } else {
+    nl.pts[(size_t)nl.table[s].start + pos] = rec;
+  }
 }
 // (3) a deleted map point leaves its 27 lists: the entry stays but can never be a neighbour again (x = +inf makes
 //     every distance +inf, which the search drops); tombstones are swept by the next full rebuild
-__global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const unsigned char *__restrict__ del,
-                                                      int hw, NlDev nl) {
-  // 32 lanes per map slot, one of its 27 lists each (a level-2 list has ~180 entries to look through)
+__global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const u32 *__restrict__ dlist,
+                                                      int ndel, NlDev nl) {
+  // 32 lanes per deleted point, one of its 27 lists each (a level-2 list has ~180 entries to look through)
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
-  const int i = (int)(t >> 5), cidx = (int)(t & 31);
-  if (i >= hw || cidx >= 27 || !del[i]) return;
+  const int d = (int)(t >> 5), cidx = (int)(t & 31);
+  if (d >= ndel || cidx >= 27) return;
+  const u32 i = dlist[d];
   float4 p = mapp[i];
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
-  const int dx = cidx % 3 - 1, dy = (cidx / 3) % 3 - 1, dz = cidx / 9 - 1;
-  u64 key = cell_key(ix + dx, iy + dy, iz + dz);
+  u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
   while (true) {
     u64 k = nl.table[s].key;
@@ -492,7 +481,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
   }
   const u32 st = nl.table[s].start, cn = nl.table[s].count;
   for (u32 j = 0; j < cn; j++)
-    if (__float_as_uint(nl.pts[(size_t)st + j].w) == (u32)i) {
+    if (__float_as_uint(nl.pts[(size_t)st + j].w) == i) {
       nl.pts[(size_t)st + j].x = INFINITY;
       break;
     }
@@ -506,15 +495,18 @@ NlDev nl_dev(const NList &nl) {
 }
 
 void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m) {
-  hipLaunchKernelGGL(k_nl_ensure, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl));
-}
-void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m) {
-  hipLaunchKernelGGL(k_nl_append, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, rank, og_base, m,
+  const long long th = (long long)m * 32;
+  hipLaunchKernelGGL(k_nl_ensure, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_new, keep, m,
                      nl_dev(nl));
 }
-void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const unsigned char *del, int hw) {
-  const long long th = (long long)hw * 32;
-  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_map, del, hw,
+void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m) {
+  const long long th = (long long)m * 32;
+  hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_new, keep, rank,
+                     og_base, m, nl_dev(nl));
+}
+void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const u32 *dlist, int ndel) {
+  const long long th = (long long)ndel * 32;
+  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_map, dlist, ndel,
                      nl_dev(nl));
 }
 

@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
                                                  const Cell *__restrict__ ltable, u32 ltmask,
                                                  const float4 *__restrict__ lpts, float linv_cf,
                                                  const float4 *__restrict__ mapp, int have_map, float ds,
-                                                 unsigned char *del, u32 *addf, u32 *counters /*[0] adds [1] deletions*/) {
+                                                 unsigned char *del, u32 *dlist, u32 *addf,
+                                                 u32 *counters /*[0] adds [1] deletions*/) {
   u32 slot = blockIdx.x * BLK + threadIdx.x;
   if (slot >= ntsize) return;
   Cell nc = ntable[slot];
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
   const float near_th = ds / 8;  // ikd_Tree.cpp:510
   const u32 NONE = 0xFFFFFFFFu;
   u32 alive = NONE;  // new point of this voxel currently in the map
-  u32 last = 0, adds = 0, dels = 0;
+  u32 last = 0, adds = 0;
   for (u32 step = 0; step < nc.count; step++) {
     u32 cur = NONE;  // next new point in input order
     for (u32 j = 0; j < nc.count; j++) {
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
         const u32 mi = __float_as_uint(q.w);
         if (del[mi] || w.rank == 1u + mi) continue;
         del[mi] = 1;
-        dels++;
+        dlist[atomicAdd(&counters[1], 1u)] = mi;  // order is irrelevant: every entry is tombstoned independently
       }
       if (alive != NONE && w.rank != NONE) {
         float4 q = newp[alive];
@@ -157,11 +158,10 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
     }
   }
   if (adds) atomicAdd(&counters[0], adds);
-  if (dels) atomicAdd(&counters[1], dels);
 }
 
 __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ mapp, int n,
-                                                    const malio_box_t *__restrict__ boxes, int nb, unsigned char *del,
+                                                    const malio_box_t *__restrict__ boxes, int nb, u32 *dlist,
                                                     u32 *counter) {
   int i = blockIdx.x * BLK + threadIdx.x;
   bool hit = false;
@@ -172,10 +172,20 @@ __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ m
       hit = hit || (bx.vertex_min[0] <= q.x && bx.vertex_max[0] > q.x && bx.vertex_min[1] <= q.y &&
                     bx.vertex_max[1] > q.y && bx.vertex_min[2] <= q.z && bx.vertex_max[2] > q.z);
     }
-    del[i] = hit ? 1 : 0;
   }
+  // one counter bump per wave, every hit takes its slot in the list of deleted indices
   unsigned long long m = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (u32)__popcll(m));
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  u32 base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (u32)__popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (hit) dlist[base + __popcll(m & ((1ull << lane) - 1))] = (u32)i;
+}
+
+__global__ void __launch_bounds__(BLK) k_map_kill_list(float4 *mapp, const u32 *__restrict__ dlist, int ndel) {
+  int d = blockIdx.x * BLK + threadIdx.x;
+  if (d < ndel) mapp[dlist[d]].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
 }
 
 __global__ void __launch_bounds__(BLK) k_compact(const float4 *__restrict__ src, const u32 *__restrict__ flag,
@@ -200,28 +210,9 @@ void swap_maps(Ctx *c) {
   std::swap(c->cap_map_in, c->cap_map_alt);
 }
 
-struct Scratch {  // freed on every exit path
-  std::vector<void *> p;
-  ~Scratch() {
-    for (void *q : p) (void)hipFree(q);
-  }
-  template <class T>
-  hipError_t get(T **out, size_t count) {
-    void *q = nullptr;
-    hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
-    if (e == hipSuccess) p.push_back(q);
-    *out = (T *)q;
-    return e;
-  }
-};
-
 __global__ void __launch_bounds__(BLK) k_alive_flags(const float4 *__restrict__ mapp, int n, u32 *keep) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i <= n) keep[i] = (i < n && !isinf(mapp[i].x)) ? 1u : 0u;  // keep[n] = 0: the scan leaves the total at [n]
-}
-__global__ void __launch_bounds__(BLK) k_map_kill(float4 *mapp, const unsigned char *__restrict__ del, int n) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n && del[i]) mapp[i].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
 }
 __global__ void __launch_bounds__(BLK) k_fill_u32(u32 *p, u32 v, int n) {
   int i = blockIdx.x * BLK + threadIdx.x;
@@ -243,7 +234,7 @@ int map_sync_search(Ctx *c) {
 int map_rebuild_search(Ctx *c) {
   c->search_dirty = false;
   if (c->map_dead > 0 && c->map_n > 0) {
-    Scratch sc;
+    ArenaScope sc(c->arena);
     u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr;
     const int n0 = c->map_n;
     MALIO_HIP(sc.get(&keep, (size_t)n0 + 1));
@@ -286,11 +277,11 @@ static int map_reserve(Ctx *c, size_t extra) {
 }
 
 // Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
-//   del[map_n] != 0 -> slot dies (x = +inf), its 27 entries per level become tombstones
+//   dlist[ndel]     -> these slots die (x = +inf), their 27 entries per level become tombstones
 //   keep[m] != 0    -> d_new[i] is appended as slot map_n + rank[i] and inserted into 27 lists per level
 // Falls back to "lists are stale" (rebuilt by the next search) when a list or the directory runs out of room or
 // too many tombstones have piled up.
-static int map_apply(Ctx *c, const unsigned char *del, u32 ndel, const float4 *d_new, const u32 *keep, const u32 *rank,
+static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, const u32 *keep, const u32 *rank,
                      int m, u32 nadd) {
   const int hw = c->map_n;
   bool in_place = !c->search_dirty && hw > 0;
@@ -303,10 +294,11 @@ static int map_apply(Ctx *c, const unsigned char *del, u32 ndel, const float4 *d
   }
   if (ndel) {
     if (in_place) {
-      nl_tombstone(c, c->nl1, c->d_map_in, del, hw);
-      nl_tombstone(c, c->nl2, c->d_map_in, del, hw);
+      nl_tombstone(c, c->nl1, c->d_map_in, dlist, (int)ndel);
+      nl_tombstone(c, c->nl2, c->d_map_in, dlist, (int)ndel);
     }
-    hipLaunchKernelGGL(k_map_kill, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, del, hw);
+    hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, dlist,
+                       (int)ndel);
     c->map_dead += (int)ndel, c->nl_tomb += (int)ndel;
   }
   if (nadd) {
@@ -345,7 +337,7 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
   MALIO_HIP(hipSetDevice(c->device));
   if (out_added) *out_added = 0;
   if (m <= 0) return MALIO_OK;
-  Scratch up;
+  ArenaScope up(c->arena);
   float4 *d_new = nullptr;
   MALIO_HIP(up.get(&d_new, (size_t)m));
   MALIO_HIP(hipMemcpyAsync(d_new, h_pts, sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, c->stream));
@@ -357,7 +349,7 @@ int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_
   if (out_added) *out_added = 0;
   if (m <= 0) return MALIO_OK;
   const float ds = (float)c->prm.filter_size_map;
-  Scratch sc;
+  ArenaScope sc(c->arena);
   u32 *addf = nullptr, *apos = nullptr, *tiles = nullptr, *counters = nullptr;
   MALIO_HIP(sc.get(&addf, (size_t)m + 1));
   MALIO_HIP(sc.get(&apos, (size_t)m + 1));
@@ -376,37 +368,32 @@ int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_
   int rc = map_sync_search(c);  // the voxel lookups below read the level-1 lists
   if (rc != MALIO_OK) return rc;
   const int hw = c->map_n;
-  CellGrid gnew;
+  CellGrid &gnew = c->gnew;
   rc = group_by_cell(c, d_new, m, 1.f / ds, gnew, nullptr, ds);
-  if (rc != MALIO_OK) {
-    free_grid(gnew);
-    return rc;
-  }
+  if (rc != MALIO_OK) return rc;
   unsigned char *del = nullptr;
+  u32 *dlist = nullptr;
   hipError_t e = sc.get(&del, (size_t)hw + 1);
+  if (e == hipSuccess) e = sc.get(&dlist, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
   if (e == hipSuccess) e = sc.get(&counters, 2);
   if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)hw + 1, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1), c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream);
-  if (e != hipSuccess) {
-    free_grid(gnew);
-    MALIO_HIP(e);
-  }
+  MALIO_HIP(e);
   const u32 ntsize = gnew.tmask + 1;
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
                      d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
-                     addf, counters);
+                     dlist, addf, counters);
   exclusive_scan_u32(c, addf, apos, tiles, m + 1);
   u32 h_tot[3] = {0, 0, 0};
   e = hipMemcpyAsync(&h_tot[0], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  free_grid(gnew);
   MALIO_HIP(e);
   if (out_added) *out_added = (int)h_tot[1];
-  return map_apply(c, del, h_tot[2], d_new, addf, apos, m, h_tot[0]);
+  return map_apply(c, dlist, h_tot[2], d_new, addf, apos, m, h_tot[0]);
 }
 
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted) {
@@ -414,16 +401,15 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   if (out_deleted) *out_deleted = 0;
   const int hw = c->map_n;
   if (nb <= 0 || hw <= 0) return MALIO_OK;
-  Scratch sc;
+  ArenaScope sc(c->arena);
   malio_box_t *d_boxes = nullptr;
-  unsigned char *del = nullptr;
-  u32 *counter = nullptr;
+  u32 *dlist = nullptr, *counter = nullptr;
   MALIO_HIP(sc.get(&d_boxes, (size_t)nb));
-  MALIO_HIP(sc.get(&del, (size_t)hw + 1));
+  MALIO_HIP(sc.get(&dlist, (size_t)hw + 1));
   MALIO_HIP(sc.get(&counter, 1));
   MALIO_HIP(hipMemcpyAsync(d_boxes, boxes, sizeof(malio_box_t) * (size_t)nb, hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipMemsetAsync(counter, 0, sizeof(u32), c->stream));
-  hipLaunchKernelGGL(k_box_delete, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, hw, d_boxes, nb, del,
+  hipLaunchKernelGGL(k_box_delete, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, hw, d_boxes, nb, dlist,
                      counter);
   u32 ndel = 0;
   MALIO_HIP(hipMemcpyAsync(&ndel, counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -431,7 +417,7 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   MALIO_HIP(hipGetLastError());
   if (out_deleted) *out_deleted = (int)ndel;
   if (ndel == 0) return MALIO_OK;
-  return map_apply(c, del, ndel, nullptr, nullptr, nullptr, 0, 0);
+  return map_apply(c, dlist, ndel, nullptr, nullptr, nullptr, 0, 0);
 }
 
 }  // namespace malio
@@ -444,7 +430,7 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   MALIO_HIP(hipSetDevice(c->device));
   const int N = c->N;
   if (N <= 0) return MALIO_ERR_NO_SCAN;
-  Scratch sc;
+  ArenaScope sc(c->arena);
   float *d_wny = nullptr;
   u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr;
   float4 *wp = nullptr, *d_add = nullptr, *d_non = nullptr;
