@@ -44,6 +44,7 @@ struct NList {
   u32 ncells = 0;
   float4 *pts = nullptr;  // [cap_pts] x, y, z, bits(map index); a deleted point's entries carry x = +inf
   u32 *cap = nullptr;     // [table size] capacity of every list (count + slack): room for incremental inserts
+  u32 *inc = nullptr;     // [table size] entries the batch being applied brings to each list (zero between batches)
   u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells
   size_t total = 0;       // entries reserved by the lists built last (capacities)
   size_t entries = 0;     // live entries at build time (27 per point)
@@ -63,7 +64,7 @@ struct NlDev {
   Cell *table;
   u32 tmask;
   float4 *pts;
-  u32 *cap, *state;
+  u32 *cap, *inc, *state;
   u32 bump_end;
   float inv_cf;
 };

@@ -298,13 +298,14 @@ void free_nlist(NList &nl) {
   if (nl.table) (void)hipFree(nl.table);
   if (nl.pts) (void)hipFree(nl.pts);
   if (nl.cap) (void)hipFree(nl.cap);
+  if (nl.inc) (void)hipFree(nl.inc);
   if (nl.state) (void)hipFree(nl.state);
   nl = NList();
 }
 
 // capacity of a list built with `cnt` entries: room for a quarter more, at least NL_MIN_SLACK
 constexpr u32 NL_MIN_SLACK = 8;
-constexpr u32 NL_NEW_CAP = 12;  // capacity handed to a list that is created by an incremental insert
+constexpr int NL_MAX_PROBES = 1024;  // linear-probe bound of the incremental kernels (a full directory must not hang them)
 __global__ void __launch_bounds__(BLK) k_nl_caps(const u32 *__restrict__ cnt, u32 *capv, u32 n) {
   u32 i = blockIdx.x * BLK + threadIdx.x;
   if (i > n) return;  // capv[n] = 0: the exclusive scan then leaves the total there
@@ -391,10 +392,13 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
     nl.cap_table = tsize;
     MALIO_HIP(hipMalloc(&nl.table, sizeof(Cell) * nl.cap_table));
     MALIO_HIP(hipMalloc(&nl.cap, sizeof(u32) * nl.cap_table));
+    if (nl.inc) (void)hipFree(nl.inc);
+    MALIO_HIP(hipMalloc(&nl.inc, sizeof(u32) * nl.cap_table));
   }
   if (!nl.state) MALIO_HIP(hipMalloc(&nl.state, sizeof(u32) * 4));
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
   MALIO_HIP(hipMemsetAsync(nl.cap, 0, sizeof(u32) * tsize, c->stream));
+  MALIO_HIP(hipMemsetAsync(nl.inc, 0, sizeof(u32) * tsize, c->stream));
   hipLaunchKernelGGL(k_nl_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, capv, tbig,
                      nl.table, nl.cap, tsize - 1);
   const u32 h_state[4] = {(u32)used, 0u, h_cnt[0], 0u};  // bump cursor, overflow flag, cells, -
@@ -417,21 +421,19 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
   u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
+  int probes = 0;
   while (true) {
+    if (++probes > NL_MAX_PROBES) {  // the directory filled up under this batch: the host rebuilds
+      atomicExch(&nl.state[1], 1u);
+      return;
+    }
     u64 old = __builtin_nontemporal_load(&nl.table[s].key);
     if (old == EMPTY_KEY) {
       old = atomicCAS(&nl.table[s].key, EMPTY_KEY, key);
-      if (old == EMPTY_KEY) {  // this thread created the cell: carve its list from the tail
-        u32 st = atomicAdd(&nl.state[0], NL_NEW_CAP);
-        if (st + NL_NEW_CAP > nl.bump_end) {
-          atomicExch(&nl.state[1], 1u);
-          st = 0;  // never written to: capacity 0
-          nl.cap[s] = 0;
-        } else {
-          nl.cap[s] = NL_NEW_CAP;
-        }
-        nl.table[s].start = st;
+      if (old == EMPTY_KEY) {  // this thread created the cell; its list is sized and placed by the next two kernels
+        nl.table[s].start = 0;
         nl.table[s].count = 0;
+        nl.cap[s] = 0;
         atomicAdd(&nl.state[2], 1u);
         return;
       }
@@ -439,6 +441,47 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
     if (old == key) return;
     s = (s + 1) & nl.tmask;
   }
+}
+// (1b) mode 0: how many entries does this batch bring to each touched cell?  (1c) mode 1: one lane per touched cell
+//      makes room - nothing to do when the slack suffices, otherwise (new cell, or a list at the map frontier that
+//      outgrew its slack) the list moves to the tail region with fresh slack.
+__global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
+                                                  NlDev nl, int mode) {
+  const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  const int i = (int)(t >> 5), cidx = (int)(t & 31);
+  if (i >= m || cidx >= 27 || !keep[i]) return;
+  float4 p = newp[i];
+  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
+  u32 s = hash_key(key) & nl.tmask;
+  int probes = 0;
+  while (true) {
+    const u64 k = nl.table[s].key;
+    if (k == key) break;
+    if (k == EMPTY_KEY || ++probes > NL_MAX_PROBES) return;  // (1) already reported the overflow
+    s = (s + 1) & nl.tmask;
+  }
+  if (mode == 0) {
+    atomicAdd(&nl.inc[s], 1u);
+    return;
+  }
+  const u32 need = atomicExch(&nl.inc[s], 0u);  // exactly one lane per touched cell sees the total (and clears it)
+  if (need == 0) return;
+  const u32 cnt = nl.table[s].count, cap = nl.cap[s];
+  if (cnt + need <= cap) return;  // fits in the slack the list was built with
+  // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the old
+  // storage is reclaimed by the next full rebuild
+  const u32 total = cnt + need;
+  const u32 newcap = total + max(NL_MIN_SLACK, total / 4);
+  const u32 st = atomicAdd(&nl.state[0], newcap);
+  if (st + newcap > nl.bump_end || st + newcap < st) {
+    atomicExch(&nl.state[1], 1u);
+    return;
+  }
+  const u32 old = nl.table[s].start;
+  for (u32 j = 0; j < cnt; j++) nl.pts[(size_t)st + j] = nl.pts[(size_t)old + j];
+  nl.table[s].start = st;
+  nl.cap[s] = newcap;
 }
 // (2) append every kept new point (map index og_base + rank) to its 27 lists
 __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ newp, const u32 *__restrict__ keep,
@@ -451,7 +494,16 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
   u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
-  while (nl.table[s].key != key) s = (s + 1) & nl.tmask;
+  int probes = 0;
+  while (true) {
+    const u64 k = nl.table[s].key;
+    if (k == key) break;
+    if (k == EMPTY_KEY || ++probes > NL_MAX_PROBES) {  // k_nl_ensure could not create the cell
+      atomicExch(&nl.state[1], 1u);
+      return;
+    }
+    s = (s + 1) & nl.tmask;
+  }
   u32 pos = atomicAdd(&nl.table[s].count, 1u);
   if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
     atomicSub(&nl.table[s].count, 1u);
@@ -489,15 +541,17 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
 
 NlDev nl_dev(const NList &nl) {
   NlDev v;
-  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.state = nl.state;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state;
   v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf;
   return v;
 }
 
 void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m) {
   const long long th = (long long)m * 32;
-  hipLaunchKernelGGL(k_nl_ensure, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_new, keep, m,
-                     nl_dev(nl));
+  const dim3 grid((unsigned)((th + BLK - 1) / BLK));
+  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl));
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl), 0);
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl), 1);
 }
 void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m) {
   const long long th = (long long)m * 32;

@@ -285,11 +285,11 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
                      int m, u32 nadd) {
   const int hw = c->map_n;
   bool in_place = !c->search_dirty && hw > 0;
-  // the directory must not fill up while cells are being created (27 new cells per new point at the very worst);
-  // tombstones stay below a fifth of the live points
+  // in place only while the directory is comfortably loaded and tombstones stay below a fifth of the live points
+  // (a batch that fills the directory or a list is detected by the kernels themselves and reported as overflow)
   if (in_place) {
-    const size_t worst1 = (size_t)c->nl1.ncells + 27 * (size_t)nadd, worst2 = (size_t)c->nl2.ncells + 27 * (size_t)nadd;
-    if (worst1 * 10 > (size_t)(c->nl1.tmask + 1) * 9 || worst2 * 10 > (size_t)(c->nl2.tmask + 1) * 9) in_place = false;
+    if ((size_t)c->nl1.ncells * 10 > (size_t)(c->nl1.tmask + 1) * 7 || (size_t)c->nl2.ncells * 10 > (size_t)(c->nl2.tmask + 1) * 7)
+      in_place = false;
     if ((size_t)(c->nl_tomb + ndel) * 5 > (size_t)(hw - c->map_dead)) in_place = false;
   }
   if (ndel) {
