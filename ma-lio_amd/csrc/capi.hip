@@ -86,6 +86,19 @@ __global__ void __launch_bounds__(BLK) k_gather_side(int N, const u32 *__restric
 
 static int check(malio_handle_t h) { return h ? MALIO_OK : MALIO_ERR_BAD_ARG; }
 
+// pinned staging buffer of the upload paths, grown on demand and kept (hipHostMalloc/hipHostFree cost ~0.7 ms each)
+static int host_stage(malio::Ctx *c, size_t bytes, void **out) {
+  if (bytes > c->cap_stage) {
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr, c->cap_stage = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    MALIO_HIP(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    c->cap_stage = want;
+  }
+  *out = c->h_stage;
+  return MALIO_OK;
+}
+
 extern "C" {
 
 const char *malio_version(void) { return "malio-hip 0.1 (gfx950, ABI 1)"; }
@@ -132,6 +145,7 @@ int malio_destroy(malio_handle_t h) {
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -169,7 +183,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   Ctx *c = h;
   MALIO_HIP(hipSetDevice(c->device));
   float4 *stage = nullptr;
-  MALIO_HIP(hipHostMalloc(&stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
+  if (int rcs = host_stage(c, sizeof(float4) * (size_t)n, (void **)&stage)) return rcs;
   for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
   if ((size_t)n > c->cap_map_in) {
     if (c->d_map_in) (void)hipFree(c->d_map_in);
@@ -183,7 +197,6 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   c->map_epoch++;
   int rc = map_rebuild_search(c);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipHostFree(stage);
   if (rc != MALIO_OK) c->map_n = 0;
   return rc;
 }
@@ -323,7 +336,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   c->h_lidpart.resize(n);
   c->h_normal_y_in.resize(n);
   float4 *stage = nullptr;
-  MALIO_HIP(hipHostMalloc(&stage, sizeof(float4) * (size_t)n, hipHostMallocDefault));
+  if (int rcs = host_stage(c, sizeof(float4) * (size_t)n, (void **)&stage)) return rcs;
   int pos[MALIO_MAX_LIDAR];
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) pos[l] = c->seg_start[l];
   for (int i = 0; i < n; i++) {
@@ -347,7 +360,6 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
   MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  (void)hipHostFree(stage);
   c->scan_sorted = false;
   c->last_M = -1;
   return MALIO_OK;

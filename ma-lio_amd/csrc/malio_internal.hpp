@@ -174,6 +174,8 @@ struct Ctx {
   // map
   NlScratch nl_scratch;
   Arena arena;       // per-call temporaries of the map update paths
+  void *h_stage = nullptr;  // pinned upload staging (map_build, scan_set), grown on demand
+  size_t cap_stage = 0;
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)

@@ -1116,8 +1116,9 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   }
   if (int rc = map_sync_search(c)) return rc;
   const int N = c->N;
+  ArenaScope sc(c->arena);
   u32 *d_far = nullptr;
-  MALIO_HIP(hipMalloc(&d_far, sizeof(u32) * (size_t)N));
+  MALIO_HIP(sc.get(&d_far, (size_t)N));
   if (c->map_n - c->map_dead > 0 && flg_EKF_inited) {
     long long th = (long long)N * 64;
     hipLaunchKernelGGL(k_far_nearest, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
@@ -1133,9 +1134,7 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   a.cov_threshold = c->prm.cov_threshold, a.fs = c->prm.filter_size_map;
   a.addf = d_addf, a.nonf = d_nonf, a.wp = d_wp;
   hipLaunchKernelGGL(k_mapinc_classify, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, a);
-  hipError_t e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_far);
-  MALIO_HIP(e);
+  MALIO_HIP(hipStreamSynchronize(c->stream));
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -1257,16 +1256,17 @@ static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc)
 // Spatial sort of the scan, once per scan, with the first pass' state (coherence only, not results).
 static int sort_scan(Ctx *c, const QuatConst &qc) {
   const int L = c->prm.lid_num;
+  ArenaScope sc(c->arena);  // everything below is synchronised before the scope ends
   float4 *d_w = nullptr;
   u32 *d_part_orig = nullptr;
-  MALIO_HIP(hipMalloc(&d_w, sizeof(float4) * (size_t)c->N));
-  MALIO_HIP(hipMalloc(&d_part_orig, sizeof(u32) * (size_t)c->N));
+  MALIO_HIP(sc.get(&d_w, (size_t)c->N));
+  MALIO_HIP(sc.get(&d_part_orig, (size_t)c->N));
   MALIO_HIP(hipMemcpyAsync(d_part_orig, c->h_lidpart.data(), sizeof(u32) * (size_t)c->N, hipMemcpyHostToDevice,
                            c->stream));
   float *d_ny_in = nullptr;  // input normal_y in upload (LiDAR-partitioned) order
   std::vector<float> ny_part(c->N);
   for (int p = 0; p < c->N; p++) ny_part[p] = c->h_normal_y_in[c->h_lidpart[p]];
-  MALIO_HIP(hipMalloc(&d_ny_in, sizeof(float) * (size_t)c->N));
+  MALIO_HIP(sc.get(&d_ny_in, (size_t)c->N));
   MALIO_HIP(hipMemcpyAsync(d_ny_in, ny_part.data(), sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_scan_world, dim3((c->N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_scan_in, c->N, qc, d_w);
   // Group every LiDAR segment by level-1 cell with a stable radix sort: unlike a counting sort on atomic ranks, the
@@ -1275,12 +1275,12 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   u32 *d_vals = nullptr, *d_vals2 = nullptr;
   void *d_tmp = nullptr;
   size_t tmp_bytes = 0;
-  MALIO_HIP(hipMalloc(&d_keys, sizeof(u64) * (size_t)c->N));
-  MALIO_HIP(hipMalloc(&d_keys2, sizeof(u64) * (size_t)c->N));
-  MALIO_HIP(hipMalloc(&d_vals, sizeof(u32) * (size_t)c->N));
-  MALIO_HIP(hipMalloc(&d_vals2, sizeof(u32) * (size_t)c->N));
+  MALIO_HIP(sc.get(&d_keys, (size_t)c->N));
+  MALIO_HIP(sc.get(&d_keys2, (size_t)c->N));
+  MALIO_HIP(sc.get(&d_vals, (size_t)c->N));
+  MALIO_HIP(sc.get(&d_vals2, (size_t)c->N));
   MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, c->N, 0, 63, c->stream));
-  MALIO_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  MALIO_HIP(sc.get((char **)&d_tmp, tmp_bytes ? tmp_bytes : 16));
   for (int l = 0; l < L; l++) {
     int n = c->seg_start[l + 1] - c->seg_start[l];
     if (n <= 0) continue;
@@ -1293,10 +1293,6 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
                        d_part_orig + c->seg_start[l], d_ny_in + c->seg_start[l], c->d_ny);
   }
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  (void)hipFree(d_keys), (void)hipFree(d_keys2), (void)hipFree(d_vals), (void)hipFree(d_vals2), (void)hipFree(d_tmp);
-  (void)hipFree(d_w);
-  (void)hipFree(d_part_orig);
-  (void)hipFree(d_ny_in);
   c->scan_sorted = true;
   return MALIO_OK;
 }
