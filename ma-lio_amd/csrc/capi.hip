@@ -139,7 +139,7 @@ int malio_destroy(malio_handle_t h) {
   free_nl_scratch(c->nl_scratch);
   free_grid(c->gnew);
   c->arena.release_all();
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_ny);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
   fr(c->d_map_alt);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
@@ -400,11 +400,14 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   if (rc != MALIO_OK) return rc;
   rc = pass_stage2(c, nullptr, d_mm, c->d_sums, want_rows);
   if (rc != MALIO_OK) return rc;
-  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * (ns + 5), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * (ns + 6), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   prof_end(c);
   rc = finish_host(c, c->h_sums, c->h_sums + ns, out);
   c->last_M = out->M;
+  // k_search_tail is launched with the next search pass only while search passes keep meeting workgroups full of
+  // uncertified queries (word 5 after the sums); without it such workgroups serve their queries themselves
+  if (converge) c->defer_enabled = c->h_sums[ns + 5] > 0.5;
   if (want_rows && out->valid) {
     // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to
     // C columns, scaled by w_loc (laserMapping.cpp:758-759), compacted in ascending original index.

@@ -217,6 +217,11 @@ struct Ctx {
   unsigned char *d_sel = nullptr;  // [N]
   unsigned char *d_nfound = nullptr;  // [N]
   // reductions
+  u32 *d_dq = nullptr;       // [N] queries k_search handed to k_search_tail
+  u32 *d_dq_ctl = nullptr;   // [0..1] deferred counts, [2..3] heavy-workgroup counts, by search-pass parity
+  int dq_parity = 0;
+  bool defer_enabled = true;  // launch k_search_tail (switched by the heavy-workgroup count of the last search pass)
+  bool last_pass_search = false;
   u64 *d_mmslots = nullptr;  // [2 parities][64 slots][5]: max_u, min_u, max_R, min_R (order-encoded doubles), count
   int mm_parity = 0;
   double *d_partials = nullptr;  // [nblocks][NSUM]

@@ -85,6 +85,9 @@ struct Pass1Args {
   double *pbnorm;  // [N] |p'| (double), range gate :599
   u64 *mm_cur;     // extrema slots this pass accumulates into (MmSlots)
   u64 *mm_next;    // the other parity: reset here for the next pass
+  u32 *dq;         // [N] queries deferred to k_search_tail
+  u32 *dq_ctl;     // [0..1] deferred count by pass parity, [2..3] workgroups with > DEFER_MIN uncertified queries
+  int parity, defer;
   u32 *nbr;  // [5][N] ORIGINAL map indices (INVALID when fewer than 5 inside the radius)
   float4 *plane;
   float *pd2;
@@ -467,6 +470,10 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, 
 //   (`pointSearchSqDis[4] > 5` rejects, :587), so whatever it finds inside d2 <= 5 is final.
 // Squared distances are computed as ikd_Tree.cpp:1697 without FMA; candidates with d2 > limit2 are dropped.
 constexpr unsigned char NF_PENDING = 0xFF;
+constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
+constexpr int TAIL_BLOCKS = 1024;  // k_search_tail: 4096 waves x 4 queries per sweep
+constexpr int TAIL_G = 16;         // lanes per deferred query (level-2 lists hold ~180..900 points)
+constexpr int DEFER_MIN = 8;                 // a workgroup serves up to this many uncertified queries itself
 struct NlView {
   const Cell *table;
   u32 tmask;
@@ -506,13 +513,73 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   return (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
 }
 
+// a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
+// per-point state, returns the accept flag, unit_cov and trace for the extrema.
+__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, const float4 w, double nb, const u32 og[5], int nf,
+                                            bool &selected, double &ucov, double &tr) {
+  selected = false, ucov = 0.0, tr = 0.0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
+  a.nfound[i] = (unsigned char)nf;
+  a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+  commit_normal_y(a, i);
+  if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
+    // ---- esti_plane<float> (common_lib.h:144-190) ----
+    float A[5][3], W[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      float4 m = a.map_in[og[k]];
+      A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
+    }
+    PH(0, 4);
+    double cov_sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
+    if ((double)W[0] > 0.00001) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
+        ucov += wk * wk * (double)W[k];
+      }
+    }
+    float nv[3], pabcd[4];
+    PH(0, 5);
+    qr_solve_5x3(A, nv);
+    PH(0, 6);
+    float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
+    pabcd[3] = (float)(1.0 / (double)n);
+    bool plane_ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from L1/L2 (one live copy
+      const float4 m = a.map_in[og[k]];  // instead of two keeps the kernel at 6 waves per SIMD)
+      if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
+    }
+    a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+    a.ucov[i] = ucov;
+    if (plane_ok) {
+      float pd2;
+      if (residual_gate(pabcd, w.x, w.y, w.z, nb, pd2)) {
+        selected = true;
+        a.pd2[i] = pd2;
+      }
+    }
+  }
+  a.sel[i] = selected ? 1 : 0;
+  PH(0, 7);
+  const float4 q = a.scan[i];
+  const int packed = __float_as_int(q.w);
+  tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
+  a.trace[i] = tr;
+}
+
 // ---- SEARCH pass, one kernel (laserMapping.cpp:563-612 + the rejected-point trace of :725-743) ----------------
 // A workgroup owns SQ = 64 consecutive sorted queries and runs three phases:
 //   A  wave 0, lane = query: a1 world transform (double, Eigen's operation order) -> LDS, world4, |p'|
 //   B  all 4 waves, G = 4 lanes per query: a2 level-1 neighbour-list search (8 x 16-byte loads in flight per lane),
 //      result (5 map ids or "not certified") -> LDS; waves 1-3 retire
-//   C  wave 0, lane = query: level-2 search for the few uncertified queries (all 64 lanes per query), a3 plane fit,
-//      gates, a6/a8 trace, extrema -> slots
+//   B' all 4 waves: level-2 search for the uncertified queries, one query per wave at a time (64 lanes per query)
+//   C  wave 0, lane = query: a3 plane fit, gates, a6/a8 trace, extrema -> slots
 // One kernel instead of three saves two kernel boundaries (each costs a few us of drain + cache writeback at
 // this size) and lets the latency-bound plane fit of one workgroup overlap with the memory-bound search of the
 // others on the same CU.
@@ -535,6 +602,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
       double nb;
       world_point(a.qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
+      a.pbnorm[i] = nb;
       s_nb[threadIdx.x] = nb;
     }
     s_w[threadIdx.x] = w;
@@ -554,89 +622,62 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
     }
   }
   __syncthreads();
-  if (threadIdx.x >= SQ) return;
   PH(0, 2);
+  // ---- level 2: the queries level 1 could not certify are served one at a time by a whole wave (64 lanes striding
+  // over the ~180..900-point level-2 list); the workgroup's 4 waves share them round-robin, so a workgroup full of
+  // unmatched queries (map frontier, thinned map) costs 16 serial searches per wave instead of 64 in wave 0 ----
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool pend = (q0 + lane < a.N) && s_nf[lane] == NF_PENDING;  // lane <-> query, the same in every wave
+    unsigned long long todo = __ballot(pend);
+    if (todo) {  // workgroup-uniform: every wave reads the same flags
+      const int npend = __popcll(todo);
+      const bool heavy = npend > DEFER_MIN;
+      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + a.parity], 1u);  // steers the host's defer switch
+      if (heavy && a.defer) {
+        // too many for this workgroup: hand them to k_search_tail, which spreads them one per wave over the GPU
+        if (wave == 0) {
+          u32 base = 0;
+          if (lane == 0) base = atomicAdd(&a.dq_ctl[a.parity], (u32)npend);
+          base = __shfl(base, 0);
+          if (pend) {
+            a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)(q0 + lane);
+            s_nf[lane] = NF_DEFERRED;
+          }
+        }
+      } else {
+        int ord = 0;
+        while (todo) {
+          const int l = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          if ((ord++ & 3) != wave) continue;
+          const float4 ww = s_w[l];
+          Top5 t;
+          nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
+          if (lane < 5) {
+            s_og[lane][l] = lane == 0 ? t.og[0] : lane == 1 ? t.og[1] : lane == 2 ? t.og[2] : lane == 3 ? t.og[3] : t.og[4];
+          } else if (lane == 5) {
+            int nf = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+            s_nf[l] = (unsigned char)nf;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x >= SQ) return;
   // ---- phase C (wave 0) ----
   const int lane = threadIdx.x;
   u32 og[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) og[k] = s_og[k][lane];
-  int nf = s_nf[lane];
-  {  // level 2: the wave serves its uncertified queries one at a time, 64 lanes striding over the level-2 list
-    unsigned long long todo = __ballot(mine && nf == NF_PENDING);
-    while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const float4 ww = s_w[l];
-      Top5 t;
-      nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
-      if (lane == l) {
-        nf = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) og[k] = t.og[k], nf += (t.og[k] != INVALID);
-      }
-    }
-  }
+  const int nf = s_nf[lane];
   PH(0, 3);
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
-  if (mine) {
-    const float4 w = s_w[lane];
-#pragma unroll
-    for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
-    a.nfound[i] = (unsigned char)nf;
-    a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
-    a.pbnorm[i] = s_nb[lane];
-    commit_normal_y(a, i);
-    if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
-      // ---- esti_plane<float> (common_lib.h:144-190) ----
-      float A[5][3], W[5];
-#pragma unroll
-      for (int k = 0; k < 5; k++) {
-        float4 m = a.map_in[og[k]];
-        A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
-      }
-      PH(0, 4);
-      double cov_sum = 0;
-#pragma unroll
-      for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
-      if ((double)W[0] > 0.00001) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-          double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
-          ucov += wk * wk * (double)W[k];
-        }
-      }
-      float nv[3], pabcd[4];
-      PH(0, 5);
-      qr_solve_5x3(A, nv);
-      PH(0, 6);
-      float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-      pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
-      pabcd[3] = (float)(1.0 / (double)n);
-      bool plane_ok = true;
-#pragma unroll
-      for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from L1/L2 (one live copy
-        const float4 m = a.map_in[og[k]];  // instead of two keeps the kernel at 6 waves per SIMD)
-        if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
-      }
-      a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
-      a.ucov[i] = ucov;
-      if (plane_ok) {
-        float pd2;
-        if (residual_gate(pabcd, w.x, w.y, w.z, s_nb[lane], pd2)) {
-          selected = true;
-          a.pd2[i] = pd2;
-        }
-      }
-    }
-    a.sel[i] = selected ? 1 : 0;
-    PH(0, 7);
-    const float4 q = a.scan[i];
-    const int packed = __float_as_int(q.w);
-    tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
-    a.trace[i] = tr;
-  }
+  if (mine && nf != NF_DEFERRED) point_phase(a, i, s_w[lane], s_nb[lane], og, nf, selected, ucov, tr);
   PH(0, 8);
   {  // a4 over this wave's 64 queries
     double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
@@ -645,9 +686,52 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
     mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
     const unsigned long long bal = __ballot(selected);
     if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, (u64)__popcll(bal));
-    if (blockIdx.x == 0) mm_reset_slot(a.mm_next, lane);  // MM_SLOTS == 64 lanes
+    if (blockIdx.x == 0) {
+      mm_reset_slot(a.mm_next, lane);  // MM_SLOTS == 64 lanes
+      if (lane == 0) a.dq_ctl[a.parity ^ 1] = 0, a.dq_ctl[2 + (a.parity ^ 1)] = 0;  // next pass' deferral counters
+    }
   }
   PH(0, 9);
+}
+
+// Deferred level-2 work of k_search: 16 lanes per query on the level-2 list, then the first lane of each group runs
+// the point phase. Workgroups whose queries are mostly unmatched - the map frontier, a thinned map - would otherwise serialise
+// 16 such searches per wave while the rest of the GPU idles.
+__global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
+  // 16 lanes per query: 4 queries per wave search concurrently, then their first lanes run the point phase together
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & (TAIL_G - 1);
+  const u32 grp = (blockIdx.x * BLK + threadIdx.x) / TAIL_G, ngrp = (gridDim.x * BLK) / TAIL_G;
+  const u32 cnt = a.dq_ctl[a.parity];
+  double mxu = -INFINITY, mnu = INFINITY, mxr = -INFINITY, mnr = INFINITY;
+  u64 nsel = 0;
+  const u32 sweeps = (cnt + ngrp - 1) / ngrp;
+  for (u32 sw = 0; sw < sweeps; sw++) {  // wave-uniform trip count: the shuffles inside need every lane
+    const u32 j = sw * ngrp + grp;
+    if (j - (u32)(lane / TAIL_G) >= cnt) break;  // none of this wave's 4 queries exists (wave-uniform)
+    const bool live = j < cnt;
+    const int i = (int)a.dq[live ? j : 0];
+    const float4 w = a.world4[i];
+    Top5 t;
+    nl_search<TAIL_G>(nl2, w.x, w.y, w.z, sub, 5.0f, t);
+    if (live && sub == 0) {
+      int nf = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+      bool selected;
+      double ucov, tr;
+      point_phase(a, i, w, a.pbnorm[i], t.og, nf, selected, ucov, tr);
+      if (selected) {
+        nsel++;
+        mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
+        if (a.extrinsic_est_en) mxr = fmax(mxr, tr), mnr = fmin(mnr, tr);
+      }
+    }
+  }
+  if (sweeps == 0) return;
+  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) nsel += __shfl_xor(nsel, d);
+  if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, nsel);
 }
 
 // REUSE pass (ekfom_data.converge == false, :583-595): neighbours, plane and flag are kept; the
@@ -685,12 +769,14 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
 __global__ void k_mm_init(u64 *slots) { mm_reset_slot(slots, threadIdx.x); }
 
 // Staged (multi-GPU) path: one wave folds the slots into [max_u, -min_u, max_R, -min_R, M] for the all-reduce.
-__global__ void __launch_bounds__(64) k_minmax_reduce(const u64 *__restrict__ slots, int extrinsic_est_en, double *out) {
+__global__ void __launch_bounds__(64) k_minmax_reduce(const u64 *__restrict__ slots, int extrinsic_est_en,
+                                                      const u32 *__restrict__ heavy, double *out) {
   double o5[5];
   mm_fold_wave(slots, extrinsic_est_en, o5);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 5; k++) out[k] = o5[k];
+    out[5] = (double)*heavy;  // not reduced across ranks: each rank steers its own defer switch
   }
 }
 
@@ -709,6 +795,7 @@ struct Pass2Args {
   WeightConst wc;
   const double *minmax4;  // [max_ucov, -min_ucov, max_R, -min_R] when the caller reduced them (multi-GPU), else null
   const u64 *mmslots;  // extrema slots of stage 1 (single-GPU path: folded here by the first wave)
+  const u32 *heavy;    // workgroups of the search kernel that were full of uncertified queries (this pass)
   double *mm_out;         // where workgroup 0 publishes the folded extrema + M for the host
   double *partials;       // [nblocks][NSUM]
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
@@ -792,6 +879,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       if (blockIdx.x == 0 && a.mm_out) {
 #pragma unroll
         for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
+        a.mm_out[5] = (double)*a.heavy;
       }
     }
   }
@@ -1168,7 +1256,7 @@ int measure_alloc(Ctx *c) {
     auto fr = [](void *p) {
       if (p) (void)hipFree(p);
     };
-    fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
+    fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_dq), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
         fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_ny);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
@@ -1176,6 +1264,7 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_scan, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_perm, sizeof(u32) * K));
     MALIO_HIP(hipMalloc(&c->d_nbr, sizeof(u32) * 5 * K));
+    MALIO_HIP(hipMalloc(&c->d_dq, sizeof(u32) * K));
     MALIO_HIP(hipMalloc(&c->d_plane, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_pd2, sizeof(float) * K));
     MALIO_HIP(hipMalloc(&c->d_world, sizeof(float) * 3 * K));
@@ -1192,6 +1281,10 @@ int measure_alloc(Ctx *c) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     c->cap_partials = nb + nb / 8 + 16;
     MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));
+  }
+  if (!c->d_dq_ctl) {
+    MALIO_HIP(hipMalloc(&c->d_dq_ctl, sizeof(u32) * 4));
+    MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
   }
   if (!c->d_mmslots) {
     MALIO_HIP(hipMalloc(&c->d_mmslots, sizeof(u64) * 2 * MM_SLOTS * 5));
@@ -1317,23 +1410,30 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
   a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
   a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
+  a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.parity = c->dq_parity, a.defer = c->defer_enabled ? 1 : 0;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;
   c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
   const int nb = (c->N + BLK - 1) / BLK;
   if (converge) {
+    c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
+    a.parity = c->dq_parity;
     c->nbr_epoch = c->map_epoch;
     hipLaunchKernelGGL(k_search, dim3((c->N + SQ - 1) / SQ), dim3(BLK), 0, c->stream, a, view_of(c->nl1),
                        view_of(c->nl2));
     prof_mark(c, "k_search");
+    if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
+      hipLaunchKernelGGL(k_search_tail, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
+      prof_mark(c, "k_search_tail");
+    }
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_reuse");
   }
   if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
     hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en,
-                       d_minmax4_out);
+                       (const u32 *)(c->d_dq_ctl + 2 + c->dq_parity), d_minmax4_out);
     prof_mark(c, "k_minmax_reduce");
   }
   MALIO_HIP(hipGetLastError());
@@ -1372,6 +1472,7 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
   a.minmax4 = d_minmax4_in;
   a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
+  a.heavy = c->d_dq_ctl + 2 + c->dq_parity;
   a.partials = c->d_partials;
   a.rows = nullptr;
   if (want_rows) {
