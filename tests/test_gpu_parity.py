@@ -300,3 +300,45 @@ def test_config4_on_one_gpu(capi, orc, scenes):
     u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
     assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
     assert np.abs(u["state"] - v["state"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_unmatched_workgroups_deferred_or_inline_same_bits(capi, orc, scenes):
+    """Workgroups full of queries level 1 cannot certify (here: half of the scene has no map) are either served in
+    place or handed to k_search_tail, depending on what the previous search pass saw. Both routes must give the same
+    bits, and the oracle's answer."""
+    sc = scenes.make_scene(seed=77, N=30000, Nmap=200000, L=2)
+    cx = scenes.SURFACE_SHIFT[0]
+    thin = sc["map"][sc["map"][:, 0] < cx + 2.0]           # the other half of the scan finds nothing within sqrt(5) m
+    easy = scenes.make_scene(seed=78, N=4000, Nmap=40000, L=2)
+
+    def run(prime_with_easy_scene):
+        eng = capi.Engine(sc["params"])
+        if prime_with_easy_scene:                            # a pass without heavy workgroups switches deferral off
+            eng.map_build(easy["map"])
+            eng.scan_set(easy["scan"], easy["tables"], easy["temporal_comp"])
+            eng.measure(easy["state0"], True)
+        eng.map_build(thin)
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        r = eng.measure(sc["state0"], True, want_rows=True)
+        return eng, r, eng.scan_get()
+
+    e1, r1, s1 = run(False)   # deferral on (default for a fresh handle)
+    e2, r2, s2 = run(True)    # deferral off: served inside k_search
+    assert r1["M"] == r2["M"] and 0.2 * sc["N"] < r1["M"] < 0.8 * sc["N"]
+    for k in ("HtRinvH", "HtRinvh", "h_x", "h", "R"):
+        np.testing.assert_array_equal(r1[k], r2[k])
+    for k in ("selected", "res_last", "nearest_cnt", "normal_y", "world"):
+        np.testing.assert_array_equal(s1[k], s2[k])
+    o = orc.Oracle(sc["params"], threads=4, use_ref=True)
+    o.map_build(thin)
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ro = o.h_share_model(sc["state0"], True)
+    so = o.scan_get()
+    assert ro["M"] == r1["M"]
+    np.testing.assert_array_equal(s1["selected"], so["selected"])
+    np.testing.assert_array_equal(s1["res_last"], so["res_last"])
+    # a second search pass on the hard scan: e2 has learnt to defer, still the same bits
+    r3 = e2.measure(sc["state0"], True, want_rows=True)
+    np.testing.assert_array_equal(r3["HtRinvH"], r1["HtRinvH"])
+    np.testing.assert_array_equal(r3["h_x"], r1["h_x"])
