@@ -62,6 +62,7 @@ CASES = [
     dict(seed=207, N=2500, Nmap=40000, L=3, origin=(1000.0, -800.0, 30.0)),  # float plane fit far from the origin
     dict(seed=208, N=100, Nmap=3000, L=2),                                   # less than one workgroup
     dict(seed=209, N=2000, Nmap=30000, L=3, prior_dpos=1.5, prior_drot_deg=4.0),  # poor prior: many rejected points
+    dict(seed=210, N=2400, Nmap=30000, L=4),                                 # MALIO_MAX_LIDAR LiDARs (C = 30, n = 41)
 ]
 
 
@@ -342,3 +343,30 @@ def test_unmatched_workgroups_deferred_or_inline_same_bits(capi, orc, scenes):
     r3 = e2.measure(sc["state0"], True, want_rows=True)
     np.testing.assert_array_equal(r3["HtRinvH"], r1["HtRinvH"])
     np.testing.assert_array_equal(r3["h_x"], r1["h_x"])
+
+
+@pytest.mark.gpu
+def test_call_order_errors(capi, scenes):
+    """Misuse is reported, not executed: no map, no scan, stale neighbour ids, unsupported k."""
+    sc = scenes.make_scene(seed=3, N=500, Nmap=5000, L=2)
+    eng = capi.Engine(sc["params"])
+    with pytest.raises(RuntimeError):
+        eng.measure(sc["state0"], True)                      # no scan
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    with pytest.raises(RuntimeError):
+        eng.measure(sc["state0"], True)                      # no map
+    with pytest.raises(RuntimeError):
+        eng.nearest_search(sc["scan"][:4], 5)                # no map
+    eng.map_build(sc["map"])
+    with pytest.raises(RuntimeError):
+        eng.nearest_search(sc["scan"][:4], 6)                # k > 5
+    with pytest.raises(RuntimeError):
+        eng.scan_get()                                       # no pass ran on this scan yet
+    assert eng.measure(sc["state0"], True)["M"] > 0
+    assert eng.map_delete_boxes(np.array([[0, 0, 0, 0, 0, 0]], np.float32)) == 0   # empty box: nothing changes
+    eng.scan_get()                                           # ... so the neighbour ids are still valid
+    assert eng.map_add(sc["map"][:50] + np.float32(0.01), True) >= 0
+    with pytest.raises(RuntimeError):
+        eng.scan_get()                                       # the map changed under the neighbour ids
+    assert eng.measure(sc["state0"], True)["M"] > 0          # a new search pass makes them valid again
+    eng.scan_get()
