@@ -1198,11 +1198,11 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
 int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
                     u32 *d_nonf, float4 *d_wp) {
   if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
+  if (int rc = map_sync_search(c)) return rc;  // (a rebuild renumbers the map: caught by the epoch test below)
   if (c->map_n > 0 && c->nbr_epoch != c->map_epoch) {
     c->err = "map_incremental: the map changed after the last search pass of this scan";
     return MALIO_ERR_BAD_ARG;
   }
-  if (int rc = map_sync_search(c)) return rc;
   const int N = c->N;
   ArenaScope sc(c->arena);
   u32 *d_far = nullptr;
