@@ -145,6 +145,7 @@ int malio_destroy(malio_handle_t h) {
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
@@ -395,19 +396,20 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   const bool want_rows = out->h_x || out->h || out->R;
   prof_begin(c);
   const int ns = sums_len(c);
-  double *d_mm = c->d_sums + ns;  // 5 doubles right after the sums: one D2H copy brings both
   int rc = pass_stage1(c, s, converge, nullptr);
   if (rc != MALIO_OK) return rc;
-  rc = pass_stage2(c, nullptr, d_mm, c->d_sums, want_rows);
+  // The two result kernels store straight into pinned, device-mapped host memory (2.4 KB over PCIe): no copy kernel
+  // between the last kernel and the host (worth ~1 us per pass).
+  rc = pass_stage2(c, nullptr, c->d_res + ns, c->d_res, want_rows);
   if (rc != MALIO_OK) return rc;
-  MALIO_HIP(hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(double) * (ns + 6), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   prof_end(c);
-  rc = finish_host(c, c->h_sums, c->h_sums + ns, out);
+  const double *res = c->h_res;
+  rc = finish_host(c, res, res + ns, out);
   c->last_M = out->M;
   // k_search_tail is launched with the next search pass only while search passes keep meeting workgroups full of
   // uncertified queries (word 5 after the sums); without it such workgroups serve their queries themselves
-  if (converge) c->defer_enabled = c->h_sums[ns + 5] > 0.5;
+  if (converge) c->defer_enabled = res[ns + 5] > 0.5;
   if (want_rows && out->valid) {
     // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to
     // C columns, scaled by w_loc (laserMapping.cpp:758-759), compacted in ascending original index.

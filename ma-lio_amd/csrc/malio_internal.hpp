@@ -227,6 +227,7 @@ struct Ctx {
   double *d_partials = nullptr;  // [nblocks][NSUM]
   double *d_sums = nullptr;      // [NSUM_OUT]
   double *h_sums = nullptr;      // pinned
+  double *h_res = nullptr, *d_res = nullptr;  // pinned + its device-visible alias: results stored by the kernels
   double *h_minmax = nullptr;    // pinned [5]
   double *d_rows = nullptr;      // optional dense rows [N][C+2]
   size_t cap_rows = 0;

@@ -1295,6 +1295,9 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8 + 16)));
     MALIO_HIP(hipHostMalloc(&c->h_sums, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 8), hipHostMallocDefault));
     MALIO_HIP(hipHostMalloc(&c->h_minmax, sizeof(double) * 8, hipHostMallocDefault));
+    // result mailbox of the fused single-GPU pass: the kernels write it, the host reads it after the stream sync
+    MALIO_HIP(hipHostMalloc(&c->h_res, sizeof(double) * (MALIO_MAX_LIDAR * NSUM + 16), hipHostMallocMapped | hipHostMallocCoherent));
+    MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_res, c->h_res, 0));
   }
   return MALIO_OK;
 }
