@@ -121,6 +121,14 @@ def secondary_figures(eng, sc, scenes, capi):
     k = float(np.median(kms))
     out["undistort"] = {"raw_points": n, "kernel_ms": k, "points_per_s": n / (k * 1e-3),
                         "hbm_frac": 32.0 * n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # row f-2: voxel down-sampling of that raw cloud (host buffers in and out, as the reference's filter call)
+    und, _ = eng.undistort(pts, beg, kt, kT, ext_q, ext_t, q_end, p_end, imu_t, cp)
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter()
+        ds = eng.voxel_downsample(und, 0.5)
+        ts.append(time.perf_counter() - t)
+    out["voxel_downsample"] = {"raw_points": n, "voxels": int(ds.shape[0]), "wall_ms": float(np.median(ts) * 1e3)}
     # one whole turn of the mapping loop on the bench workload, as the integration calls it (laserMapping.cpp:985-1060):
     # scan upload + tables, iterated update (includes the once-per-scan spatial sort), map_incremental at the posterior
     wny = np.full(sc["N"], 0.001, np.float32)

@@ -165,6 +165,18 @@ int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, in
  * Copies min(cap, size) valid points in map order, *out_n = size. Order differs from the tree's traversal. */
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);
 
+/* ---- voxel down-sampling ------------------------------------------------ */
+/* downSizeFilterSurf.setInputCloud(cloud); downSizeFilterSurf.filter(*out)   laserMapping.cpp:93,860,968-971:
+ * pcl::VoxelGrid<PointType> with its defaults (all fields averaged, min_points_per_voxel 0), leaf = filter_size_surf.
+ * Output: one point per occupied voxel in ascending voxel-index order (PCL's order); *out_n = number of voxels, at
+ * most `cap` points are written. PCL is not vendored with the reference: its published algorithm is restated
+ * (csrc/voxel.hip) and parity with a PCL build is unpinned. normal_mode selects what happens to the summed
+ * normal_x/y/z: divided by the count, or normalised to unit length (pcl::CentroidPoint's AccumulatorNormal). */
+#define MALIO_VOXEL_NORMAL_MEAN 0
+#define MALIO_VOXEL_NORMAL_NORMALIZE 1
+int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, float leaf, int normal_mode,
+                           malio_point_t *out, int cap, int *out_n);
+
 /* ---- per scan ------------------------------------------------------------------------------- */
 /* replaces the per-scan globals h_share_model reads: feats_down_body (laserMapping.cpp:86,982),
  * pose_unc[lid][k] (:1028-1048), kf.temporal_comp[lid-1] (IMU_Processing.hpp:510-522). Uploads the

@@ -18,7 +18,7 @@ ERR_NO_DEVICE = -1
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_voxel_downsample", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -236,6 +236,16 @@ class Engine:
         got = C.c_int(0)
         self._chk(lib().malio_map_get(self.h, _p(out, Point), n, C.byref(got)), "malio_map_get")
         return out[:n]
+
+    def voxel_downsample(self, pts12, leaf, normal_mode=1):
+        """pcl::VoxelGrid (all fields) as restated in csrc/voxel.hip: [n,12] -> [n_voxels,12] in voxel-index order."""
+        pts12 = np.ascontiguousarray(pts12, np.float32).reshape(-1, 12)
+        n = pts12.shape[0]
+        out = np.zeros((max(n, 1), 12), np.float32)
+        got = C.c_int(0)
+        self._chk(lib().malio_voxel_downsample(self.h, _p(pts12, Point), n, C.c_float(leaf), int(normal_mode),
+                                               _p(out, Point), n, C.byref(got)), "malio_voxel_downsample")
+        return out[:got.value].copy()
 
     def map_size(self):
         n = C.c_int(0)

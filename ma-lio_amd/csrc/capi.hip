@@ -294,6 +294,13 @@ int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   return MALIO_OK;
 }
 
+int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, float leaf, int normal_mode,
+                           malio_point_t *out, int cap, int *out_n) {
+  if (check(h) || !out_n || n < 0 || cap < 0 || (n > 0 && !pts) || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
+  if (normal_mode != MALIO_VOXEL_NORMAL_MEAN && normal_mode != MALIO_VOXEL_NORMAL_NORMALIZE) return MALIO_ERR_BAD_ARG;
+  return voxel_downsample(h, pts, n, leaf, normal_mode, out, cap, out_n);
+}
+
 // ---- scan -----------------------------------------------------------------------------------------
 int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
                    const int *pose_unc_len, const malio_pose_t *temporal_comp) {

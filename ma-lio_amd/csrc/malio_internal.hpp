@@ -284,6 +284,10 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
 
+// voxel.hip
+int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,
+                     int *out_n);
+
 // measure.hip
 int measure_alloc(Ctx *c);
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out);

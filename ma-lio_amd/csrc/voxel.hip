@@ -1,0 +1,206 @@
+// Voxel down-sampling of an undistorted cloud: what the reference does between the
+// undistortion and the measurement update with `downSizeFilterSurf.setInputCloud(...); .filter(...)`
+// (src/laserMapping.cpp:93,860,968-971) - pcl::VoxelGrid<pcl::PointXYZINormal> with its defaults
+// (downsample_all_data = true, min_points_per_voxel = 0, no filter field), one call per LiDAR.
+//
+// PCL is a third-party dependency that is NOT under /root/reference (CMakeLists.txt:56 `find_package(PCL 1.8
+// REQUIRED)`, unpinned; Ubuntu 20.04 ships 1.10), so this restates its published algorithm
+// (filters/impl/voxel_grid.hpp `applyFilter`, common/impl/accumulators.hpp) - PARITY IS UNPINNED:
+//   1. bounding box of the finite points; inverse leaf = 1 / leaf (float)
+//   2. min_b = floor(min * inv), max_b = floor(max * inv), div_b = max_b - min_b + 1; if dx*dy*dz exceeds INT_MAX
+//      the filter warns and returns the input unchanged
+//   3. idx = (floor(x*inv) - min_b.x) + (floor(y*inv) - min_b.y) * div.x + (floor(z*inv) - min_b.z) * div.x*div.y
+//   4. points sorted by idx; one output point per distinct idx, in ascending idx order
+//   5. centroid of every field: xyz, intensity, curvature = float sum / n; the normal (normal_x/y/z + pad) is
+//      summed and then either divided by n or normalised to unit length - PCL changed this between releases
+//      (CentroidPoint's AccumulatorNormal normalises), hence the `normal_mode` switch. The mapping loop overwrites
+//      normal_x right after the filter (:973) and the update rewrites normal_y, so the choice rarely matters.
+// Within a voxel PCL adds the points in whatever order its (unstable) integer sort left them; here the sort is
+// stable, i.e. input order - float sums can differ from a PCL build in the last bits for that reason alone.
+#include "malio_internal.hpp"
+#include <hipcub/hipcub.hpp>
+
+namespace malio {
+namespace {
+
+__device__ __forceinline__ u32 fenc(float x) {  // order-preserving float -> u32
+  u32 b = __float_as_uint(x);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+inline float fdec_host(u32 k) {
+  u32 b = (k >> 31) ? (k & 0x7FFFFFFFu) : ~k;
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+
+// 12 floats per point, pcl::PointXYZINormal layout: x y z _ nx ny nz _ intensity curvature _ _
+__global__ void __launch_bounds__(BLK) k_vg_bounds(const float *__restrict__ pts, int n, u32 *mm /*[6] min xyz, max xyz*/) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  float v[3] = {INFINITY, INFINITY, INFINITY}, w[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (i < n) {
+    const float x = pts[(size_t)i * 12], y = pts[(size_t)i * 12 + 1], z = pts[(size_t)i * 12 + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) v[0] = w[0] = x, v[1] = w[1] = y, v[2] = w[2] = z;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      v[a] = fminf(v[a], __shfl_xor(v[a], d));
+      w[a] = fmaxf(w[a], __shfl_xor(w[a], d));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (v[a] != INFINITY) atomicMin(&mm[a], fenc(v[a]));
+      if (w[a] != -INFINITY) atomicMax(&mm[3 + a], fenc(w[a]));
+    }
+  }
+}
+
+struct VgGrid {
+  float inv[3];
+  int min_b[3];
+  int mul[3];
+};
+
+__global__ void __launch_bounds__(BLK) k_vg_keys(const float *__restrict__ pts, int n, VgGrid g, u32 *keys, u32 *vals) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[(size_t)i * 12], y = pts[(size_t)i * 12 + 1], z = pts[(size_t)i * 12 + 2];
+  u32 key = 0xFFFFFFFFu;  // non-finite points sort to the end and are dropped (PCL skips them)
+  if (isfinite(x) && isfinite(y) && isfinite(z)) {
+    const int i0 = (int)(floorf(x * g.inv[0]) - (float)g.min_b[0]);
+    const int i1 = (int)(floorf(y * g.inv[1]) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(z * g.inv[2]) - (float)g.min_b[2]);
+    key = (u32)(i0 * g.mul[0] + i1 * g.mul[1] + i2 * g.mul[2]);
+  }
+  keys[i] = key;
+  vals[i] = (u32)i;
+}
+
+__global__ void __launch_bounds__(BLK) k_vg_heads(const u32 *__restrict__ keys, int n, u32 *head) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i > n) return;  // head[n] = 0 so that the exclusive scan leaves the total at [n]
+  head[i] = (i < n && keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(BLK) k_vg_first(const u32 *__restrict__ head, const u32 *__restrict__ pos, int n,
+                                                  u32 *first) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && head[i]) first[pos[i]] = (u32)i;
+}
+
+// one thread per output voxel: float sums in sorted (= input) order, then the accumulators' get()
+__global__ void __launch_bounds__(BLK) k_vg_centroid(const float *__restrict__ pts, const u32 *__restrict__ keys,
+                                                     const u32 *__restrict__ vals, const u32 *__restrict__ first, int nvox,
+                                                     int n, int normal_mode, float *out) {
+  int o = blockIdx.x * BLK + threadIdx.x;
+  if (o >= nvox) return;
+  const u32 b = first[o];
+  const u32 key = keys[b];
+  float sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0, nw = 0, si = 0, sc = 0;
+  u32 cnt = 0;
+  for (u32 j = b; j < (u32)n && keys[j] == key; j++, cnt++) {
+    const float *p = pts + (size_t)vals[j] * 12;
+    sx += p[0], sy += p[1], sz += p[2];
+    nx += p[4], ny += p[5], nz += p[6], nw += p[7];
+    si += p[8], sc += p[9];
+  }
+  const float fn = (float)cnt;
+  float *q = out + (size_t)o * 12;
+  q[0] = sx / fn, q[1] = sy / fn, q[2] = sz / fn, q[3] = 1.0f;
+  if (normal_mode == MALIO_VOXEL_NORMAL_NORMALIZE) {
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);  // Eigen: v /= v.norm(), zero stays zero
+    if (len > 0.f) nx /= len, ny /= len, nz /= len, nw /= len;
+    q[4] = nx, q[5] = ny, q[6] = nz, q[7] = nw;
+  } else {
+    q[4] = nx / fn, q[5] = ny / fn, q[6] = nz / fn, q[7] = nw / fn;
+  }
+  q[8] = si / fn, q[9] = sc / fn, q[10] = 0.f, q[11] = 0.f;
+}
+
+}  // namespace
+
+int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,
+                     int *out_n) {
+  MALIO_HIP(hipSetDevice(c->device));
+  *out_n = 0;
+  if (n <= 0) return MALIO_OK;
+  if (!(leaf > 0.f)) {
+    c->err = "malio_voxel_downsample: leaf size must be positive";
+    return MALIO_ERR_BAD_ARG;
+  }
+  ArenaScope sc(c->arena);
+  float *d_pts = nullptr, *d_out = nullptr;
+  u32 *d_mm = nullptr, *k1 = nullptr, *k2 = nullptr, *v1 = nullptr, *v2 = nullptr, *head = nullptr, *pos = nullptr,
+      *first = nullptr, *tiles = nullptr;
+  char *tmp = nullptr;
+  MALIO_HIP(sc.get(&d_pts, (size_t)n * 12));
+  MALIO_HIP(sc.get(&d_mm, 6));
+  MALIO_HIP(hipMemcpyAsync(d_pts, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  const u32 mm0[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  MALIO_HIP(hipMemcpyAsync(d_mm, mm0, sizeof(mm0), hipMemcpyHostToDevice, c->stream));
+  const int nb = (n + BLK - 1) / BLK;
+  hipLaunchKernelGGL(k_vg_bounds, dim3(nb), dim3(BLK), 0, c->stream, d_pts, n, d_mm);
+  u32 mm[6];
+  MALIO_HIP(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  if (mm[0] == 0xFFFFFFFFu) return MALIO_OK;  // no finite point at all
+  VgGrid g;
+  int div[3];
+  // PCL forms dx*dy*dz in int64 and compares with INT_MAX; that product itself wraps for absurd extents, so the test
+  // is applied after every factor (same answer whenever PCL's arithmetic is defined)
+  bool too_small = false;
+  long long cells = 1;
+  for (int a = 0; a < 3; a++) {
+    const float mn = fdec_host(mm[a]), mx = fdec_host(mm[3 + a]);
+    g.inv[a] = 1.0f / leaf;
+    g.min_b[a] = (int)std::floor(mn * g.inv[a]);
+    div[a] = (int)std::floor(mx * g.inv[a]) - g.min_b[a] + 1;
+    const float ext = (mx - mn) * g.inv[a];
+    if (!(ext < 4.0e9f)) too_small = true;
+    if (!too_small) {
+      cells *= (long long)ext + 1;
+      if (cells > 0x7FFFFFFFll) too_small = true;
+    }
+  }
+  if (too_small) {
+    // "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+    *out_n = n;
+    memcpy(out, pts, sizeof(malio_point_t) * (size_t)std::min(n, cap));
+    return MALIO_OK;
+  }
+  g.mul[0] = 1, g.mul[1] = div[0], g.mul[2] = div[0] * div[1];
+  size_t tmp_bytes = 0;
+  MALIO_HIP(sc.get(&k1, (size_t)n));
+  MALIO_HIP(sc.get(&k2, (size_t)n));
+  MALIO_HIP(sc.get(&v1, (size_t)n));
+  MALIO_HIP(sc.get(&v2, (size_t)n));
+  MALIO_HIP(sc.get(&head, (size_t)n + 1));
+  MALIO_HIP(sc.get(&pos, (size_t)n + 1));
+  MALIO_HIP(sc.get(&first, (size_t)n + 1));
+  MALIO_HIP(sc.get(&tiles, (size_t)(n + 1 + 1023) / 1024 + 2));
+  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
+  MALIO_HIP(sc.get(&tmp, tmp_bytes ? tmp_bytes : 16));
+  hipLaunchKernelGGL(k_vg_keys, dim3(nb), dim3(BLK), 0, c->stream, d_pts, n, g, k1, v1);
+  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
+  hipLaunchKernelGGL(k_vg_heads, dim3((n + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, k2, n, head);
+  exclusive_scan_u32(c, head, pos, tiles, n + 1);
+  u32 nvox = 0;
+  MALIO_HIP(hipMemcpyAsync(&nvox, pos + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_vg_first, dim3(nb), dim3(BLK), 0, c->stream, head, pos, n, first);
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  *out_n = (int)nvox;
+  const int take = std::min((int)nvox, cap);
+  if (take <= 0) return MALIO_OK;
+  MALIO_HIP(sc.get(&d_out, (size_t)nvox * 12));
+  hipLaunchKernelGGL(k_vg_centroid, dim3((nvox + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_pts, k2, v2, first, (int)nvox,
+                     n, normal_mode, d_out);
+  MALIO_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * 12 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+}  // namespace malio

@@ -107,6 +107,27 @@ class KdTreeGpu {
   bool built_ = false;
 };
 
+// pcl::VoxelGrid<PointType> downSizeFilterSurf (laserMapping.cpp:93): setLeafSize (:860), setInputCloud + filter (:970-971)
+class VoxelGridGpu {
+ public:
+  explicit VoxelGridGpu(Handle &h) : h_(h) {}
+  void setLeafSize(float lx, float, float) { leaf_ = lx; }  // the reference uses one size for the three axes
+  void setInputCloud(const PointVector &cloud) { in_ = &cloud; }
+  void filter(PointVector &output) {
+    const int n = in_ ? (int)in_->size() : 0;
+    output.resize((size_t)n);
+    int m = 0;
+    h_.check(malio_voxel_downsample(h_.get(), n ? in_->data() : nullptr, n, leaf_, MALIO_VOXEL_NORMAL_NORMALIZE,
+                                    output.data(), n, &m), "VoxelGrid::filter");
+    output.resize((size_t)m);
+  }
+
+ private:
+  Handle &h_;
+  const PointVector *in_ = nullptr;
+  float leaf_ = 0.5f;
+};
+
 // The per-scan globals + the two calls on the hot path.
 class Mapping {
  public:

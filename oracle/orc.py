@@ -299,3 +299,13 @@ class RefTree(VoxMap):
 
     def size(self):
         return self._l.refikd_validnum(self.h)
+
+
+def voxel_downsample(pts12, leaf, normalize_normal=True):
+    """Restated pcl::VoxelGrid (oracle/orc_voxel.cpp): [n,12] -> [n_voxels,12] in ascending voxel-index order."""
+    pts12 = _f32(pts12).reshape(-1, 12)
+    n = pts12.shape[0]
+    out = np.zeros((max(n, 1), 12), np.float32)
+    m = lib().orc_voxel_downsample(_p(pts12, C.c_float), n, C.c_float(leaf), int(bool(normalize_normal)),
+                                   _p(out, C.c_float), n)
+    return out[:m].copy()
