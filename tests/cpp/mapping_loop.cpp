@@ -99,6 +99,14 @@ int main(int argc, char **argv) {
     double cs = 0;
     for (auto &p : storage) cs += (double)p.x + 2.0 * (double)p.y + 3.0 * (double)p.z + 1000.0 * (double)p.normal_y;
     printf("flatten %zu checksum %a\n", storage.size(), cs);
+    malio::VoxelGridGpu downSizeFilterSurf(handle);                        // :93
+    downSizeFilterSurf.setLeafSize(1.0f, 1.0f, 1.0f);                    // :860
+    downSizeFilterSurf.setInputCloud(feats_down_body);                    // :970
+    malio::PointVector feats_down;
+    downSizeFilterSurf.filter(feats_down);                                // :971
+    double vs = 0;
+    for (auto &p : feats_down) vs += (double)p.x + 2.0 * (double)p.y + 3.0 * (double)p.z + (double)p.intensity;
+    printf("voxel %zu checksum %a\n", feats_down.size(), vs);
     malio::PointVector q(feats_down_world.begin(), feats_down_world.begin() + 4);
     for (auto &p : q) p.x = (float)x.pos[0] + 6.f, p.y = (float)x.pos[1], p.z = (float)x.pos[2];
     std::vector<malio::PointVector> near;

@@ -82,3 +82,9 @@ def test_cpp_mirror_mapping_loop_equals_ctypes_path(tmp_path, orc, capi, scenes,
     for p in m:
         cs += p[0] + 2.0 * p[1] + 3.0 * p[2] + 1000.0 * p[5]
     assert hexf(got["flatten"][2]) == cs
+    vg = eng.voxel_downsample(sc["scan"], 1.0).astype(np.float64)
+    assert int(got["voxel"][0]) == vg.shape[0]
+    vs = 0.0
+    for p in vg:
+        vs += p[0] + 2.0 * p[1] + 3.0 * p[2] + p[8]
+    assert hexf(got["voxel"][2]) == vs
