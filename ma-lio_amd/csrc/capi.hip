@@ -233,7 +233,7 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
   MALIO_HIP(hipMemcpyAsync(idx.data(), d_idx, sizeof(u32) * idx.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(d2.data(), d_d2, sizeof(float) * d2.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
-  std::vector<float4> mp(c->map_n);  // original order
+  std::vector<float4> mp(c->map_n);  // map array (slot index = map id)
   MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) {

@@ -179,7 +179,7 @@ struct Ctx {
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
-  float4 *d_map_in = nullptr;  // [map_n] original order: x y z normal_y (plane fit + Nearest_Points)
+  float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
   float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
   size_t cap_map_in = 0, cap_map_alt = 0;
   int map_dead = 0;  // slots of d_map_in[0, map_n) that hold a deleted point (x = +inf)
@@ -209,7 +209,7 @@ struct Ctx {
   float4 *d_plane = nullptr;   // [N] pabcd
   float *d_pd2 = nullptr;      // [N]
   float *d_world = nullptr;    // [3][N]
-  float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_transform -> k_knn/k_plane)
+  float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_search phase A; k_search_tail, k_far_nearest)
   double *d_pbnorm = nullptr;  // [N]
   float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
   double *d_ucov = nullptr;    // [N] unit_cov

@@ -1,8 +1,12 @@
 // The per-pass hot path: one h_share_model pass (laserMapping.cpp:552-760) fused with the
-// H^T R^-1 H / H^T R^-1 h accumulation of esekfom.hpp:621-635, as three gfx950 kernels:
-//   k_pass1<SEARCH>  a1-a3 (+a6 trace): world transform, 5-NN in the spatial hash, float plane fit, gates
-//   k_rows_reduce    a5/a7/a10: Jacobian row, FIC weights, per-workgroup LDS outer-product reduction
+// H^T R^-1 H / H^T R^-1 h accumulation of esekfom.hpp:621-635, as gfx950 kernels:
+//   k_search         a1-a3 (+a6/a8 trace) of a SEARCH pass: world transform, 5-NN on the two-level neighbour lists,
+//                    float plane fit, gates - one kernel, three phases per workgroup (see its header)
+//   k_search_tail    the level-2 searches of workgroups full of uncertified queries, spread over the GPU
+//   k_reuse          the same for a REUSE pass (neighbours and plane kept)
+//   k_rows_reduce    a5/a7/a10: Jacobian row, FIC weights, per-workgroup 16x16 f64 MFMA outer-product accumulation
 //   k_final_reduce   deterministic fixed-order sum of the workgroup partials
+// plus the map_incremental selection (k_far_nearest, k_mapinc_classify) and the batched Nearest_Search (k_nearest).
 // Compiled with -ffp-contract=off: the float stages (distances, QR plane fit, gates) and the double
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
@@ -79,7 +83,7 @@ struct Pass1Args {
   float plane_th;
   double cov_threshold;
   int extrinsic_est_en;
-  const float4 *map_in;  // [Nmap] original order: x y z normal_y
+  const float4 *map_in;  // [map slots] x y z normal_y (index = map id)
   // per-point outputs (sorted order)
   float4 *world4;  // [N] world point of the search pass
   double *pbnorm;  // [N] |p'| (double), range gate :599
