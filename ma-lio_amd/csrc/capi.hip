@@ -139,6 +139,7 @@ int malio_destroy(malio_handle_t h) {
   free_nl_scratch(c->nl_scratch);
   free_grid(c->gnew);
   c->arena.release_all();
+  for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
   fr(c->d_map_alt);
   fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);

@@ -164,6 +164,13 @@ struct ArenaScope {  // allocations made through a scope die with it
   }
 };
 
+// undistorted cloud of one LiDAR kept in HBM between malio_undistort_resident and malio_scan_set_resident
+struct ResCloud {
+  float *d = nullptr;  // [n][12] pcl::PointXYZINormal layout
+  size_t cap = 0;
+  int n = 0;
+};
+
 struct Ctx {
   malio_params_t prm{};
   int device = 0;
@@ -174,6 +181,7 @@ struct Ctx {
   // map
   NlScratch nl_scratch;
   Arena arena;       // per-call temporaries of the map update paths
+  ResCloud res[MALIO_MAX_LIDAR];
   void *h_stage = nullptr;  // pinned upload staging (map_build, scan_set), grown on demand
   size_t cap_stage = 0;
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)

@@ -4,17 +4,18 @@
 // std::map lookups), the three log_se3 of that interval read from a per-scan table (they only depend on the
 // interval; the reference recomputes them per point), three exp_se3 + three 3x4 products in double, Eigen's
 // matrix->quaternion conversion, then the rigid compensation of :498-503 in Eigen's quaternion-vector order.
-// Also emits, per point, how many IMU stamps lie strictly above its time (D_i): the host turns that into the
-// reference's single-step `if` counter (:484-494, the uncertainty-interval index written to `intensity`).
+// Also emits, per point, how many IMU stamps lie strictly above its time (D_i); a suffix-min scan turns that into
+// the reference's single-step `if` counter (:484-494, the uncertainty-interval index written to `intensity`).
 // Algorithmic bytes: 16 B read + 16 B written per raw point.
 #include <algorithm>
 #include "malio_internal.hpp"
+#include <hipcub/hipcub.hpp>
 
 namespace malio {
 
 struct UndArgs {
   int n;
-  const float4 *in;  // x y z curvature[ms]
+  const float *in12;  // [n][12] pcl::PointXYZINormal: x y z . nx ny nz . intensity curvature[ms] . .
   float4 *out;       // x y z (w: 1 if compensated, 0 if the spline could not bound the point's time)
   int *D;            // [n] IMU stamps above the point's time (counted down from cov_pointer0)
   double lidar_beg_time;
@@ -89,7 +90,8 @@ __device__ __forceinline__ void se3_mul_d(double R[9], double t[3], const double
 __global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= a.n) return;
-  const float4 p = a.in[i];
+  const float *pin = a.in12 + (size_t)i * 12;
+  const float4 p = make_float4(pin[0], pin[1], pin[2], pin[9]);
   const double point_t = (double)p.w / 1000.0 + a.lidar_beg_time;  // :482
   // D_i: stamps imu_t[k], k <= cov_pointer0, that are > point_t (imu_t ascending)
   {
@@ -186,6 +188,100 @@ __global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
 int spline_interval(const double *times, int n, double ts);
 void spline_interval_logs(const double *poses16, int n, double *logs6);
 
+// ---- the reference's pointer walk (:484-494) on the device ----------------------------------------------------
+// Going from the last point to the second, cov_pointer steps down by at most ONE per point, so the interval count
+// is A_i = min(D_i, A_{i+1} + 1) with A_n = 0. With B_i = A_i + i this is B_i = min(D_i + i, B_{i+1}), B_n = n: a
+// suffix minimum, i.e. an inclusive min-scan over the reversed sequence. intensity <- A_i - 1 (:504); point i opens
+// an uncertainty entry when A_i > A_{i+1}, and that entry's number is A_i - 1.
+__global__ void __launch_bounds__(BLK) k_und_rev(const int *__restrict__ D, int n, int *rev) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  rev[n - 1 - i] = i >= 1 ? D[i] + i : 0x7FFFFFFF;
+}
+__global__ void __launch_bounds__(BLK) k_und_final(const float *__restrict__ in12, const float4 *__restrict__ und,
+                                                   const int *__restrict__ brev, int n, float *out12, int *entry, int entry_cap,
+                                                   int *n_entries) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  float v[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) v[k] = in12[(size_t)i * 12 + k];
+  if (i >= 1) {
+    const int A = min(n, brev[n - 1 - i]) - i;
+    const int An = (i + 1 < n) ? min(n, brev[n - 2 - i]) - (i + 1) : 0;
+    if (A > An && A - 1 < entry_cap) entry[A - 1] = i;
+    if (i == 1) *n_entries = A;
+    const float4 u = und[i];
+    if (u.w != 0.f) v[0] = u.x, v[1] = u.y, v[2] = u.z, v[8] = (float)(A - 1);
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) out12[(size_t)i * 12 + k] = v[k];
+}
+
+// Undistort n points (device, 12 floats each) into d_out12 (device). Entry points (descending point index, as the
+// reference's walk meets them) and their count go to the host arrays when given.
+int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, const double *knot_times,
+                   const double *knot_poses, int n_knots, const double ext_q[4], const double ext_t[3],
+                   const double end_q[4], const double end_t[3], const double *imu_stamps, int n_imu, int cov_pointer0,
+                   float *d_out12, int *out_entry_point, int *out_n_entries) {
+  // per-scan tables: rows of the control poses and the per-interval log twists
+  std::vector<double> T12((size_t)n_knots * 12), logs((size_t)(n_knots - 1) * 6);
+  for (int k = 0; k < n_knots; k++)
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 4; cc++) T12[(size_t)k * 12 + r * 4 + cc] = knot_poses[(size_t)k * 16 + r * 4 + cc];
+  spline_interval_logs(knot_poses, n_knots, logs.data());
+  ArenaScope sc(c->arena);
+  float4 *d_und = nullptr;
+  int *d_D = nullptr, *d_rev = nullptr, *d_brev = nullptr, *d_entry = nullptr, *d_ne = nullptr;
+  double *d_tab = nullptr;
+  char *d_tmp = nullptr;
+  const size_t ntab = (size_t)n_knots + T12.size() + logs.size() + (size_t)n_imu;
+  const int entry_cap = n_imu + 4;
+  MALIO_HIP(sc.get(&d_und, (size_t)n));
+  MALIO_HIP(sc.get(&d_D, (size_t)n));
+  MALIO_HIP(sc.get(&d_rev, (size_t)n));
+  MALIO_HIP(sc.get(&d_brev, (size_t)n));
+  MALIO_HIP(sc.get(&d_entry, (size_t)entry_cap));
+  MALIO_HIP(sc.get(&d_ne, 1));
+  MALIO_HIP(sc.get(&d_tab, ntab));
+  std::vector<double> tab;
+  tab.insert(tab.end(), knot_times, knot_times + n_knots);
+  tab.insert(tab.end(), T12.begin(), T12.end());
+  tab.insert(tab.end(), logs.begin(), logs.end());
+  tab.insert(tab.end(), imu_stamps, imu_stamps + n_imu);
+  MALIO_HIP(hipMemcpyAsync(d_tab, tab.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemsetAsync(d_ne, 0, sizeof(int), c->stream));
+  UndArgs a;
+  a.n = n, a.in12 = d_in12, a.out = d_und, a.D = d_D, a.lidar_beg_time = lidar_beg_time;
+  a.knot_t = d_tab, a.knot_T = d_tab + n_knots, a.knot_log = d_tab + n_knots + T12.size(), a.K = n_knots;
+  a.imu_t = d_tab + n_knots + T12.size() + logs.size(), a.n_imu = n_imu, a.cov_pointer0 = cov_pointer0;
+  for (int k = 0; k < 4; k++) a.eq[k] = ext_q[k], a.lq[k] = end_q[k];
+  for (int k = 0; k < 3; k++) a.et[k] = ext_t[k], a.lt[k] = end_t[k];
+  const int nb = (n + BLK - 1) / BLK;
+  prof_begin(c);
+  hipLaunchKernelGGL(k_undistort, dim3(nb), dim3(BLK), 0, c->stream, a);
+  prof_mark(c, "k_undistort");
+  hipLaunchKernelGGL(k_und_rev, dim3(nb), dim3(BLK), 0, c->stream, d_D, n, d_rev);
+  size_t tmp_bytes = 0;
+  MALIO_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_bytes, d_rev, d_brev, hipcub::Min(), n, c->stream));
+  MALIO_HIP(sc.get(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+  MALIO_HIP(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_rev, d_brev, hipcub::Min(), n, c->stream));
+  hipLaunchKernelGGL(k_und_final, dim3(nb), dim3(BLK), 0, c->stream, d_in12, d_und, d_brev, n, d_out12, d_entry,
+                     entry_cap, d_ne);
+  int ne = 0;
+  std::vector<int> ent(entry_cap);
+  MALIO_HIP(hipMemcpyAsync(&ne, d_ne, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(ent.data(), d_entry, sizeof(int) * entry_cap, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  prof_end(c);
+  MALIO_HIP(hipGetLastError());
+  if (ne > entry_cap) ne = entry_cap;
+  if (out_entry_point)
+    for (int k = 0; k < ne; k++) out_entry_point[k] = ent[k];
+  if (out_n_entries) *out_n_entries = ne;
+  return MALIO_OK;
+}
+
 }  // namespace malio
 
 using namespace malio;
@@ -200,58 +296,54 @@ extern "C" int malio_undistort(malio_handle_t h, malio_point_t *pts, int n, doub
     return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
   MALIO_HIP(hipSetDevice(c->device));
-  // per-scan tables: rows of the control poses and the per-interval log twists
-  std::vector<double> T12((size_t)n_knots * 12), logs((size_t)(n_knots - 1) * 6);
-  for (int k = 0; k < n_knots; k++)
-    for (int r = 0; r < 3; r++)
-      for (int cc = 0; cc < 4; cc++) T12[(size_t)k * 12 + r * 4 + cc] = knot_poses[(size_t)k * 16 + r * 4 + cc];
-  spline_interval_logs(knot_poses, n_knots, logs.data());
-  std::vector<float4> hin(n);
-  for (int i = 0; i < n; i++) hin[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].curvature);
-  float4 *d_in = nullptr, *d_out = nullptr;
-  int *d_D = nullptr;
-  double *d_tab = nullptr;
-  const size_t ntab = (size_t)n_knots + T12.size() + logs.size() + (size_t)n_imu;
-  MALIO_HIP(hipMalloc(&d_in, sizeof(float4) * (size_t)n));
-  MALIO_HIP(hipMalloc(&d_out, sizeof(float4) * (size_t)n));
-  MALIO_HIP(hipMalloc(&d_D, sizeof(int) * (size_t)n));
-  MALIO_HIP(hipMalloc(&d_tab, sizeof(double) * ntab));
-  std::vector<double> tab;
-  tab.insert(tab.end(), knot_times, knot_times + n_knots);
-  tab.insert(tab.end(), T12.begin(), T12.end());
-  tab.insert(tab.end(), logs.begin(), logs.end());
-  tab.insert(tab.end(), imu_stamps, imu_stamps + n_imu);
-  MALIO_HIP(hipMemcpyAsync(d_tab, tab.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, c->stream));
-  MALIO_HIP(hipMemcpyAsync(d_in, hin.data(), sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  UndArgs a;
-  a.n = n, a.in = d_in, a.out = d_out, a.D = d_D, a.lidar_beg_time = lidar_beg_time;
-  a.knot_t = d_tab, a.knot_T = d_tab + n_knots, a.knot_log = d_tab + n_knots + T12.size(), a.K = n_knots;
-  a.imu_t = d_tab + n_knots + T12.size() + logs.size(), a.n_imu = n_imu, a.cov_pointer0 = cov_pointer0;
-  for (int k = 0; k < 4; k++) a.eq[k] = ext_q[k], a.lq[k] = end_q[k];
-  for (int k = 0; k < 3; k++) a.et[k] = ext_t[k], a.lt[k] = end_t[k];
-  prof_begin(c);
-  hipLaunchKernelGGL(k_undistort, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, a);
-  prof_mark(c, "k_undistort");
-  std::vector<float4> hout(n);
-  std::vector<int> D(n);
-  MALIO_HIP(hipMemcpyAsync(hout.data(), d_out, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(D.data(), d_D, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  ArenaScope sc(c->arena);
+  float *d_in = nullptr, *d_out = nullptr;
+  MALIO_HIP(sc.get(&d_in, (size_t)n * 12));
+  MALIO_HIP(sc.get(&d_out, (size_t)n * 12));
+  MALIO_HIP(hipMemcpyAsync(d_in, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int rc = undistort_core(c, d_in, n, lidar_beg_time, knot_times, knot_poses, n_knots, ext_q, ext_t, end_q, end_t, imu_stamps,
+                          n_imu, cov_pointer0, d_out, out_entry_point, out_n_entries);
+  if (rc != MALIO_OK) return rc;
+  // x, y, z and intensity are rewritten in place like :501-504 (the other fields come back unchanged)
+  MALIO_HIP(hipMemcpyAsync(pts, d_out, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  prof_end(c);
-  (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_D), (void)hipFree(d_tab);
-  // The reference's pointer walk (:484-494): going from the last point to the second, cov_pointer steps down by
-  // at most ONE per point, so the interval count is A_i = min(D_i, A_{i+1} + 1); intensity <- A_i - 1 (:504).
-  int A = 0, ne = 0;
-  for (int i = n - 1; i >= 1; i--) {
-    int An = std::min(D[i], A + 1);
-    if (An > A && out_entry_point) out_entry_point[ne] = i;
-    if (An > A) ne++;
-    A = An;
-    if (hout[i].w != 0.f) {
-      pts[i].x = hout[i].x, pts[i].y = hout[i].y, pts[i].z = hout[i].z;
-      pts[i].intensity = (float)(A - 1);
-    }
+  return MALIO_OK;
+}
+
+// Same, but the undistorted cloud of LiDAR `lid` stays in HBM for malio_scan_set_resident (voxel filter + scan upload
+// without a host round trip). Only the entry points travel back.
+extern "C" int malio_undistort_resident(malio_handle_t h, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
+                                        const double *knot_times, const double *knot_poses, int n_knots,
+                                        const double ext_q[4], const double ext_t[3], const double end_q[4],
+                                        const double end_t[3], const double *imu_stamps, int n_imu, int cov_pointer0,
+                                        int *out_entry_point, int *out_n_entries, malio_point_t *out_entry_pts) {
+  if (!h || lid < 0 || lid >= h->prm.lid_num || !pts || n <= 0 || !knot_times || !knot_poses || n_knots < 4 || !ext_q ||
+      !ext_t || !end_q || !end_t || !imu_stamps || n_imu <= 0)
+    return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  ResCloud &rcld = c->res[lid];
+  if ((size_t)n > rcld.cap) {
+    if (rcld.d) (void)hipFree(rcld.d);
+    rcld.d = nullptr, rcld.cap = (size_t)n + (size_t)n / 4 + 1024;
+    MALIO_HIP(hipMalloc(&rcld.d, sizeof(float) * 12 * rcld.cap));
   }
+  rcld.n = 0;
+  ArenaScope sc(c->arena);
+  float *d_in = nullptr;
+  MALIO_HIP(sc.get(&d_in, (size_t)n * 12));
+  MALIO_HIP(hipMemcpyAsync(d_in, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  int ne = 0;
+  std::vector<int> ent((size_t)n_imu + 4);
+  int rc = undistort_core(c, d_in, n, lidar_beg_time, knot_times, knot_poses, n_knots, ext_q, ext_t, end_q, end_t, imu_stamps,
+                          n_imu, cov_pointer0, rcld.d, ent.data(), &ne);
+  if (rc != MALIO_OK) return rc;
+  rcld.n = n;
+  if (out_entry_point)
+    for (int k = 0; k < ne; k++) out_entry_point[k] = ent[k];
   if (out_n_entries) *out_n_entries = ne;
+  if (out_entry_pts)  // the undistorted points that open the uncertainty entries (:484-494 needs their pose/time)
+    for (int k = 0; k < ne; k++)
+      MALIO_HIP(hipMemcpy(&out_entry_pts[k], rcld.d + (size_t)ent[k] * 12, sizeof(malio_point_t), hipMemcpyDeviceToHost));
   return MALIO_OK;
 }
