@@ -129,6 +129,24 @@ def secondary_figures(eng, sc, scenes, capi):
         ds = eng.voxel_downsample(und, 0.5)
         ts.append(time.perf_counter() - t)
     out["voxel_downsample"] = {"raw_points": n, "voxels": int(ds.shape[0]), "wall_ms": float(np.median(ts) * 1e3)}
+    # front end of one LiDAR, host-buffer chain vs resident chain (raw points -> scan installed)
+    if sc["L"] >= 1:
+        tabs1, tc1 = sc["tables"], sc["temporal_comp"]
+        th, tr = [], []
+        for _ in range(4):
+            t = time.perf_counter()
+            u1, _ = eng.undistort(pts, beg, kt, kT, ext_q, ext_t, q_end, p_end, imu_t, cp)
+            d1 = eng.voxel_downsample(u1, 0.5)
+            d1[:, 4] = d1[:, 8]
+            d1[:, 8] = 0
+            eng.scan_set(d1, tabs1, tc1)
+            th.append(time.perf_counter() - t)
+            t = time.perf_counter()
+            eng.undistort_resident(0, pts, beg, kt, kT, ext_q, ext_t, q_end, p_end, imu_t, cp)
+            eng.scan_set_resident(0.5, tabs1, tc1, want_body=True)
+            tr.append(time.perf_counter() - t)
+        out["front_end"] = {"raw_points": n, "host_chain_ms": float(np.median(th) * 1e3),
+                            "resident_chain_ms": float(np.median(tr) * 1e3)}
     # one whole turn of the mapping loop on the bench workload, as the integration calls it (laserMapping.cpp:985-1060):
     # scan upload + tables, iterated update (includes the once-per-scan spatial sort), map_incremental at the posterior
     wny = np.full(sc["N"], 0.001, np.float32)

@@ -177,6 +177,22 @@ int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);
 int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, float leaf, int normal_mode,
                            malio_point_t *out, int cap, int *out_n);
 
+/* ---- resident front end: undistortion -> voxel filter -> scan, without host round trips of the clouds -------- */
+/* malio_undistort_resident == malio_undistort for LiDAR `lid`, but the undistorted cloud stays in HBM; only the entry
+ * point indices (and, if wanted, those few points) come back for the uncertainty tables (IMU_Processing.hpp:484-494).
+ * malio_scan_set_resident then runs downSizeFilterSurf on every resident cloud (laserMapping.cpp:968-971), applies
+ * normal_x <- intensity, intensity <- LiDAR number (:972-976), concatenates in LiDAR order (:982) and installs the
+ * result as the scan (== malio_scan_set on that cloud). out_body (may be NULL) receives feats_down_body, *out_n its
+ * size; scan indices used by malio_scan_get / malio_map_incremental are positions in that cloud. */
+int malio_undistort_resident(malio_handle_t h, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
+                             const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
+                             const double ext_t[3], const double end_q[4], const double end_t[3],
+                             const double *imu_stamps, int n_imu, int cov_pointer0, int *out_entry_point,
+                             int *out_n_entries, malio_point_t *out_entry_pts);
+int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const malio_pose_t *const *pose_unc,
+                            const int *pose_unc_len, const malio_pose_t *temporal_comp, malio_point_t *out_body, int cap,
+                            int *out_n);
+
 /* ---- per scan ------------------------------------------------------------------------------- */
 /* replaces the per-scan globals h_share_model reads: feats_down_body (laserMapping.cpp:86,982),
  * pose_unc[lid][k] (:1028-1048), kf.temporal_comp[lid-1] (IMU_Processing.hpp:510-522). Uploads the

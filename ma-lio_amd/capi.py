@@ -18,7 +18,7 @@ ERR_NO_DEVICE = -1
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_voxel_downsample", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -342,6 +342,43 @@ class Engine:
                                         v(end_t), _p(imu, C.c_double), len(imu), int(cov_pointer0), _p(ent, C.c_int),
                                         C.byref(ne)), "malio_undistort")
         return pts, ent[:ne.value].copy()
+
+    def undistort_resident(self, lid, pts12, lidar_beg_time, knot_times, knot_poses, ext_q, ext_t, end_q, end_t, imu_stamps,
+                           cov_pointer0):
+        """malio_undistort_resident: the cloud stays in HBM; returns (entry point indices, entry points [k,12])."""
+        pts = np.ascontiguousarray(pts12, np.float32)
+        kt = np.ascontiguousarray(knot_times, np.float64)
+        kp = np.ascontiguousarray(knot_poses, np.float64).reshape(-1, 16)
+        imu = np.ascontiguousarray(imu_stamps, np.float64)
+        v = lambda a: _p(np.ascontiguousarray(a, np.float64), C.c_double)
+        ent = np.zeros(max(len(imu), 1) + 4, np.int32)
+        epts = np.zeros((ent.shape[0], 12), np.float32)
+        ne = C.c_int(0)
+        self._res_n = getattr(self, "_res_n", {})
+        self._res_n[int(lid)] = pts.shape[0]
+        self._chk(lib().malio_undistort_resident(self.h, int(lid), _p(pts, Point), pts.shape[0], C.c_double(lidar_beg_time),
+                                                 _p(kt, C.c_double), _p(kp, C.c_double), len(kt), v(ext_q), v(ext_t),
+                                                 v(end_q), v(end_t), _p(imu, C.c_double), len(imu), int(cov_pointer0),
+                                                 _p(ent, C.c_int), C.byref(ne), _p(epts, Point)), "malio_undistort_resident")
+        return ent[:ne.value].copy(), epts[:ne.value].copy()
+
+    def scan_set_resident(self, leaf, pose_tables, temporal_comp, normal_mode=1, want_body=True, cap=None):
+        """malio_scan_set_resident: voxel filter + scan upload from the resident clouds. Returns feats_down_body."""
+        L = self.L
+        arrs = [np.ascontiguousarray(t, np.float64).reshape(-1, 59) for t in pose_tables]
+        ptrs = (C.POINTER(Pose) * L)(*[a.ctypes.data_as(C.POINTER(Pose)) for a in arrs])
+        lens = (C.c_int * L)(*[a.shape[0] for a in arrs])
+        tc = np.ascontiguousarray(temporal_comp, np.float64).reshape(-1, 59) if L > 1 else None
+        cap = int(cap if cap is not None else sum(getattr(self, "_res_n", {}).values()))
+        out = np.zeros((cap if want_body else 1, 12), np.float32)
+        n = C.c_int(0)
+        self._chk(lib().malio_scan_set_resident(self.h, C.c_float(leaf), int(normal_mode), ptrs, lens,
+                                                tc.ctypes.data_as(C.POINTER(Pose)) if tc is not None else None,
+                                                _p(out, Point) if want_body else None, cap if want_body else 0,
+                                                C.byref(n)), "malio_scan_set_resident")
+        self.N = n.value
+        self._res_n = {}
+        return out[:n.value].copy() if want_body else None
 
     # ---- multi-GPU staging (device pointers are plain ints, e.g. torch.Tensor.data_ptr()) ----
     def sums_len(self):

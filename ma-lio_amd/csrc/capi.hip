@@ -303,14 +303,9 @@ int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, fl
 }
 
 // ---- scan -----------------------------------------------------------------------------------------
-int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
-                   const int *pose_unc_len, const malio_pose_t *temporal_comp) {
-  if (check(h) || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
-  Ctx *c = h;
+// per-scan tables: folded pose_unc entries (trace as a quadratic form) and the temporal compensation
+static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *pose_unc_len, const malio_pose_t *temporal_comp) {
   const int L = c->prm.lid_num;
-  if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
-  MALIO_HIP(hipSetDevice(c->device));
-  // uncertainty tables
   int tot = 0;
   for (int l = 0; l < L; l++) {
     if (pose_unc_len[l] < 2 || !pose_unc[l]) return MALIO_ERR_BAD_ARG;  // the reference indexes size()-2
@@ -325,11 +320,36 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     c->cap_unc = tot + 64;
     MALIO_HIP(hipMalloc(&c->d_unc, sizeof(UncEntry) * c->cap_unc));
   }
-  MALIO_HIP(hipMemcpyAsync(c->d_unc, ue.data(), sizeof(UncEntry) * tot, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemcpy(c->d_unc, ue.data(), sizeof(UncEntry) * tot, hipMemcpyHostToDevice));
   for (int l = 0; l + 1 < L; l++) {
     for (int k = 0; k < 4; k++) c->tcq[l][k] = temporal_comp[l].q[k];
     for (int k = 0; k < 3; k++) c->tct[l][k] = temporal_comp[l].t[k];
   }
+  return MALIO_OK;
+}
+
+// per-scan state that every new scan starts from (d_scan_in holds the LiDAR-partitioned upload)
+static int scan_reset(Ctx *c, int n) {
+  MALIO_HIP(hipMemsetAsync(c->d_sel, 0, (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_nfound, 0, (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_nbr, 0xFF, sizeof(u32) * 5 * (size_t)n, c->stream));
+  c->nbr_epoch = c->map_epoch;
+  MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
+  MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  c->scan_sorted = false;
+  c->last_M = -1;
+  return MALIO_OK;
+}
+
+int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
+                   const int *pose_unc_len, const malio_pose_t *temporal_comp) {
+  if (check(h) || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  const int L = c->prm.lid_num;
+  if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP(hipSetDevice(c->device));
+  if (int rct = scan_tables(c, pose_unc, pose_unc_len, temporal_comp)) return rct;
   // partition by LiDAR slot (stable) and pack to 16 B: x y z (lid | int(normal_x) << 8)
   c->N = n;
   int cnt[MALIO_MAX_LIDAR] = {0};
@@ -362,16 +382,81 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     c->h_normal_y_in[i] = body[i].normal_y;
   }
   MALIO_HIP(hipMemcpyAsync(c->d_scan_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_sel, 0, (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_nfound, 0, (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_nbr, 0xFF, sizeof(u32) * 5 * (size_t)n, c->stream));
-  c->nbr_epoch = c->map_epoch;
-  MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
-  MALIO_HIP(hipStreamSynchronize(c->stream));
-  c->scan_sorted = false;
-  c->last_M = -1;
-  return MALIO_OK;
+  return scan_reset(c, n);
+}
+
+// ---- resident front end: voxel filter + scan upload straight from the undistorted clouds in HBM -------------------
+namespace malio {
+// one down-sampled LiDAR cloud -> its segment of the scan: the field shuffle of laserMapping.cpp:972-976
+// (normal_x <- intensity [the voxel mean of the uncertainty index], intensity <- LiDAR number) and the 16-byte pack
+__global__ void __launch_bounds__(BLK) k_pack_resident(const float *__restrict__ down12, int n, int lid, int dst0,
+                                                       float4 *scan_in, float *ny, float *body12) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const float *p = down12 + (size_t)i * 12;
+  int idx = (int)p[8];  // int(laser_p.normal_x), laserMapping.cpp:694,737
+  if (idx > 0x3FFFFF) idx = 0x3FFFFF;
+  if (idx < -0x3FFFFF) idx = -0x3FFFFF;
+  const int packed = (int)(((unsigned)idx << 8) | (unsigned)lid);
+  scan_in[dst0 + i] = make_float4(p[0], p[1], p[2], __int_as_float(packed));
+  ny[dst0 + i] = p[5];
+  if (body12) {
+    float *q = body12 + (size_t)(dst0 + i) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) q[k] = p[k];
+    q[4] = p[8];
+    q[8] = (float)lid;
+  }
+}
+}  // namespace malio
+
+int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const malio_pose_t *const *pose_unc,
+                            const int *pose_unc_len, const malio_pose_t *temporal_comp, malio_point_t *out_body, int cap,
+                            int *out_n) {
+  if (check(h) || !pose_unc || !pose_unc_len || !out_n || cap < 0 || (cap > 0 && !out_body) || !(leaf > 0.f)) return MALIO_ERR_BAD_ARG;
+  if (normal_mode != MALIO_VOXEL_NORMAL_MEAN && normal_mode != MALIO_VOXEL_NORMAL_NORMALIZE) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  const int L = c->prm.lid_num;
+  if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP(hipSetDevice(c->device));
+  if (int rct = scan_tables(c, pose_unc, pose_unc_len, temporal_comp)) return rct;
+  ArenaScope sc(c->arena);
+  const float *down[MALIO_MAX_LIDAR] = {nullptr};
+  int m[MALIO_MAX_LIDAR] = {0};
+  int n = 0;
+  for (int l = 0; l < L; l++) {  // downSizeFilterSurf per LiDAR (:968-971), clouds concatenated in LiDAR order (:982)
+    if (c->res[l].n <= 0) continue;
+    float *d = nullptr;
+    bool pass = false;
+    int rc = voxel_downsample_dev(c, sc, c->res[l].d, c->res[l].n, leaf, normal_mode, &d, &m[l], &pass);
+    if (rc != MALIO_OK) return rc;
+    down[l] = pass ? c->res[l].d : d;
+    n += m[l];
+  }
+  *out_n = n;
+  if (n <= 0) return MALIO_ERR_NO_SCAN;
+  c->N = n;
+  c->seg_start[0] = 0;
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? m[l] : 0);
+  int rc = measure_alloc(c);
+  if (rc != MALIO_OK) return rc;
+  float *d_ny = nullptr, *d_body = nullptr;
+  MALIO_HIP(sc.get(&d_ny, (size_t)n));
+  const bool want_body = out_body && cap > 0;
+  if (want_body) MALIO_HIP(sc.get(&d_body, (size_t)n * 12));
+  for (int l = 0; l < L; l++)
+    if (m[l] > 0)
+      hipLaunchKernelGGL(k_pack_resident, dim3((m[l] + BLK - 1) / BLK), dim3(BLK), 0, c->stream, down[l], m[l], l,
+                         c->seg_start[l], c->d_scan_in, d_ny, d_body);
+  c->h_lidpart.resize(n);
+  for (int i = 0; i < n; i++) c->h_lidpart[i] = (u32)i;  // already grouped by LiDAR: scan index = upload position
+  c->h_normal_y_in.resize(n);
+  MALIO_HIP(hipMemcpyAsync(c->h_normal_y_in.data(), d_ny, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (want_body)
+    MALIO_HIP(hipMemcpyAsync(out_body, d_body, sizeof(float) * 12 * (size_t)std::min(n, cap), hipMemcpyDeviceToHost, c->stream));
+  rc = scan_reset(c, n);  // synchronises: the arena memory above is free to go
+  for (int l = 0; l < L; l++) c->res[l].n = 0;  // consumed
+  return rc;
 }
 
 int malio_sums_len(malio_handle_t h) { return h ? sums_len(h) : 0; }

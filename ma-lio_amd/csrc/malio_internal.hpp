@@ -293,6 +293,8 @@ int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
 
 // voxel.hip
+int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,
+                         int *out_n, bool *passthrough);
 int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,
                      int *out_n);
 

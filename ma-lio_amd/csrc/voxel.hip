@@ -122,23 +122,16 @@ __global__ void __launch_bounds__(BLK) k_vg_centroid(const float *__restrict__ p
 
 }  // namespace
 
-int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,
-                     int *out_n) {
-  MALIO_HIP(hipSetDevice(c->device));
-  *out_n = 0;
+// Device core. d_pts: [n][12] in HBM. On return *d_out (arena memory of the CALLER's scope: `sc`) holds *out_n points,
+// or *passthrough is set when PCL's "leaf size too small" branch applies (output = input).
+int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,
+                         int *out_n, bool *passthrough) {
+  *out_n = 0, *d_out = nullptr, *passthrough = false;
   if (n <= 0) return MALIO_OK;
-  if (!(leaf > 0.f)) {
-    c->err = "malio_voxel_downsample: leaf size must be positive";
-    return MALIO_ERR_BAD_ARG;
-  }
-  ArenaScope sc(c->arena);
-  float *d_pts = nullptr, *d_out = nullptr;
   u32 *d_mm = nullptr, *k1 = nullptr, *k2 = nullptr, *v1 = nullptr, *v2 = nullptr, *head = nullptr, *pos = nullptr,
       *first = nullptr, *tiles = nullptr;
   char *tmp = nullptr;
-  MALIO_HIP(sc.get(&d_pts, (size_t)n * 12));
   MALIO_HIP(sc.get(&d_mm, 6));
-  MALIO_HIP(hipMemcpyAsync(d_pts, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   const u32 mm0[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   MALIO_HIP(hipMemcpyAsync(d_mm, mm0, sizeof(mm0), hipMemcpyHostToDevice, c->stream));
   const int nb = (n + BLK - 1) / BLK;
@@ -165,10 +158,9 @@ int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int no
       if (cells > 0x7FFFFFFFll) too_small = true;
     }
   }
-  if (too_small) {
-    // "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+  if (too_small) {  // "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+    *passthrough = true;
     *out_n = n;
-    memcpy(out, pts, sizeof(malio_point_t) * (size_t)std::min(n, cap));
     return MALIO_OK;
   }
   g.mul[0] = 1, g.mul[1] = div[0], g.mul[2] = div[0] * div[1];
@@ -192,14 +184,40 @@ int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int no
   hipLaunchKernelGGL(k_vg_first, dim3(nb), dim3(BLK), 0, c->stream, head, pos, n, first);
   MALIO_HIP(hipStreamSynchronize(c->stream));
   *out_n = (int)nvox;
-  const int take = std::min((int)nvox, cap);
-  if (take <= 0) return MALIO_OK;
-  MALIO_HIP(sc.get(&d_out, (size_t)nvox * 12));
+  if (nvox == 0) return MALIO_OK;
+  MALIO_HIP(sc.get(d_out, (size_t)nvox * 12));
   hipLaunchKernelGGL(k_vg_centroid, dim3((nvox + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_pts, k2, v2, first, (int)nvox,
-                     n, normal_mode, d_out);
+                     n, normal_mode, *d_out);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,
+                     int *out_n) {
+  MALIO_HIP(hipSetDevice(c->device));
+  *out_n = 0;
+  if (n <= 0) return MALIO_OK;
+  if (!(leaf > 0.f)) {
+    c->err = "malio_voxel_downsample: leaf size must be positive";
+    return MALIO_ERR_BAD_ARG;
+  }
+  ArenaScope sc(c->arena);
+  float *d_pts = nullptr, *d_out = nullptr;
+  MALIO_HIP(sc.get(&d_pts, (size_t)n * 12));
+  MALIO_HIP(hipMemcpyAsync(d_pts, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  bool pass = false;
+  int m = 0;
+  int rc = voxel_downsample_dev(c, sc, d_pts, n, leaf, normal_mode, &d_out, &m, &pass);
+  if (rc != MALIO_OK) return rc;
+  *out_n = m;
+  const int take = std::min(m, cap);
+  if (take <= 0) return MALIO_OK;
+  if (pass) {
+    memcpy(out, pts, sizeof(malio_point_t) * (size_t)take);
+    return MALIO_OK;
+  }
   MALIO_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * 12 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
 

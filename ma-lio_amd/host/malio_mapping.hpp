@@ -8,6 +8,7 @@
 //   kf.update_iterated_dyn_share_modified(R, t)   -> malio::Mapping::update_iterated_dyn_share_modified
 //                                                                             (esekfom.hpp:495)
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -142,6 +143,23 @@ class Mapping {
     feats_down_size_ = (int)feats_down_body.size();
     h_.check(malio_scan_set(h_.get(), feats_down_body.data(), feats_down_size_, ptr.data(), len.data(),
                             L > 1 ? temporal_comp.data() : nullptr), "set_scan");
+  }
+  // Resident front end: the undistorted clouds stay in HBM (one malio_undistort_resident call per LiDAR, see
+  // INTEGRATION.md §4b), then downSizeFilterSurf + the field shuffle + the concatenation of laserMapping.cpp:966-983 run
+  // on the device and the result becomes the scan. feats_down_body comes back for the caller's own bookkeeping.
+  void set_scan_resident(float filter_size_surf, const std::vector<std::vector<Pose>> &pose_unc,
+                         const std::vector<Pose> &temporal_comp, PointVector &feats_down_body, int max_points) {
+    const int L = h_.params().lid_num;
+    std::vector<const Pose *> ptr(L);
+    std::vector<int> len(L);
+    for (int l = 0; l < L; l++) ptr[l] = pose_unc[l].data(), len[l] = (int)pose_unc[l].size();
+    feats_down_body.resize((size_t)max_points);
+    int n = 0;
+    h_.check(malio_scan_set_resident(h_.get(), filter_size_surf, MALIO_VOXEL_NORMAL_NORMALIZE, ptr.data(), len.data(),
+                                     L > 1 ? temporal_comp.data() : nullptr, feats_down_body.data(), max_points, &n),
+             "set_scan_resident");
+    feats_down_body.resize((size_t)std::min(n, max_points));
+    feats_down_size_ = n;
   }
   // void h_share_model(state_ikfom &s, esekfom::dyn_share_datastruct<double> &ekfom_data), laserMapping.cpp:552.
   // want_rows = true reproduces h_x / h / R exactly as the reference fills them (:642-644); false hands the
