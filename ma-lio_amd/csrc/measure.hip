@@ -119,22 +119,24 @@ __device__ __forceinline__ u32 hash_key_d(u64 k) {  // must equal hash_key() in 
 
 // Sorted (ascending) 5-slot candidate list with the total order (d2, original map index).
 struct Top5 {
-  float d[5];
-  u32 og[5];
+  // (d2 bits << 32 | map index): squared distances are >= +0, so their float bits order like the values and ONE
+  // 64-bit compare implements the total order (d2, map index). The candidate loop is VALU-issue bound (6 waves per
+  // SIMD share one pipe), and this form needs ~25 instructions per candidate where separate (d2, index) compares
+  // and selects needed ~120.
+  u64 k[5];
+  __device__ __forceinline__ float d(int i) const { return __uint_as_float((u32)(k[i] >> 32)); }
+  __device__ __forceinline__ u32 og(int i) const { return (u32)k[i]; }
 };
-__device__ __forceinline__ void top5_insert(Top5 &t, float d2, u32 og) {
-  if (!(d2 < t.d[4] || (d2 == t.d[4] && og < t.og[4]))) return;
-  t.d[4] = d2;
-  t.og[4] = og;
+__device__ __forceinline__ u64 top5_key(float d2, u32 og) { return ((u64)__float_as_uint(d2) << 32) | (u64)og; }
+__device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
+  if (!(key < t.k[4])) return;
+  t.k[4] = key;
 #pragma unroll
   for (int k = 4; k > 0; k--) {
-    bool sw = t.d[k] < t.d[k - 1] || (t.d[k] == t.d[k - 1] && t.og[k] < t.og[k - 1]);
-    float dk = t.d[k], dk1 = t.d[k - 1];
-    u32 ik = t.og[k], ik1 = t.og[k - 1];
-    t.d[k] = sw ? dk1 : dk;
-    t.d[k - 1] = sw ? dk : dk1;
-    t.og[k] = sw ? ik1 : ik;
-    t.og[k - 1] = sw ? ik : ik1;
+    const u64 a = t.k[k - 1], b = t.k[k];
+    const bool sw = b < a;
+    t.k[k - 1] = sw ? b : a;
+    t.k[k] = sw ? a : b;
   }
 }
 
@@ -160,22 +162,22 @@ __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 
 // 5 rounds of a 64-bit (d2 bits | map index) min-reduction over xor-shuffles.
 template <int G>
 __device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
+  const u64 skey = top5_key(sentinel, INVALID);
   Top5 out;
 #pragma unroll
   for (int r = 0; r < 5; r++) {
-    u64 key = ((u64)__float_as_uint(t.d[0]) << 32) | (u64)t.og[0];
+    const u64 key = t.k[0];
     u64 mn = key;
 #pragma unroll
     for (int sft = G / 2; sft > 0; sft >>= 1) {
       u64 other = __shfl_xor(mn, sft);
       mn = other < mn ? other : mn;
     }
-    out.d[r] = __uint_as_float((u32)(mn >> 32));
-    out.og[r] = (u32)mn;
-    if (key == mn && t.og[0] != INVALID) {
+    out.k[r] = mn;
+    if (key == mn && (u32)key != INVALID) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) t.d[k] = t.d[k + 1], t.og[k] = t.og[k + 1];
-      t.d[4] = sentinel, t.og[4] = INVALID;
+      for (int k = 0; k < 4; k++) t.k[k] = t.k[k + 1];
+      t.k[4] = skey;
     }
   }
   t = out;
@@ -489,7 +491,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
                                           Top5 &t) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
-  for (int k = 0; k < 5; k++) t.d[k] = sentinel, t.og[k] = INVALID;
+  for (int k = 0; k < 5; k++) t.k[k] = top5_key(sentinel, INVALID);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
   u64 key = cell_key_d((int)kxf, (int)kyf, (int)kzf);
@@ -504,7 +506,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
     for (int u = 0; u < 8; u++) {
       float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-      if (j + (u32)(u * G) < count && !(d2 > limit2)) top5_insert(t, d2, __float_as_uint(m[u].w));
+      if (j + (u32)(u * G) < count && !(d2 > limit2)) top5_insert(t, top5_key(d2, __float_as_uint(m[u].w)));
     }
   }
   if (G > 1) merge_group<G>(t, sentinel);
@@ -514,7 +516,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
   float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
   float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
-  return (t.og[4] != INVALID) && (t.d[4] <= g1 * g1 * 0.99999f);
+  return (t.og(4) != INVALID) && (t.d(4) <= g1 * g1 * 0.99999f);
 }
 
 // a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
@@ -621,7 +623,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
     const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t);
     if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) s_og[k][ql] = t.og[k];
+      for (int k = 0; k < 5; k++) s_og[k][ql] = t.og(k);
       s_nf[ql] = certified ? 5 : NF_PENDING;
     }
   }
@@ -659,11 +661,11 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
           Top5 t;
           nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
           if (lane < 5) {
-            s_og[lane][l] = lane == 0 ? t.og[0] : lane == 1 ? t.og[1] : lane == 2 ? t.og[2] : lane == 3 ? t.og[3] : t.og[4];
+            s_og[lane][l] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
           } else if (lane == 5) {
             int nf = 0;
 #pragma unroll
-            for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+            for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
             s_nf[l] = (unsigned char)nf;
           }
         }
@@ -720,10 +722,11 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
     if (live && sub == 0) {
       int nf = 0;
 #pragma unroll
-      for (int k = 0; k < 5; k++) nf += (t.og[k] != INVALID);
+      for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
       bool selected;
       double ucov, tr;
-      point_phase(a, i, w, a.pbnorm[i], t.og, nf, selected, ucov, tr);
+      const u32 og5[5] = {t.og(0), t.og(1), t.og(2), t.og(3), t.og(4)};
+      point_phase(a, i, w, a.pbnorm[i], og5, nf, selected, ucov, tr);
       if (selected) {
         nsel++;
         mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -1025,9 +1028,9 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   int c = 0;
   for (int j = 0; j < 5; j++) {
     if (j < k) {
-      bool ok = t.og[j] != INVALID;
-      out_idx[(size_t)qi * k + j] = t.og[j];
-      out_d2[(size_t)qi * k + j] = ok ? t.d[j] : INFINITY;
+      bool ok = t.og(j) != INVALID;
+      out_idx[(size_t)qi * k + j] = t.og(j);
+      out_d2[(size_t)qi * k + j] = ok ? t.d(j) : INFINITY;
       c += ok;
     }
   }
