@@ -475,6 +475,7 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, 
 //   level 2 (FINAL = true, cf2 >= sqrt 5): guaranteed radius >= cf2 covers the reference's acceptance radius
 //   (`pointSearchSqDis[4] > 5` rejects, :587), so whatever it finds inside d2 <= 5 is final.
 // Squared distances are computed as ikd_Tree.cpp:1697 without FMA; candidates with d2 > limit2 are dropped.
+constexpr int NL1_G = 4;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
 constexpr unsigned char NF_PENDING = 0xFF;
 constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
 constexpr int TAIL_BLOCKS = 1024;  // k_search_tail: 4096 waves x 4 queries per sweep
@@ -589,9 +590,10 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, const flo
 // One kernel instead of three saves two kernel boundaries (each costs a few us of drain + cache writeback at
 // this size) and lets the latency-bound plane fit of one workgroup overlap with the memory-bound search of the
 // others on the same CU.
-constexpr int NL1_G = 4;   // lanes per query on the level-1 lists (~45 candidates; measured 1: 30, 2: 24, 4: 20 us)
-constexpr int SQ = BLK / NL1_G;
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
+constexpr int SQ = 64;             // queries per workgroup: one per lane of wave 0 in phases A and C
+constexpr int KS_BLK = SQ * NL1_G;  // workgroup size of k_search
+constexpr int KS_WAVES = KS_BLK / 64;
+__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ float4 s_w[SQ];
   __shared__ u32 s_og[5][SQ];
   __shared__ unsigned char s_nf[SQ];
@@ -656,7 +658,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(6, 6))
         while (todo) {
           const int l = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
-          if ((ord++ & 3) != wave) continue;
+          if ((ord++ % KS_WAVES) != wave) continue;
           const float4 ww = s_w[l];
           Top5 t;
           nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
@@ -1430,7 +1432,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
     c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
     a.parity = c->dq_parity;
     c->nbr_epoch = c->map_epoch;
-    hipLaunchKernelGGL(k_search, dim3((c->N + SQ - 1) / SQ), dim3(BLK), 0, c->stream, a, view_of(c->nl1),
+    hipLaunchKernelGGL(k_search, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
                        view_of(c->nl2));
     prof_mark(c, "k_search");
     if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
