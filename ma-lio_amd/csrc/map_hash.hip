@@ -516,10 +516,12 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
 //     every distance +inf, which the search drops); tombstones are swept by the next full rebuild
 __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const u32 *__restrict__ dlist,
                                                       int ndel, NlDev nl) {
-  // 32 lanes per deleted point, one of its 27 lists each (a level-2 list has ~180 entries to look through)
+  // 16 lanes per (deleted point, one of its 27 lists): a level-2 list has 180..900 entries to look through
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
-  const int d = (int)(t >> 5), cidx = (int)(t & 31);
-  if (d >= ndel || cidx >= 27) return;
+  const int sub = (int)(t & 15);
+  const long long pc = t >> 4;
+  const int d = (int)(pc / 27), cidx = (int)(pc % 27);
+  if (d >= ndel) return;
   const u32 i = dlist[d];
   float4 p = mapp[i];
   int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
@@ -532,11 +534,14 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
     s = (s + 1) & nl.tmask;
   }
   const u32 st = nl.table[s].start, cn = nl.table[s].count;
-  for (u32 j = 0; j < cn; j++)
-    if (__float_as_uint(nl.pts[(size_t)st + j].w) == i) {
-      nl.pts[(size_t)st + j].x = INFINITY;
-      break;
-    }
+  for (u32 j = (u32)sub; j < cn; j += 16 * 4) {  // 4 independent loads in flight per lane
+    u32 og[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) og[u] = __float_as_uint(nl.pts[(size_t)st + min(j + 16u * u, cn - 1)].w);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (og[u] == i && j + 16u * u < cn) nl.pts[(size_t)st + j + 16u * u].x = INFINITY;  // one entry per list matches
+  }
 }
 
 NlDev nl_dev(const NList &nl) {
@@ -559,7 +564,7 @@ void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u3
                      og_base, m, nl_dev(nl));
 }
 void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const u32 *dlist, int ndel) {
-  const long long th = (long long)ndel * 32;
+  const long long th = (long long)ndel * 27 * 16;
   hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_map, dlist, ndel,
                      nl_dev(nl));
 }
