@@ -106,19 +106,33 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
     w.dist = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
     w.near = w.dist < near_th;
     u32 inbox = 0;
-    for (u32 j = 0; j < ec; j++) {
-      const float4 q = lpts[(size_t)es + j];  // x = +inf for a tombstone: fails the box test
-      // Search_by_range / Delete_by_range leaf test (ikd_Tree.cpp:1263-1274, :807): min <= q < max
-      if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
-        continue;
-      const u32 mi = __float_as_uint(q.w);
-      if (del[mi]) continue;
-      inbox++;
-      Winner b;
-      b.x = q.x, b.y = q.y, b.z = q.z, b.cov = mapp[mi].w, b.rank = 1u + mi;
-      b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
-      b.near = b.dist < near_th;
-      if (displaces(w, b)) w = b;
+    u32 cand[8];  // stored points inside the box (a 0.5 m voxel rarely holds more than two)
+    int nc = 0;
+    bool cand_overflow = false;
+    for (u32 j0 = 0; j0 < ec; j0 += 4) {  // 4 independent loads in flight: the list is ~45 entries from L2/HBM
+      float4 q4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) q4[u] = lpts[(size_t)es + min(j0 + (u32)u, ec - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float4 q = q4[u];  // x = +inf for a tombstone: fails the box test
+        // Search_by_range / Delete_by_range leaf test (ikd_Tree.cpp:1263-1274, :807): min <= q < max
+        if (j0 + (u32)u >= ec ||
+            !(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
+          continue;
+        const u32 mi = __float_as_uint(q.w);
+        if (del[mi]) continue;
+        inbox++;
+        if (nc < 8)
+          cand[nc++] = mi;
+        else
+          cand_overflow = true;
+        Winner b;
+        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = mapp[mi].w, b.rank = 1u + mi;
+        b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+        b.near = b.dist < near_th;
+        if (displaces(w, b)) w = b;
+      }
     }
     if (alive != NONE) {
       float4 q = newp[alive];
@@ -134,14 +148,23 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
     // ikd_Tree.cpp:1688-1691
     bool same = fabs((double)(p.x - w.x)) < 1e-6 && fabs((double)(p.y - w.y)) < 1e-6 && fabs((double)(p.z - w.z)) < 1e-6;
     if (inbox > 1 || same) {
-      for (u32 j = 0; j < ec; j++) {
-        const float4 q = lpts[(size_t)es + j];
-        if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
-          continue;
-        const u32 mi = __float_as_uint(q.w);
-        if (del[mi] || w.rank == 1u + mi) continue;
-        del[mi] = 1;
-        dlist[atomicAdd(&counters[1], 1u)] = mi;  // order is irrelevant: every entry is tombstoned independently
+      if (!cand_overflow) {
+        for (int k = 0; k < nc; k++) {
+          const u32 mi = cand[k];
+          if (w.rank == 1u + mi) continue;
+          del[mi] = 1;
+          dlist[atomicAdd(&counters[1], 1u)] = mi;  // order is irrelevant: every entry is tombstoned independently
+        }
+      } else {
+        for (u32 j = 0; j < ec; j++) {
+          const float4 q = lpts[(size_t)es + j];
+          if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
+            continue;
+          const u32 mi = __float_as_uint(q.w);
+          if (del[mi] || w.rank == 1u + mi) continue;
+          del[mi] = 1;
+          dlist[atomicAdd(&counters[1], 1u)] = mi;
+        }
       }
       if (alive != NONE && w.rank != NONE) {
         float4 q = newp[alive];
