@@ -261,14 +261,18 @@ int malio_compound_inv_pose_cov(const malio_pose_t *pose_1, const malio_pose_t *
 int malio_eval_point_uncertainty(const malio_point_t *pi, const malio_pose_t *pose, double cov_point[9]);
 
 /* ---- multi-GPU staging: scan points sharded, map replicated -------------------- */
-/* Stage 1: search/plane/gates + local [max_unit_cov, -min_unit_cov, max_R, -min_R] into d_minmax4
- * (device, 4 doubles) -> caller all-reduces with MAX. Stage 2: rows + local sums into d_sums (device,
- * malio_sums_len() doubles: HtRinvH upper triangle, HtRinvh, sum c^2 n n^T (6), M) -> all-reduce SUM.
- * Finish: host-side weight/valid logic on the reduced sums, fills `out` like malio_measure. */
+/* Stage 1: search/plane/gates + the local extrema into d_minmax, a device buffer of MALIO_MINMAX_LEN (8) doubles:
+ *   [0..3] max_unit_cov, -min_unit_cov, max_R, -min_R  -> the caller all-reduces THESE FOUR with MAX
+ *   [4]    local number of accepted points, [5] local search diagnostic (workgroups full of unmatched queries),
+ *   [6..7] reserved                                     -> left as they are (per rank)
+ * Stage 2: rows + local sums into d_sums (device, malio_sums_len() doubles: HtRinvH upper triangle, HtRinvh,
+ * sum c^2 n n^T (6), M) -> all-reduce SUM. Finish: host-side weight/valid logic on the reduced sums (and the rank's
+ * own copy of the 8 extrema words), fills `out` like malio_measure. */
+#define MALIO_MINMAX_LEN 8
 int malio_sums_len(malio_handle_t h);
-int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax4);
-int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_sums);
-int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax4_host,
+int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax);
+int malio_measure_stage2(malio_handle_t h, const double *d_minmax, double *d_sums);
+int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

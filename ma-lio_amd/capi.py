@@ -396,6 +396,7 @@ class Engine:
     def finish(self, sums_host, minmax_host):
         sums_host = np.ascontiguousarray(sums_host, np.float64)
         minmax_host = np.ascontiguousarray(minmax_host, np.float64)
+        assert minmax_host.shape[0] >= 8, "the extrema buffer is MALIO_MINMAX_LEN = 8 doubles"
         out = MeasureOut()
         rc = self._chk(lib().malio_measure_finish(self.h, _p(sums_host, C.c_double), _p(minmax_host, C.c_double),
                                                   C.byref(out)), "malio_measure_finish")

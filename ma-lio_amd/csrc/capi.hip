@@ -472,12 +472,13 @@ int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_su
   int rc = pass_stage2(h, d_minmax4, nullptr, d_sums, false);
   return rc;
 }
-int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax4_host,
+int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out) {
-  if (check(h) || !sums_host || !minmax4_host || !out) return MALIO_ERR_BAD_ARG;
+  if (check(h) || !sums_host || !minmax_host || !out) return MALIO_ERR_BAD_ARG;
   prof_end(h);
-  int rc = finish_host(h, sums_host, minmax4_host, out);
+  int rc = finish_host(h, sums_host, minmax_host, out);
   h->last_M = out->M;
+  if (h->last_pass_search) h->defer_enabled = minmax_host[5] > 0.5;  // see malio_measure
   return rc;
 }
 

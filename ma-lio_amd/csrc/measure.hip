@@ -1428,6 +1428,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;
   c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
   const int nb = (c->N + BLK - 1) / BLK;
+  c->last_pass_search = converge != 0;
   if (converge) {
     c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
     a.parity = c->dq_parity;
