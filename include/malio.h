@@ -183,7 +183,8 @@ int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, fl
  * malio_scan_set_resident then runs downSizeFilterSurf on every resident cloud (laserMapping.cpp:968-971), applies
  * normal_x <- intensity, intensity <- LiDAR number (:972-976), concatenates in LiDAR order (:982) and installs the
  * result as the scan (== malio_scan_set on that cloud). out_body (may be NULL) receives feats_down_body, *out_n its
- * size; scan indices used by malio_scan_get / malio_map_incremental are positions in that cloud. */
+ * size; scan indices used by malio_scan_get / malio_map_incremental are positions in that cloud.
+ * out_entry_point / out_entry_pts (both optional) need room for n_imu entries. */
 int malio_undistort_resident(malio_handle_t h, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
                              const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
                              const double ext_t[3], const double end_q[4], const double end_t[3],
