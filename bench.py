@@ -194,11 +194,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU (the driver's launch); MALIO_DIST_BACKEND=gloo lets several ranks share one GPU so that the
+    # multi-rank code path can be exercised on a single-GPU box (development only: gloo stages through the host)
+    backend = os.environ.get("MALIO_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, "--gpus must equal WORLD_SIZE"
 
     cfg = scenes.CONFIGS[args.config]
@@ -209,7 +216,7 @@ def main():
         sc["scan"] = sc_r["scan"]
     N, L = sc["N"], sc["L"]
 
-    eng = capi.Engine(sc["params"], device=local_rank)
+    eng = capi.Engine(sc["params"], device=dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.map_build(sc["map"])
     eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])

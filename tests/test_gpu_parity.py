@@ -370,3 +370,32 @@ def test_call_order_errors(capi, scenes):
         eng.scan_get()                                       # the map changed under the neighbour ids
     assert eng.measure(sc["state0"], True)["M"] > 0          # a new search pass makes them valid again
     eng.scan_get()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
+    """The N > 1 code path of bench.py (scan sharded over ranks, MAX + SUM all-reduce per pass, C finish) with two
+    ranks on the one GPU a test box has: MALIO_DIST_BACKEND=gloo (RCCL refuses two ranks per device). The global
+    count of accepted points must be the sum of what each shard accepts on its own."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29633", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "2", "--config", "3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MALIO_DIST_BACKEND="gloo")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    js = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert js["n_gpus"] == 2 and js["scaling"] == "weak" and js["value"] > 0
+    Ms = []
+    sc = scenes.make_scene(cfg=3)
+    for r in range(2):   # bench.py: same map / tables / prior on every rank, the scan shard differs
+        scan = sc["scan"] if r == 0 else scenes.make_scene(cfg=3, scan_seed=1000 + r)["scan"]
+        eng = capi.Engine(sc["params"])
+        eng.map_build(sc["map"])
+        eng.scan_set(scan, sc["tables"], sc["temporal_comp"])
+        Ms.append(eng.measure(sc["state0"], True)["M"])
+    assert js["config"]["M_accepted"] == sum(Ms)
