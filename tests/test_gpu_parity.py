@@ -399,3 +399,38 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
         eng.scan_set(scan, sc["tables"], sc["temporal_comp"])
         Ms.append(eng.measure(sc["state0"], True)["M"])
     assert js["config"]["M_accepted"] == sum(Ms)
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes):
+    """dist.HipBackend.pass_fn with two ranks (gloo, sharing the GPU): plain two-collective sequence and the
+    speculative single all-gather give the same bits on both ranks, and match ONE engine fed the whole scan."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outp = str(tmp_path / "res.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", os.path.join(root, "tests", "dist_gpu_worker.py"), outp]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r0, r1 = json.load(open(outp))
+    assert r0 == r1                                              # every rank holds the same bits
+    assert r0["plain"]["H"] == r0["spec"]["H"] and r0["plain"]["h"] == r0["spec"]["h"]
+    assert r0["spec"]["stats"]["hits"] >= 3 and r0["spec"]["stats"]["misses"] == 0
+    sc = scenes.make_scene(cfg=3)
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ref = eng.measure(sc["state0"], True)
+    H = np.array(r0["spec"]["H"]).reshape(eng.C, eng.C)
+    assert r0["spec"]["M"] == ref["M"] and r0["spec"]["w"] == pytest.approx(ref["w_loc"], rel=1e-12)
+    assert np.allclose(H, ref["HtRinvH"], rtol=0, atol=1e-12 * np.abs(ref["HtRinvH"]).max())
+    st2 = np.array(sc["state0"], np.float64).copy()
+    st2[:3] += (0.02, -0.01, 0.015)
+    ref2 = eng.measure(st2, True)
+    H2 = np.array(r0["moved"]["H"]).reshape(eng.C, eng.C)
+    assert r0["moved"]["M"] == ref2["M"]
+    assert np.allclose(H2, ref2["HtRinvH"], rtol=0, atol=1e-12 * np.abs(ref2["HtRinvH"]).max())
