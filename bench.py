@@ -317,7 +317,7 @@ def main():
             "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
             "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step%s" % (
                 cfg["name"], N, L, sc["Nmap"], "" if not distributed else
-                "; scan sharded %d x %d pts, map replicated, 2 RCCL all-reduces per pass" % (world, N)),
+                "; scan sharded %d x %d pts, map replicated, one RCCL all-gather per pass while the extrema of the previous pass still hold (else two collectives)" % (world, N)),
                 "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"] if isinstance(out, dict) else out.M),
                 "seed": sc["seed"]},
             "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
