@@ -10,8 +10,8 @@ over one fused multi-LiDAR scan that is already resident in HBM, against the res
 
 N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map.
 N > 1 (weak scaling): every rank holds the replicated map and its own 100k-point shard of an
-N x 100k-point scan; each pass does the two tiny all-reduces of SURVEY.md §8(e) over RCCL
-(MAX of 5 doubles, SUM of 97 L doubles).
+N x 100k-point scan; a pass exchanges the extrema and the 97 L sums of SURVEY.md §8(e) over RCCL - in one
+all-gather while the previous pass' extrema still hold, else in two collectives (ma-lio_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields). The CPU oracle is used only for
 the `cpu_baseline` leg (rank 0, N = 1), never inside the timed GPU region.
