@@ -165,6 +165,21 @@ int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, in
  * Copies min(cap, size) valid points in map order, *out_n = size. Order differs from the tree's traversal. */
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);
 
+/* ---- sensor decode: City-dataset records -> the cloud Preprocess::process hands on ----- */
+/* Livox Avia / Tele: 19-byte records x y z (f32 LE), reflectivity, tag, line (u8), offset_time (u32 LE)
+ * (file_player/src/ROSThread.cpp:776-796,817-833) through Preprocess::avia_handler (MA_LIO/src/preprocess.cpp:59-107):
+ * tag/line test, every point_filter_num-th valid point, curvature = offset_time / 1e6 [ms] (dropped above 100),
+ * "differs from the previous point or outside the blind sphere" test with the precedence as written (:96).
+ * eof_point != 0 reproduces file_player's `while(!file.eof())` loop, which appends one default (all-zero) point.
+ * out: pl_surf in record order; *maximum_time as Preprocess::maximum_time (-9999 when nothing was looked at). */
+int malio_decode_livox(malio_handle_t h, const unsigned char *records, int n_records, int n_scans, int point_filter_num,
+                       double blind, int eof_point, malio_point_t *out, int cap, int *out_n, double *maximum_time);
+/* Ouster: 22-byte records x y z intensity (f32 LE), ring (u16), t (u32 LE) (ROSThread.cpp:947-957) through
+ * Preprocess::oust64_handler (preprocess.cpp:109-149): every point_filter_num-th record, blind sphere,
+ * curvature = t * time_unit_scale * 1e-9f [ms]. */
+int malio_decode_ouster(malio_handle_t h, const unsigned char *records, int n_records, int point_filter_num, double blind,
+                        float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time);
+
 /* ---- voxel down-sampling ------------------------------------------------ */
 /* downSizeFilterSurf.setInputCloud(cloud); downSizeFilterSurf.filter(*out)   laserMapping.cpp:93,860,968-971:
  * pcl::VoxelGrid<PointType> with its defaults (all fields averaged, min_points_per_voxel 0), leaf = filter_size_surf.

@@ -18,7 +18,7 @@ ERR_NO_DEVICE = -1
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -236,6 +236,28 @@ class Engine:
         got = C.c_int(0)
         self._chk(lib().malio_map_get(self.h, _p(out, Point), n, C.byref(got)), "malio_map_get")
         return out[:n]
+
+    def decode_livox(self, records, n_scans, point_filter_num, blind, eof_point=False):
+        """19-byte Livox records (bytes / uint8 array) -> (pl_surf [m,12], maximum_time), Preprocess::avia_handler."""
+        rec = np.frombuffer(bytes(records), np.uint8) if not isinstance(records, np.ndarray) else np.ascontiguousarray(records, np.uint8)
+        n = rec.size // 19
+        out = np.zeros((n + 2, 12), np.float32)
+        m, mt = C.c_int(0), C.c_double(0)
+        self._chk(lib().malio_decode_livox(self.h, rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(n_scans),
+                                           int(point_filter_num), C.c_double(blind), int(bool(eof_point)), _p(out, Point),
+                                           n + 2, C.byref(m), C.byref(mt)), "malio_decode_livox")
+        return out[:m.value].copy(), mt.value
+
+    def decode_ouster(self, records, point_filter_num, blind, time_unit_scale):
+        """22-byte Ouster records -> (pl_surf [m,12], maximum_time), Preprocess::oust64_handler."""
+        rec = np.frombuffer(bytes(records), np.uint8) if not isinstance(records, np.ndarray) else np.ascontiguousarray(records, np.uint8)
+        n = rec.size // 22
+        out = np.zeros((n + 1, 12), np.float32)
+        m, mt = C.c_int(0), C.c_double(0)
+        self._chk(lib().malio_decode_ouster(self.h, rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(point_filter_num),
+                                            C.c_double(blind), C.c_float(time_unit_scale), _p(out, Point), n + 1,
+                                            C.byref(m), C.byref(mt)), "malio_decode_ouster")
+        return out[:m.value].copy(), mt.value
 
     def voxel_downsample(self, pts12, leaf, normal_mode=1):
         """pcl::VoxelGrid (all fields) as restated in csrc/voxel.hip: [n,12] -> [n_voxels,12] in voxel-index order."""

@@ -295,6 +295,22 @@ int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   return MALIO_OK;
 }
 
+int malio_decode_livox(malio_handle_t h, const unsigned char *records, int n_records, int n_scans, int point_filter_num,
+                       double blind, int eof_point, malio_point_t *out, int cap, int *out_n, double *maximum_time) {
+  if (check(h) || n_records < 0 || (n_records > 0 && !records) || point_filter_num < 1 || n_scans < 0 || !out_n || cap < 0 ||
+      (cap > 0 && !out))
+    return MALIO_ERR_BAD_ARG;
+  return decode_livox(h, records, n_records, n_scans, point_filter_num, blind, eof_point, out, cap, out_n, maximum_time);
+}
+
+int malio_decode_ouster(malio_handle_t h, const unsigned char *records, int n_records, int point_filter_num, double blind,
+                        float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time) {
+  if (check(h) || n_records < 0 || (n_records > 0 && !records) || point_filter_num < 1 || !out_n || cap < 0 ||
+      (cap > 0 && !out))
+    return MALIO_ERR_BAD_ARG;
+  return decode_ouster(h, records, n_records, point_filter_num, blind, time_unit_scale, out, cap, out_n, maximum_time);
+}
+
 int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, float leaf, int normal_mode,
                            malio_point_t *out, int cap, int *out_n) {
   if (check(h) || !out_n || n < 0 || cap < 0 || (n > 0 && !pts) || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;

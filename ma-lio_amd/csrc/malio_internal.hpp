@@ -292,6 +292,12 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
 
+// decode.hip
+int decode_livox(Ctx *c, const unsigned char *rec, int n_rec, int n_scans, int pfn, double blind, int eof_point,
+                 malio_point_t *out, int cap, int *out_n, double *maximum_time);
+int decode_ouster(Ctx *c, const unsigned char *rec, int n, int pfn, double blind, float time_unit_scale, malio_point_t *out,
+                  int cap, int *out_n, double *maximum_time);
+
 // voxel.hip
 int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,
                          int *out_n, bool *passthrough);

@@ -309,3 +309,25 @@ def voxel_downsample(pts12, leaf, normalize_normal=True):
     m = lib().orc_voxel_downsample(_p(pts12, C.c_float), n, C.c_float(leaf), int(bool(normalize_normal)),
                                    _p(out, C.c_float), n)
     return out[:m].copy()
+
+
+def decode_livox(records, n_scans, point_filter_num, blind, eof_point=False):
+    """Restated file_player reader + Preprocess::avia_handler (oracle/orc_decode.cpp)."""
+    rec = np.frombuffer(bytes(records), np.uint8) if not isinstance(records, np.ndarray) else np.ascontiguousarray(records, np.uint8)
+    n = rec.size // 19
+    out = np.zeros((n + 2, 12), np.float32)
+    mt = C.c_double(0)
+    m = lib().orc_decode_livox(rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(n_scans), int(point_filter_num),
+                               C.c_double(blind), int(bool(eof_point)), _p(out, C.c_float), n + 2, C.byref(mt))
+    return out[:m].copy(), mt.value
+
+
+def decode_ouster(records, point_filter_num, blind, time_unit_scale):
+    """Restated file_player reader + Preprocess::oust64_handler (oracle/orc_decode.cpp)."""
+    rec = np.frombuffer(bytes(records), np.uint8) if not isinstance(records, np.ndarray) else np.ascontiguousarray(records, np.uint8)
+    n = rec.size // 22
+    out = np.zeros((n + 1, 12), np.float32)
+    mt = C.c_double(0)
+    m = lib().orc_decode_ouster(rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(point_filter_num), C.c_double(blind),
+                                C.c_float(time_unit_scale), _p(out, C.c_float), n + 1, C.byref(mt))
+    return out[:m].copy(), mt.value
