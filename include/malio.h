@@ -245,6 +245,17 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
                      const malio_state_t *x_propagated, const double *P_propagated, const double *HtRinvH,
                      const double *HtRinvh, int *t_io, int *converge_out, int *done_out, double *P_out);
 
+/* ---- IMU propagation ------------------------------------------------------------- */
+/* One kf.predict(dt, Q, in) (esekfom.hpp:388-492) with the process model of use-ikfom.hpp:67-112 (get_f, df_dx,
+ * df_dw): x <- x (+) f(x, in) dt, P <- F P F^T + (dt f_w) Q (dt f_w)^T. predict_cont (:171-279) and back_predict
+ * (:281-385) are the same step on kf's x_cont / x_unc and P_unc_: pass those instead. Pure host code, no handle and
+ * no GPU. x, P (n x n row-major, n = 17+6 lid_num) in/out; P may be NULL to advance the state only. Q: 12 x 12
+ * row-major process noise in the order ng, na, nbg, nba (use-ikfom.hpp:29-35, filled at IMU_Processing.hpp:325-330).
+ * acc / gyro: input_ikfom.acc / .gyro (the caller applies the mean-acc scale of IMU_Processing.hpp:318). The loops
+ * of IMU_Processing::UndistortPcl (:262-400) that call predict stay with the caller. */
+int malio_predict(int lid_num, malio_state_t *x, double *P, double dt, const double *Q, const double *acc,
+                  const double *gyro);
+
 /* ---- undistortion (IMU_Processing.hpp:475-507 + BsplineSE3.cpp:84-118) --------------------- */
 /* Per-raw-point SE(3) cubic B-spline pose + rigid compensation into the LiDAR's own scan-end frame.
  * pts (in/out, sorted by curvature as :229-233): x,y,z rewritten, intensity <- uncertainty-interval

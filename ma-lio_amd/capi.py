@@ -15,13 +15,14 @@ LIB_PATH = os.path.join(_HERE, "libmalio_hip.so")
 MAX_LIDAR = 4
 OK, NO_EFFECTIVE_POINTS, SMALL_M_FALLBACK = 0, 1, 2
 ERR_NO_DEVICE = -1
+ERR_BAD_ARG = -3
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -443,6 +444,20 @@ def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh
     if rc != OK:
         raise MalioError(f"malio_ieskf_step rc={rc}")
     return state_to_flat(x, L), t_io.value, bool(conv.value), bool(done.value), P_out
+
+
+def predict(L, x_flat, P, dt, Q, acc, gyro):
+    """malio_predict (pure host, no GPU): one esekf::predict step. Returns (x_new_flat, P_new)."""
+    x = state_from_flat(x_flat, L)
+    P = None if P is None else np.array(P, np.float64, order="C")
+    Q = np.ascontiguousarray(Q, np.float64)
+    acc = np.ascontiguousarray(acc, np.float64)
+    gyro = np.ascontiguousarray(gyro, np.float64)
+    rc = lib().malio_predict(int(L), C.byref(x), None if P is None else _p(P, C.c_double), C.c_double(dt),
+                             _p(Q, C.c_double), _p(acc, C.c_double), _p(gyro, C.c_double))
+    if rc != OK:
+        raise MalioError(f"malio_predict rc={rc}")
+    return state_to_flat(x, L), P
 
 
 def spline_feed(traj8, cap=4096):

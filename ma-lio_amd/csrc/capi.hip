@@ -647,4 +647,10 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
                     converge_out, done_out, P_out);
 }
 
+int malio_predict(int lid_num, malio_state_t *x, double *P, double dt, const double *Q, const double *acc,
+                  const double *gyro) {
+  if (lid_num < 1 || lid_num > MALIO_MAX_LIDAR || !x || !acc || !gyro || (P && !Q)) return MALIO_ERR_BAD_ARG;
+  return predict_step(lid_num, x, P, dt, Q, acc, gyro);
+}
+
 }  // extern "C"

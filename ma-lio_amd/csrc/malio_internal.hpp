@@ -314,6 +314,8 @@ int sums_len(const Ctx *c);
 int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*original map index*/, float *d_d2, int *d_cnt);
 
+// host/predict.cpp
+int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
 int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,

@@ -194,6 +194,38 @@ class Mapping {
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {
     h_.check(malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
   }
+  // kf.predict(dt, Q, in) (esekfom.hpp:388-492; also predict_cont :171 / back_predict :281 when handed x_cont /
+  // x_unc and P_unc_), IMU_Processing.hpp:332,345,364,386,399. Host code; Q is 12 x 12 row-major.
+  static void predict(int lid_num, malio_state_t &x, std::vector<double> &P, double dt, const std::vector<double> &Q,
+                      const double acc[3], const double gyro[3]) {
+    int rc = malio_predict(lid_num, &x, P.data(), dt, Q.data(), acc, gyro);
+    if (rc != MALIO_OK) throw std::runtime_error("malio_predict rc=" + std::to_string(rc));
+  }
+  // "Calculate each LiDAR state uncertainty", laserMapping.cpp:1028-1048: the per-LiDAR tables h_share_model indexes,
+  // from the backward-propagated kf.lidar_uncertainty (IMU_Processing.hpp:366-400). The last entry of every list is
+  // dropped (`size() - 1`); secondary LiDARs are carried into the primary's frame by ext_l (+) entry, then the
+  // temporal compensation, then ext_0^-1, each call writing over its own second argument as the reference does.
+  static std::vector<std::vector<Pose>> pose_uncertainty_tables(const std::vector<Pose> &extrinsic,
+                                                                const std::vector<std::vector<Pose>> &lidar_uncertainty,
+                                                                const std::vector<Pose> &temporal_comp) {
+    const int lid_num = (int)lidar_uncertainty.size();
+    std::vector<std::vector<Pose>> pose_unc(lid_num);
+    Pose pose_point{};
+    for (int num = 0; num < lid_num; num++) {
+      const int cnt = (int)lidar_uncertainty[num].size() - 1;
+      for (int i = 0; i < cnt; i++) {
+        if (num == 0) {
+          pose_unc[num].push_back(lidar_uncertainty[num][i]);
+          continue;
+        }
+        malio_compound_pose_cov(&extrinsic[num], &lidar_uncertainty[num][i], &pose_point);
+        malio_compound_pose_cov(&temporal_comp[num - 1], &pose_point, &pose_point);
+        malio_compound_inv_pose_cov(&extrinsic[0], &pose_point, &pose_point);
+        pose_unc[num].push_back(pose_point);
+      }
+    }
+    return pose_unc;
+  }
   // void map_incremental(), laserMapping.cpp:398-446, without bringing Nearest_Points to the host.
   // state_point = kf.get_x() after the update (:1053); feats_down_world is the caller's cloud: only its normal_y
   // is read (the value the reference would store with each added point). Returns add_point_size (:445).

@@ -170,6 +170,15 @@ class Oracle:
                     trace=trace[:nt].copy(), solve_time=st.value)
 
 
+def predict(L, state, P, dt, Q, acc, gyro):
+    """esekfom.hpp:388-492 + use-ikfom.hpp:67-112 (dense, as the reference forms it). Returns (state, P)."""
+    state = np.array(state, np.float64)
+    P = np.array(P, np.float64, order="C")
+    lib().orc_predict(int(L), _p(state, C.c_double), _p(P, C.c_double), C.c_double(dt), _p(_f64(Q), C.c_double),
+                      _p(_f64(acc), C.c_double), _p(_f64(gyro), C.c_double))
+    return state, P
+
+
 def esti_plane(near12, threshold, cov_threshold):
     near12 = _f32(near12)
     pabcd = np.zeros(4, np.float32)

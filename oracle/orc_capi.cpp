@@ -228,6 +228,18 @@ int orc_update_iterated(void *hh, double *state, double *P, double R, int *stats
   return (int)tr.size();
 }
 
+// esekfom.hpp:388-492 + use-ikfom.hpp:67-112. state/P in-out, Q 12x12 row-major.
+void orc_predict(int L, double *state, double *P, double dt, const double *Q, const double *acc, const double *gyro) {
+  State x = state_from(state, L);
+  int n = x.dof();
+  Mat Pm(n, n), Qm(12, 12);
+  std::memcpy(Pm.a.data(), P, sizeof(double) * n * n);
+  std::memcpy(Qm.a.data(), Q, sizeof(double) * 144);
+  predict(x, Pm, dt, Qm, V3{acc[0], acc[1], acc[2]}, V3{gyro[0], gyro[1], gyro[2]});
+  state_to(x, state);
+  std::memcpy(P, Pm.a.data(), sizeof(double) * n * n);
+}
+
 // ---- unit-level entry points -----------------------------------------------------------------
 int orc_esti_plane(const float *near12, float threshold, double cov_threshold, float *pabcd, double *plane_cov) {
   std::vector<Pt> v(5);

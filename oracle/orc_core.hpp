@@ -130,6 +130,10 @@ struct UpdateStats {
 void update_iterated(Scene &sc, State &x, Mat &P, double R, UpdateStats &st,
                      std::vector<State> *trace_states = nullptr);
 
+// esekfom.hpp:388-492 (predict; predict_cont :171-279 and back_predict :281-385 are the same body on other members)
+// with the process model of use-ikfom.hpp:67-112. Q is 12 x 12 (ng, na, nbg, nba).
+void predict(State &x, Mat &P, double dt, const Mat &Q, V3 acc, V3 gyro);
+
 // ---- undistortion (a13/a14) ----------------------------------------------------------------
 // BsplineSE3.cpp:26-118,121-230 ; quat_ops.h:87-92,151-257
 struct Spline {

@@ -585,3 +585,139 @@ void Scene::map_incremental(const State &state_point, bool flg_EKF_inited, std::
   }
 }
 }  // namespace orc
+
+// ---------------------------------------------------------------------------------------------------------
+// esekf::predict / predict_cont / back_predict (esekfom.hpp:171-279, 281-385, 388-491) share one body: they differ
+// only in WHICH state/covariance pair they advance (x_/P_, x_cont/P_unc_, x_unc/P_unc_). That body, with the process
+// model of src/use-ikfom.hpp:67-112 (get_f, df_dx, df_dw) for the runtime-parametric state:
+//   f_   (m = 18 + 6 L, "flatted": the S2 entry has 3 rows)     f_x_ (m x n), f_w_ (m x 12)
+//   x.oplus(f_, dt)                                               (:398)
+//   F_x1 = I; vect rows copied; SO3 rows: F_x1 block = exp(seg, scalar(1/2)) - integer division, i.e. exp with scale
+//   0 = IDENTITY (the same quirk as S2.hpp:287) - and rows of f_x/f_w multiplied by A_matrix(seg), seg = -f dt;
+//   S2 rows: F_x1 block = Nx(x) * exp(...)=I * Mx(x_before, 0), rows = -Nx * hat(x_before) * A_matrix(seg)^T * rows
+//   F_x1 += f_x_final dt;  P = F_x1 P F_x1^T + (dt f_w_final) Q (dt f_w_final)^T          (:487-488)
+// Process noise order (use-ikfom.hpp:29-35): ng, na, nbg, nba (3 each).
+namespace orc {
+void predict(State &x_, Mat &P_, double dt, const Mat &Q, V3 acc, V3 gyro) {
+  const int L = x_.L, n = x_.dof(), m = n + 1;
+  const int i_rot = 3, i_vel = 6 * (L + 1), i_bg = i_vel + 3, i_ba = i_vel + 6, i_grav = i_vel + 9;
+  // get_f (:67-81)
+  std::vector<double> f_(m, 0.0);
+  V3 omega = gyro - x_.bg;
+  V3 a_inertial = x_.rot * (acc - x_.ba);
+  for (int i = 0; i < 3; i++) {
+    f_[i] = x_.vel[i];
+    f_[i + 3] = omega[i];
+    f_[i + i_vel] = a_inertial[i] + x_.grav[i];
+  }
+  // df_dx (:83-101)
+  Mat f_x_(m, n), f_w_(m, 12);
+  M3 R = toR(x_.rot);
+  V3 acc_ = acc - x_.ba;
+  M3 RhA = (-1.0) * (R * hat(acc_));
+  double grav_matrix[3][2];
+  S2_Mx(x_.grav, 0.0, 0.0, grav_matrix);
+  for (int i = 0; i < 3; i++) {
+    f_x_(i, i_vel + i) = 1.0;
+    f_x_(i_rot + i, i_bg + i) = -1.0;
+    for (int j = 0; j < 3; j++) {
+      f_x_(i_vel + i, i_rot + j) = RhA.m[i][j];
+      f_x_(i_vel + i, i_ba + j) = -R.m[i][j];
+    }
+    for (int j = 0; j < 2; j++) f_x_(i_vel + i, i_grav + j) = grav_matrix[i][j];
+  }
+  // df_dw (:104-112)
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) f_w_(i_vel + i, 3 + j) = -R.m[i][j];
+    f_w_(i_rot + i, i) = -1.0;
+    f_w_(i_bg + i, 6 + i) = 1.0;
+    f_w_(i_ba + i, 9 + i) = 1.0;
+  }
+  State x_before = x_;
+  // x_.oplus(f_, dt): vect += f dt; SO3 *= exp(f dt) (scale/2 is a double division there, SOn.hpp:252); S2: rotate by
+  // exp(f dt) (S2.hpp:129-134) - f is zero for the gravity entry, the extrinsics and the biases
+  auto f3 = [&](int o) { return V3{f_[o], f_[o + 1], f_[o + 2]}; };
+  x_.pos = x_.pos + dt * f3(0);
+  x_.rot = x_.rot * so3_exp(f3(i_rot), dt);
+  for (int l = 0; l < L; l++) x_.offset_R[l] = x_.offset_R[l] * so3_exp(f3(6 + 3 * l), dt);
+  for (int l = 0; l < L; l++) x_.offset_T[l] = x_.offset_T[l] + dt * f3(6 + 3 * L + 3 * l);
+  x_.vel = x_.vel + dt * f3(i_vel);
+  x_.bg = x_.bg + dt * f3(i_bg);
+  x_.ba = x_.ba + dt * f3(i_ba);
+  x_.grav = toR(so3_exp(f3(i_grav), dt)) * x_.grav;
+
+  Mat F_x1 = Mat::I(n), f_x_final(n, n), f_w_final(n, 12);
+  // vect states: idx == dim for every block before the S2 entry
+  auto copy_rows = [&](int idx, int dof) {
+    for (int j = 0; j < dof; j++) {
+      for (int i = 0; i < n; i++) f_x_final(idx + j, i) = f_x_(idx + j, i);
+      for (int i = 0; i < 12; i++) f_w_final(idx + j, i) = f_w_(idx + j, i);
+    }
+  };
+  copy_rows(0, 3);
+  for (int l = 0; l < L; l++) copy_rows(6 + 3 * L + 3 * l, 3);
+  copy_rows(i_vel, 3), copy_rows(i_bg, 3), copy_rows(i_ba, 3);
+  // SO3 states
+  std::vector<int> so3 = {i_rot};
+  for (int l = 0; l < L; l++) so3.push_back(6 + 3 * l);
+  for (int idx : so3) {
+    V3 seg{-1 * f_[idx] * dt, -1 * f_[idx + 1] * dt, -1 * f_[idx + 2] * dt};
+    M3 Rres = toR(mtk_exp_scale(seg, 0.0));  // scalar(1/2) == 0
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) F_x1(idx + i, idx + j) = Rres.m[i][j];
+    M3 A = A_matrix(seg);
+    for (int c = 0; c < n; c++) {
+      V3 col{f_x_(idx, c), f_x_(idx + 1, c), f_x_(idx + 2, c)};
+      V3 r = A * col;
+      for (int k = 0; k < 3; k++) f_x_final(idx + k, c) = r[k];
+    }
+    for (int c = 0; c < 12; c++) {
+      V3 col{f_w_(idx, c), f_w_(idx + 1, c), f_w_(idx + 2, c)};
+      V3 r = A * col;
+      for (int k = 0; k < 3; k++) f_w_final(idx + k, c) = r[k];
+    }
+  }
+  {  // S2 state: idx = dim = i_grav
+    V3 seg{f_[i_grav] * dt, f_[i_grav + 1] * dt, f_[i_grav + 2] * dt};
+    M3 Rres = toR(mtk_exp_scale(seg, 0.0));
+    double Nx[2][3], Mx[3][2];
+    S2_Nx_yy(x_.grav, Nx);
+    S2_Mx(x_before.grav, 0.0, 0.0, Mx);
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) {
+        double s = 0;
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) s += Nx[i][a] * Rres.m[a][b] * Mx[b][j];
+        F_x1(i_grav + i, i_grav + j) = s;
+      }
+    M3 T = Rres * hat(x_before.grav) * transpose(A_matrix(seg));
+    for (int c = 0; c < n; c++)
+      for (int i = 0; i < 2; i++) {
+        double s = 0;
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) s += -Nx[i][a] * T.m[a][b] * f_x_(i_grav + b, c);
+        f_x_final(i_grav + i, c) = s;
+      }
+    for (int c = 0; c < 12; c++)
+      for (int i = 0; i < 2; i++) {
+        double s = 0;
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) s += -Nx[i][a] * T.m[a][b] * f_w_(i_grav + b, c);
+        f_w_final(i_grav + i, c) = s;
+      }
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) F_x1(i, j) += f_x_final(i, j) * dt;
+  Mat G(n, 12);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 12; j++) G(i, j) = dt * f_w_final(i, j);
+  Mat Ft(n, n), Gt(12, n);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) Ft(j, i) = F_x1(i, j);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 12; j++) Gt(j, i) = G(i, j);
+  Mat A1 = F_x1 * P_ * Ft, A2 = G * Q * Gt;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) P_(i, j) = A1(i, j) + A2(i, j);
+}
+}  // namespace orc

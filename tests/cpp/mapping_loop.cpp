@@ -113,6 +113,23 @@ int main(int argc, char **argv) {
     std::vector<std::vector<float>> d2;
     ikdtree.Nearest_Search(q, 5, near, d2);
     printf("knn %zu d2 %a\n", near[0].size(), near[0].empty() ? 0.0 : (double)d2[0][0]);
+    // the next scan's forward propagation starts from the posterior: one kf.predict (IMU_Processing.hpp:332)
+    std::vector<double> Q(144, 0.0);
+    for (int i = 0; i < 3; i++) Q[i * 13] = 0.1, Q[(3 + i) * 13] = 0.1, Q[(6 + i) * 13] = 1e-4, Q[(9 + i) * 13] = 1e-4;
+    const double acc[3] = {0.1, -0.2, 9.7}, gyro[3] = {0.01, 0.02, -0.03};
+    malio::Mapping::predict(L, x, P, 0.005, Q, acc, gyro);
+    printf("predict %a %a %a %a\n", x.pos[0], x.vel[2], P[0], P[(size_t)4 * (17 + 6 * L) + 5]);
+    // laserMapping.cpp:1028-1048 with the scene's tables standing in for kf.lidar_uncertainty and the first entry
+    // of every table for the extrinsic
+    if (L > 1) {
+      std::vector<malio::Pose> extrinsic(L);
+      for (int l = 0; l < L; l++) extrinsic[l] = pose_unc[l][0];
+      auto tabs = malio::Mapping::pose_uncertainty_tables(extrinsic, pose_unc, temporal_comp);
+      double ts = 0;
+      for (int l = 0; l < L; l++)
+        for (auto &p : tabs[l]) ts += p.t[0] + 2 * p.q[1] + 1e6 * p.cov[7] + 1e6 * p.cov[35];
+      printf("tables %zu %zu checksum %a\n", tabs[0].size(), tabs[L - 1].size(), ts);
+    }
   } catch (const std::exception &e) {
     fprintf(stderr, "error: %s\n", e.what());
     return 3;

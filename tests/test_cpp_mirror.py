@@ -88,3 +88,19 @@ def test_cpp_mirror_mapping_loop_equals_ctypes_path(tmp_path, orc, capi, scenes,
     for p in vg:
         vs += p[0] + 2.0 * p[1] + 3.0 * p[2] + p[8]
     assert hexf(got["voxel"][2]) == vs
+    Q = np.diag([0.1] * 6 + [1e-4] * 6)
+    xp, Pp = capi.predict(sc["L"], u["state"], u["P"], 0.005, Q, [0.1, -0.2, 9.7], [0.01, 0.02, -0.03])
+    iv = 6 * (sc["L"] + 1) + sc["L"] + 1          # flat index of vel (quaternions take 4)
+    if sc["L"] > 1:
+        tabs, ts = sc["tables"], 0.0
+        for l in range(sc["L"]):
+            for i in range(tabs[l].shape[0] - 1):
+                p = tabs[l][i]
+                if l > 0:
+                    p = capi.compound(tabs[l][0], p)
+                    p = capi.compound(sc["temporal_comp"][l - 1], p, alias=True)
+                    p = capi.compound(tabs[0][0], p, inverse=True, alias=True)
+                ts += p[4] + 2 * p[1] + 1e6 * p[23 + 7] + 1e6 * p[23 + 35]
+        assert [int(got["tables"][0]), int(got["tables"][1])] == [tabs[0].shape[0] - 1, tabs[-1].shape[0] - 1]
+        assert hexf(got["tables"][3]) == ts
+    assert [hexf(v) for v in got["predict"]] == [xp[0], xp[iv + 2], Pp[0, 0], Pp[4, 5]]
