@@ -10,155 +10,11 @@
 #include <cstring>
 #include <vector>
 #include "../csrc/malio_internal.hpp"
+#include "manifold.hpp"
 
 namespace malio {
+using namespace mf;
 namespace {
-
-constexpr double TOL = 1e-11;               // MTK::tolerance<double>, mtkmath.hpp:122
-constexpr double G_LEN = 98090.0 / 10000.0;  // S2<double, 98090, 10000, 1>, use-ikfom.hpp:8
-
-struct Vec3 {
-  double v[3];
-};
-inline Vec3 cross3(const double *a, const double *b) {
-  return {{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}};
-}
-// Hamilton product of (x,y,z,w) quaternions
-inline void qmul(const double *a, const double *b, double *r) {
-  double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-  double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-  double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-  double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-  r[0] = x, r[1] = y, r[2] = z, r[3] = w;
-}
-inline void quat_R(const double *q, double R[3][3]) {
-  double x = q[0], y = q[1], z = q[2], w = q[3];
-  R[0][0] = 1 - 2 * (y * y + z * z), R[0][1] = 2 * (x * y - w * z), R[0][2] = 2 * (x * z + w * y);
-  R[1][0] = 2 * (x * y + w * z), R[1][1] = 1 - 2 * (x * x + z * z), R[1][2] = 2 * (y * z - w * x);
-  R[2][0] = 2 * (x * z - w * y), R[2][1] = 2 * (y * z + w * x), R[2][2] = 1 - 2 * (x * x + y * y);
-}
-// cos / sinc of sqrt(x2) with the Taylor branch of mtkmath.hpp:142-174
-inline void cos_sinc(double x2, double &c, double &s) {
-  const double bound = 1.2207031250000000e-04;  // sqrt(sqrt(DBL_EPSILON))
-  if (x2 >= bound) {
-    double x = std::sqrt(x2);
-    c = std::cos(x), s = std::sin(x) / x;
-    return;
-  }
-  const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
-  c = 1., s = 1.;
-  double term = -0.5 * x2;
-  for (int i = 0; i < 3; ++i) {
-    c += term;
-    term *= inv[2 * i];
-    s += term;
-    term *= -inv[2 * i + 1] * x2;
-  }
-}
-// quaternion of the rotation vector `v` scaled by `scale` (MTK::exp with half-angle, SOn.hpp:332-336)
-inline void rotvec_quat(const double *v, double scale, double *q) {
-  double h = scale / 2, c, s;
-  cos_sinc(h * h * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), c, s);
-  q[0] = s * h * v[0], q[1] = s * h * v[1], q[2] = s * h * v[2], q[3] = c;
-}
-// log of a unit quaternion as a rotation vector (SOn.hpp:341-345 -> mtkmath.hpp:268-288)
-inline void quat_rotvec(const double *q, double *v) {
-  double nv = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-  if (nv < TOL) nv = TOL;
-  double s = 2.0 / nv * std::atan(nv / q[3]);
-  v[0] = s * q[0], v[1] = s * q[1], v[2] = s * q[2];
-}
-inline void hat3(const double *v, double H[3][3]) {
-  H[0][0] = 0, H[0][1] = -v[2], H[0][2] = v[1];
-  H[1][0] = v[2], H[1][1] = 0, H[1][2] = -v[0];
-  H[2][0] = -v[1], H[2][1] = v[0], H[2][2] = 0;
-}
-// MTK::A_matrix(v)^T (mtkmath.hpp:235-247), row-major 3x3
-inline void A_matrix_T(const double *v, double At[9]) {
-  double sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], n = std::sqrt(sq);
-  double A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  if (!(n < TOL)) {
-    double H[3][3], H2[3][3];
-    hat3(v, H);
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) H2[i][j] = H[i][0] * H[0][j] + H[i][1] * H[1][j] + H[i][2] * H[2][j];
-    double a = (1 - std::cos(n)) / sq, b = (1 - std::sin(n) / n) / sq;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) A[i][j] += a * H[i][j] + b * H2[i][j];
-  }
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) At[i * 3 + j] = A[j][i];
-}
-
-// ---- S2 (gravity) : S2.hpp, S2_typ == 1 ------------------------------------------------------------
-inline void s2_Bx(const double *g, double B[3][2]) {  // S2.hpp:225-241
-  if (g[0] + G_LEN > TOL) {
-    double d = G_LEN + g[0];
-    B[0][0] = -g[1], B[0][1] = -g[2];
-    B[1][0] = G_LEN - g[1] * g[1] / d, B[1][1] = -g[2] * g[1] / d;
-    B[2][0] = -g[2] * g[1] / d, B[2][1] = G_LEN - g[2] * g[2] / d;
-    for (int i = 0; i < 3; i++) B[i][0] /= G_LEN, B[i][1] /= G_LEN;
-  } else {
-    memset(B, 0, sizeof(double) * 6);
-    B[1][1] = -1, B[2][0] = 1;
-  }
-}
-inline void s2_boxplus(double *g, double d0, double d1) {  // S2.hpp:136-142
-  double B[3][2];
-  s2_Bx(g, B);
-  double Bu[3] = {B[0][0] * d0 + B[0][1] * d1, B[1][0] * d0 + B[1][1] * d1, B[2][0] * d0 + B[2][1] * d1};
-  double q[4], R[3][3];
-  rotvec_quat(Bu, 1.0, q);
-  quat_R(q, R);
-  double r[3];
-  for (int i = 0; i < 3; i++) r[i] = R[i][0] * g[0] + R[i][1] * g[1] + R[i][2] * g[2];
-  g[0] = r[0], g[1] = r[1], g[2] = r[2];
-}
-inline void s2_boxminus(const double *g, const double *o, double res[2]) {  // S2.hpp:144-167
-  Vec3 c = cross3(g, o);
-  double v_sin = std::sqrt(c.v[0] * c.v[0] + c.v[1] * c.v[1] + c.v[2] * c.v[2]);
-  double v_cos = g[0] * o[0] + g[1] * o[1] + g[2] * o[2];
-  double theta = std::atan2(v_sin, v_cos);
-  if (v_sin < TOL) {
-    res[0] = std::fabs(theta) > TOL ? 3.1415926 : 0.0;
-    res[1] = 0;
-    return;
-  }
-  double B[3][2];
-  s2_Bx(o, B);
-  Vec3 hv = cross3(o, g);  // hat(other) * vec
-  for (int j = 0; j < 2; j++) res[j] = theta / v_sin * (B[0][j] * hv.v[0] + B[1][j] * hv.v[1] + B[2][j] * hv.v[2]);
-}
-// res_temp_S2 = Nx(x_.grav) * Mx(x_propagated.grav, delta)   (esekfom.hpp:560-564, S2.hpp:269-290)
-inline void s2_NxMx(const double *g_cur, const double *g_prop, double d0, double d1, double out[4]) {
-  double Bc[3][2], Hc[3][3], Nx[2][3];
-  s2_Bx(g_cur, Bc);
-  hat3(g_cur, Hc);
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 3; j++)
-      Nx[i][j] = (Bc[0][i] * Hc[0][j] + Bc[1][i] * Hc[1][j] + Bc[2][i] * Hc[2][j]) / G_LEN / G_LEN;
-  double Bp[3][2], Hp[3][3], left[3][3];
-  s2_Bx(g_prop, Bp);
-  hat3(g_prop, Hp);
-  if (std::sqrt(d0 * d0 + d1 * d1) < TOL) {
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) left[i][j] = -Hp[i][j];
-  } else {
-    // exp(Bu, scalar(1/2)): 1/2 is INTEGER division == 0 in the reference (S2.hpp:287), so the
-    // exponential factor is the identity; only -hat(vec) * A_matrix(Bu)^T * Bx remains.
-    double Bu[3] = {Bp[0][0] * d0 + Bp[0][1] * d1, Bp[1][0] * d0 + Bp[1][1] * d1, Bp[2][0] * d0 + Bp[2][1] * d1};
-    double At[9];
-    A_matrix_T(Bu, At);
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++)
-        left[i][j] = -(Hp[i][0] * At[0 * 3 + j] + Hp[i][1] * At[1 * 3 + j] + Hp[i][2] * At[2 * 3 + j]);
-  }
-  double Mx[3][2];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 2; j++) Mx[i][j] = left[i][0] * Bp[0][j] + left[i][1] * Bp[1][j] + left[i][2] * Bp[2][j];
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2; j++) out[i * 2 + j] = Nx[i][0] * Mx[0][j] + Nx[i][1] * Mx[1][j] + Nx[i][2] * Mx[2][j];
-}
 
 // ---- whole-state boxplus / boxminus ------------------------------------------------------------------
 void state_boxplus(malio_state_t &x, int L, const double *dx) {

@@ -15,72 +15,11 @@
 #include <cstring>
 #include <vector>
 #include "../csrc/malio_internal.hpp"
+#include "manifold.hpp"
 
 namespace malio {
+using namespace mf;
 namespace {
-
-constexpr double TOL = 1e-11;                // MTK::tolerance<double>, mtkmath.hpp:122
-constexpr double G_LEN = 98090.0 / 10000.0;  // S2<double, 98090, 10000, 1>, use-ikfom.hpp:8
-
-inline void cos_sinc(double x2, double &c, double &s) {  // mtkmath.hpp:142-174
-  const double bound = 1.2207031250000000e-04;
-  if (x2 >= bound) {
-    double x = std::sqrt(x2);
-    c = std::cos(x), s = std::sin(x) / x;
-    return;
-  }
-  const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
-  c = 1., s = 1.;
-  double term = -0.5 * x2;
-  for (int i = 0; i < 3; ++i) {
-    c += term;
-    term *= inv[2 * i];
-    s += term;
-    term *= -inv[2 * i + 1] * x2;
-  }
-}
-inline void qmul(const double *a, const double *b, double *r) {
-  double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-  double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-  double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-  double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-  r[0] = x, r[1] = y, r[2] = z, r[3] = w;
-}
-inline void quat_R(const double *q, double R[3][3]) {
-  double x = q[0], y = q[1], z = q[2], w = q[3];
-  R[0][0] = 1 - 2 * (y * y + z * z), R[0][1] = 2 * (x * y - w * z), R[0][2] = 2 * (x * z + w * y);
-  R[1][0] = 2 * (x * y + w * z), R[1][1] = 1 - 2 * (x * x + z * z), R[1][2] = 2 * (y * z - w * x);
-  R[2][0] = 2 * (x * z - w * y), R[2][1] = 2 * (y * z + w * x), R[2][2] = 1 - 2 * (x * x + y * y);
-}
-inline void hat3(const double *v, double H[3][3]) {
-  H[0][0] = 0, H[0][1] = -v[2], H[0][2] = v[1];
-  H[1][0] = v[2], H[1][1] = 0, H[1][2] = -v[0];
-  H[2][0] = -v[1], H[2][1] = v[0], H[2][2] = 0;
-}
-inline void A_matrix(const double *v, double A[3][3]) {  // mtkmath.hpp:235-247
-  double sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], n = std::sqrt(sq);
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) A[i][j] = i == j;
-  if (n < TOL) return;
-  double H[3][3];
-  hat3(v, H);
-  double a = (1 - std::cos(n)) / sq, b = (1 - std::sin(n) / n) / sq;
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++)
-      A[i][j] += a * H[i][j] + b * (H[i][0] * H[0][j] + H[i][1] * H[1][j] + H[i][2] * H[2][j]);
-}
-inline void s2_Bx(const double *g, double B[3][2]) {  // S2.hpp:225-241 (S2_typ == 1)
-  if (g[0] + G_LEN > TOL) {
-    double d = G_LEN + g[0];
-    B[0][0] = -g[1], B[0][1] = -g[2];
-    B[1][0] = G_LEN - g[1] * g[1] / d, B[1][1] = -g[2] * g[1] / d;
-    B[2][0] = -g[2] * g[1] / d, B[2][1] = G_LEN - g[2] * g[2] / d;
-    for (int i = 0; i < 3; i++) B[i][0] /= G_LEN, B[i][1] /= G_LEN;
-  } else {
-    std::memset(B, 0, sizeof(double) * 6);
-    B[1][1] = -1, B[2][0] = 1;
-  }
-}
 
 // One 3 x w band of S: rows [r, r+3) of F*P gain dt * B * P[c .. c+w)
 struct Band {
