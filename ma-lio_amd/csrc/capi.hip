@@ -88,6 +88,10 @@ static int check(malio_handle_t h) { return h ? MALIO_OK : MALIO_ERR_BAD_ARG; }
 
 // pinned staging buffer of the upload paths, grown on demand and kept (hipHostMalloc/hipHostFree cost ~0.7 ms each)
 static int host_stage(malio::Ctx *c, size_t bytes, void **out) {
+  if (c->stage_pending) {  // malio_scan_set returns with its upload still in flight
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    c->stage_pending = false;
+  }
   if (bytes > c->cap_stage) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->h_stage = nullptr, c->cap_stage = 0;
@@ -142,11 +146,12 @@ int malio_destroy(malio_handle_t h) {
   for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
   fr(c->d_map_alt);
-  fr(c->d_scan_in), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
+  fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_mbox) (void)hipHostFree(c->h_mbox);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
@@ -344,15 +349,10 @@ static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *p
   return MALIO_OK;
 }
 
-// per-scan state that every new scan starts from (d_scan_in holds the LiDAR-partitioned upload)
-static int scan_reset(Ctx *c, int n) {
-  MALIO_HIP(hipMemsetAsync(c->d_sel, 0, (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_nfound, 0, (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_nbr, 0xFF, sizeof(u32) * 5 * (size_t)n, c->stream));
+// per-scan state that every new scan starts from. The per-point arrays (selection flags, neighbour cache, planes) are
+// cleared by the kernel that sorts the scan at the first pass (k_gather_scan); nothing reads them before that.
+static int scan_reset(Ctx *c) {
   c->nbr_epoch = c->map_epoch;
-  MALIO_HIP(hipMemsetAsync(c->d_pd2, 0, sizeof(float) * (size_t)n, c->stream));
-  MALIO_HIP(hipMemsetAsync(c->d_plane, 0, sizeof(float4) * (size_t)n, c->stream));
-  MALIO_HIP(hipStreamSynchronize(c->stream));
   c->scan_sorted = false;
   c->last_M = -1;
   return MALIO_OK;
@@ -366,39 +366,37 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
   MALIO_HIP(hipSetDevice(c->device));
   if (int rct = scan_tables(c, pose_unc, pose_unc_len, temporal_comp)) return rct;
-  // partition by LiDAR slot (stable) and pack to 16 B: x y z (lid | int(normal_x) << 8)
+  // Group by LiDAR slot (stable) and pack to 24 B in ONE pass over the caller's cloud: slot l fills its own region of
+  // the pinned staging buffer, the regions are copied back to back into HBM, nothing waits for the copies here.
   c->N = n;
-  int cnt[MALIO_MAX_LIDAR] = {0};
-  for (int i = 0; i < n; i++) {
-    int lid = (int)body[i].intensity;  // laserMapping.cpp:570
-    if (lid < 0 || lid >= L) return MALIO_ERR_BAD_ARG;
-    cnt[lid]++;
-  }
-  c->seg_start[0] = 0;
-  for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? cnt[l] : 0);
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
-  c->h_lidpart.resize(n);
-  c->h_normal_y_in.resize(n);
-  float4 *stage = nullptr;
-  if (int rcs = host_stage(c, sizeof(float4) * (size_t)n, (void **)&stage)) return rcs;
-  int pos[MALIO_MAX_LIDAR];
-  for (int l = 0; l < MALIO_MAX_LIDAR; l++) pos[l] = c->seg_start[l];
+  UploadRec *stage = nullptr;
+  if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n * (size_t)L, (void **)&stage)) return rcs;
+  int cnt[MALIO_MAX_LIDAR] = {0};
   for (int i = 0; i < n; i++) {
-    int lid = (int)body[i].intensity;
+    const int lid = (int)body[i].intensity;  // laserMapping.cpp:570
+    if (lid < 0 || lid >= L) {
+      c->N = 0;
+      return MALIO_ERR_BAD_ARG;
+    }
     int idx = (int)body[i].normal_x;  // int(laser_p.normal_x), laserMapping.cpp:694,737
     if (idx > 0x3FFFFF) idx = 0x3FFFFF;
     if (idx < -0x3FFFFF) idx = -0x3FFFFF;
-    int packed = (int)(((unsigned)idx << 8) | (unsigned)lid);
-    float w;
-    memcpy(&w, &packed, 4);
-    int p = pos[lid]++;
-    stage[p] = make_float4(body[i].x, body[i].y, body[i].z, w);
-    c->h_lidpart[p] = (u32)i;
-    c->h_normal_y_in[i] = body[i].normal_y;
+    UploadRec &r = stage[(size_t)lid * n + cnt[lid]++];
+    r.x = body[i].x, r.y = body[i].y, r.z = body[i].z;
+    r.w = ((unsigned)idx << 8) | (unsigned)lid;
+    r.part = (u32)i;
+    r.ny = body[i].normal_y;
   }
-  MALIO_HIP(hipMemcpyAsync(c->d_scan_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  return scan_reset(c, n);
+  c->seg_start[0] = 0;
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? cnt[l] : 0);
+  for (int l = 0; l < L; l++)
+    if (cnt[l] > 0)
+      MALIO_HIP(hipMemcpyAsync(c->d_upload + c->seg_start[l], stage + (size_t)l * n, sizeof(UploadRec) * (size_t)cnt[l],
+                               hipMemcpyHostToDevice, c->stream));
+  c->stage_pending = true;
+  return scan_reset(c);
 }
 
 // ---- resident front end: voxel filter + scan upload straight from the undistorted clouds in HBM -------------------
@@ -406,16 +404,19 @@ namespace malio {
 // one down-sampled LiDAR cloud -> its segment of the scan: the field shuffle of laserMapping.cpp:972-976
 // (normal_x <- intensity [the voxel mean of the uncertainty index], intensity <- LiDAR number) and the 16-byte pack
 __global__ void __launch_bounds__(BLK) k_pack_resident(const float *__restrict__ down12, int n, int lid, int dst0,
-                                                       float4 *scan_in, float *ny, float *body12) {
+                                                       UploadRec *upload, float *body12) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   const float *p = down12 + (size_t)i * 12;
   int idx = (int)p[8];  // int(laser_p.normal_x), laserMapping.cpp:694,737
   if (idx > 0x3FFFFF) idx = 0x3FFFFF;
   if (idx < -0x3FFFFF) idx = -0x3FFFFF;
-  const int packed = (int)(((unsigned)idx << 8) | (unsigned)lid);
-  scan_in[dst0 + i] = make_float4(p[0], p[1], p[2], __int_as_float(packed));
-  ny[dst0 + i] = p[5];
+  UploadRec r;
+  r.x = p[0], r.y = p[1], r.z = p[2];
+  r.w = ((unsigned)idx << 8) | (unsigned)lid;
+  r.part = (u32)(dst0 + i);  // already grouped by LiDAR: scan index = upload position
+  r.ny = p[5];
+  upload[dst0 + i] = r;
   if (body12) {
     float *q = body12 + (size_t)(dst0 + i) * 12;
 #pragma unroll
@@ -456,21 +457,18 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? m[l] : 0);
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
-  float *d_ny = nullptr, *d_body = nullptr;
-  MALIO_HIP(sc.get(&d_ny, (size_t)n));
+  float *d_body = nullptr;
   const bool want_body = out_body && cap > 0;
   if (want_body) MALIO_HIP(sc.get(&d_body, (size_t)n * 12));
   for (int l = 0; l < L; l++)
     if (m[l] > 0)
       hipLaunchKernelGGL(k_pack_resident, dim3((m[l] + BLK - 1) / BLK), dim3(BLK), 0, c->stream, down[l], m[l], l,
-                         c->seg_start[l], c->d_scan_in, d_ny, d_body);
-  c->h_lidpart.resize(n);
-  for (int i = 0; i < n; i++) c->h_lidpart[i] = (u32)i;  // already grouped by LiDAR: scan index = upload position
-  c->h_normal_y_in.resize(n);
-  MALIO_HIP(hipMemcpyAsync(c->h_normal_y_in.data(), d_ny, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  if (want_body)
+                         c->seg_start[l], c->d_upload, d_body);
+  if (want_body) {
     MALIO_HIP(hipMemcpyAsync(out_body, d_body, sizeof(float) * 12 * (size_t)std::min(n, cap), hipMemcpyDeviceToHost, c->stream));
-  rc = scan_reset(c, n);  // synchronises: the arena memory above is free to go
+    MALIO_HIP(hipStreamSynchronize(c->stream));  // out_body is the caller's memory
+  }
+  rc = scan_reset(c);
   for (int l = 0; l < L; l++) c->res[l].n = 0;  // consumed
   return rc;
 }

@@ -164,6 +164,16 @@ struct ArenaScope {  // allocations made through a scope die with it
   }
 };
 
+// One scan point as it crosses PCIe (24 B instead of the 48 B of pcl::PointXYZINormal): body-frame xyz, the packed
+// (LiDAR slot | int(normal_x) << 8) word of laserMapping.cpp:570,694,737, its index in the caller's cloud and the
+// input normal_y (returned untouched where the reference does not write it).
+struct UploadRec {
+  float x, y, z;
+  u32 w;
+  u32 part;
+  float ny;
+};
+
 // undistorted cloud of one LiDAR kept in HBM between malio_undistort_resident and malio_scan_set_resident
 struct ResCloud {
   float *d = nullptr;  // [n][12] pcl::PointXYZINormal layout
@@ -184,6 +194,8 @@ struct Ctx {
   ResCloud res[MALIO_MAX_LIDAR];
   void *h_stage = nullptr;  // pinned upload staging (map_build, scan_set), grown on demand
   size_t cap_stage = 0;
+  u32 *h_mbox = nullptr;       // pinned: small device->host readbacks (counts) land here, one stream sync serves all
+  bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
@@ -199,11 +211,9 @@ struct Ctx {
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
   bool scan_sorted = false;
-  float4 *d_scan_in = nullptr;  // [N] lid-partitioned upload order: x y z packed(lid | idx<<8)
+  UploadRec *d_upload = nullptr;  // [N] scan as uploaded, grouped by LiDAR (see UploadRec)
   float4 *d_scan = nullptr;     // [N] sorted
   u32 *d_perm = nullptr;        // [N] sorted -> original index
-  std::vector<u32> h_lidpart;   // host: upload position -> original index
-  std::vector<float> h_normal_y_in;  // input normal_y (returned untouched where the reference does not write it)
   int last_M = -1;
   int seg_start[MALIO_MAX_LIDAR + 1] = {0};
   size_t cap_scan = 0;
@@ -283,6 +293,7 @@ void free_nl_scratch(NlScratch &s);
 // map_update.hip
 int map_add(Ctx *c, const float4 *h_pts, int n, int downsample_on, int *out_added);
 int map_add_dev(Ctx *c, const float4 *d_pts, int n, int downsample_on, int *out_added);  // d_pts: device memory
+int map_add_pair_dev(Ctx *c, const float4 *d_pts, int m_ds, int m_plain, int *out_added);  // [0,m_ds): down-sampled add, rest: plain add
 int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
                     int *out_counts);
 // measure.hip: PointToAdd / PointNoNeedDownsample membership + world points, all in ORIGINAL scan order

@@ -205,10 +205,9 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   }
   hipLaunchKernelGGL(k_gbc_scatter, dim3(nb), dim3(BLK), 0, c->stream, d_in, d_in_orig, n, slot_of, rank_of, start,
                      g.pts, g.orig);
-  u32 h_ncells = 0;
-  MALIO_HIP(hipMemcpyAsync(&h_ncells, ncells, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipStreamSynchronize(c->stream));
-  u32 tsize = next_pow2(std::max(1024u, 4u * h_ncells));
+  // the compact table is sized for the worst case (every point in its own cell) instead of reading the cell count
+  // back: this runs once per scan on ~2 k points, where a host round trip costs more than clearing a few KB
+  u32 tsize = next_pow2(std::max(1024u, 4u * (u32)n));
   if ((size_t)tsize > g.cap_table) {
     if (g.table) (void)hipFree(g.table);
     g.table = nullptr;
@@ -218,9 +217,8 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize);
   hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
                      g.table, tsize - 1);
-  MALIO_HIP(hipStreamSynchronize(c->stream));
   g.tmask = tsize - 1;
-  g.ncells = h_ncells;
+  g.ncells = 0;  // not read back
   g.n = n;
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
@@ -449,39 +447,63 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
                                                   NlDev nl, int mode) {
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
-  if (i >= m || cidx >= 27 || !keep[i]) return;
-  float4 p = newp[i];
-  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
-  u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
-  u32 s = hash_key(key) & nl.tmask;
-  int probes = 0;
-  while (true) {
-    const u64 k = nl.table[s].key;
-    if (k == key) break;
-    if (k == EMPTY_KEY || ++probes > NL_MAX_PROBES) return;  // (1) already reported the overflow
-    s = (s + 1) & nl.tmask;
+  bool live = i < m && cidx < 27 && keep[i] != 0;
+  u32 s = 0;
+  if (live) {
+    float4 p = newp[i];
+    int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+    u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
+    s = hash_key(key) & nl.tmask;
+    int probes = 0;
+    while (true) {
+      const u64 k = nl.table[s].key;
+      if (k == key) break;
+      if (k == EMPTY_KEY || ++probes > NL_MAX_PROBES) {  // (1) already reported the overflow
+        live = false;
+        break;
+      }
+      s = (s + 1) & nl.tmask;
+    }
   }
   if (mode == 0) {
-    atomicAdd(&nl.inc[s], 1u);
+    if (live) atomicAdd(&nl.inc[s], 1u);
     return;
   }
-  const u32 need = atomicExch(&nl.inc[s], 0u);  // exactly one lane per touched cell sees the total (and clears it)
-  if (need == 0) return;
-  const u32 cnt = nl.table[s].count, cap = nl.cap[s];
-  if (cnt + need <= cap) return;  // fits in the slack the list was built with
-  // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the old
-  // storage is reclaimed by the next full rebuild
-  const u32 total = cnt + need;
-  const u32 newcap = total + max(NL_MIN_SLACK, total / 4);
-  const u32 st = atomicAdd(&nl.state[0], newcap);
-  if (st + newcap > nl.bump_end || st + newcap < st) {
-    atomicExch(&nl.state[1], 1u);
-    return;
+  // exactly one lane per touched cell sees the batch's total for that cell (and clears it)
+  u32 cnt = 0, old = 0, st = 0, newcap = 0;
+  bool mv = false;
+  if (live) {
+    const u32 need = atomicExch(&nl.inc[s], 0u);
+    if (need != 0) {
+      cnt = nl.table[s].count;
+      if (cnt + need > nl.cap[s]) {
+        // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
+        // old storage is reclaimed by the next full rebuild
+        const u32 total = cnt + need;
+        newcap = total + max(NL_MIN_SLACK, total / 4);
+        st = atomicAdd(&nl.state[0], newcap);
+        if (st + newcap > nl.bump_end || st + newcap < st) {
+          atomicExch(&nl.state[1], 1u);
+        } else {
+          mv = true;
+          old = nl.table[s].start;
+        }
+      }
+    }
   }
-  const u32 old = nl.table[s].start;
-  for (u32 j = 0; j < cnt; j++) nl.pts[(size_t)st + j] = nl.pts[(size_t)old + j];
-  nl.table[s].start = st;
-  nl.cap[s] = newcap;
+  // the lists that move are copied by the whole wave, one after the other (a level-2 list has hundreds of entries)
+  unsigned long long todo = __ballot(mv);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const u32 o = __shfl(old, src), d = __shfl(st, src), n = __shfl(cnt, src);
+    for (u32 j = lane; j < n; j += 64) nl.pts[(size_t)d + j] = nl.pts[(size_t)o + j];
+  }
+  if (mv) {
+    nl.table[s].start = st;
+    nl.cap[s] = newcap;
+  }
 }
 // (2) append every kept new point (map index og_base + rank) to its 27 lists
 __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ newp, const u32 *__restrict__ keep,

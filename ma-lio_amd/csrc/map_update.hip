@@ -299,6 +299,17 @@ static int map_reserve(Ctx *c, size_t extra) {
   return MALIO_OK;
 }
 
+// Counts the host needs come back through a small pinned buffer: a copy into pinned memory is queued like a kernel
+// (into pageable memory it is staged and blocks), so several of them cost one stream synchronisation.
+static hipError_t mbox(Ctx *c, u32 **out) {
+  if (!c->h_mbox) {
+    hipError_t e = hipHostMalloc((void **)&c->h_mbox, sizeof(u32) * 64, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+  }
+  *out = c->h_mbox;
+  return hipSuccess;
+}
+
 // Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
 //   dlist[ndel]     -> these slots die (x = +inf), their 27 entries per level become tombstones
 //   keep[m] != 0    -> d_new[i] is appended as slot map_n + rank[i] and inserted into 27 lists per level
@@ -334,9 +345,11 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
       nl_ensure(c, c->nl2, d_new, keep, m);
       nl_append(c, c->nl1, d_new, keep, rank, (u32)hw, m);
       nl_append(c, c->nl2, d_new, keep, rank, (u32)hw, m);
-      u32 st1[4], st2[4];
-      MALIO_HIP(hipMemcpyAsync(st1, c->nl1.state, sizeof(st1), hipMemcpyDeviceToHost, c->stream));
-      MALIO_HIP(hipMemcpyAsync(st2, c->nl2.state, sizeof(st2), hipMemcpyDeviceToHost, c->stream));
+      u32 *mb = nullptr;
+      MALIO_HIP(mbox(c, &mb));
+      u32 *st1 = mb + 16, *st2 = mb + 20;
+      MALIO_HIP(hipMemcpyAsync(st1, c->nl1.state, sizeof(u32) * 4, hipMemcpyDeviceToHost, c->stream));
+      MALIO_HIP(hipMemcpyAsync(st2, c->nl2.state, sizeof(u32) * 4, hipMemcpyDeviceToHost, c->stream));
       MALIO_HIP(hipStreamSynchronize(c->stream));
       c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
       if (st1[1] || st2[1]) in_place = false;  // a list or the tail region overflowed
@@ -368,20 +381,29 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
 }
 
 int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_added) {
+  // set_downsample_param(filter_size_map_min) is what arms DOWNSAMPLE_SWITCH (ikd_Tree.cpp:486); a non-positive
+  // size means it was never armed
+  const bool ds_on = downsample_on && (float)c->prm.filter_size_map > 0.f;
+  return ds_on ? map_add_pair_dev(c, d_new, m, 0, out_added) : map_add_pair_dev(c, d_new, 0, m, out_added);
+}
+
+// Add_Points(d_new[0 .. m_ds), true) followed by Add_Points(d_new[m_ds .. m_ds + m_plain), false) as ONE batch: the
+// second call neither reads the map nor is read by the first, so applying both at once leaves the same map (slots in
+// the same order) and halves the list maintenance and the host round trips of map_incremental (laserMapping.cpp:443-444).
+// out_added = return value of the down-sampling call (0 when there is none, ikd_Tree.cpp:563-583).
+int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *out_added) {
   MALIO_HIP(hipSetDevice(c->device));
   if (out_added) *out_added = 0;
+  const int m = m_ds + m_plain;
   if (m <= 0) return MALIO_OK;
   const float ds = (float)c->prm.filter_size_map;
   ArenaScope sc(c->arena);
   u32 *addf = nullptr, *apos = nullptr, *tiles = nullptr, *counters = nullptr;
   MALIO_HIP(sc.get(&addf, (size_t)m + 1));
   MALIO_HIP(sc.get(&apos, (size_t)m + 1));
-  // set_downsample_param(filter_size_map_min) is what arms DOWNSAMPLE_SWITCH (ikd_Tree.cpp:486); a non-positive
-  // size means it was never armed
-  if (!downsample_on || !(ds > 0.f)) {
+  if (m_ds <= 0) {
     hipLaunchKernelGGL(k_fill_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf, 1u, m);
     hipLaunchKernelGGL(k_iota_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, apos, m);
-    // Add_Points returns 0 on this branch (tmp_counter untouched, ikd_Tree.cpp:563-583)
     return map_apply(c, nullptr, 0, d_new, addf, apos, m, (u32)m);
   }
   if (ds > 2.0f * c->cell) {
@@ -392,24 +414,27 @@ int map_add_dev(Ctx *c, const float4 *d_new, int m, int downsample_on, int *out_
   if (rc != MALIO_OK) return rc;
   const int hw = c->map_n;
   CellGrid &gnew = c->gnew;
-  rc = group_by_cell(c, d_new, m, 1.f / ds, gnew, nullptr, ds);
+  rc = group_by_cell(c, d_new, m_ds, 1.f / ds, gnew, nullptr, ds);
   if (rc != MALIO_OK) return rc;
   unsigned char *del = nullptr;
-  u32 *dlist = nullptr;
+  u32 *dlist = nullptr, *mb = nullptr;
   hipError_t e = sc.get(&del, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&dlist, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
   if (e == hipSuccess) e = sc.get(&counters, 2);
+  if (e == hipSuccess) e = mbox(c, &mb);
   if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)hw + 1, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1), c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream);
   MALIO_HIP(e);
+  if (m_plain > 0)
+    hipLaunchKernelGGL(k_fill_u32, dim3((m_plain + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf + m_ds, 1u, m_plain);
   const u32 ntsize = gnew.tmask + 1;
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
                      d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
                      dlist, addf, counters);
   exclusive_scan_u32(c, addf, apos, tiles, m + 1);
-  u32 h_tot[3] = {0, 0, 0};
+  u32 *h_tot = mb + 8;  // kept points (both parts) | return value of the down-sampling call | deleted map points
   e = hipMemcpyAsync(&h_tot[0], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -435,8 +460,11 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   hipLaunchKernelGGL(k_box_delete, dim3((hw + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, hw, d_boxes, nb, dlist,
                      counter);
   u32 ndel = 0;
-  MALIO_HIP(hipMemcpyAsync(&ndel, counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  MALIO_HIP(hipMemcpyAsync(mb + 24, counter, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
+  ndel = mb[24];
   MALIO_HIP(hipGetLastError());
   if (out_deleted) *out_deleted = (int)ndel;
   if (ndel == 0) return MALIO_OK;
@@ -473,20 +501,24 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   if (rc != MALIO_OK) return rc;
   exclusive_scan_u32(c, addf, apos, tiles, N + 1);
   exclusive_scan_u32(c, nonf, npos, tiles, N + 1);
-  u32 h_tot[2] = {0, 0};
-  MALIO_HIP(hipMemcpyAsync(&h_tot[0], apos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(&h_tot[1], npos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  MALIO_HIP(hipMemcpyAsync(&mb[0], apos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(&mb[1], npos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  const int na = (int)h_tot[0], nn = (int)h_tot[1];
-  MALIO_HIP(sc.get(&d_add, (size_t)na));
-  MALIO_HIP(sc.get(&d_non, (size_t)nn));
+  const int na = (int)mb[0], nn = (int)mb[1];
+  MALIO_HIP(sc.get(&d_add, (size_t)na + (size_t)nn));  // PointToAdd | PointNoNeedDownsample, back to back
+  d_non = d_add + na;
   hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, addf, apos, N,
                      (const u32 *)nullptr, d_add);
   hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, nonf, npos, N,
                      (const u32 *)nullptr, d_non);
   int added = 0;
-  rc = map_add_dev(c, d_add, na, 1, &added);                 // ikdtree.Add_Points(PointToAdd, true)           :443
-  if (rc == MALIO_OK) rc = map_add_dev(c, d_non, nn, 0, nullptr);  // ikdtree.Add_Points(PointNoNeedDownsample, false) :444
+  // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)   (:443-444)
+  if ((float)c->prm.filter_size_map > 0.f)
+    rc = map_add_pair_dev(c, d_add, na, nn, &added);
+  else
+    rc = map_add_pair_dev(c, d_add, 0, na + nn, nullptr);
   if (out_counts) out_counts[0] = na, out_counts[1] = nn, out_counts[2] = added;
   return rc;
 }

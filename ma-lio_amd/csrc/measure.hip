@@ -1266,10 +1266,10 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_dq), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_scan_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_ny);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_ny);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
-    MALIO_HIP(hipMalloc(&c->d_scan_in, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_upload, sizeof(UploadRec) * K));
     MALIO_HIP(hipMalloc(&c->d_scan, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_perm, sizeof(u32) * K));
     MALIO_HIP(hipMalloc(&c->d_nbr, sizeof(u32) * 5 * K));
@@ -1311,35 +1311,41 @@ int measure_alloc(Ctx *c) {
   return MALIO_OK;
 }
 
-// world positions for the spatial sort of the scan (float is enough: ordering only)
-__global__ void __launch_bounds__(BLK) k_scan_world(const float4 *__restrict__ in, int n, QuatConst qc, float4 *out) {
+// Sort key of a scan point: (LiDAR slot, level-1 cell of its world position under the first pass' state). Float is
+// enough for the position (ordering only). The cell coordinates enter modulo 1024 (1152 m at the default edge, more
+// than twice any det_range the reference ships): a scan wider than that would merely interleave two far-apart cells,
+// which costs locality, not correctness. One 32-bit key for the whole scan - the slot in the top bits keeps the LiDAR
+// segments contiguous and in order - so ONE stable radix sort of 4 digit passes groups all segments at once; ties keep
+// the upload order.
+__global__ void __launch_bounds__(BLK) k_scan_keys(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
+                                                   u32 *keys, u32 *vals) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  float4 q = in[i];
-  int lid = __float_as_int(q.w) & 0xFF;
+  const UploadRec q = in[i];
+  const int lid = (int)(q.w & 0xFF);
   D3 p{(double)q.x, (double)q.y, (double)q.z};
   D3 X = (lid == 0) ? qrot(qc.q0, p) + qc.t0 : qrot(qc.qtc[lid], qrot(qc.ql[lid], p) + qc.tl[lid]) + qc.ttc[lid];
   D3 pg = qrot(qc.rot, X) + qc.pos;
-  out[i] = make_float4((float)pg.x, (float)pg.y, (float)pg.z, 0.f);
-}
-// sort key of a scan point: its level-1 cell (row-major cell order; ties keep the upload order - radix sort is stable)
-__global__ void __launch_bounds__(BLK) k_scan_keys(const float4 *__restrict__ w, int n, float inv_cf, u64 *keys, u32 *vals) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  float4 p = w[i];
-  keys[i] = cell_key_d((int)floorf(p.x * inv_cf), (int)floorf(p.y * inv_cf), (int)floorf(p.z * inv_cf));
+  const u32 cx = (u32)(int)floorf((float)pg.x * inv_cf) & 1023u, cy = (u32)(int)floorf((float)pg.y * inv_cf) & 1023u,
+            cz = (u32)(int)floorf((float)pg.z * inv_cf) & 1023u;
+  keys[i] = ((u32)lid << 30) | (cz << 20) | (cy << 10) | cx;
   vals[i] = (u32)i;
 }
-__global__ void __launch_bounds__(BLK) k_gather_scan(const float4 *__restrict__ in, const u32 *__restrict__ src, int n,
-                                                     int dst0, float4 *out_scan, u32 *out_perm,
-                                                     const u32 *__restrict__ part_orig,
-                                                     const float *__restrict__ ny_in, float *out_ny) {
+// the sorted scan + the per-scan state every new scan starts from (nothing reads these arrays before the first pass)
+__global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict__ in, const u32 *__restrict__ src, int n,
+                                                     float4 *out_scan, u32 *out_perm, float *out_ny, unsigned char *sel,
+                                                     unsigned char *nfound, u32 *nbr, float *pd2, float4 *plane) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  u32 s = src[i];  // index inside the LiDAR segment upload
-  out_scan[dst0 + i] = in[s];
-  out_perm[dst0 + i] = part_orig[s];
-  out_ny[dst0 + i] = ny_in[s];
+  const UploadRec r = in[src[i]];
+  out_scan[i] = make_float4(r.x, r.y, r.z, __uint_as_float(r.w));
+  out_perm[i] = r.part;
+  out_ny[i] = r.ny;
+  sel[i] = 0, nfound[i] = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) nbr[(size_t)k * n + i] = 0xFFFFFFFFu;
+  pd2[i] = 0.f;
+  plane[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
@@ -1360,44 +1366,26 @@ static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc)
 
 // Spatial sort of the scan, once per scan, with the first pass' state (coherence only, not results).
 static int sort_scan(Ctx *c, const QuatConst &qc) {
-  const int L = c->prm.lid_num;
-  ArenaScope sc(c->arena);  // everything below is synchronised before the scope ends
-  float4 *d_w = nullptr;
-  u32 *d_part_orig = nullptr;
-  MALIO_HIP(sc.get(&d_w, (size_t)c->N));
-  MALIO_HIP(sc.get(&d_part_orig, (size_t)c->N));
-  MALIO_HIP(hipMemcpyAsync(d_part_orig, c->h_lidpart.data(), sizeof(u32) * (size_t)c->N, hipMemcpyHostToDevice,
-                           c->stream));
-  float *d_ny_in = nullptr;  // input normal_y in upload (LiDAR-partitioned) order
-  std::vector<float> ny_part(c->N);
-  for (int p = 0; p < c->N; p++) ny_part[p] = c->h_normal_y_in[c->h_lidpart[p]];
-  MALIO_HIP(sc.get(&d_ny_in, (size_t)c->N));
-  MALIO_HIP(hipMemcpyAsync(d_ny_in, ny_part.data(), sizeof(float) * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_scan_world, dim3((c->N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_scan_in, c->N, qc, d_w);
-  // Group every LiDAR segment by level-1 cell with a stable radix sort: unlike a counting sort on atomic ranks, the
-  // resulting order - and with it every fixed-order reduction over the sorted scan - is identical in every run.
-  u64 *d_keys = nullptr, *d_keys2 = nullptr;
-  u32 *d_vals = nullptr, *d_vals2 = nullptr;
+  // The temporaries live in the arena and are handed back when this returns, with the kernels still queued: every
+  // arena user enqueues on c->stream, so the stream's order is the only synchronisation needed.
+  ArenaScope sc(c->arena);
+  const int N = c->N;
+  u32 *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
   void *d_tmp = nullptr;
   size_t tmp_bytes = 0;
-  MALIO_HIP(sc.get(&d_keys, (size_t)c->N));
-  MALIO_HIP(sc.get(&d_keys2, (size_t)c->N));
-  MALIO_HIP(sc.get(&d_vals, (size_t)c->N));
-  MALIO_HIP(sc.get(&d_vals2, (size_t)c->N));
-  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, c->N, 0, 63, c->stream));
+  MALIO_HIP(sc.get(&d_keys, (size_t)N));
+  MALIO_HIP(sc.get(&d_keys2, (size_t)N));
+  MALIO_HIP(sc.get(&d_vals, (size_t)N));
+  MALIO_HIP(sc.get(&d_vals2, (size_t)N));
+  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, N, 0, 32, c->stream));
   MALIO_HIP(sc.get((char **)&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  for (int l = 0; l < L; l++) {
-    int n = c->seg_start[l + 1] - c->seg_start[l];
-    if (n <= 0) continue;
-    hipLaunchKernelGGL(k_scan_keys, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_w + c->seg_start[l], n,
-                       c->nl1.inv_cf, d_keys, d_vals);
-    size_t tb = tmp_bytes;
-    MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 63, c->stream));
-    hipLaunchKernelGGL(k_gather_scan, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                       c->d_scan_in + c->seg_start[l], d_vals2, n, c->seg_start[l], c->d_scan, c->d_perm,
-                       d_part_orig + c->seg_start[l], d_ny_in + c->seg_start[l], c->d_ny);
-  }
-  MALIO_HIP(hipStreamSynchronize(c->stream));
+  const dim3 grid((N + BLK - 1) / BLK);
+  hipLaunchKernelGGL(k_scan_keys, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, d_keys, d_vals);
+  // A stable radix sort: unlike a counting sort on atomic ranks, the resulting order - and with it every fixed-order
+  // reduction over the sorted scan - is identical in every run.
+  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, N, 0, 32, c->stream));
+  hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, d_vals2, N, c->d_scan, c->d_perm, c->d_ny,
+                     c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
   c->scan_sorted = true;
   return MALIO_OK;
 }
