@@ -245,6 +245,14 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
                      const malio_state_t *x_propagated, const double *P_propagated, const double *HtRinvH,
                      const double *HtRinvh, int *t_io, int *converge_out, int *done_out, double *P_out);
 
+/* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */
+/* Every entry point accepts ordinary (pageable) host memory, as the reference's std::vector / pcl clouds are. A copy
+ * out of pageable memory is staged by the runtime in chunks and blocks the caller; out of page-locked memory it is one
+ * DMA the call does not wait for. A caller that can choose where its clouds live (the raw points handed to
+ * malio_undistort[_resident], the out_body of malio_scan_set_resident) gets them here; any device of the process. */
+int malio_host_alloc(size_t bytes, void **out);
+int malio_host_free(void *p);
+
 /* ---- IMU propagation ------------------------------------------------------------- */
 /* One kf.predict(dt, Q, in) (esekfom.hpp:388-492) with the process model of use-ikfom.hpp:67-112 (get_f, df_dx,
  * df_dw): x <- x (+) f(x, in) dt, P <- F P F^T + (dt f_w) Q (dt f_w)^T. predict_cont (:171-279) and back_predict

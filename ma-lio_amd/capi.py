@@ -22,7 +22,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -385,15 +385,21 @@ class Engine:
                                                  _p(ent, C.c_int), C.byref(ne), _p(epts, Point)), "malio_undistort_resident")
         return ent[:ne.value].copy(), epts[:ne.value].copy()
 
-    def scan_set_resident(self, leaf, pose_tables, temporal_comp, normal_mode=1, want_body=True, cap=None):
-        """malio_scan_set_resident: voxel filter + scan upload from the resident clouds. Returns feats_down_body."""
+    def scan_set_resident(self, leaf, pose_tables, temporal_comp, normal_mode=1, want_body=True, cap=None, out=None):
+        """malio_scan_set_resident: voxel filter + scan upload from the resident clouds. Returns feats_down_body
+        (a view of `out` when the caller supplies the buffer, e.g. a PinnedArray's array)."""
         L = self.L
         arrs = [np.ascontiguousarray(t, np.float64).reshape(-1, 59) for t in pose_tables]
         ptrs = (C.POINTER(Pose) * L)(*[a.ctypes.data_as(C.POINTER(Pose)) for a in arrs])
         lens = (C.c_int * L)(*[a.shape[0] for a in arrs])
         tc = np.ascontiguousarray(temporal_comp, np.float64).reshape(-1, 59) if L > 1 else None
         cap = int(cap if cap is not None else sum(getattr(self, "_res_n", {}).values()))
-        out = np.zeros((cap if want_body else 1, 12), np.float32)
+        own = out is None
+        if own:
+            out = np.zeros((cap if want_body else 1, 12), np.float32)
+        else:
+            assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape[1] == 12
+            cap = min(cap, out.shape[0])
         n = C.c_int(0)
         self._chk(lib().malio_scan_set_resident(self.h, C.c_float(leaf), int(normal_mode), ptrs, lens,
                                                 tc.ctypes.data_as(C.POINTER(Pose)) if tc is not None else None,
@@ -401,7 +407,9 @@ class Engine:
                                                 C.byref(n)), "malio_scan_set_resident")
         self.N = n.value
         self._res_n = {}
-        return out[:n.value].copy() if want_body else None
+        if not want_body:
+            return None
+        return out[:n.value].copy() if own else out[:n.value]
 
     # ---- multi-GPU staging (device pointers are plain ints, e.g. torch.Tensor.data_ptr()) ----
     def sums_len(self):
@@ -444,6 +452,28 @@ def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh
     if rc != OK:
         raise MalioError(f"malio_ieskf_step rc={rc}")
     return state_to_flat(x, L), t_io.value, bool(conv.value), bool(done.value), P_out
+
+
+class PinnedArray:
+    """NumPy view of a page-locked host buffer (malio_host_alloc); keep the object alive while the view is used."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = C.c_void_p()
+        rc = lib().malio_host_alloc(C.c_size_t(max(nbytes, 1)), C.byref(self.ptr))
+        if rc != OK:
+            raise MalioError(f"malio_host_alloc rc={rc}")
+        buf = (C.c_char * max(nbytes, 1)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().malio_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 def predict(L, x_flat, P, dt, Q, acc, gyro):

@@ -366,13 +366,13 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
   MALIO_HIP(hipSetDevice(c->device));
   if (int rct = scan_tables(c, pose_unc, pose_unc_len, temporal_comp)) return rct;
-  // Group by LiDAR slot (stable) and pack to 24 B in ONE pass over the caller's cloud: slot l fills its own region of
-  // the pinned staging buffer, the regions are copied back to back into HBM, nothing waits for the copies here.
+  // ONE pass over the caller's cloud: pack to 20 B in the caller's order into pinned memory, count the points of each
+  // LiDAR slot; one copy into HBM that nothing here waits for. The scan sort groups the slots (its key leads with it).
   c->N = n;
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
   UploadRec *stage = nullptr;
-  if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n * (size_t)L, (void **)&stage)) return rcs;
+  if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n, (void **)&stage)) return rcs;
   int cnt[MALIO_MAX_LIDAR] = {0};
   for (int i = 0; i < n; i++) {
     const int lid = (int)body[i].intensity;  // laserMapping.cpp:570
@@ -383,18 +383,15 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     int idx = (int)body[i].normal_x;  // int(laser_p.normal_x), laserMapping.cpp:694,737
     if (idx > 0x3FFFFF) idx = 0x3FFFFF;
     if (idx < -0x3FFFFF) idx = -0x3FFFFF;
-    UploadRec &r = stage[(size_t)lid * n + cnt[lid]++];
+    cnt[lid]++;
+    UploadRec &r = stage[i];
     r.x = body[i].x, r.y = body[i].y, r.z = body[i].z;
     r.w = ((unsigned)idx << 8) | (unsigned)lid;
-    r.part = (u32)i;
     r.ny = body[i].normal_y;
   }
   c->seg_start[0] = 0;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? cnt[l] : 0);
-  for (int l = 0; l < L; l++)
-    if (cnt[l] > 0)
-      MALIO_HIP(hipMemcpyAsync(c->d_upload + c->seg_start[l], stage + (size_t)l * n, sizeof(UploadRec) * (size_t)cnt[l],
-                               hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemcpyAsync(c->d_upload, stage, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   c->stage_pending = true;
   return scan_reset(c);
 }
@@ -414,7 +411,6 @@ __global__ void __launch_bounds__(BLK) k_pack_resident(const float *__restrict__
   UploadRec r;
   r.x = p[0], r.y = p[1], r.z = p[2];
   r.w = ((unsigned)idx << 8) | (unsigned)lid;
-  r.part = (u32)(dst0 + i);  // already grouped by LiDAR: scan index = upload position
   r.ny = p[5];
   upload[dst0 + i] = r;
   if (body12) {
@@ -643,6 +639,16 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
     return MALIO_ERR_BAD_ARG;
   return ieskf_step(lid_num, max_iteration, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
                     converge_out, done_out, P_out);
+}
+
+int malio_host_alloc(size_t bytes, void **out) {
+  if (!out || bytes == 0) return MALIO_ERR_BAD_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? MALIO_OK : MALIO_ERR_ALLOC;
+}
+int malio_host_free(void *p) {
+  if (!p) return MALIO_OK;
+  return hipHostFree(p) == hipSuccess ? MALIO_OK : MALIO_ERR_HIP;
 }
 
 int malio_predict(int lid_num, malio_state_t *x, double *P, double dt, const double *Q, const double *acc,

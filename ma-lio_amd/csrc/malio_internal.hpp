@@ -164,13 +164,12 @@ struct ArenaScope {  // allocations made through a scope die with it
   }
 };
 
-// One scan point as it crosses PCIe (24 B instead of the 48 B of pcl::PointXYZINormal): body-frame xyz, the packed
-// (LiDAR slot | int(normal_x) << 8) word of laserMapping.cpp:570,694,737, its index in the caller's cloud and the
-// input normal_y (returned untouched where the reference does not write it).
+// One scan point as it crosses PCIe (20 B instead of the 48 B of pcl::PointXYZINormal), in the caller's order:
+// body-frame xyz, the packed (LiDAR slot | int(normal_x) << 8) word of laserMapping.cpp:570,694,737 and the input
+// normal_y (returned untouched where the reference does not write it). Grouping by LiDAR is left to the scan sort.
 struct UploadRec {
   float x, y, z;
   u32 w;
-  u32 part;
   float ny;
 };
 
@@ -211,7 +210,7 @@ struct Ctx {
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
   bool scan_sorted = false;
-  UploadRec *d_upload = nullptr;  // [N] scan as uploaded, grouped by LiDAR (see UploadRec)
+  UploadRec *d_upload = nullptr;  // [N] scan as uploaded, caller's order (see UploadRec)
   float4 *d_scan = nullptr;     // [N] sorted
   u32 *d_perm = nullptr;        // [N] sorted -> original index
   int last_M = -1;
@@ -324,6 +323,19 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
 int sums_len(const Ctx *c);
 int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*original map index*/, float *d_d2, int *d_cnt);
+
+// Small results the host needs (counts, a few points) come back through one pinned buffer: a copy into pinned memory
+// is queued like a kernel (into pageable memory it is staged and blocks), so several of them cost one stream
+// synchronisation. 64 KB; words [0, 64) are used by the map code, the rest by whoever needs a bigger read-back.
+constexpr size_t MBOX_WORDS = 16384;
+inline hipError_t mbox(Ctx *c, u32 **out) {
+  if (!c->h_mbox) {
+    hipError_t e = hipHostMalloc((void **)&c->h_mbox, sizeof(u32) * MBOX_WORDS, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+  }
+  *out = c->h_mbox;
+  return hipSuccess;
+}
 
 // host/predict.cpp
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);

@@ -299,17 +299,6 @@ static int map_reserve(Ctx *c, size_t extra) {
   return MALIO_OK;
 }
 
-// Counts the host needs come back through a small pinned buffer: a copy into pinned memory is queued like a kernel
-// (into pageable memory it is staged and blocks), so several of them cost one stream synchronisation.
-static hipError_t mbox(Ctx *c, u32 **out) {
-  if (!c->h_mbox) {
-    hipError_t e = hipHostMalloc((void **)&c->h_mbox, sizeof(u32) * 64, hipHostMallocDefault);
-    if (e != hipSuccess) return e;
-  }
-  *out = c->h_mbox;
-  return hipSuccess;
-}
-
 // Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
 //   dlist[ndel]     -> these slots die (x = +inf), their 27 entries per level become tombstones
 //   keep[m] != 0    -> d_new[i] is appended as slot map_n + rank[i] and inserted into 27 lists per level

@@ -1314,9 +1314,9 @@ int measure_alloc(Ctx *c) {
 // Sort key of a scan point: (LiDAR slot, level-1 cell of its world position under the first pass' state). Float is
 // enough for the position (ordering only). The cell coordinates enter modulo 1024 (1152 m at the default edge, more
 // than twice any det_range the reference ships): a scan wider than that would merely interleave two far-apart cells,
-// which costs locality, not correctness. One 32-bit key for the whole scan - the slot in the top bits keeps the LiDAR
-// segments contiguous and in order - so ONE stable radix sort of 4 digit passes groups all segments at once; ties keep
-// the upload order.
+// which costs locality, not correctness. One 32-bit key for the whole scan - the slot in the top bits makes the LiDAR
+// segments contiguous and ordered, whatever the upload order - so ONE stable radix sort of 4 digit passes does all
+// the grouping; ties keep the upload order.
 __global__ void __launch_bounds__(BLK) k_scan_keys(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
                                                    u32 *keys, u32 *vals) {
   int i = blockIdx.x * BLK + threadIdx.x;
@@ -1337,9 +1337,10 @@ __global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict
                                                      unsigned char *nfound, u32 *nbr, float *pd2, float4 *plane) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  const UploadRec r = in[src[i]];
+  const u32 s = src[i];  // index in the caller's cloud
+  const UploadRec r = in[s];
   out_scan[i] = make_float4(r.x, r.y, r.z, __uint_as_float(r.w));
-  out_perm[i] = r.part;
+  out_perm[i] = s;
   out_ny[i] = r.ny;
   sel[i] = 0, nfound[i] = 0;
 #pragma unroll

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(BLK) k_und_rev(const int *__restrict__ D, int 
 }
 __global__ void __launch_bounds__(BLK) k_und_final(const float *__restrict__ in12, const float4 *__restrict__ und,
                                                    const int *__restrict__ brev, int n, float *out12, int *entry, int entry_cap,
-                                                   int *n_entries) {
+                                                   int *n_entries, float *entry_pts) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   float v[12];
@@ -209,10 +209,16 @@ __global__ void __launch_bounds__(BLK) k_und_final(const float *__restrict__ in1
   if (i >= 1) {
     const int A = min(n, brev[n - 1 - i]) - i;
     const int An = (i + 1 < n) ? min(n, brev[n - 2 - i]) - (i + 1) : 0;
-    if (A > An && A - 1 < entry_cap) entry[A - 1] = i;
     if (i == 1) *n_entries = A;
     const float4 u = und[i];
     if (u.w != 0.f) v[0] = u.x, v[1] = u.y, v[2] = u.z, v[8] = (float)(A - 1);
+    if (A > An && A - 1 < entry_cap) {  // this point opens uncertainty entry A - 1
+      entry[A - 1] = i;
+      if (entry_pts) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) entry_pts[(size_t)(A - 1) * 12 + k] = v[k];
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 12; k++) out12[(size_t)i * 12 + k] = v[k];
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(BLK) k_und_final(const float *__restrict__ in1
 int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, const double *knot_times,
                    const double *knot_poses, int n_knots, const double ext_q[4], const double ext_t[3],
                    const double end_q[4], const double end_t[3], const double *imu_stamps, int n_imu, int cov_pointer0,
-                   float *d_out12, int *out_entry_point, int *out_n_entries) {
+                   float *d_out12, int *out_entry_point, int *out_n_entries, malio_point_t *out_entry_pts) {
   // per-scan tables: rows of the control poses and the per-interval log twists
   std::vector<double> T12((size_t)n_knots * 12), logs((size_t)(n_knots - 1) * 6);
   for (int k = 0; k < n_knots; k++)
@@ -243,6 +249,8 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   MALIO_HIP(sc.get(&d_brev, (size_t)n));
   MALIO_HIP(sc.get(&d_entry, (size_t)entry_cap));
   MALIO_HIP(sc.get(&d_ne, 1));
+  float *d_entry_pts = nullptr;  // the undistorted points that open the entries, for a caller that keeps the cloud in HBM
+  if (out_entry_pts) MALIO_HIP(sc.get(&d_entry_pts, (size_t)entry_cap * 12));
   MALIO_HIP(sc.get(&d_tab, ntab));
   std::vector<double> tab;
   tab.insert(tab.end(), knot_times, knot_times + n_knots);
@@ -267,17 +275,28 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   MALIO_HIP(sc.get(&d_tmp, tmp_bytes ? tmp_bytes : 16));
   MALIO_HIP(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_rev, d_brev, hipcub::Min(), n, c->stream));
   hipLaunchKernelGGL(k_und_final, dim3(nb), dim3(BLK), 0, c->stream, d_in12, d_und, d_brev, n, d_out12, d_entry,
-                     entry_cap, d_ne);
-  int ne = 0;
-  std::vector<int> ent(entry_cap);
-  MALIO_HIP(hipMemcpyAsync(&ne, d_ne, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(ent.data(), d_entry, sizeof(int) * entry_cap, hipMemcpyDeviceToHost, c->stream));
+                     entry_cap, d_ne, d_entry_pts);
+  // read-backs through the pinned buffer: [64] count, [65 ..) entry indices, then the entry points
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  if (65 + (size_t)entry_cap * 13 > MBOX_WORDS) {
+    c->err = "malio_undistort: too many IMU stamps for one scan";
+    return MALIO_ERR_BAD_ARG;
+  }
+  int *h_ne = (int *)(mb + 64), *h_ent = (int *)(mb + 65);
+  float *h_pts = (float *)(mb + 65 + entry_cap);
+  MALIO_HIP(hipMemcpyAsync(h_ne, d_ne, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(h_ent, d_entry, sizeof(int) * entry_cap, hipMemcpyDeviceToHost, c->stream));
+  if (out_entry_pts)
+    MALIO_HIP(hipMemcpyAsync(h_pts, d_entry_pts, sizeof(float) * 12 * entry_cap, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   prof_end(c);
   MALIO_HIP(hipGetLastError());
+  int ne = *h_ne;
   if (ne > entry_cap) ne = entry_cap;
   if (out_entry_point)
-    for (int k = 0; k < ne; k++) out_entry_point[k] = ent[k];
+    for (int k = 0; k < ne; k++) out_entry_point[k] = h_ent[k];
+  if (out_entry_pts) memcpy(out_entry_pts, h_pts, sizeof(malio_point_t) * (size_t)ne);
   if (out_n_entries) *out_n_entries = ne;
   return MALIO_OK;
 }
@@ -302,7 +321,7 @@ extern "C" int malio_undistort(malio_handle_t h, malio_point_t *pts, int n, doub
   MALIO_HIP(sc.get(&d_out, (size_t)n * 12));
   MALIO_HIP(hipMemcpyAsync(d_in, pts, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
   int rc = undistort_core(c, d_in, n, lidar_beg_time, knot_times, knot_poses, n_knots, ext_q, ext_t, end_q, end_t, imu_stamps,
-                          n_imu, cov_pointer0, d_out, out_entry_point, out_n_entries);
+                          n_imu, cov_pointer0, d_out, out_entry_point, out_n_entries, nullptr);
   if (rc != MALIO_OK) return rc;
   // x, y, z and intensity are rewritten in place like :501-504 (the other fields come back unchanged)
   MALIO_HIP(hipMemcpyAsync(pts, d_out, sizeof(float) * 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -336,14 +355,11 @@ extern "C" int malio_undistort_resident(malio_handle_t h, int lid, const malio_p
   int ne = 0;
   std::vector<int> ent((size_t)n_imu + 4);
   int rc = undistort_core(c, d_in, n, lidar_beg_time, knot_times, knot_poses, n_knots, ext_q, ext_t, end_q, end_t, imu_stamps,
-                          n_imu, cov_pointer0, rcld.d, ent.data(), &ne);
+                          n_imu, cov_pointer0, rcld.d, ent.data(), &ne, out_entry_pts);  // points: :484-494 needs their pose/time
   if (rc != MALIO_OK) return rc;
   rcld.n = n;
   if (out_entry_point)
     for (int k = 0; k < ne; k++) out_entry_point[k] = ent[k];
   if (out_n_entries) *out_n_entries = ne;
-  if (out_entry_pts)  // the undistorted points that open the uncertainty entries (:484-494 needs their pose/time)
-    for (int k = 0; k < ne; k++)
-      MALIO_HIP(hipMemcpy(&out_entry_pts[k], rcld.d + (size_t)ent[k] * 12, sizeof(malio_point_t), hipMemcpyDeviceToHost));
   return MALIO_OK;
 }

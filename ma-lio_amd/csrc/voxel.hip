@@ -133,6 +133,9 @@ __global__ void __launch_bounds__(BLK) k_vg_centroid(const float *__restrict__ p
   q[8] = si / fn, q[9] = sc / fn, q[10] = 0.f, q[11] = 0.f;
 }
 
+// extrema slots: [3 min | 3 max] as order-preserving u32
+__global__ void k_vg_init(u32 *mm) { mm[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xFFFFFFFFu : 0u; }
+
 }  // namespace
 
 // Device core. d_pts: [n][12] in HBM. On return *d_out (arena memory of the CALLER's scope: `sc`) holds *out_n points,
@@ -145,13 +148,14 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
       *first = nullptr, *tiles = nullptr;
   char *tmp = nullptr;
   MALIO_HIP(sc.get(&d_mm, (size_t)VG_SLOTS * 6));
-  u32 mms[VG_SLOTS * 6];
-  for (int s = 0; s < VG_SLOTS; s++)
-    for (int a = 0; a < 3; a++) mms[s * 6 + a] = 0xFFFFFFFFu, mms[s * 6 + 3 + a] = 0u;
-  MALIO_HIP(hipMemcpyAsync(d_mm, mms, sizeof(mms), hipMemcpyHostToDevice, c->stream));
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  u32 *mms = mb + 1024;  // pinned: [VG_SLOTS][3 min | 3 max]
+  static_assert(1024 + VG_SLOTS * 6 + 1 <= MBOX_WORDS, "mailbox too small");
+  hipLaunchKernelGGL(k_vg_init, dim3(1), dim3(VG_SLOTS * 6), 0, c->stream, d_mm);
   const int nb = (n + BLK - 1) / BLK;
   hipLaunchKernelGGL(k_vg_bounds, dim3(nb), dim3(BLK), 0, c->stream, d_pts, n, d_mm);
-  MALIO_HIP(hipMemcpyAsync(mms, d_mm, sizeof(mms), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(mms, d_mm, sizeof(u32) * VG_SLOTS * 6, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   u32 mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
   for (int s = 0; s < VG_SLOTS; s++)
@@ -196,10 +200,11 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
   MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
   hipLaunchKernelGGL(k_vg_heads, dim3((n + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, k2, n, head);
   exclusive_scan_u32(c, head, pos, tiles, n + 1);
-  u32 nvox = 0;
-  MALIO_HIP(hipMemcpyAsync(&nvox, pos + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  u32 *h_nvox = mb + 1024 + VG_SLOTS * 6;
+  MALIO_HIP(hipMemcpyAsync(h_nvox, pos + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   hipLaunchKernelGGL(k_vg_first, dim3(nb), dim3(BLK), 0, c->stream, head, pos, n, first);
   MALIO_HIP(hipStreamSynchronize(c->stream));
+  const u32 nvox = *h_nvox;
   *out_n = (int)nvox;
   if (nvox == 0) return MALIO_OK;
   MALIO_HIP(sc.get(d_out, (size_t)nvox * 12));

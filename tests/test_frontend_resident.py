@@ -77,3 +77,25 @@ def test_resident_front_end_equals_host_chain(capi, scenes, L):
     # the resident clouds were consumed
     with pytest.raises(RuntimeError):
         res.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    # same chain with the caller's clouds in page-locked memory (malio_host_alloc): same bytes, fewer stalls
+    pins = [capi.PinnedArray(r.shape, np.float32) for r in raws]
+    pout = capi.PinnedArray((sum(r.shape[0] for r in raws), 12), np.float32)
+    for l in range(L):
+        pins[l].array[:] = raws[l]
+        ent, _ = res.undistort_resident(l, pins[l].array, beg, kt, kT, st["offR"][l], st["offT"][l], q_end, p_end, imu_t, cp)
+        np.testing.assert_array_equal(ent, ents_h[l])
+    body_p = res.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"], out=pout.array)
+    np.testing.assert_array_equal(body_p, body_h)
+
+
+@pytest.mark.gpu
+def test_host_alloc_errors(capi):
+    import ctypes as C
+    lib = capi.lib()
+    p = C.c_void_p()
+    assert lib.malio_host_alloc(C.c_size_t(0), C.byref(p)) == capi.ERR_BAD_ARG
+    assert lib.malio_host_alloc(C.c_size_t(16), None) == capi.ERR_BAD_ARG
+    assert lib.malio_host_free(None) == capi.OK
+    a = capi.PinnedArray((1000, 12), np.float32)
+    a.array[:] = 1.5
+    assert float(a.array.sum()) == 1.5 * 12000
