@@ -63,11 +63,16 @@ CASES = [
     dict(seed=208, N=100, Nmap=3000, L=2),                                   # less than one workgroup
     dict(seed=209, N=2000, Nmap=30000, L=3, prior_dpos=1.5, prior_drot_deg=4.0),  # poor prior: many rejected points
     dict(seed=210, N=2400, Nmap=30000, L=4),                                 # MALIO_MAX_LIDAR LiDARs (C = 30, n = 41)
+    # a scan longer than the 1152 m period of the sort key's cell coordinates (two far cells share a key: only locality)
+    # (700 m lever arms: P is compared against the reference algorithm's own sensitivity to summation order)
+    dict(seed=211, N=3000, Nmap=180000, L=3, kind="tunnel", det_range=800.0, yardstick=True),
 ]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: "s%d" % k["seed"])
 def test_pass_and_update_parity(capi, orc, scenes, kw):
+    kw = dict(kw)
+    yardstick = kw.pop("yardstick", False)
     sc = scenes.make_scene(**kw)
     eng, o = make_pair(capi, orc, sc)
     compare_pass(eng, o, sc["state0"], True)
@@ -80,6 +85,15 @@ def test_pass_and_update_parity(capi, orc, scenes, kw):
     o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
     assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    if yardstick:  # the oracle on the same points in another order (see test_full_size_configs)
+        perm = np.random.default_rng(9).permutation(sc["N"])
+        o.scan_set(sc["scan"][perm], sc["tables"], sc["temporal_comp"])
+        w = o.update_iterated(sc["state0"], sc["P0"])
+        dg = np.sqrt(np.abs(np.diag(v["P"])))
+        floor_P = (np.abs(w["P"] - v["P"]) / (np.outer(dg, dg) + 1e-300)).max()
+        assert np.abs(u["state"] - v["state"]).max() < max(1e-8, 10 * np.abs(w["state"] - v["state"]).max())
+        assert_P_close(u["P"], v["P"], rel=max(2e-3, 10 * floor_P))
+        return
     assert np.abs(u["state"] - v["state"]).max() < 1e-8
     assert_P_close(u["P"], v["P"])
     # side effects after the update (what map_incremental consumes)
