@@ -27,8 +27,21 @@ __device__ long long g_phase[4][16];
   do {                                                                                 \
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_phase[kid][k] = wall_clock64(); \
   } while (0)
+// grid-wide spread of one kernel: entry and exit time of every workgroup (plain stores: same-address atomics from
+// 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
+__device__ long long g_span[2][8192];
+#define PH_ENTER()                                                                    \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[0][blockIdx.x] = wall_clock64(); \
+  } while (0)
+#define PH_EXIT()                                                                     \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[1][blockIdx.x] = wall_clock64(); \
+  } while (0)
 #else
 #define PH(kid, k)
+#define PH_ENTER()
+#define PH_EXIT()
 #endif
 
 struct D3 {
@@ -121,23 +134,23 @@ __device__ __forceinline__ u32 hash_key_d(u64 k) {  // must equal hash_key() in 
 struct Top5 {
   // (d2 bits << 32 | map index): squared distances are >= +0, so their float bits order like the values and ONE
   // 64-bit compare implements the total order (d2, map index). The candidate loop is VALU-issue bound (6 waves per
-  // SIMD share one pipe), and this form needs ~25 instructions per candidate where separate (d2, index) compares
-  // and selects needed ~120.
+  // SIMD share one pipe): separate (d2, index) compares and selects needed ~120 instructions per candidate, a
+  // compare-exchange chain on packed keys ~45 with two branches, the branch-free form below 36.
   u64 k[5];
   __device__ __forceinline__ float d(int i) const { return __uint_as_float((u32)(k[i] >> 32)); }
   __device__ __forceinline__ u32 og(int i) const { return (u32)k[i]; }
 };
 __device__ __forceinline__ u64 top5_key(float d2, u32 og) { return ((u64)__float_as_uint(d2) << 32) | (u64)og; }
 __device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
-  if (!(key < t.k[4])) return;
-  t.k[4] = key;
-#pragma unroll
-  for (int k = 4; k > 0; k--) {
-    const u64 a = t.k[k - 1], b = t.k[k];
-    const bool sw = b < a;
-    t.k[k - 1] = sw ? b : a;
-    t.k[k] = sw ? a : b;
-  }
+  // The list is sorted, so the five comparisons against the key are independent of each other (no compare-exchange
+  // chain) and every slot is a two-way select on them: slot k takes its left neighbour when the key sorts before
+  // that neighbour, the key when it sorts before slot k only, and keeps its value otherwise.
+  const bool c0 = key < t.k[0], c1 = key < t.k[1], c2 = key < t.k[2], c3 = key < t.k[3], c4 = key < t.k[4];
+  t.k[4] = c3 ? t.k[3] : (c4 ? key : t.k[4]);
+  t.k[3] = c2 ? t.k[2] : (c3 ? key : t.k[3]);
+  t.k[2] = c1 ? t.k[1] : (c2 ? key : t.k[2]);
+  t.k[1] = c0 ? t.k[0] : (c1 ? key : t.k[1]);
+  t.k[0] = c0 ? key : t.k[0];
 }
 
 // One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
@@ -507,7 +520,10 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
     for (int u = 0; u < 8; u++) {
       float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-      if (j + (u32)(u * G) < count && !(d2 > limit2)) top5_insert(t, top5_key(d2, __float_as_uint(m[u].w)));
+      // d2 <= limit2 <=> key < sentinel key, which the list is padded with: no separate range test. A slot past the
+      // end of the list (its load was clamped to the last entry) gets the largest key and sorts after everything.
+      const u64 key = top5_key(d2, __float_as_uint(m[u].w));
+      top5_insert(t, j + (u32)(u * G) < count ? key : ~0ull);
     }
   }
   if (G > 1) merge_group<G>(t, sentinel);
@@ -593,7 +609,10 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, const flo
 constexpr int SQ = 64;             // queries per workgroup: one per lane of wave 0 in phases A and C
 constexpr int KS_BLK = SQ * NL1_G;  // workgroup size of k_search
 constexpr int KS_WAVES = KS_BLK / 64;
-__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(6, 6))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
+#ifndef KS_WPE
+#define KS_WPE 7
+#endif
+__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ float4 s_w[SQ];
   __shared__ u32 s_og[5][SQ];
   __shared__ unsigned char s_nf[SQ];
@@ -603,6 +622,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(6, 
   const int i = q0 + (int)threadIdx.x;  // meaningful for wave 0 only
   const bool mine = threadIdx.x < SQ && i < a.N;
   PH(0, 0);
+  PH_ENTER();
   if (threadIdx.x < SQ) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
@@ -700,6 +720,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(6, 
     }
   }
   PH(0, 9);
+  PH_EXIT();
 }
 
 // Deferred level-2 work of k_search: 16 lanes per query on the level-2 list, then the first lane of each group runs
@@ -977,6 +998,11 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
 #ifdef MALIO_PHASE_CLOCK
 extern "C" int malio_debug_phase(long long *out64) {
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
+}
+extern "C" int malio_debug_span(long long *out, int n) {  // [2][n]: entry, exit of workgroups 0..n-1
+  if (n > 8192) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * n, 0) != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out + n, HIP_SYMBOL(g_span), sizeof(long long) * n, sizeof(long long) * 8192) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -9,6 +9,7 @@ sc = scenes.make_scene(cfg=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
 e = capi.Engine(sc["params"]); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
 for _ in range(20):
     e.measure(sc["state0"], True)
+e.measure(sc["state0"], True)
 out = (C.c_longlong * 64)()
 assert capi.lib().malio_debug_phase(out) == 0
 ph = np.array(out[:]).reshape(4, 16)
@@ -20,3 +21,17 @@ for k, nm in names.items():
     for j in range(1, len(nm)):
         print("   %-40s %6.2f us" % (nm[j], (t[j] - t[j - 1]) / 100.0))
     print("   %-40s %6.2f us" % ("total", (t[len(nm) - 1] - t[0]) / 100.0))
+
+nb = (sc["N"] + 63) // 64
+sp = (C.c_longlong * (2 * nb))()
+assert capi.lib().malio_debug_span(sp, nb) == 0
+sp = np.array(sp[:], np.int64).reshape(2, nb)
+t0 = sp[0].min()
+ent, ex = (sp[0] - t0) / 100.0, (sp[1] - t0) / 100.0
+print("k_search grid: %d workgroups; entry: median %.2f, 90%% %.2f, last %.2f us; exit: first %.2f, median %.2f, 90%% %.2f, last %.2f us; "
+      "residence: median %.2f, max %.2f us" % (nb, np.median(ent), np.percentile(ent, 90), ent.max(), ex.min(), np.median(ex),
+                                              np.percentile(ex, 90), ex.max(), np.median(ex - ent), (ex - ent).max()))
+late = np.argsort(ent)[-8:]
+print("   last to enter:", [(int(b), round(float(ent[b]), 2), round(float(ex[b]), 2)) for b in late])
+slow = np.argsort(ex)[-8:]
+print("   last to exit :", [(int(b), round(float(ent[b]), 2), round(float(ex[b]), 2)) for b in slow])
