@@ -29,10 +29,14 @@ __device__ long long g_phase[4][16];
   } while (0)
 // grid-wide spread of one kernel: entry and exit time of every workgroup (plain stores: same-address atomics from
 // 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
-__device__ long long g_span[2][8192];
+__device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pending level-2 queries
 #define PH_ENTER()                                                                    \
   do {                                                                                \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[0][blockIdx.x] = wall_clock64(); \
+  } while (0)
+#define PH_NOTE(row, val)                                                             \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[row][blockIdx.x] = (val);       \
   } while (0)
 #define PH_EXIT()                                                                     \
   do {                                                                                \
@@ -41,6 +45,7 @@ __device__ long long g_span[2][8192];
 #else
 #define PH(kid, k)
 #define PH_ENTER()
+#define PH_NOTE(row, val)
 #define PH_EXIT()
 #endif
 
@@ -651,6 +656,8 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   }
   __syncthreads();
   PH(0, 2);
+  PH_NOTE(2, wall_clock64());
+  PH_NOTE(3, 0);
   // ---- level 2: the queries level 1 could not certify are served one at a time by a whole wave (64 lanes striding
   // over the ~180..900-point level-2 list); the workgroup's 4 waves share them round-robin, so a workgroup full of
   // unmatched queries (map frontier, thinned map) costs 16 serial searches per wave instead of 64 in wave 0 ----
@@ -660,6 +667,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     unsigned long long todo = __ballot(pend);
     if (todo) {  // workgroup-uniform: every wave reads the same flags
       const int npend = __popcll(todo);
+      PH_NOTE(3, npend);
       const bool heavy = npend > DEFER_MIN;
       if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + a.parity], 1u);  // steers the host's defer switch
       if (heavy && a.defer) {
@@ -999,10 +1007,12 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
 extern "C" int malio_debug_phase(long long *out64) {
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
 }
-extern "C" int malio_debug_span(long long *out, int n) {  // [2][n]: entry, exit of workgroups 0..n-1
+extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_span for workgroups 0..n-1
   if (n > 8192) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * n, 0) != hipSuccess) return -1;
-  return hipMemcpyFromSymbol(out + n, HIP_SYMBOL(g_span), sizeof(long long) * n, sizeof(long long) * 8192) == hipSuccess ? 0 : -1;
+  for (int r = 0; r < 4; r++)
+    if (hipMemcpyFromSymbol(out + (size_t)r * n, HIP_SYMBOL(g_span), sizeof(long long) * n, sizeof(long long) * 8192 * r) != hipSuccess)
+      return -1;
+  return 0;
 }
 #endif
 

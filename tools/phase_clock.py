@@ -23,9 +23,9 @@ for k, nm in names.items():
     print("   %-40s %6.2f us" % ("total", (t[len(nm) - 1] - t[0]) / 100.0))
 
 nb = (sc["N"] + 63) // 64
-sp = (C.c_longlong * (2 * nb))()
+sp = (C.c_longlong * (4 * nb))()
 assert capi.lib().malio_debug_span(sp, nb) == 0
-sp = np.array(sp[:], np.int64).reshape(2, nb)
+sp = np.array(sp[:], np.int64).reshape(4, nb)
 t0 = sp[0].min()
 ent, ex = (sp[0] - t0) / 100.0, (sp[1] - t0) / 100.0
 print("k_search grid: %d workgroups; entry: median %.2f, 90%% %.2f, last %.2f us; exit: first %.2f, median %.2f, 90%% %.2f, last %.2f us; "
@@ -35,3 +35,11 @@ late = np.argsort(ent)[-8:]
 print("   last to enter:", [(int(b), round(float(ent[b]), 2), round(float(ex[b]), 2)) for b in late])
 slow = np.argsort(ex)[-8:]
 print("   last to exit :", [(int(b), round(float(ent[b]), 2), round(float(ex[b]), 2)) for b in slow])
+
+tb, npend = (sp[2] - t0) / 100.0, sp[3]
+print("   end of level-1 search: median %.2f, 90%% %.2f, max %.2f us" % (np.median(tb), np.percentile(tb, 90), tb.max()))
+for lo, hi in ((0, 0), (1, 2), (3, 4), (5, 8), (9, 64)):
+    m = (npend >= lo) & (npend <= hi)
+    if m.any():
+        print("   pending level-2 queries %2d..%2d: %4d workgroups, exit median %.2f max %.2f us, after-search part median %.2f us" % (
+            lo, hi, int(m.sum()), np.median(ex[m]), ex[m].max(), np.median(ex[m] - tb[m])))
