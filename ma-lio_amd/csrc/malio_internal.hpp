@@ -241,7 +241,7 @@ struct Ctx {
   bool last_pass_search = false;
   u64 *d_mmslots = nullptr;  // [2 parities][64 slots][5]: max_u, min_u, max_R, min_R (order-encoded doubles), count
   int mm_parity = 0;
-  double *d_partials = nullptr;  // [nblocks][NSUM]
+  double *d_partials = nullptr;  // [NSUM][cap_partials]
   double *d_sums = nullptr;      // [NSUM_OUT]
   double *h_sums = nullptr;      // pinned
   double *h_res = nullptr, *d_res = nullptr;  // pinned + its device-visible alias: results stored by the kernels

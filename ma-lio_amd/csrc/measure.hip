@@ -835,7 +835,8 @@ struct Pass2Args {
   const u64 *mmslots;  // extrema slots of stage 1 (single-GPU path: folded here by the first wave)
   const u32 *heavy;    // workgroups of the search kernel that were full of uncertified queries (this pass)
   double *mm_out;         // where workgroup 0 publishes the folded extrema + M for the host
-  double *partials;       // [nblocks][NSUM]
+  double *partials;       // [NSUM][pstride]: entry-major, so the final sum reads each entry's partials contiguously
+  int pstride;
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
 };
 
@@ -998,7 +999,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       }
       v = (DW[0][ra][cb] + DW[1][ra][cb]) + (DW[2][ra][cb] + DW[3][ra][cb]);
     }
-    a.partials[(size_t)blockIdx.x * NSUM + e] = v;
+    a.partials[(size_t)e * a.pstride + blockIdx.x] = v;
   }
   PH(1, 5);
 }
@@ -1016,38 +1017,31 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_s
 }
 #endif
 
-// Fixed-order final sum: one workgroup per LiDAR, 8 groups of 128 lanes stride over that LiDAR's
-// workgroups, then the 8 group sums are added in order. out: [L][NSUM].
+// Fixed-order final sum, one wave per (LiDAR, entry): lane l adds that entry's partials l, l + 64, l + 128, ... of the
+// LiDAR's workgroups (contiguous in the entry-major layout: coalesced, all loads independent), then the 64 lane sums
+// are added by a fixed xor-butterfly. 291 waves at three LiDARs instead of three workgroups walking 130 rows each:
+// the kernel is one memory round trip deep. out: [L][NSUM].
 struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
-__global__ void __launch_bounds__(1024) k_final_reduce(const double *__restrict__ partials, SegBlocks sb, double *out) {
-  __shared__ double g[8][128];
-  const int lid = blockIdx.x;
+__global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
+                                                      int L, double *out) {
+  const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (w >= L * NSUM) return;  // wave-uniform
+  const int lid = w / NSUM, e = w - lid * NSUM;
   const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
-  const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+  const double *row = partials + (size_t)e * pstride;
   double acc = 0;
-  if (e < NSUM) {
-    // 8 independent loads in flight per lane; the summation order is fixed (b ascending within a group)
-    for (int b = b0 + grp; b < b1; b += 64) {
-      double v[8];
+  for (int b = b0 + lane; b < b1; b += 64 * 4) {
+    double v[4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        int bb = b + 8 * u;
-        v[u] = bb < b1 ? partials[(size_t)bb * NSUM + e] : 0.0;
-      }
+    for (int u = 0; u < 4; u++) v[u] = (b + 64 * u < b1) ? row[b + 64 * u] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; u++) acc += v[u];
-    }
+    for (int u = 0; u < 4; u++) acc += v[u];
   }
-  g[grp][e] = acc;
-  __syncthreads();
-  if (grp == 0 && e < NSUM) {
-    double s = g[0][e];
 #pragma unroll
-    for (int k = 1; k < 8; k++) s += g[k][e];
-    out[lid * NSUM + e] = s;
-  }
+  for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+  if (lane == 0) out[lid * NSUM + e] = acc;
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
@@ -1325,7 +1319,7 @@ int measure_alloc(Ctx *c) {
   if (nb > c->cap_partials) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     c->cap_partials = nb + nb / 8 + 16;
-    MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));
+    MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));  // [NSUM][cap_partials]
   }
   if (!c->d_dq_ctl) {
     MALIO_HIP(hipMalloc(&c->d_dq_ctl, sizeof(u32) * 4));
@@ -1511,7 +1505,7 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   a.minmax4 = d_minmax4_in;
   a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
   a.heavy = c->d_dq_ctl + 2 + c->dq_parity;
-  a.partials = c->d_partials;
+  a.partials = c->d_partials, a.pstride = (int)c->cap_partials;
   a.rows = nullptr;
   if (want_rows) {
     size_t need = (size_t)c->N * 14;
@@ -1526,7 +1520,8 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   prof_mark(c, "k_rows_reduce");
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
-  hipLaunchKernelGGL(k_final_reduce, dim3(c->prm.lid_num), dim3(1024), 0, c->stream, c->d_partials, sb, d_sums_out);
+  hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out);
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
