@@ -91,7 +91,7 @@ def _cpu_baseline(sc, budget_s):
     }
 
 
-def secondary_figures(eng, sc, scenes, capi):
+def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
     """a13 undistortion (kernel time by HIP events, 32 algorithmic bytes per raw point) and row f-1 map upkeep
     (wall time of map_incremental + the neighbour-list rebuild it triggers) on the bench workload."""
     import torch
@@ -161,7 +161,7 @@ def secondary_figures(eng, sc, scenes, capi):
     loop = {"scan_set_ms": [], "update_ms": [], "map_incremental_ms": []}
     added = 0
     for k in range(4):
-        s2 = scenes.make_scene(cfg=2, scan_seed=500 + k) if sc["N"] == 100_000 and sc["L"] == 3 else sc
+        s2 = scenes.make_scene(cfg=cfg_index, scan_seed=500 + k)  # a new scan of the same scene every turn
         torch.cuda.synchronize()
         t = time.perf_counter()
         eng.scan_set(s2["scan"], sc["tables"], sc["temporal_comp"])
@@ -309,7 +309,7 @@ def main():
     # ---- secondary figures of the other rows of the path (rank 0, single GPU): undistortion kernel and map upkeep ----
     secondary = None
     if rank == 0 and not distributed:
-        secondary = secondary_figures(eng, sc, scenes, capi)
+        secondary = secondary_figures(eng, sc, scenes, capi, args.config)
     if distributed:
         dist.barrier()
 
