@@ -10,8 +10,11 @@ over one fused multi-LiDAR scan that is already resident in HBM, against the res
 
 N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map.
 N > 1 (weak scaling): every rank holds the replicated map and its own 100k-point shard of an
-N x 100k-point scan; a pass exchanges the extrema and the 97 L sums of SURVEY.md §8(e) over RCCL - in one
-all-gather while the previous pass' extrema still hold, else in two collectives (ma-lio_amd/dist.py).
+N x 100k-point scan; a pass exchanges the extrema and the 97 L sums of SURVEY.md §8(e) - 2.4 KB per rank that the
+HOST consumes - in one all-gather while the previous pass' extrema still hold, else in two exchanges
+(ma-lio_amd/dist.py). Between the ranks of one node (this contract) the rows travel through shared memory
+(malio_xchg_*); MALIO_EXCHANGE=collective sends them through the process group (RCCL) instead. Barriers and the
+max-over-ranks timing use the process group.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields). The CPU oracle is used only for
 the `cpu_baseline` leg (rank 0, N = 1), never inside the timed GPU region.
@@ -325,7 +328,8 @@ def main():
             "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
             "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step%s" % (
                 cfg["name"], N, L, sc["Nmap"], "" if not distributed else
-                "; scan sharded %d x %d pts, map replicated, one RCCL all-gather per pass while the extrema of the previous pass still hold (else two collectives)" % (world, N)),
+                "; scan sharded %d x %d pts, map replicated, one all-gather of [sums | extrema] per pass while the extrema of the previous pass still hold (else two exchanges), rows exchanged via %s" % (
+                    world, N, "node shared memory" if getattr(be, "spec_stats", {}).get("exchange") == "shm" else "the process group (%s)" % backend)),
                 "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"] if isinstance(out, dict) else out.M),
                 "seed": sc["seed"]},
             "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,

@@ -310,6 +310,18 @@ int malio_measure_stage2(malio_handle_t h, const double *d_minmax, double *d_sum
 int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out);
 
+/* Exchange of the staged results between the ranks of ONE node through POSIX shared memory: what travels per pass is
+ * [malio_sums_len() sums | MALIO_MINMAX_LEN extrema words] = 2.4 KB that the host needs (malio_measure_finish and
+ * malio_ieskf_step run there), so a GPU collective would only add a device round trip to a latency-bound message.
+ * name: "/..." (shm_open); the rank with create != 0 makes and zeroes the segment BEFORE the others are told the name
+ * (e.g. by the launcher's rendezvous) and unlinks it on destroy. all_gather: every rank passes its row (row_doubles
+ * doubles) and receives all rows in rank order - summing them in that order gives every rank the same bits.
+ * timeout_s > 0 turns a missing rank into an error instead of a hang. Host code, no GPU involved. */
+typedef struct malio_xchg *malio_xchg_t;
+int malio_xchg_create(const char *name, int rank, int world, int row_doubles, int create, malio_xchg_t *out);
+int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, double timeout_s);
+int malio_xchg_destroy(malio_xchg_t x);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded
  * on the handle's stream. names: up to cap pointers to static strings. Returns count via *out_n. */

@@ -22,7 +22,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -452,6 +452,40 @@ def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh
     if rc != OK:
         raise MalioError(f"malio_ieskf_step rc={rc}")
     return state_to_flat(x, L), t_io.value, bool(conv.value), bool(done.value), P_out
+
+
+class NodeExchange:
+    """malio_xchg_*: all-gather of one row of doubles between the ranks of one node through shared memory."""
+
+    def __init__(self, name, rank, world, row_doubles, create, timeout_s=60.0):
+        self.h = C.c_void_p()
+        self.world, self.row, self.timeout = int(world), int(row_doubles), float(timeout_s)
+        rc = lib().malio_xchg_create(name.encode(), int(rank), int(world), int(row_doubles), int(bool(create)), C.byref(self.h))
+        if rc != OK:
+            raise MalioError(f"malio_xchg_create({name}) rc={rc}")
+        self.out = np.zeros((self.world, self.row), np.float64)
+        self._fn = lib().malio_xchg_all_gather
+        self._out_p = _p(self.out, C.c_double)
+        self._to = C.c_double(self.timeout)
+
+    def all_gather(self, row):
+        """row: contiguous float64 array of row_doubles entries. Returns the [world, row] view (overwritten by the
+        next call)."""
+        rc = self._fn(self.h, _p(row, C.c_double), self._out_p, self._to)
+        if rc != OK:
+            raise MalioError(f"malio_xchg_all_gather rc={rc} (a rank is missing?)")
+        return self.out
+
+    def close(self):
+        if self.h:
+            lib().malio_xchg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedArray:

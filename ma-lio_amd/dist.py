@@ -1,5 +1,5 @@
 """Multi-GPU host logic for the measurement update: scan points sharded across ranks,
-map replicated, two tiny collectives per pass - MAX over [max_unit_cov, -min_unit_cov, max_R, -min_R]
+map replicated, two tiny exchanges per pass - MAX over [max_unit_cov, -min_unit_cov, max_R, -min_R]
 between the search/plane stage and the row stage (the FIC weights of laserMapping.cpp:651-656,716-721 are
 scan-global), then SUM over the per-LiDAR 12x12 normal-equation blocks. One process per GPU,
 torch.distributed ("nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
@@ -9,9 +9,33 @@ A `backend` supplies the two local stages:
     stage2(minmax_tensor)   -> torch tensor [L * 97] local sums
 HipBackend drives libmalio_hip through the C ABI; the CPU tests plug in an oracle-backed stand-in.
 """
+import itertools
+import os
+import socket
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+_xchg_ids = itertools.count()
+
+
+def _single_node(group=None):
+    """True when every rank of `group` runs on this host."""
+    names = [None] * dist.get_world_size(group)
+    dist.all_gather_object(names, socket.gethostname(), group=group)
+    return len(set(names)) == 1
+
+
+def exchange_mode(group=None):
+    """How the per-pass rows travel: MALIO_EXCHANGE = shm | collective | auto (default: shared memory when all ranks
+    share a node - the contract of bench.py - else the collective of the process group)."""
+    mode = os.environ.get("MALIO_EXCHANGE", "auto")
+    if mode not in ("shm", "collective", "auto"):
+        raise ValueError("MALIO_EXCHANGE must be shm, collective or auto")
+    if mode == "auto":
+        mode = "shm" if _single_node(group) else "collective"
+    return mode
 
 NSUM = 97  # 78 (12x12 upper) + 12 (rhs) + 6 (c^2 n n^T) + 1 (count), see csrc/measure.hip
 
@@ -74,14 +98,19 @@ class HipBackend:
         """Pre-bound sharded pass for loops that repeat the same (state, converge): no Python-side conversions,
         pinned staging, finish in C (malio_measure_finish). Returns (fn, out_struct); fn() -> rc like malio_measure.
 
-        Collectives per pass. The plain sequence (sharded_measure) needs two dependent ones: MAX of the four
+        Exchanges per pass. The plain sequence (sharded_measure) needs two dependent ones: MAX of the four
         extrema before the rows can be weighted, then SUM of the normal equations. With `speculate`, a pass first
         weights its rows with the extrema of the PREVIOUS pass and sends [local sums | local extrema] in ONE
         all-gather; every rank then forms the true extrema from the gathered rows. If they equal the guess (the
         usual case from the second pass on: the extreme points of a scan rarely change between passes) the sums are
         the ones the reference would form and the pass is done after a single collective; otherwise stage 2 is run
         again with the true extrema and a second all-gather follows - the result is exact either way. The ranks add
-        the gathered rows in rank order, so every rank holds the same bits."""
+        the gathered rows in rank order, so every rank holds the same bits.
+
+        How the rows travel (exchange_mode): between the ranks of one node through shared memory
+        (capi.NodeExchange / malio_xchg_*) - the 2.4 KB are needed on the HOST, where the filter algebra runs, so a
+        device collective would only add a GPU round trip to a latency-bound message; across nodes, or with
+        MALIO_EXCHANGE=collective, through all_gather_into_tensor of the process group (RCCL on the GPU box)."""
         import ctypes as C
         from . import capi
         eng = self.eng
@@ -117,20 +146,49 @@ class HipBackend:
             return fn1, out
 
         W, rank = dist.get_world_size(group), dist.get_rank(group)
-        gathered = torch.zeros(W * row, dtype=torch.float64, device="cuda")
-        ghost = torch.zeros(W, row, dtype=torch.float64).pin_memory()
-        g = ghost.numpy()
+        mode = exchange_mode(group)
         mmg = torch.zeros(8, dtype=torch.float64, device="cuda")               # the extrema stage 2 is run with
         vp_mmg = C.c_void_p(mmg.data_ptr())
         e_pin = torch.zeros(8, dtype=torch.float64).pin_memory()
         e_np = e_pin.numpy()
-        st = {"guess": None, "hits": 0, "misses": 0}
+        st = {"guess": None, "hits": 0, "misses": 0, "exchange": mode}
         self.spec_stats = st
+        xchg = None
+        if mode == "shm":
+            name = [None]
+            if rank == 0:
+                try:                                                            # no /dev/shm, no space: use the group
+                    nm = "/malio_%d_%d" % (os.getpid(), next(_xchg_ids))
+                    xchg = capi.NodeExchange(nm, 0, W, row, create=True)
+                    name[0] = nm
+                except capi.MalioError:
+                    name[0] = None
+            dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if name[0] is None:
+                mode = st["exchange"] = "collective"
+            elif rank != 0:                                                     # created and zeroed before the name left
+                xchg = capi.NodeExchange(name[0], rank, W, row, create=False)
+            dist.barrier(group)
+        if mode == "shm":
+            gathered = ghost = None
+
+            def all_rows():
+                host.copy_(buf, non_blocking=True)
+                stream.synchronize()
+                return xchg.all_gather(hostn)
+        else:
+            gathered = torch.zeros(W * row, dtype=torch.float64, device="cuda")
+            ghost = torch.zeros(W, row, dtype=torch.float64).pin_memory()
+            g_np = ghost.numpy()
+
+            def all_rows():
+                dist.all_gather_into_tensor(gathered, buf, group=group)
+                ghost.copy_(gathered.view(W, row), non_blocking=True)
+                stream.synchronize()
+                return g_np
 
         def gather_and_finish(E):
-            dist.all_gather_into_tensor(gathered, buf, group=group)
-            ghost.copy_(gathered.view(W, row), non_blocking=True)
-            stream.synchronize()
+            g = all_rows()
             if E is None:
                 E = g[:, ns:ns + 4].max(axis=0)
                 if st["guess"] is None or not np.array_equal(E, st["guess"]):
@@ -138,9 +196,10 @@ class HipBackend:
             acc = g[0, :ns].copy()
             for r in range(1, W):                                               # rank order: same bits everywhere
                 acc += g[r, :ns]
+            own = g[rank, ns + 4:].copy()
             hostn[:ns] = acc
             hostn[ns:ns + 4] = E
-            hostn[ns + 4:] = g[rank, ns + 4:]
+            hostn[ns + 4:] = own
             return f3(h, hp_sums, hp_mm, op), E
 
         def stage2_with(E):
@@ -161,6 +220,8 @@ class HipBackend:
                     st["hits"] += 1
                     return rc
                 st["misses"] += 1
+            elif mode == "shm":
+                E = all_rows()[:, ns:ns + 4].max(axis=0)                        # only the extrema words are valid yet
             else:
                 dist.all_reduce(mm4, op=dist.ReduceOp.MAX, group=group)
                 e_pin[:4].copy_(mm4, non_blocking=True)
@@ -172,7 +233,7 @@ class HipBackend:
                 return rc
             rc, _ = gather_and_finish(E)
             return rc
-        fn._keep = (s, out, buf, host, gathered, ghost, mmg, e_pin)
+        fn._keep = (s, out, buf, host, gathered, ghost, mmg, e_pin, xchg)
         return fn, out
 
 

@@ -416,9 +416,11 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
 
 
 @pytest.mark.gpu
-def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes):
-    """dist.HipBackend.pass_fn with two ranks (gloo, sharing the GPU): plain two-collective sequence and the
-    speculative single all-gather give the same bits on both ranks, and match ONE engine fed the whole scan."""
+@pytest.mark.parametrize("exchange", ["shm", "collective"])
+def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes, exchange):
+    """dist.HipBackend.pass_fn with two ranks (gloo, sharing the GPU): plain two-exchange sequence and the
+    speculative single all-gather give the same bits on both ranks, and match ONE engine fed the whole scan -
+    with the rows travelling through shared memory (the single-node default) or through the process group."""
     import json
     import os
     import subprocess
@@ -426,14 +428,16 @@ def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outp = str(tmp_path / "res.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29641", os.path.join(root, "tests", "dist_gpu_worker.py"), outp]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+           "127.0.0.1", "--master-port", "29641" if exchange == "shm" else "29643",
+           os.path.join(root, "tests", "dist_gpu_worker.py"), outp]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MALIO_EXCHANGE=exchange)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-3000:]
     r0, r1 = json.load(open(outp))
     assert r0 == r1                                              # every rank holds the same bits
     assert r0["plain"]["H"] == r0["spec"]["H"] and r0["plain"]["h"] == r0["spec"]["h"]
     assert r0["spec"]["stats"]["hits"] >= 3 and r0["spec"]["stats"]["misses"] == 0
+    assert r0["spec"]["stats"]["exchange"] == exchange
     sc = scenes.make_scene(cfg=3)
     eng = capi.Engine(sc["params"])
     eng.map_build(sc["map"])

@@ -1,0 +1,52 @@
+"""Worker of tests/test_node_exchange.py: one rank of a shared-memory exchange (host only, no GPU)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ge.load_package()
+from malio_amd import capi  # noqa: E402
+
+
+def main():
+    name, rank, world, row, epochs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    die_at = int(sys.argv[6]) if len(sys.argv) > 6 else -1
+    if rank != 0:  # the creator must be first: wait for the segment to appear
+        t0 = time.time()
+        while not os.path.exists("/dev/shm" + name):
+            if time.time() - t0 > 30:
+                sys.exit(3)
+            time.sleep(0.005)
+        time.sleep(0.05)
+    x = capi.NodeExchange(name, rank, world, row, create=(rank == 0), timeout_s=3.0)
+    mine = np.zeros(row, np.float64)
+    acc = 0.0
+    for e in range(1, epochs + 1):
+        if e == die_at and rank == world - 1:
+            os._exit(0)  # a rank disappears: the others must get an error, not hang
+        mine[:] = rank * 1000.0 + e + np.arange(row) * 1e-3
+        try:
+            g = x.all_gather(mine)
+        except capi.MalioError:
+            print("TIMEOUT rank %d epoch %d" % (rank, e), flush=True)
+            x.close()
+            sys.exit(0)
+        want = (np.arange(world)[:, None] * 1000.0 + e) + np.arange(row)[None, :] * 1e-3
+        if not np.array_equal(g, want):
+            print("MISMATCH rank %d epoch %d" % (rank, e), flush=True)
+            sys.exit(2)
+        s = g[0].copy()
+        for r in range(1, world):  # rank order: the same bits on every rank
+            s += g[r]
+        acc += float(s.sum())
+    print("OK rank %d acc %r" % (rank, acc), flush=True)
+    x.close()
+
+
+if __name__ == "__main__":
+    main()
