@@ -307,8 +307,20 @@ int malio_eval_point_uncertainty(const malio_point_t *pi, const malio_pose_t *po
 int malio_sums_len(malio_handle_t h);
 int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax);
 int malio_measure_stage2(malio_handle_t h, const double *d_minmax, double *d_sums);
+/* Speculative variant (one exchange per pass): call malio_measure_stage1 with d_minmax = NULL (no fold launch), then
+ * this with the extrema GUESSED from the previous pass in d_minmax_in; it weights the rows with the guess and also
+ * writes this shard's own MALIO_MINMAX_LEN words to d_minmax_out. The caller exchanges [sums | own extrema], forms
+ * the true extrema (MAX over ranks of the first four words) and, if they differ from the guess, repeats this call
+ * (or malio_measure_stage2) with the true values. */
+int malio_measure_stage2_emit(malio_handle_t h, const double *d_minmax_in, double *d_minmax_out, double *d_sums);
 int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out);
+
+/* The handle's result buffer: page-locked host memory that the kernels can write (host pointer, its device alias,
+ * length in doubles >= malio_sums_len() + MALIO_MINMAX_LEN; exists once a scan was set). Passing the device alias as
+ * d_sums / d_minmax to the stage calls makes the results land in host memory without a copy kernel: synchronise the
+ * stream and read *host. malio_measure uses it itself, so do not mix the two styles between a stage 1 and its finish. */
+int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_doubles);
 
 /* Exchange of the staged results between the ranks of ONE node through POSIX shared memory: what travels per pass is
  * [malio_sums_len() sums | MALIO_MINMAX_LEN extrema words] = 2.4 KB that the host needs (malio_measure_finish and

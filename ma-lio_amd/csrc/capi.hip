@@ -472,15 +472,19 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
 int malio_sums_len(malio_handle_t h) { return h ? sums_len(h) : 0; }
 
 int malio_measure_stage1(malio_handle_t h, const malio_state_t *s, int converge, double *d_minmax4) {
-  if (check(h) || !s || !d_minmax4) return MALIO_ERR_BAD_ARG;
+  if (check(h) || !s) return MALIO_ERR_BAD_ARG;
   MALIO_HIP_H(hipSetDevice(h->device));
   prof_begin(h);
-  return pass_stage1(h, s, converge, d_minmax4);
+  return pass_stage1(h, s, converge, d_minmax4);  // NULL: the extrema are emitted by malio_measure_stage2_emit
 }
 int malio_measure_stage2(malio_handle_t h, const double *d_minmax4, double *d_sums) {
   if (check(h) || !d_minmax4 || !d_sums) return MALIO_ERR_BAD_ARG;
   int rc = pass_stage2(h, d_minmax4, nullptr, d_sums, false);
   return rc;
+}
+int malio_measure_stage2_emit(malio_handle_t h, const double *d_minmax4_in, double *d_minmax_out, double *d_sums) {
+  if (check(h) || !d_minmax4_in || !d_minmax_out || !d_sums) return MALIO_ERR_BAD_ARG;
+  return pass_stage2(h, d_minmax4_in, d_minmax_out, d_sums, false);
 }
 int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out) {
@@ -639,6 +643,13 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
     return MALIO_ERR_BAD_ARG;
   return ieskf_step(lid_num, max_iteration, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
                     converge_out, done_out, P_out);
+}
+
+int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_doubles) {
+  if (check(h) || !host || !dev || !len_doubles) return MALIO_ERR_BAD_ARG;
+  if (!h->h_res) return MALIO_ERR_NO_SCAN;
+  *host = h->h_res, *dev = h->d_res, *len_doubles = sums_len(h) + 16;
+  return MALIO_OK;
 }
 
 int malio_host_alloc(size_t bytes, void **out) {

@@ -909,6 +909,17 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   // ---- a4 fold: the first wave of every workgroup folds the 64 extrema slots of stage 1 (2.5 KB from L2) ----
   if (a.minmax4) {
     if (threadIdx.x < 4) mm_s[threadIdx.x] = a.minmax4[threadIdx.x];
+    if (blockIdx.x == 0 && a.mm_out && threadIdx.x < 64) {
+      // staged path with the extrema supplied by the caller (a guess, or all-reduced): this shard's own extrema are
+      // still wanted - the caller verifies its guess against them - and are folded here instead of by a separate launch
+      double o5[5];
+      mm_fold_wave(a.mmslots, a.extrinsic_est_en, o5);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
+        a.mm_out[5] = (double)*a.heavy;
+      }
+    }
   } else if (threadIdx.x < 64) {
     double o5[5];
     mm_fold_wave(a.mmslots, a.extrinsic_est_en, o5);

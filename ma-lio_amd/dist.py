@@ -125,6 +125,7 @@ class HipBackend:
         out = capi.MeasureOut()
         lib = capi.lib()
         f1, f2, f3 = lib.malio_measure_stage1, lib.malio_measure_stage2, lib.malio_measure_finish
+        f2e = lib.malio_measure_stage2_emit
         h, sp, op, cv = eng.h, C.byref(s), C.byref(out), int(bool(converge))
         vp_mm, vp_sums = C.c_void_p(p_mm), C.c_void_p(p_sums)
         hp_sums = C.cast(host.data_ptr(), C.POINTER(C.c_double))
@@ -132,17 +133,11 @@ class HipBackend:
         multi = dist.is_initialized() and dist.get_world_size(group) > 1
         stream = torch.cuda.current_stream()
         if not multi:
+            fm = lib.malio_measure                                              # one rank: nothing to exchange
+
             def fn1():
-                rc = f1(h, sp, cv, vp_mm)
-                if rc < 0:
-                    return rc
-                rc = f2(h, vp_mm, vp_sums)
-                if rc < 0:
-                    return rc
-                host.copy_(buf, non_blocking=True)
-                stream.synchronize()
-                return f3(h, hp_sums, hp_mm, op)
-            fn1._keep = (s, out, buf, host)
+                return fm(h, sp, cv, op)
+            fn1._keep = (s, out)
             return fn1, out
 
         W, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -171,9 +166,14 @@ class HipBackend:
             dist.barrier(group)
         if mode == "shm":
             gathered = ghost = None
+            # the stage kernels store [sums | extrema] straight into the handle's pinned result buffer: no copy kernel
+            rb, rb_dev = eng.result_buffer()
+            hostn = rb[:row]
+            vp_sums, vp_mm = C.c_void_p(rb_dev), C.c_void_p(rb_dev + 8 * ns)
+            hp_sums = C.cast(hostn.ctypes.data, C.POINTER(C.c_double))
+            hp_mm = C.cast(hostn.ctypes.data + 8 * ns, C.POINTER(C.c_double))
 
             def all_rows():
-                host.copy_(buf, non_blocking=True)
                 stream.synchronize()
                 return xchg.all_gather(hostn)
         else:
@@ -202,17 +202,21 @@ class HipBackend:
             hostn[ns + 4:] = own
             return f3(h, hp_sums, hp_mm, op), E
 
-        def stage2_with(E):
+        def stage2_with(E, emit=False):
             e_np[:4] = E
             mmg.copy_(e_pin, non_blocking=True)
+            if emit:                                                            # rows + this shard's own extrema words
+                return f2e(h, vp_mmg, vp_mm, vp_sums)
             return f2(h, vp_mmg, vp_sums)
 
         def fn():
-            rc = f1(h, sp, cv, vp_mm)                                           # local extrema -> buf[ns:ns+8]
+            spec = speculate and st["guess"] is not None
+            # local extrema -> row[ns:ns+8]: by stage 1's fold launch, or (speculating) by stage 2 itself
+            rc = f1(h, sp, cv, None if spec else vp_mm)
             if rc < 0:
                 return rc
-            if speculate and st["guess"] is not None:
-                rc = stage2_with(st["guess"])
+            if spec:
+                rc = stage2_with(st["guess"], emit=True)
                 if rc < 0:
                     return rc
                 rc, E = gather_and_finish(None)
