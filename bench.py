@@ -302,7 +302,7 @@ def main():
         dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
         achieved = ALG_BYTES_SEARCH_PASS * N / (dom_ms * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC run of this same workload, if any
-        tj = os.path.join(ROOT, "profiles", "round1", "r01h_pmc_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "round1", "r01i_pmc_traffic.json")
         if args.config == 2 and os.path.exists(tj):
             traffic = json.load(open(tj))["traffic_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
