@@ -41,7 +41,8 @@ enum {
   MALIO_ERR_BAD_ARG = -3,
   MALIO_ERR_NO_MAP = -4,
   MALIO_ERR_NO_SCAN = -5,
-  MALIO_ERR_ALLOC = -6
+  MALIO_ERR_ALLOC = -6,
+  MALIO_ERR_TIMEOUT = -7 /* malio_xchg_all_gather: a rank did not show up */
 };
 
 typedef struct malio_ctx *malio_handle_t;

@@ -16,6 +16,7 @@ MAX_LIDAR = 4
 OK, NO_EFFECTIVE_POINTS, SMALL_M_FALLBACK = 0, 1, 2
 ERR_NO_DEVICE = -1
 ERR_BAD_ARG = -3
+ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",

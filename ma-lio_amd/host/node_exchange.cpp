@@ -94,7 +94,7 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
       sched_yield();  // oversubscribed hosts (tests: several ranks per core) must not livelock
       if (timeout_s > 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-        return MALIO_ERR_HIP;  // a rank died or fell out of step: fail instead of hanging the node
+        return MALIO_ERR_TIMEOUT;  // a rank died or fell out of step: fail instead of hanging the node
     }
   }
   std::memcpy(out_all, x->data(buf, 0), sizeof(double) * (size_t)x->world * x->row);
