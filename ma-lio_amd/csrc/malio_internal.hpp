@@ -284,9 +284,9 @@ void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
-void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m);
-void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
-void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
+void nl_ensure(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m);  // both levels at once
+void nl_append(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
+void nl_tombstone(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
 void free_nl_scratch(NlScratch &s);
 
 // map_update.hip

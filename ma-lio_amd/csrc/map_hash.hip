@@ -409,8 +409,11 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
 
 // ---- incremental maintenance (called by map_update.hip; same stream, never concurrent with a search) -----------
 // (1) make sure the 27 cells around every kept new point have a directory entry and a list to append to
+// All four kernels serve both list levels in one launch: blockIdx.y picks the level (two launches of latency-bound
+// kernels back to back cost twice the latency, one launch of both overlaps them).
 __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
-                                                   NlDev nl) {
+                                                   NlDev nl_a, NlDev nl_b) {
+  const NlDev nl = blockIdx.y ? nl_b : nl_a;
   // 32 lanes per point, one of its 27 cells each
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
@@ -444,7 +447,8 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
 //      makes room - nothing to do when the slack suffices, otherwise (new cell, or a list at the map frontier that
 //      outgrew its slack) the list moves to the tail region with fresh slack.
 __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
-                                                  NlDev nl, int mode) {
+                                                  NlDev nl_a, NlDev nl_b, int mode) {
+  const NlDev nl = blockIdx.y ? nl_b : nl_a;
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
   bool live = i < m && cidx < 27 && keep[i] != 0;
@@ -507,7 +511,9 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
 }
 // (2) append every kept new point (map index og_base + rank) to its 27 lists
 __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ newp, const u32 *__restrict__ keep,
-                                                   const u32 *__restrict__ rank, u32 og_base, int m, NlDev nl) {
+                                                   const u32 *__restrict__ rank, u32 og_base, int m, NlDev nl_a,
+                                                   NlDev nl_b) {
+  const NlDev nl = blockIdx.y ? nl_b : nl_a;
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
   if (i >= m || cidx >= 27 || !keep[i]) return;
@@ -537,7 +543,8 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
 // (3) a deleted map point leaves its 27 lists: the entry stays but can never be a neighbour again (x = +inf makes
 //     every distance +inf, which the search drops); tombstones are swept by the next full rebuild
 __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const u32 *__restrict__ dlist,
-                                                      int ndel, NlDev nl) {
+                                                      int ndel, NlDev nl_a, NlDev nl_b) {
+  const NlDev nl = blockIdx.y ? nl_b : nl_a;
   // 16 lanes per (deleted point, one of its 27 lists): a level-2 list has 180..900 entries to look through
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int sub = (int)(t & 15);
@@ -573,22 +580,24 @@ NlDev nl_dev(const NList &nl) {
   return v;
 }
 
-void nl_ensure(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, int m) {
+void nl_ensure(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m) {
   const long long th = (long long)m * 32;
-  const dim3 grid((unsigned)((th + BLK - 1) / BLK));
-  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl));
-  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl), 0);
-  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, nl_dev(nl), 1);
+  const dim3 grid((unsigned)((th + BLK - 1) / BLK), 2);
+  const NlDev a = nl_dev(nl_a), b = nl_dev(nl_b);
+  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b);
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b, 0);
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b, 1);
 }
-void nl_append(Ctx *c, NList &nl, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m) {
+void nl_append(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base,
+               int m) {
   const long long th = (long long)m * 32;
-  hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_new, keep, rank,
-                     og_base, m, nl_dev(nl));
+  hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, c->stream, d_new, keep, rank,
+                     og_base, m, nl_dev(nl_a), nl_dev(nl_b));
 }
-void nl_tombstone(Ctx *c, NList &nl, const float4 *d_map, const u32 *dlist, int ndel) {
+void nl_tombstone(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel) {
   const long long th = (long long)ndel * 27 * 16;
-  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, d_map, dlist, ndel,
-                     nl_dev(nl));
+  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, c->stream, d_map, dlist,
+                     ndel, nl_dev(nl_a), nl_dev(nl_b));
 }
 
 }  // namespace malio

@@ -317,8 +317,7 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
   }
   if (ndel) {
     if (in_place) {
-      nl_tombstone(c, c->nl1, c->d_map_in, dlist, (int)ndel);
-      nl_tombstone(c, c->nl2, c->d_map_in, dlist, (int)ndel);
+      nl_tombstone(c, c->nl1, c->nl2, c->d_map_in, dlist, (int)ndel);
     }
     hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, dlist,
                        (int)ndel);
@@ -330,10 +329,8 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
     hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, rank, m,
                        (const u32 *)nullptr, c->d_map_in + hw);
     if (in_place) {
-      nl_ensure(c, c->nl1, d_new, keep, m);
-      nl_ensure(c, c->nl2, d_new, keep, m);
-      nl_append(c, c->nl1, d_new, keep, rank, (u32)hw, m);
-      nl_append(c, c->nl2, d_new, keep, rank, (u32)hw, m);
+      nl_ensure(c, c->nl1, c->nl2, d_new, keep, m);
+      nl_append(c, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
       u32 *mb = nullptr;
       MALIO_HIP(mbox(c, &mb));
       u32 *st1 = mb + 16, *st2 = mb + 20;
