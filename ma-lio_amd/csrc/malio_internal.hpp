@@ -193,7 +193,8 @@ struct Ctx {
   ResCloud res[MALIO_MAX_LIDAR];
   void *h_stage = nullptr;  // pinned upload staging (map_build, scan_set), grown on demand
   size_t cap_stage = 0;
-  u32 *h_mbox = nullptr;       // pinned: small device->host readbacks (counts) land here, one stream sync serves all
+  u32 *h_mbox = nullptr, *d_mbox = nullptr;  // pinned + device alias: small results for the host (counts), written
+                                             // by kernels or copies; one stream sync serves all
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
@@ -279,7 +280,8 @@ struct Ctx {
 // group `n` device points (float4, xyz used) by spatial-hash cell into `g` (allocates/grows g's buffers)
 int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g, const u32 *d_in_orig = nullptr,
                   float div_cell = 0.f);  // div_cell > 0: cell index = floor(x / div_cell) (ikd-Tree voxel rule)
-int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n);  // d_tiles: [(n+1023)/1024 + 1]
+int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n, u32 *total_out = nullptr,
+                       const u32 *fwd = nullptr, int nfwd = 0);  // d_tiles: [(n+1023)/1024 + 1]
 void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);
@@ -324,16 +326,18 @@ int sums_len(const Ctx *c);
 int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*original map index*/, float *d_d2, int *d_cnt);
 
-// Small results the host needs (counts, a few points) come back through one pinned buffer: a copy into pinned memory
-// is queued like a kernel (into pageable memory it is staged and blocks), so several of them cost one stream
-// synchronisation. 64 KB; words [0, 64) are used by the map code, the rest by whoever needs a bigger read-back.
+// Small results the host needs (counts, a few points) come back through one pinned, device-mapped buffer: kernels
+// store into it directly (no copy launch at all), and a copy into pinned memory is queued like a kernel (into pageable
+// memory it is staged and blocks); either way one stream synchronisation serves everything. 64 KB; words [0, 64) are used by the map code, the rest by whoever needs a bigger read-back.
 constexpr size_t MBOX_WORDS = 16384;
-inline hipError_t mbox(Ctx *c, u32 **out) {
+inline hipError_t mbox(Ctx *c, u32 **out, u32 **dev = nullptr) {
   if (!c->h_mbox) {
-    hipError_t e = hipHostMalloc((void **)&c->h_mbox, sizeof(u32) * MBOX_WORDS, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void **)&c->h_mbox, sizeof(u32) * MBOX_WORDS, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->d_mbox, c->h_mbox, 0);
     if (e != hipSuccess) return e;
   }
   *out = c->h_mbox;
+  if (dev) *dev = c->d_mbox;
   return hipSuccess;
 }
 

@@ -162,11 +162,50 @@ void free_grid(CellGrid &g) {
   g = CellGrid();
 }
 
-int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n) {
+// Second (last) kernel of a scan of up to 1024 tiles: every workgroup sums the totals of the tiles before it (<= 1024
+// values, one block reduction) instead of waiting for a separate single-workgroup scan of the tile sums. The
+// workgroup that owns the last element can hand the grand total (callers scan n = m + 1 flags with a zero at the end,
+// so out[n - 1] is the count) and a few more words straight to the host's mapped buffer.
+__global__ void __launch_bounds__(BLK) k_scan_add_fused(u32 *out, const u32 *__restrict__ tile_sums, int n, u32 *total_out,
+                                                        const u32 *__restrict__ fwd, int nfwd) {
+  __shared__ u32 wsum[BLK / 64];
+  u32 part = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += BLK) part += tile_sums[t];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  u32 off = 0;
+#pragma unroll
+  for (int w = 0; w < BLK / 64; w++) off += wsum[w];
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (base + k < n) {
+      const u32 v = out[base + k] + off;
+      out[base + k] = v;
+      if (total_out && base + k == n - 1) total_out[0] = v;
+    }
+  if (total_out && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < nfwd) total_out[1 + threadIdx.x] = fwd[threadIdx.x];
+}
+
+__global__ void k_publish_total(const u32 *__restrict__ last, const u32 *__restrict__ fwd, int nfwd, u32 *total_out) {
+  if (threadIdx.x == 0) total_out[0] = *last;
+  if ((int)threadIdx.x < nfwd) total_out[1 + threadIdx.x] = fwd[threadIdx.x];
+}
+
+// total_out (optional, device-visible, e.g. the mapped mailbox): receives out[n - 1] and then fwd[0 .. nfwd)
+int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n, u32 *total_out, const u32 *fwd,
+                       int nfwd) {
   int ntiles = (n + 1023) / 1024;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(BLK), 0, c->stream, d_in, d_out, d_tiles, n);
+  if (ntiles <= 1024) {
+    hipLaunchKernelGGL(k_scan_add_fused, dim3(ntiles), dim3(BLK), 0, c->stream, d_out, d_tiles, n, total_out, fwd, nfwd);
+    return MALIO_OK;
+  }
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(BLK), 0, c->stream, d_tiles, ntiles);
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(BLK), 0, c->stream, d_out, d_tiles, n);
+  if (total_out) hipLaunchKernelGGL(k_publish_total, dim3(1), dim3(64), 0, c->stream, d_out + (n - 1), fwd, nfwd, total_out);
   return MALIO_OK;
 }
 
@@ -182,15 +221,14 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   u32 *cnt = nullptr, *start = nullptr, *slot_of = nullptr, *rank_of = nullptr, *tiles = nullptr, *ncells = nullptr;
   int ntiles = (tbig + 1023) / 1024;
   MALIO_HIP(sc.get(&keys, (size_t)tbig));
-  MALIO_HIP(sc.get(&cnt, (size_t)tbig));
+  MALIO_HIP(sc.get(&cnt, (size_t)tbig + 1));  // + the cell counter: one clear for both
+  ncells = cnt + tbig;
   MALIO_HIP(sc.get(&start, (size_t)tbig));
   MALIO_HIP(sc.get(&slot_of, (size_t)n));
   MALIO_HIP(sc.get(&rank_of, (size_t)n));
   MALIO_HIP(sc.get(&tiles, (size_t)ntiles + 1));
-  MALIO_HIP(sc.get(&ncells, 1));
   hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
-  MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));
-  MALIO_HIP(hipMemsetAsync(ncells, 0, sizeof(u32), c->stream));
+  MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * ((size_t)tbig + 1), c->stream));
   int nb = (n + BLK - 1) / BLK;
   hipLaunchKernelGGL(k_gbc_insert, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, inv_cell, div_cell, keys, cnt, tbig - 1,
                      slot_of, rank_of, ncells);

@@ -299,6 +299,11 @@ static int map_reserve(Ctx *c, size_t extra) {
   return MALIO_OK;
 }
 
+// the two list-state words the host looks at after an in-place update, into the host's mapped buffer
+__global__ void k_publish_states(const u32 *__restrict__ s1, const u32 *__restrict__ s2, u32 *out) {
+  out[threadIdx.x] = threadIdx.x < 4 ? s1[threadIdx.x] : s2[threadIdx.x - 4];
+}
+
 // Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
 //   dlist[ndel]     -> these slots die (x = +inf), their 27 entries per level become tombstones
 //   keep[m] != 0    -> d_new[i] is appended as slot map_n + rank[i] and inserted into 27 lists per level
@@ -331,11 +336,10 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
     if (in_place) {
       nl_ensure(c, c->nl1, c->nl2, d_new, keep, m);
       nl_append(c, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
-      u32 *mb = nullptr;
-      MALIO_HIP(mbox(c, &mb));
+      u32 *mb = nullptr, *mbd = nullptr;
+      MALIO_HIP(mbox(c, &mb, &mbd));
       u32 *st1 = mb + 16, *st2 = mb + 20;
-      MALIO_HIP(hipMemcpyAsync(st1, c->nl1.state, sizeof(u32) * 4, hipMemcpyDeviceToHost, c->stream));
-      MALIO_HIP(hipMemcpyAsync(st2, c->nl2.state, sizeof(u32) * 4, hipMemcpyDeviceToHost, c->stream));
+      hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, c->stream, c->nl1.state, c->nl2.state, mbd + 16);
       MALIO_HIP(hipStreamSynchronize(c->stream));
       c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
       if (st1[1] || st2[1]) in_place = false;  // a list or the tail region overflowed
@@ -385,7 +389,8 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   const float ds = (float)c->prm.filter_size_map;
   ArenaScope sc(c->arena);
   u32 *addf = nullptr, *apos = nullptr, *tiles = nullptr, *counters = nullptr;
-  MALIO_HIP(sc.get(&addf, (size_t)m + 1));
+  MALIO_HIP(sc.get(&addf, (size_t)m + 1 + 2));  // keep flags, then the two counters of k_vox_add: one clear for both
+  counters = addf + m + 1;
   MALIO_HIP(sc.get(&apos, (size_t)m + 1));
   if (m_ds <= 0) {
     hipLaunchKernelGGL(k_fill_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf, 1u, m);
@@ -403,15 +408,13 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   rc = group_by_cell(c, d_new, m_ds, 1.f / ds, gnew, nullptr, ds);
   if (rc != MALIO_OK) return rc;
   unsigned char *del = nullptr;
-  u32 *dlist = nullptr, *mb = nullptr;
+  u32 *dlist = nullptr, *mb = nullptr, *mbd = nullptr;
   hipError_t e = sc.get(&del, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&dlist, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
-  if (e == hipSuccess) e = sc.get(&counters, 2);
-  if (e == hipSuccess) e = mbox(c, &mb);
+  if (e == hipSuccess) e = mbox(c, &mb, &mbd);
   if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)hw + 1, c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1), c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1 + 2), c->stream);
   MALIO_HIP(e);
   if (m_plain > 0)
     hipLaunchKernelGGL(k_fill_u32, dim3((m_plain + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf + m_ds, 1u, m_plain);
@@ -419,11 +422,11 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
                      d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
                      dlist, addf, counters);
-  exclusive_scan_u32(c, addf, apos, tiles, m + 1);
-  u32 *h_tot = mb + 8;  // kept points (both parts) | return value of the down-sampling call | deleted map points
-  e = hipMemcpyAsync(&h_tot[0], apos + m, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_tot[1], counters, sizeof(u32) * 2, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  // kept points (both parts) | return value of the down-sampling call | deleted map points: stored into the host's
+  // mapped buffer by the scan's last kernel
+  u32 *h_tot = mb + 8;
+  exclusive_scan_u32(c, addf, apos, tiles, m + 1, mbd + 8, counters, 2);
+  e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipGetLastError();
   MALIO_HIP(e);
   if (out_added) *out_added = (int)h_tot[1];
@@ -469,30 +472,28 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   if (N <= 0) return MALIO_ERR_NO_SCAN;
   ArenaScope sc(c->arena);
   float *d_wny = nullptr;
-  u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr;
+  u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr, *tiles2 = nullptr;
   float4 *wp = nullptr, *d_add = nullptr, *d_non = nullptr;
   MALIO_HIP(sc.get(&addf, (size_t)N + 1));
   MALIO_HIP(sc.get(&nonf, (size_t)N + 1));
   MALIO_HIP(sc.get(&apos, (size_t)N + 1));
   MALIO_HIP(sc.get(&npos, (size_t)N + 1));
   MALIO_HIP(sc.get(&tiles, (size_t)(N + 1 + 1023) / 1024 + 2));
+  MALIO_HIP(sc.get(&tiles2, (size_t)(N + 1 + 1023) / 1024 + 2));
   MALIO_HIP(sc.get(&wp, (size_t)N));
   if (h_world_normal_y) {
     MALIO_HIP(sc.get(&d_wny, (size_t)N));
     MALIO_HIP(hipMemcpyAsync(d_wny, h_world_normal_y, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, c->stream));
   }
-  MALIO_HIP(hipMemsetAsync(addf + N, 0, sizeof(u32), c->stream));
-  MALIO_HIP(hipMemsetAsync(nonf + N, 0, sizeof(u32), c->stream));
-  int rc = mapinc_classify(c, state_point, flg_EKF_inited, d_wny, addf, nonf, wp);
+  u32 *mb = nullptr, *mbd = nullptr;
+  MALIO_HIP(mbox(c, &mb, &mbd));
+  int rc = mapinc_classify(c, state_point, flg_EKF_inited, d_wny, addf, nonf, wp);  // also zeroes addf[N], nonf[N]
   if (rc != MALIO_OK) return rc;
-  exclusive_scan_u32(c, addf, apos, tiles, N + 1);
-  exclusive_scan_u32(c, nonf, npos, tiles, N + 1);
-  u32 *mb = nullptr;
-  MALIO_HIP(mbox(c, &mb));
-  MALIO_HIP(hipMemcpyAsync(&mb[0], apos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(&mb[1], npos + N, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  // the two list lengths go straight from the scans' last kernels into the host's mapped buffer: no copy launches
+  exclusive_scan_u32(c, addf, apos, tiles, N + 1, mbd + 0);
+  exclusive_scan_u32(c, nonf, npos, tiles2, N + 1, mbd + 2);
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  const int na = (int)mb[0], nn = (int)mb[1];
+  const int na = (int)mb[0], nn = (int)mb[2];
   MALIO_HIP(sc.get(&d_add, (size_t)na + (size_t)nn));  // PointToAdd | PointNoNeedDownsample, back to back
   d_non = d_add + na;
   hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, addf, apos, N,

@@ -1201,6 +1201,7 @@ struct MapIncArgs {
 __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= a.N) return;
+  if (i == 0) a.addf[a.N] = 0u, a.nonf[a.N] = 0u;  // the closing zero the exclusive scans of the flags expect
   const u32 o = a.perm[i];
   const float4 q = a.scan[i];
   const int lid = (int)(__float_as_uint(q.w) & 0xFF);

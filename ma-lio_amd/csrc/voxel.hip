@@ -148,8 +148,8 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
       *first = nullptr, *tiles = nullptr;
   char *tmp = nullptr;
   MALIO_HIP(sc.get(&d_mm, (size_t)VG_SLOTS * 6));
-  u32 *mb = nullptr;
-  MALIO_HIP(mbox(c, &mb));
+  u32 *mb = nullptr, *mbd = nullptr;
+  MALIO_HIP(mbox(c, &mb, &mbd));
   u32 *mms = mb + 1024;  // pinned: [VG_SLOTS][3 min | 3 max]
   static_assert(1024 + VG_SLOTS * 6 + 1 <= MBOX_WORDS, "mailbox too small");
   hipLaunchKernelGGL(k_vg_init, dim3(1), dim3(VG_SLOTS * 6), 0, c->stream, d_mm);
@@ -199,9 +199,8 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
   hipLaunchKernelGGL(k_vg_keys, dim3(nb), dim3(BLK), 0, c->stream, d_pts, n, g, k1, v1);
   MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
   hipLaunchKernelGGL(k_vg_heads, dim3((n + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, k2, n, head);
-  exclusive_scan_u32(c, head, pos, tiles, n + 1);
   u32 *h_nvox = mb + 1024 + VG_SLOTS * 6;
-  MALIO_HIP(hipMemcpyAsync(h_nvox, pos + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  exclusive_scan_u32(c, head, pos, tiles, n + 1, mbd + 1024 + VG_SLOTS * 6);  // the voxel count lands in the mapped buffer
   hipLaunchKernelGGL(k_vg_first, dim3(nb), dim3(BLK), 0, c->stream, head, pos, n, first);
   MALIO_HIP(hipStreamSynchronize(c->stream));
   const u32 nvox = *h_nvox;
