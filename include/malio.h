@@ -246,6 +246,17 @@ int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state
                      const malio_state_t *x_propagated, const double *P_propagated, const double *HtRinvH,
                      const double *HtRinvh, int *t_io, int *converge_out, int *done_out, double *P_out);
 
+/* ---- order of the scan inside the engine -------------------------------------------------------------------- */
+/* The kernels want neighbouring queries to be neighbours in space. By default (AUTO) a scan handed over in host
+ * buffers (malio_scan_set) is sorted by (LiDAR slot, map cell) at its first pass (~0.1 ms for 100 k points), while
+ * a scan built by malio_scan_set_resident is used as it is: the voxel filter leaves every LiDAR's cloud sorted by
+ * voxel index, which is coherent enough (the search pass is ~6 us slower, the sort is saved). SORT forces the sort
+ * for both, KEEP skips it for malio_scan_set too - the caller then promises a spatially coherent cloud with the LiDAR
+ * slots in ascending blocks (a cloud that is not grouped like that is sorted anyway). Results are identical sets of
+ * rows either way; sums differ in the last bits with the order, as they do in the reference under OpenMP scheduling. */
+enum { MALIO_SCAN_ORDER_AUTO = 0, MALIO_SCAN_ORDER_SORT = 1, MALIO_SCAN_ORDER_KEEP = 2 };
+int malio_scan_order(malio_handle_t h, int mode);
+
 /* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */
 /* Every entry point accepts ordinary (pageable) host memory, as the reference's std::vector / pcl clouds are. A copy
  * out of pageable memory is staged by the runtime in chunks and blocks the caller; out of page-locked memory it is one

@@ -374,12 +374,16 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   UploadRec *stage = nullptr;
   if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n, (void **)&stage)) return rcs;
   int cnt[MALIO_MAX_LIDAR] = {0};
+  int last_lid = 0;
+  bool grouped = true;  // LiDAR slots in ascending blocks: what MALIO_SCAN_ORDER_KEEP needs
   for (int i = 0; i < n; i++) {
     const int lid = (int)body[i].intensity;  // laserMapping.cpp:570
     if (lid < 0 || lid >= L) {
       c->N = 0;
       return MALIO_ERR_BAD_ARG;
     }
+    grouped &= lid >= last_lid;
+    last_lid = lid;
     int idx = (int)body[i].normal_x;  // int(laser_p.normal_x), laserMapping.cpp:694,737
     if (idx > 0x3FFFFF) idx = 0x3FFFFF;
     if (idx < -0x3FFFFF) idx = -0x3FFFFF;
@@ -393,6 +397,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? cnt[l] : 0);
   MALIO_HIP(hipMemcpyAsync(c->d_upload, stage, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   c->stage_pending = true;
+  c->scan_keep_order = c->scan_order_mode == MALIO_SCAN_ORDER_KEEP && grouped;  // not grouped: sorted after all
   return scan_reset(c);
 }
 
@@ -465,6 +470,9 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
     MALIO_HIP(hipStreamSynchronize(c->stream));  // out_body is the caller's memory
   }
   rc = scan_reset(c);
+  // the voxel filter leaves every LiDAR's cloud sorted by voxel index and the clouds follow each other in slot order:
+  // spatially coherent and grouped as it is
+  c->scan_keep_order = c->scan_order_mode != MALIO_SCAN_ORDER_SORT;
   for (int l = 0; l < L; l++) c->res[l].n = 0;  // consumed
   return rc;
 }
@@ -649,6 +657,12 @@ int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_
   if (check(h) || !host || !dev || !len_doubles) return MALIO_ERR_BAD_ARG;
   if (!h->h_res) return MALIO_ERR_NO_SCAN;
   *host = h->h_res, *dev = h->d_res, *len_doubles = sums_len(h) + 16;
+  return MALIO_OK;
+}
+
+int malio_scan_order(malio_handle_t h, int mode) {
+  if (check(h) || mode < MALIO_SCAN_ORDER_AUTO || mode > MALIO_SCAN_ORDER_KEEP) return MALIO_ERR_BAD_ARG;
+  h->scan_order_mode = mode;
   return MALIO_OK;
 }
 

@@ -211,6 +211,8 @@ struct Ctx {
   // scan (device arrays in SORTED order: grouped by lidar, then by hash cell of the world position)
   int N = 0;
   bool scan_sorted = false;
+  bool scan_keep_order = false;  // this scan is used in its upload order (no spatial sort), see malio_scan_order
+  int scan_order_mode = 0;       // MALIO_SCAN_ORDER_*
   UploadRec *d_upload = nullptr;  // [N] scan as uploaded, caller's order (see UploadRec)
   float4 *d_scan = nullptr;     // [N] sorted
   u32 *d_perm = nullptr;        // [N] sorted -> original index

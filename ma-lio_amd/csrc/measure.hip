@@ -1408,6 +1408,10 @@ static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc)
 }
 
 // Spatial sort of the scan, once per scan, with the first pass' state (coherence only, not results).
+__global__ void __launch_bounds__(BLK) k_scan_iota(u32 *p, int n) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) p[i] = (u32)i;
+}
 static int sort_scan(Ctx *c, const QuatConst &qc) {
   // The temporaries live in the arena and are handed back when this returns, with the kernels still queued: every
   // arena user enqueues on c->stream, so the stream's order is the only synchronisation needed.
@@ -1423,6 +1427,13 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, N, 0, 32, c->stream));
   MALIO_HIP(sc.get((char **)&d_tmp, tmp_bytes ? tmp_bytes : 16));
   const dim3 grid((N + BLK - 1) / BLK);
+  if (c->scan_keep_order) {  // malio_scan_order: the upload order is kept (it is grouped by LiDAR slot)
+    hipLaunchKernelGGL(k_scan_iota, grid, dim3(BLK), 0, c->stream, d_vals2, N);
+    hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, d_vals2, N, c->d_scan, c->d_perm, c->d_ny,
+                       c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
+    c->scan_sorted = true;
+    return MALIO_OK;
+  }
   hipLaunchKernelGGL(k_scan_keys, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, d_keys, d_vals);
   // A stable radix sort: unlike a counting sort on atomic ranks, the resulting order - and with it every fixed-order
   // reduction over the sorted scan - is identical in every run.

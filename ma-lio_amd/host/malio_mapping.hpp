@@ -194,6 +194,8 @@ class Mapping {
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {
     h_.check(malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
   }
+  // order of the scan inside the engine (malio_scan_order): MALIO_SCAN_ORDER_AUTO / _SORT / _KEEP
+  void set_scan_order(int mode) { h_.check(malio_scan_order(h_.get(), mode), "scan_order"); }
   // kf.predict(dt, Q, in) (esekfom.hpp:388-492; also predict_cont :171 / back_predict :281 when handed x_cont /
   // x_unc and P_unc_), IMU_Processing.hpp:332,345,364,386,399. Host code; Q is 12 x 12 row-major.
   static void predict(int lid_num, malio_state_t &x, std::vector<double> &P, double dt, const std::vector<double> &Q,

@@ -55,6 +55,7 @@ def test_resident_front_end_equals_host_chain(capi, scenes, L):
 
     res = capi.Engine(sc["params"])
     res.map_build(sc["map"])
+    res.scan_order(1)          # sort like the host-buffer chain does, so that sums can be compared bit for bit
     for l in range(L):
         ent, epts = res.undistort_resident(l, raws[l], beg, kt, kT, st["offR"][l], st["offT"][l], q_end, p_end, imu_t, cp)
         np.testing.assert_array_equal(ent, ents_h[l])
@@ -77,6 +78,26 @@ def test_resident_front_end_equals_host_chain(capi, scenes, L):
     # the resident clouds were consumed
     with pytest.raises(RuntimeError):
         res.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    # default order of a resident scan: as the voxel filter left it (no spatial sort). Same accepted points, same
+    # per-point values; sums (and what is scaled by the weight derived from them) to rounding: another summation order.
+    res.scan_order(0)
+    for l in range(L):
+        res.undistort_resident(l, raws[l], beg, kt, kT, st["offR"][l], st["offT"][l], q_end, p_end, imu_t, cp)
+    body_k = res.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    np.testing.assert_array_equal(body_k, body_h)
+    host.scan_set(body_h, sc["tables"], sc["temporal_comp"])
+    r_s = host.measure(sc["state0"], True, want_rows=True)
+    r_k = res.measure(sc["state0"], True, want_rows=True)
+    assert r_k["M"] == r_s["M"]
+    np.testing.assert_array_equal(r_k["R"], r_s["R"])        # per-point values do not depend on the order ...
+    for k in ("h_x", "h"):                                    # ... the rows carry the localization weight, which does
+        assert np.allclose(r_k[k], r_s[k], rtol=1e-13, atol=0)
+    assert np.abs(r_k["HtRinvH"] - r_s["HtRinvH"]).max() <= 1e-12 * np.abs(r_s["HtRinvH"]).max()
+    assert np.abs(r_k["HtRinvh"] - r_s["HtRinvh"]).max() <= 1e-12 * np.abs(r_s["HtRinvh"]).max()
+    np.testing.assert_array_equal(res.scan_get()["selected"], host.scan_get()["selected"])
+    with pytest.raises(RuntimeError):
+        res.scan_order(7)
+    res.scan_order(1)
     # same chain with the caller's clouds in page-locked memory (malio_host_alloc): same bytes, fewer stalls
     pins = [capi.PinnedArray(r.shape, np.float32) for r in raws]
     pout = capi.PinnedArray((sum(r.shape[0] for r in raws), 12), np.float32)
