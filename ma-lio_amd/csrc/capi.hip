@@ -500,7 +500,7 @@ int malio_measure_finish(malio_handle_t h, const double *sums_host, const double
   prof_end(h);
   int rc = finish_host(h, sums_host, minmax_host, out);
   h->last_M = out->M;
-  if (h->last_pass_search) h->defer_enabled = minmax_host[5] > 0.5;  // see malio_measure
+  if (h->last_pass_search) h->defer_enabled = minmax_host[5] >= DEFER_SCORE_MIN;  // see malio_measure
   return rc;
 }
 
@@ -525,7 +525,7 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   c->last_M = out->M;
   // k_search_tail is launched with the next search pass only while search passes keep meeting workgroups full of
   // uncertified queries (word 5 after the sums); without it such workgroups serve their queries themselves
-  if (converge) c->defer_enabled = res[ns + 5] > 0.5;
+  if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;
   if (want_rows && out->valid) {
     // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to
     // C columns, scaled by w_loc (laserMapping.cpp:758-759), compacted in ascending original index.

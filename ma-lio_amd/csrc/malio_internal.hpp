@@ -343,6 +343,11 @@ inline hipError_t mbox(Ctx *c, u32 **out, u32 **dev = nullptr) {
   return hipSuccess;
 }
 
+// k_search_tail costs ~17 us even for a handful of queries (launch + one dependent chain): it is only worth launching
+// when at least this many workgroups were loaded with uncertified queries (each counts 1, or 64 when more than half of
+// its queries are), i.e. when serving them in place would stretch the search kernel by more than that.
+constexpr double DEFER_SCORE_MIN = 64.0;
+
 // host/predict.cpp
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp

@@ -669,7 +669,9 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       const int npend = __popcll(todo);
       PH_NOTE(3, npend);
       const bool heavy = npend > DEFER_MIN;
-      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + a.parity], 1u);  // steers the host's defer switch
+      // steers the host's defer switch (DEFER_SCORE_MIN): a workgroup more than half full of uncertified queries
+      // would take tens of microseconds longer on its own and counts as 64, a mildly loaded one as 1
+      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + a.parity], npend > 32 ? 64u : 1u);
       if (heavy && a.defer) {
         // too many for this workgroup: hand them to k_search_tail, which spreads them one per wave over the GPU
         if (wave == 0) {
