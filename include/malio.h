@@ -344,6 +344,9 @@ int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_
 typedef struct malio_xchg *malio_xchg_t;
 int malio_xchg_create(const char *name, int rank, int world, int row_doubles, int create, malio_xchg_t *out);
 int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, double timeout_s);
+/* Creator only, once every rank has opened the segment: removes the name (the mappings stay), so that nothing is left
+ * in /dev/shm however the job ends. */
+int malio_xchg_unlink(malio_xchg_t x);
 int malio_xchg_destroy(malio_xchg_t x);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -22,9 +22,19 @@ _xchg_ids = itertools.count()
 
 def _single_node(group=None):
     """True when every rank of `group` runs on this host."""
+    lw, w = os.environ.get("LOCAL_WORLD_SIZE"), os.environ.get("WORLD_SIZE")
+    if group is None and lw and w:                                              # the launcher told us
+        return int(lw) == int(w)
     names = [None] * dist.get_world_size(group)
     dist.all_gather_object(names, socket.gethostname(), group=group)
     return len(set(names)) == 1
+
+
+def _agree(ok, group=None):
+    """Logical AND of `ok` over the ranks (a device all-reduce: works with every backend the ranks already use)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
 
 
 def exchange_mode(group=None):
@@ -150,20 +160,30 @@ class HipBackend:
         self.spec_stats = st
         xchg = None
         if mode == "shm":
-            name = [None]
+            # every rank derives the same segment name (the calls are collective, so the counters agree); rank 0 creates
+            # and zeroes it, the first agreement doubles as "it exists before anybody else opens it"
+            tag = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "run") if ch.isalnum())[:24]
+            name = "/malio_%s_%s_%d_%d" % (tag, os.environ.get("MASTER_PORT", "0"), W, next(_xchg_ids))
+            ok = True
             if rank == 0:
                 try:                                                            # no /dev/shm, no space: use the group
-                    nm = "/malio_%d_%d" % (os.getpid(), next(_xchg_ids))
-                    xchg = capi.NodeExchange(nm, 0, W, row, create=True)
-                    name[0] = nm
+                    xchg = capi.NodeExchange(name, 0, W, row, create=True)
                 except capi.MalioError:
-                    name[0] = None
-            dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            if name[0] is None:
+                    ok = False
+            ok = _agree(ok, group)
+            if ok and rank != 0:
+                try:
+                    xchg = capi.NodeExchange(name, rank, W, row, create=False)
+                except capi.MalioError:
+                    ok = False
+            all_open = _agree(ok, group)
+            if rank == 0 and xchg is not None:
+                xchg.unlink()                                                   # mapped everywhere (or abandoned)
+            if not all_open:
+                if xchg is not None:
+                    xchg.close()
+                xchg = None
                 mode = st["exchange"] = "collective"
-            elif rank != 0:                                                     # created and zeroed before the name left
-                xchg = capi.NodeExchange(name[0], rank, W, row, create=False)
-            dist.barrier(group)
         if mode == "shm":
             gathered = ghost = None
             # the stage kernels store [sums | extrema] straight into the handle's pinned result buffer: no copy kernel

@@ -9,6 +9,7 @@
 // all_gather(e): write own row into buffer e & 1, publish seq[rank] = e (release), wait until every seq[r] >= e
 // (acquire), read all rows. Two buffers suffice: a rank can only start epoch e + 2 after every rank published e + 1,
 // which each does after it has finished reading epoch e.
+#include <errno.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -45,6 +46,10 @@ int malio_xchg_create(const char *name, int rank, int world, int row_doubles, in
   x->rank = rank, x->world = world, x->row = row_doubles, x->owner = create != 0, x->name = name;
   x->bytes = (size_t)world * 64 + sizeof(double) * 2 * (size_t)world * row_doubles;
   int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+  if (fd < 0 && create && errno == EEXIST) {  // left behind by a run that died: the name belongs to this job now
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  }
   if (fd < 0) {
     delete x;
     return MALIO_ERR_ALLOC;
@@ -98,6 +103,15 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
     }
   }
   std::memcpy(out_all, x->data(buf, 0), sizeof(double) * (size_t)x->world * x->row);
+  return MALIO_OK;
+}
+
+int malio_xchg_unlink(malio_xchg_t x) {  // once every rank has opened the segment its name is no longer needed
+  if (!x) return MALIO_ERR_BAD_ARG;
+  if (x->owner) {
+    shm_unlink(x->name.c_str());
+    x->owner = false;
+  }
   return MALIO_OK;
 }
 

@@ -24,6 +24,7 @@ def main():
             time.sleep(0.005)
         time.sleep(0.05)
     x = capi.NodeExchange(name, rank, world, row, create=(rank == 0), timeout_s=3.0)
+    first = True
     mine = np.zeros(row, np.float64)
     acc = 0.0
     for e in range(1, epochs + 1):
@@ -32,6 +33,10 @@ def main():
         mine[:] = rank * 1000.0 + e + np.arange(row) * 1e-3
         try:
             g = x.all_gather(mine)
+            if first and rank == 0:   # everybody took part in an exchange, so everybody has the segment mapped
+                x.unlink()
+                assert not os.path.exists("/dev/shm" + name)
+            first = False
         except capi.MalioError:
             print("TIMEOUT rank %d epoch %d" % (rank, e), flush=True)
             x.close()
