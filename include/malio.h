@@ -344,6 +344,13 @@ int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_
 typedef struct malio_xchg *malio_xchg_t;
 int malio_xchg_create(const char *name, int rank, int world, int row_doubles, int create, malio_xchg_t *out);
 int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, double timeout_s);
+/* One exchange of the speculating pass in a single call: gathers every rank's row = [ns sums | extrema words ...],
+ * forms the true extrema (MAX over ranks of words ns .. ns+3) into extrema4_out and, unless they differ bitwise from
+ * guess4 (the extrema the rows were weighted with; NULL = do not check), the rank-ordered sum of the ns sums into
+ * sums_out (may alias row_in). Returns MALIO_OK, 1 when the guess missed (sums_out untouched: weight the rows again
+ * with extrema4_out and call this with guess4 = NULL), or an error. */
+int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double *guess4, double *sums_out,
+                      double *extrema4_out, double timeout_s);
 /* Creator only, once every rank has opened the segment: removes the name (the mappings stay), so that nothing is left
  * in /dev/shm however the job ends. */
 int malio_xchg_unlink(malio_xchg_t x);

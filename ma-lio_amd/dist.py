@@ -222,12 +222,60 @@ class HipBackend:
             hostn[ns + 4:] = own
             return f3(h, hp_sums, hp_mm, op), E
 
+        up = {"E": None}                                                        # extrema currently in `mmg`
+
         def stage2_with(E, emit=False):
-            e_np[:4] = E
-            mmg.copy_(e_pin, non_blocking=True)
+            if up["E"] is None or not np.array_equal(E, up["E"]):              # upload the extrema only when they change
+                e_np[:4] = E
+                mmg.copy_(e_pin, non_blocking=True)
+                up["E"] = np.array(E, np.float64)
             if emit:                                                            # rows + this shard's own extrema words
                 return f2e(h, vp_mmg, vp_mm, vp_sums)
             return f2(h, vp_mmg, vp_sums)
+
+        if mode == "shm":
+            # after the stream sync ONE call gathers the rows, forms the true extrema, checks the guess and adds the
+            # rows in rank order (malio_xchg_reduce): the host side of a speculating pass is three calls into the library
+            xr, xh, to = lib.malio_xchg_reduce, xchg.h, C.c_double(xchg.timeout)
+            E_buf = np.zeros(4, np.float64)
+            E_ptr = C.cast(E_buf.ctypes.data, C.POINTER(C.c_double))
+            g_buf = np.zeros(4, np.float64)
+            g_ptr = C.cast(g_buf.ctypes.data, C.POINTER(C.c_double))
+
+            def fn():
+                spec = speculate and st["guess"] is not None
+                rc = f1(h, sp, cv, None if spec else vp_mm)
+                if rc < 0:
+                    return rc
+                if spec:
+                    rc = stage2_with(st["guess"], emit=True)
+                    if rc < 0:
+                        return rc
+                    g_buf[:] = st["guess"]
+                    stream.synchronize()
+                    r = xr(xh, hp_sums, ns, g_ptr, hp_sums, E_ptr, to)          # sums and extrema land in hostn
+                    if r == 0:
+                        hostn[ns:ns + 4] = E_buf
+                        st["hits"] += 1
+                        return f3(h, hp_sums, hp_mm, op)
+                    if r != 1:
+                        raise capi.MalioError("malio_xchg_reduce rc=%d (a rank is missing?)" % r)
+                    st["misses"] += 1
+                    E = E_buf.copy()
+                else:
+                    E = all_rows()[:, ns:ns + 4].max(axis=0)                    # only the extrema words are valid yet
+                st["guess"] = E
+                rc = stage2_with(E)
+                if rc < 0:
+                    return rc
+                stream.synchronize()
+                r = xr(xh, hp_sums, ns, None, hp_sums, E_ptr, to)
+                if r != 0:
+                    raise capi.MalioError("malio_xchg_reduce rc=%d (a rank is missing?)" % r)
+                hostn[ns:ns + 4] = E
+                return f3(h, hp_sums, hp_mm, op)
+            fn._keep = (s, out, mmg, e_pin, xchg, E_buf, g_buf, rb)
+            return fn, out
 
         def fn():
             spec = speculate and st["guess"] is not None
@@ -244,8 +292,6 @@ class HipBackend:
                     st["hits"] += 1
                     return rc
                 st["misses"] += 1
-            elif mode == "shm":
-                E = all_rows()[:, ns:ns + 4].max(axis=0)                        # only the extrema words are valid yet
             else:
                 dist.all_reduce(mm4, op=dist.ReduceOp.MAX, group=group)
                 e_pin[:4].copy_(mm4, non_blocking=True)

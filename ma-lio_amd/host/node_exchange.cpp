@@ -21,6 +21,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 #include "../../include/malio.h"
 
 struct malio_xchg {
@@ -30,6 +31,7 @@ struct malio_xchg {
   char *base = nullptr;
   uint64_t epoch = 0;
   std::string name;
+  std::vector<double> all;  // [world][row] scratch of malio_xchg_reduce
   std::atomic<uint64_t> *seq(int r) const { return reinterpret_cast<std::atomic<uint64_t> *>(base + (size_t)r * 64); }
   double *data(int buf, int r) const {
     return reinterpret_cast<double *>(base + (size_t)world * 64) + ((size_t)buf * world + r) * row;
@@ -103,6 +105,31 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
     }
   }
   std::memcpy(out_all, x->data(buf, 0), sizeof(double) * (size_t)x->world * x->row);
+  return MALIO_OK;
+}
+
+int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double *guess4, double *sums_out,
+                      double *extrema4_out, double timeout_s) {
+  if (!x || !row_in || !sums_out || !extrema4_out || ns < 0 || ns + 4 > x->row) return MALIO_ERR_BAD_ARG;
+  x->all.resize((size_t)x->world * x->row);
+  int rc = malio_xchg_all_gather(x, row_in, x->all.data(), timeout_s);
+  if (rc != MALIO_OK) return rc;
+  double E[4];
+  for (int k = 0; k < 4; k++) {
+    E[k] = x->all[(size_t)ns + k];
+    for (int r = 1; r < x->world; r++) {
+      const double v = x->all[(size_t)r * x->row + ns + k];
+      if (v > E[k]) E[k] = v;
+    }
+  }
+  const bool miss = guess4 && std::memcmp(E, guess4, sizeof(E)) != 0;  // bitwise: the rows were weighted with guess4
+  std::memcpy(extrema4_out, E, sizeof(E));
+  if (miss) return 1;
+  for (int e = 0; e < ns; e++) {  // rank order: every rank forms the same bits
+    double s = x->all[e];
+    for (int r = 1; r < x->world; r++) s += x->all[(size_t)r * x->row + e];
+    sums_out[e] = s;
+  }
   return MALIO_OK;
 }
 
