@@ -30,6 +30,8 @@ def test_all_gather_in_rank_order_and_in_step(capi, world, row):
     for rc, o in outs:
         assert rc == 0 and "OK rank" in o, o
         accs.add(o.strip().split("acc ")[1])
+        red = [ln for ln in o.splitlines() if ln.startswith("REDUCE")][0].split()
+        assert red[3:] == ["1", "0", "0", "True", "True", "True"], o   # miss reported, hit summed, in-place summed
     assert len(accs) == 1  # every rank formed the same sums, bit for bit
 
 

@@ -49,6 +49,27 @@ def main():
         for r in range(1, world):  # rank order: the same bits on every rank
             s += g[r]
         acc += float(s.sum())
+    # malio_xchg_reduce: row = [ns sums | 4 extrema words | ...]; a right guess gives the rank-ordered sums, a wrong one
+    # is reported with the true extrema and leaves the sums alone
+    import ctypes as C
+    lib = capi.lib()
+    ns = row - 8
+    if ns > 0:
+        r_in = np.zeros(row, np.float64)
+        r_in[:ns] = (rank + 1) * (1.0 + np.arange(ns) * 0.25)
+        r_in[ns:ns + 4] = [rank, -rank, 10.0 - rank, 0.5]
+        E_true = np.array([world - 1, 0.0, 10.0, 0.5])
+        sums = np.full(ns, -1.0)
+        E = np.zeros(4)
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        wrong = E_true + [0, 0, 1e-9, 0]
+        rc1 = lib.malio_xchg_reduce(x.h, p(r_in), ns, p(wrong), p(sums), p(E), C.c_double(3.0))
+        untouched = bool(np.all(sums == -1.0)) and np.array_equal(E, E_true)
+        rc2 = lib.malio_xchg_reduce(x.h, p(r_in), ns, p(E_true), p(sums), p(E), C.c_double(3.0))
+        want = sum((r + 1) for r in range(world)) * (1.0 + np.arange(ns) * 0.25)
+        rc3 = lib.malio_xchg_reduce(x.h, p(r_in), ns, None, p(r_in), p(E), C.c_double(3.0))   # in place, no check
+        print("REDUCE rank %d %d %d %d %s %s %s" % (rank, rc1, rc2, rc3, untouched, np.array_equal(sums, want),
+                                                    np.array_equal(r_in[:ns], want)), flush=True)
     print("OK rank %d acc %r" % (rank, acc), flush=True)
     x.close()
 
