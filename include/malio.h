@@ -351,10 +351,21 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
  * with extrema4_out and call this with guess4 = NULL), or an error. */
 int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double *guess4, double *sums_out,
                       double *extrema4_out, double timeout_s);
+int malio_xchg_row(malio_xchg_t x); /* row_doubles the exchange was created with */
 /* Creator only, once every rank has opened the segment: removes the name (the mappings stay), so that nothing is left
  * in /dev/shm however the job ends. */
 int malio_xchg_unlink(malio_xchg_t x);
 int malio_xchg_destroy(malio_xchg_t x);
+
+/* One pass over a scan sharded across the ranks of one node, in one call: malio_measure with scan-global extrema and
+ * normal equations summed over all ranks (every rank gets the same bits and runs malio_ieskf_step on them). x must
+ * have been created with row_doubles = malio_sums_len(h) + MALIO_MINMAX_LEN. The first pass after a scan was set
+ * exchanges the extrema, then the sums; later passes weight their rows with the previous pass' extrema and need ONE
+ * exchange (two again when the extrema moved). stats2 (may be NULL): passes that needed one / two exchanges so far. */
+int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s, int converge, malio_measure_out_t *out,
+                       int *stats2);
+
+int malio_node_stats(malio_handle_t h, int *stats2); /* the two counters of malio_measure_node */
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded

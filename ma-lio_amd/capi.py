@@ -23,7 +23,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -415,6 +415,12 @@ class Engine:
     def scan_order(self, mode):
         """malio_scan_order: 0 auto (host scans sorted, resident scans as they are), 1 always sort, 2 never sort."""
         self._chk(lib().malio_scan_order(self.h, int(mode)), "malio_scan_order")
+
+    def node_stats(self):
+        """(passes of malio_measure_node that needed one exchange, passes that needed two) so far."""
+        st = (C.c_int * 2)()
+        self._chk(lib().malio_node_stats(self.h, st), "malio_node_stats")
+        return int(st[0]), int(st[1])
 
     def result_buffer(self):
         """malio_result_buffer: (float64 NumPy view of the pinned host buffer, device alias as int)."""

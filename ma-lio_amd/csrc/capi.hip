@@ -151,6 +151,8 @@ int malio_destroy(malio_handle_t h) {
   fr(c->d_sums), fr(c->d_rows);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_node_mm) (void)hipHostFree(c->h_node_mm);
+  if (c->d_node_mm) (void)hipFree(c->d_node_mm);
   if (c->h_mbox) (void)hipHostFree(c->h_mbox);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
@@ -352,6 +354,7 @@ static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *p
 // per-scan state that every new scan starts from. The per-point arrays (selection flags, neighbour cache, planes) are
 // cleared by the kernel that sorts the scan at the first pass (k_gather_scan); nothing reads them before that.
 static int scan_reset(Ctx *c) {
+  c->node_guess_valid = false;  // malio_measure_node: a new scan starts with a plain (two-exchange) pass
   c->nbr_epoch = c->map_epoch;
   c->scan_sorted = false;
   c->last_M = -1;
@@ -494,6 +497,74 @@ int malio_measure_stage2_emit(malio_handle_t h, const double *d_minmax4_in, doub
   if (check(h) || !d_minmax4_in || !d_minmax_out || !d_sums) return MALIO_ERR_BAD_ARG;
   return pass_stage2(h, d_minmax4_in, d_minmax_out, d_sums, false);
 }
+int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s, int converge, malio_measure_out_t *out,
+                       int *stats2) {
+  if (check(h) || !x || !s || !out) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  const int ns = sums_len(c);
+  if (malio_xchg_row(x) != ns + MALIO_MINMAX_LEN) return MALIO_ERR_BAD_ARG;
+  if (!c->d_node_mm) {
+    MALIO_HIP(hipMalloc(&c->d_node_mm, sizeof(double) * MALIO_MINMAX_LEN));
+    MALIO_HIP(hipHostMalloc(&c->h_node_mm, sizeof(double) * MALIO_MINMAX_LEN, hipHostMallocDefault));
+  }
+  const double timeout_s = 60.0;
+  double *res = c->h_res;  // [sums | extrema words]: written by the kernels, exchanged, reduced in place
+  auto upload = [&](const double *E) -> int {  // the extrema stage 2 weights the rows with; only when they change
+    if (c->node_uploaded_valid && memcmp(E, c->node_uploaded, sizeof(double) * 4) == 0) return MALIO_OK;
+    memcpy(c->h_node_mm, E, sizeof(double) * 4);
+    MALIO_HIP(hipMemcpyAsync(c->d_node_mm, c->h_node_mm, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream));
+    memcpy(c->node_uploaded, E, sizeof(double) * 4);
+    c->node_uploaded_valid = true;
+    return MALIO_OK;
+  };
+  prof_begin(c);
+  const bool spec = c->node_guess_valid;
+  int rc = pass_stage1(c, s, converge, spec ? nullptr : c->d_res + ns);
+  if (rc != MALIO_OK) return rc;
+  double E[4];
+  bool have_sums = false;
+  if (spec) {
+    if ((rc = upload(c->node_guess)) != MALIO_OK) return rc;
+    if ((rc = pass_stage2(c, c->d_node_mm, c->d_res + ns, c->d_res, false)) != MALIO_OK) return rc;
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    rc = malio_xchg_reduce(x, res, ns, c->node_guess, res, E, timeout_s);
+    if (rc < 0) return rc;
+    have_sums = rc == MALIO_OK;
+    if (have_sums) c->node_hits++;
+  } else {
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    const double nan4[4] = {NAN, NAN, NAN, NAN};  // never equal: only the extrema are wanted from this exchange
+    rc = malio_xchg_reduce(x, res, ns, nan4, res, E, timeout_s);
+    if (rc < 0) return rc;
+  }
+  if (!have_sums) {  // first pass of a scan, or the extrema moved: weight the rows with the true extrema
+    if (spec) c->node_misses++;
+    if ((rc = upload(E)) != MALIO_OK) return rc;
+    if ((rc = pass_stage2(c, c->d_node_mm, nullptr, c->d_res, false)) != MALIO_OK) return rc;
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    double E2[4];
+    rc = malio_xchg_reduce(x, res, ns, nullptr, res, E2, timeout_s);
+    if (rc != MALIO_OK) return rc < 0 ? rc : MALIO_ERR_HIP;
+  }
+  prof_end(c);
+  memcpy(c->node_guess, E, sizeof(E));
+  c->node_guess_valid = true;
+  memcpy(res + ns, E, sizeof(E));  // finish_host reads the global extrema here, then this rank's own words
+  rc = finish_host(c, res, res + ns, out);
+  c->last_M = out->M;
+  if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;
+  if (stats2) stats2[0] = c->node_hits, stats2[1] = c->node_misses;
+  return rc;
+}
+
+int malio_node_stats(malio_handle_t h, int *stats2) {
+  if (check(h) || !stats2) return MALIO_ERR_BAD_ARG;
+  stats2[0] = h->node_hits, stats2[1] = h->node_misses;
+  return MALIO_OK;
+}
+
 int malio_measure_finish(malio_handle_t h, const double *sums_host, const double *minmax_host,
                          malio_measure_out_t *out) {
   if (check(h) || !sums_host || !minmax_host || !out) return MALIO_ERR_BAD_ARG;

@@ -193,6 +193,12 @@ struct Ctx {
   ResCloud res[MALIO_MAX_LIDAR];
   void *h_stage = nullptr;  // pinned upload staging (map_build, scan_set), grown on demand
   size_t cap_stage = 0;
+  // malio_measure_node: extrema the rows are weighted with (device copy + pinned staging), the guess carried from pass
+  // to pass of one scan
+  double *d_node_mm = nullptr, *h_node_mm = nullptr;
+  double node_guess[4] = {0, 0, 0, 0}, node_uploaded[4] = {0, 0, 0, 0};
+  bool node_guess_valid = false, node_uploaded_valid = false;
+  int node_hits = 0, node_misses = 0;
   u32 *h_mbox = nullptr, *d_mbox = nullptr;  // pinned + device alias: small results for the host (counts), written
                                              // by kernels or copies; one stream sync serves all
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`

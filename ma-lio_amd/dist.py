@@ -233,38 +233,31 @@ class HipBackend:
                 return f2e(h, vp_mmg, vp_mm, vp_sums)
             return f2(h, vp_mmg, vp_sums)
 
-        if mode == "shm":
-            # after the stream sync ONE call gathers the rows, forms the true extrema, checks the guess and adds the
-            # rows in rank order (malio_xchg_reduce): the host side of a speculating pass is three calls into the library
-            xr, xh, to = lib.malio_xchg_reduce, xchg.h, C.c_double(xchg.timeout)
-            E_buf = np.zeros(4, np.float64)
-            E_ptr = C.cast(E_buf.ctypes.data, C.POINTER(C.c_double))
-            g_buf = np.zeros(4, np.float64)
-            g_ptr = C.cast(g_buf.ctypes.data, C.POINTER(C.c_double))
+        if mode == "shm" and speculate:
+            # the whole pass - stage 1, stage 2 with the guessed extrema, exchange, verification, finish - is one call
+            # into the library (malio_measure_node), exactly what a C++ integration would use
+            fnode, xh = lib.malio_measure_node, xchg.h
+            stats2 = (C.c_int * 2)()
 
             def fn():
-                spec = speculate and st["guess"] is not None
-                rc = f1(h, sp, cv, None if spec else vp_mm)
+                rc = fnode(h, xh, sp, cv, op, stats2)
+                st["hits"], st["misses"] = stats2[0] - base[0], stats2[1] - base[1]
+                return rc
+            base = list(eng.node_stats())
+            fn._keep = (s, out, xchg, stats2)
+            return fn, out
+        if mode == "shm":
+            # plain two-exchange sequence through shared memory (speculate=False): kept in Python, it is the reference
+            # the speculating pass is tested against
+            E_buf = np.zeros(4, np.float64)
+            E_ptr = C.cast(E_buf.ctypes.data, C.POINTER(C.c_double))
+            xr, xh, to = lib.malio_xchg_reduce, xchg.h, C.c_double(xchg.timeout)
+
+            def fn():
+                rc = f1(h, sp, cv, vp_mm)
                 if rc < 0:
                     return rc
-                if spec:
-                    rc = stage2_with(st["guess"], emit=True)
-                    if rc < 0:
-                        return rc
-                    g_buf[:] = st["guess"]
-                    stream.synchronize()
-                    r = xr(xh, hp_sums, ns, g_ptr, hp_sums, E_ptr, to)          # sums and extrema land in hostn
-                    if r == 0:
-                        hostn[ns:ns + 4] = E_buf
-                        st["hits"] += 1
-                        return f3(h, hp_sums, hp_mm, op)
-                    if r != 1:
-                        raise capi.MalioError("malio_xchg_reduce rc=%d (a rank is missing?)" % r)
-                    st["misses"] += 1
-                    E = E_buf.copy()
-                else:
-                    E = all_rows()[:, ns:ns + 4].max(axis=0)                    # only the extrema words are valid yet
-                st["guess"] = E
+                E = all_rows()[:, ns:ns + 4].max(axis=0)                        # only the extrema words are valid yet
                 rc = stage2_with(E)
                 if rc < 0:
                     return rc
@@ -274,7 +267,7 @@ class HipBackend:
                     raise capi.MalioError("malio_xchg_reduce rc=%d (a rank is missing?)" % r)
                 hostn[ns:ns + 4] = E
                 return f3(h, hp_sums, hp_mm, op)
-            fn._keep = (s, out, mmg, e_pin, xchg, E_buf, g_buf, rb)
+            fn._keep = (s, out, mmg, e_pin, xchg, E_buf, rb)
             return fn, out
 
         def fn():

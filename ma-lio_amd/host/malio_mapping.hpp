@@ -189,6 +189,19 @@ class Mapping {
       ekfom_data.R.resize(out.M);
     }
   }
+  // h_share_model of a scan sharded over the ranks of one node (malio_measure_node): same fused outputs, scan-global
+  // weights, normal equations of the whole scan; every rank then runs the same filter step on the same bits
+  void h_share_model_node(malio_xchg_t x, const malio_state_t &s, dyn_share_datastruct &ekfom_data) {
+    const int C = 6 * (1 + h_.params().lid_num);
+    malio_measure_out_t out;
+    memset(&out, 0, sizeof(out));
+    int rc = malio_measure_node(h_.get(), x, &s, ekfom_data.converge ? 1 : 0, &out, nullptr);
+    h_.check(rc, "measure_node");
+    ekfom_data.valid = out.valid != 0;
+    ekfom_data.rows = out.M, ekfom_data.cols = C, ekfom_data.w_loc = out.w_loc;
+    ekfom_data.HtRinvH.assign(out.HtRinvH, out.HtRinvH + (size_t)C * C);
+    ekfom_data.HtRinvh.assign(out.HtRinvh, out.HtRinvh + C);
+  }
   // kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time), laserMapping.cpp:1052.
   // P: n x n row-major, n = 17 + 6 lid_num.
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {

@@ -133,6 +133,8 @@ int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double
   return MALIO_OK;
 }
 
+int malio_xchg_row(malio_xchg_t x) { return x ? x->row : 0; }
+
 int malio_xchg_unlink(malio_xchg_t x) {  // once every rank has opened the segment its name is no longer needed
   if (!x) return MALIO_ERR_BAD_ARG;
   if (x->owner) {
