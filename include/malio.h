@@ -366,6 +366,11 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
                        int *stats2);
 
 int malio_node_stats(malio_handle_t h, int *stats2); /* the two counters of malio_measure_node */
+/* malio_update_iterated with malio_measure_node as h_dyn_share: every rank calls it with the same x and P and gets
+ * the same posterior (bit for bit). Returns MALIO_SMALL_M_FALLBACK when fewer points than states were accepted
+ * (esekfom.hpp:574-582 needs the rows of every rank: not a sharded path). */
+int malio_update_iterated_node(malio_handle_t h, malio_xchg_t x, malio_state_t *state, double *P, double R, int *stats,
+                               double *solve_time);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded

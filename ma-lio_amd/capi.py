@@ -23,7 +23,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -415,6 +415,18 @@ class Engine:
     def scan_order(self, mode):
         """malio_scan_order: 0 auto (host scans sorted, resident scans as they are), 1 always sort, 2 never sort."""
         self._chk(lib().malio_scan_order(self.h, int(mode)), "malio_scan_order")
+
+    def update_iterated_node(self, xchg, state_flat, P, R=0.001):
+        """malio_update_iterated_node: the iterated update over a scan sharded across the ranks of one node."""
+        n = 17 + 6 * self.L
+        s = state_from_flat(state_flat, self.L)
+        P = np.array(P, np.float64, order="C").reshape(n, n)
+        stats = (C.c_int * 4)()
+        st = C.c_double(0)
+        rc = self._chk(lib().malio_update_iterated_node(self.h, xchg.h, C.byref(s), _p(P, C.c_double), C.c_double(R), stats,
+                                                        C.byref(st)), "malio_update_iterated_node")
+        return dict(rc=rc, state=state_to_flat(s, self.L), P=P, passes=int(stats[0]), searches=int(stats[1]),
+                    M=int(stats[2]), solve_time=st.value)
 
     def node_stats(self):
         """(passes of malio_measure_node that needed one exchange, passes that needed two) so far."""

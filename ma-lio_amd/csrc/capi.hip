@@ -559,6 +559,14 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
   return rc;
 }
 
+int malio_update_iterated_node(malio_handle_t h, malio_xchg_t xchg, malio_state_t *x, double *P, double R, int *stats,
+                               double *solve_time) {
+  if (check(h) || !xchg || !x || !P) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP_H(hipSetDevice(h->device));
+  if (solve_time) *solve_time = 0;
+  return ieskf_update(h, xchg, x, P, R, stats, solve_time);
+}
+
 int malio_node_stats(malio_handle_t h, int *stats2) {
   if (check(h) || !stats2) return MALIO_ERR_BAD_ARG;
   stats2[0] = h->node_hits, stats2[1] = h->node_misses;
@@ -702,7 +710,7 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
 int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats, double *solve_time) {
   if (check(h) || !x || !P) return MALIO_ERR_BAD_ARG;
   MALIO_HIP_H(hipSetDevice(h->device));
-  return ieskf_update(h, x, P, R, stats, solve_time);
+  return ieskf_update(h, nullptr, x, P, R, stats, solve_time);
 }
 
 // Diagnostics (not part of the reference interface): {level-1 directory cells, map points, level-2 directory cells}.

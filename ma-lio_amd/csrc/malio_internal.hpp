@@ -357,7 +357,7 @@ constexpr double DEFER_SCORE_MIN = 64.0;
 // host/predict.cpp
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp
-int ieskf_update(Ctx *c, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
 int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
                const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
                int *done_out, double *P_out);

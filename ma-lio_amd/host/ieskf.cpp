@@ -256,7 +256,7 @@ int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_sta
                    converge_out, done_out, P_out);
 }
 
-int ieskf_update(Ctx *c, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
+int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
   const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
   malio_state_t x_ = *xio;
   const malio_state_t x_propagated = x_;
@@ -268,11 +268,14 @@ int ieskf_update(Ctx *c, malio_state_t *xio, double *Pio, double R, int *stats, 
   for (int i = -1; i < maximum_iter; i++) {  // esekfom.hpp:509
     memset(&mo, 0, sizeof(mo));
     searches += converge ? 1 : 0;
-    int rc = malio_measure((malio_handle_t)c, &x_, converge, &mo);
+    // h_dyn_share: the fused pass over this GPU's scan, or - with an exchange - over the scan sharded across the node
+    int rc = xchg ? malio_measure_node((malio_handle_t)c, xchg, &x_, converge, &mo, nullptr)
+                  : malio_measure((malio_handle_t)c, &x_, converge, &mo);
     passes++;
     if (rc < 0) return rc;
     if (!mo.valid) continue;  // :514-517
     lastM = mo.M;
+    if (xchg && n > mo.M) return MALIO_SMALL_M_FALLBACK;  // the M x M form needs every rank's rows: not a sharded path
     auto t0 = std::chrono::steady_clock::now();
     GainFn gain;
     if (n > mo.M) {

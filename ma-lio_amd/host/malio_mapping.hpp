@@ -202,6 +202,11 @@ class Mapping {
     ekfom_data.HtRinvH.assign(out.HtRinvH, out.HtRinvH + (size_t)C * C);
     ekfom_data.HtRinvh.assign(out.HtRinvh, out.HtRinvh + C);
   }
+  // the iterated update over a scan sharded across the ranks of one node (every rank: same x, P in, same posterior out)
+  void update_iterated_dyn_share_modified_node(malio_xchg_t x, malio_state_t &state, std::vector<double> &P, double R,
+                                               double &solve_time) {
+    h_.check(malio_update_iterated_node(h_.get(), x, &state, P.data(), R, nullptr, &solve_time), "update_iterated_node");
+  }
   // kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time), laserMapping.cpp:1052.
   // P: n x n row-major, n = 17 + 6 lid_num.
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {

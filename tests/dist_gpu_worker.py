@@ -44,6 +44,22 @@ fn2, out2 = be.pass_fn(st2, True, speculate=True)
 for _ in range(3):
     assert fn2() >= 0
 res["moved"] = dict(M=int(out2.M), H=[float(x) for x in out2.HtRinvH[:eng.C * eng.C]])
+# the whole iterated update, sharded, in one library call per rank (shared-memory exchange; host-only hand-shake here)
+from malio_amd.dist import exchange_mode  # noqa: E402
+if exchange_mode() == "shm":
+    name = "/malio_worker_upd_%s" % os.environ.get("MASTER_PORT", "0")
+    row = eng.sums_len() + 8
+    x = capi.NodeExchange(name, 0, W, row, create=True) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        x = capi.NodeExchange(name, rank, W, row, create=False)
+    dist.barrier()
+    if rank == 0:
+        x.unlink()
+    eng.scan_set(scan_all[lo:hi], sc["tables"], sc["temporal_comp"])
+    u = eng.update_iterated_node(x, sc["state0"], sc["P0"])
+    res["update"] = dict(state=[float(v) for v in u["state"]], P00=float(u["P"][0, 0]), passes=u["passes"], M=u["M"])
+    x.close()
 allres = [None] * W
 dist.all_gather_object(allres, res)
 if rank == 0:

@@ -446,6 +446,13 @@ def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes, exch
     H = np.array(r0["spec"]["H"]).reshape(eng.C, eng.C)
     assert r0["spec"]["M"] == ref["M"] and r0["spec"]["w"] == pytest.approx(ref["w_loc"], rel=1e-12)
     assert np.allclose(H, ref["HtRinvH"], rtol=0, atol=1e-12 * np.abs(ref["HtRinvH"]).max())
+    if exchange == "shm":   # the sharded iterated update against the single-engine one
+        uref = eng.update_iterated(sc["state0"], sc["P0"])
+        up = r0["update"]
+        assert (up["passes"], up["M"]) == (uref["passes"], uref["M"])
+        assert np.abs(np.array(up["state"]) - uref["state"]).max() < 1e-9
+        assert up["P00"] == pytest.approx(uref["P"][0, 0], rel=2e-3)   # P carries the order sensitivity of esekfom.hpp:637,714
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     st2 = np.array(sc["state0"], np.float64).copy()
     st2[:3] += (0.02, -0.01, 0.015)
     ref2 = eng.measure(st2, True)
