@@ -288,6 +288,22 @@ def main():
                 "iter_ms": float(np.median(ts) * 1e3 / max(passes, 1)),
                 "host_algebra_ms": float(np.median(solve) * 1e3)}  # a11: the n x n filter algebra of all passes
 
+    elif getattr(be, "xchg", None) is not None:   # the sharded update, one library call per rank (malio_update_iterated_node)
+        ts, passes = [], 0
+        for _ in range(10):
+            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            step()                   # per-scan spatial sort happens on the first pass; keep it out
+            fence()
+            t = time.perf_counter()
+            u = eng.update_iterated_node(be.xchg, state, sc["P0"])
+            fence()
+            ts.append(time.perf_counter() - t)
+            passes = u["passes"]
+        tmed = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmed, op=dist.ReduceOp.MAX)
+        eskf = {"update_ms": float(tmed.item() * 1e3), "passes": passes, "iter_ms": float(tmed.item() * 1e3 / max(passes, 1)),
+                "sharded": True}
+
     # ---- roofline of the dominant kernel: hipEvents on the engine's stream, same command ----
     roofline = None
     if rank == 0:

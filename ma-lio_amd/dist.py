@@ -233,6 +233,7 @@ class HipBackend:
                 return f2e(h, vp_mmg, vp_mm, vp_sums)
             return f2(h, vp_mmg, vp_sums)
 
+        self.xchg = xchg                                                        # None unless the rows travel through shared memory
         if mode == "shm" and speculate:
             # the whole pass - stage 1, stage 2 with the guessed extrema, exchange, verification, finish - is one call
             # into the library (malio_measure_node), exactly what a C++ integration would use
