@@ -62,7 +62,8 @@ def test_oracle_voxelgrid_edge_cases(orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n,leaf,mode", [(1, 200000, 0.5, 1), (2, 30000, 0.3, 0), (3, 500, 2.0, 1), (4, 1, 0.5, 0)])
+@pytest.mark.parametrize("seed,n,leaf,mode", [(1, 200000, 0.5, 1), (2, 30000, 0.3, 0), (3, 500, 2.0, 1), (4, 1, 0.5, 0),
+                                              (5, 1_200_000, 0.5, 1)])  # > 1 M points: the three-kernel scan path
 def test_gpu_voxelgrid_equals_oracle(orc, capi, scenes, seed, n, leaf, mode):
     rng = np.random.default_rng(seed)
     p = _cloud(rng, n)
