@@ -335,7 +335,15 @@ static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *p
     c->unc_off[l] = tot, c->unc_len[l] = pose_unc_len[l];
     tot += pose_unc_len[l];
   }
-  std::vector<UncEntry> ue(tot);
+  // folded entries are staged in the pinned mailbox (words 4096..) when they fit, so that the copy is queued like
+  // everything else instead of blocking the call (a few KB; the stream is synchronised by every pass, long before the
+  // next scan overwrites the staging area)
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  const size_t bytes = sizeof(UncEntry) * (size_t)tot;
+  const bool staged = bytes <= sizeof(u32) * (MBOX_WORDS - 4096);
+  std::vector<UncEntry> ue_heap(staged ? 0 : tot);
+  UncEntry *ue = staged ? reinterpret_cast<UncEntry *>(mb + 4096) : ue_heap.data();
   for (int l = 0; l < L; l++)
     for (int k = 0; k < pose_unc_len[l]; k++) fold_entry(pose_unc[l][k], ue[c->unc_off[l] + k]);
   if ((size_t)tot > c->cap_unc) {
@@ -343,7 +351,10 @@ static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *p
     c->cap_unc = tot + 64;
     MALIO_HIP(hipMalloc(&c->d_unc, sizeof(UncEntry) * c->cap_unc));
   }
-  MALIO_HIP(hipMemcpy(c->d_unc, ue.data(), sizeof(UncEntry) * tot, hipMemcpyHostToDevice));
+  if (staged)
+    MALIO_HIP(hipMemcpyAsync(c->d_unc, ue, bytes, hipMemcpyHostToDevice, c->stream));
+  else
+    MALIO_HIP(hipMemcpy(c->d_unc, ue, bytes, hipMemcpyHostToDevice));
   for (int l = 0; l + 1 < L; l++) {
     for (int k = 0; k < 4; k++) c->tcq[l][k] = temporal_comp[l].q[k];
     for (int k = 0; k < 3; k++) c->tct[l][k] = temporal_comp[l].t[k];

@@ -601,13 +601,17 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
     s = (s + 1) & nl.tmask;
   }
   const u32 st = nl.table[s].start, cn = nl.table[s].count;
+  const int gsh = (threadIdx.x & 63) & ~15;  // first lane of this 16-lane group inside the wave
   for (u32 j = (u32)sub; j < cn; j += 16 * 4) {  // 4 independent loads in flight per lane
     u32 og[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) og[u] = __float_as_uint(nl.pts[(size_t)st + min(j + 16u * u, cn - 1)].w);
+    bool hit = false;
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (og[u] == i && j + 16u * u < cn) nl.pts[(size_t)st + j + 16u * u].x = INFINITY;  // one entry per list matches
+      if (og[u] == i && j + 16u * u < cn) nl.pts[(size_t)st + j + 16u * u].x = INFINITY, hit = true;
+    // one entry per list matches: once a lane of the group has found it the rest of the list need not be read
+    if ((__ballot(hit) >> gsh) & 0xFFFFull) break;
   }
 }
 
