@@ -47,3 +47,17 @@ def test_bad_args(capi):
     prm = capi.make_params(dict(lid_num=9))
     assert lib.malio_create(C.byref(prm), 0, C.byref(h)) == -3
     assert lib.malio_destroy(None) == -3
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/malio.h is the boundary a C or cgo/JNI/ctypes binding compiles against: C99, no C++ anywhere."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "malio.h"\n'
+                   'int main(void) { malio_xchg_t x = 0; malio_handle_t h = 0; (void)x; (void)h;\n'
+                   '  return (MALIO_ERR_TIMEOUT == -7 && MALIO_SCAN_ORDER_KEEP == 2 && sizeof(malio_point_t) == 48) ? 0 : 1; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", exe])
+    assert subprocess.call([exe]) == 0
