@@ -57,5 +57,34 @@ def main():
         print(name, "M", r["M"], "passes", u["passes"], os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024, "KiB")
 
 
+def predict_fixture():
+    """tests/golden/predict_chain.npz: 50 steps of esekf::predict (oracle restatement) on a 3-LiDAR state, 200 Hz."""
+    L = 3
+    sc = scenes.make_scene(seed=105, N=200, Nmap=3000, L=L)
+    rng = np.random.default_rng(105)
+    x = np.array(sc["state0"], np.float64)
+    iv = 7 + 7 * L                                       # flat index of vel (quaternions take 4)
+    x[iv:iv + 3] = [1.5, -0.4, 0.1]
+    x[iv + 3:iv + 9] = rng.normal(size=6) * 0.01         # bg, ba
+    x_start = x.copy()
+    P = np.array(sc["P0"], np.float64)
+    Q = np.diag([1e-2] * 3 + [1e-1] * 3 + [1e-4] * 3 + [1e-3] * 3)
+    accs, gyros, xs, P10 = [], [], [], None
+    for k in range(50):
+        t = k * 0.005
+        acc = np.array([np.sin(t) * 2, np.cos(2 * t), 9.8 + 0.3 * np.sin(3 * t)])
+        gyro = np.array([0.3 * np.cos(t), 0.2 * np.sin(2 * t), 0.5])
+        x, P = orc.predict(L, x, P, 0.005, Q, acc, gyro)
+        accs.append(acc), gyros.append(gyro), xs.append(x.copy())
+        if k == 9:
+            P10 = P.copy()
+    np.savez_compressed(os.path.join(HERE, "predict_chain.npz"), L=L, x_start=x_start, P0=np.array(sc["P0"], np.float64),
+                        Q=Q, dt=0.005, acc=np.array(accs), gyro=np.array(gyros), x=np.array(xs), P_10=P10, P_50=P)
+    print("predict_chain", os.path.getsize(os.path.join(HERE, "predict_chain.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "predict":
+        predict_fixture()     # python tests/golden/make_golden.py predict   (leaves the scene fixtures untouched)
+    else:
+        main()

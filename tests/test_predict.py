@@ -265,3 +265,23 @@ def test_state_only_and_errors(capi, orc, scenes):
     assert lib.malio_predict(L, None, None, C.c_double(0.01), None, a, a) == capi.ERR_BAD_ARG
     assert lib.malio_predict(L, C.byref(s), None, C.c_double(0.01), None, None, a) == capi.ERR_BAD_ARG
     assert lib.malio_predict(L, C.byref(s), P, C.c_double(0.01), None, a, a) == capi.ERR_BAD_ARG  # P without Q
+
+
+def test_golden_chain(capi, orc):
+    """tests/golden/predict_chain.npz (tests/golden/make_golden.py predict): the committed pin of the propagation step -
+    the oracle must keep reproducing it bit for bit, the product's banded form to rounding."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "predict_chain.npz"))
+    L, dt, Q = int(z["L"]), float(z["dt"]), z["Q"]
+    xo = xg = z["x_start"]
+    Po = Pg = z["P0"]
+    for k in range(z["acc"].shape[0]):
+        xo, Po = orc.predict(L, xo, Po, dt, Q, z["acc"][k], z["gyro"][k])
+        xg, Pg = capi.predict(L, xg, Pg, dt, Q, z["acc"][k], z["gyro"][k])
+        assert np.array_equal(xo, z["x"][k])
+        assert np.allclose(xg, z["x"][k], rtol=0, atol=1e-11)
+        if k == 9:
+            assert np.array_equal(Po, z["P_10"])
+            assert np.allclose(Pg, z["P_10"], rtol=1e-10, atol=1e-18)
+    assert np.array_equal(Po, z["P_50"])
+    assert np.allclose(Pg, z["P_50"], rtol=1e-10, atol=1e-18)
