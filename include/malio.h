@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MALIO_ABI_VERSION 1
+#define MALIO_ABI_VERSION 2
 #define MALIO_MAX_LIDAR 4       /* reference ships lid_num in {1,2,3} (src/use-ikfom.hpp:12-41) */
 #define MALIO_NUM_MATCH_POINTS 5 /* include/common_lib.h:22 */
 
@@ -85,7 +85,11 @@ typedef struct malio_params {
   double localize_thresh_max, localize_thresh_min;
   double filter_size_map; /* filter_size_map_min: ikdtree.set_downsample_param, laserMapping.cpp:999 */
   float cell_size;        /* level-1 neighbour-list cell edge [m]; 0 = default 1.125 (>= sqrt(5)/2; level 2 uses twice this) */
-  int32_t reserved[3];
+  int32_t reserved;
+  double limit;           /* convergence threshold of the iterated update on every tangent component: esekf's member
+                           * `limit[n]` (esekfom.hpp:894), compared at :649-657; init_dyn_share sets every entry to
+                           * 0.001 (:160-163). 0 = that value. A tighter limit keeps the loop iterating up to
+                           * max_iteration + 1 passes (BASELINE config 5: "10 IESKF iterations"). */
 } malio_params_t;
 
 /* == the parts of state_ikfom (src/use-ikfom.hpp:14-27) h_share_model reads, plus the rest of the
@@ -226,7 +230,11 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
 /* Side effects later reference code relies on, in original scan order; any pointer
  * may be NULL: feats_down_body[i].normal_y (:699,730,741) | Nearest_Points[i] (:582, read by
  * map_incremental :411-435) + sizes | point_selected_surf[i] | res_last[i] (:609) |
- * feats_down_world xyz (:576-578) | normvec (n, pd2) (:604-607). */
+ * feats_down_world xyz (:576-578) | normvec (n, pd2) (:604-607).
+ * Nearest_Points are the 5 nearest map points of the last SEARCH pass at ANY distance, ascending, like
+ * ikdtree.Nearest_Search leaves them (ikd_Tree.cpp:426-461 has no radius; nearest_count = min(5, map size)): points
+ * with fewer than five neighbours inside the sqrt(5) m acceptance radius get an exact unrestricted search here, so
+ * the reference's own map_incremental loop (:411-435) can run unchanged on what this returns. */
 int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, int *nearest_count,
                    uint8_t *selected, float *res_last, float *world_xyz, float *normvec4);
 
@@ -236,13 +244,20 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
 int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats,
                           double *solve_time);
 
+/* h_dyn_share is a plain function in the reference (esekfom.hpp:130,512): whatever it does - tracing, or finding the
+ * map changed under it - happens once per pass on the calling thread. fn(pass, user) is called before every
+ * measurement pass of malio_update_iterated[_node] with the 0-based pass number; NULL removes it. */
+int malio_set_pass_hook(malio_handle_t h, void (*fn)(int pass, void *user), void *user);
+
 /* One iteration of the update loop AFTER its measurement pass (esekfom.hpp:521-720, the M >= n branch
  * :621-637), on the reduced normal equations. Pure host code, needs no handle and no GPU: a multi-GPU
  * driver calls it between its collectives. iter_index = loop index i of esekfom.hpp:509 (-1 ...
  * max_iteration-1); x: in = state the pass was evaluated at, out = x [+] dx; t_io = converged-iteration
  * counter (:658); converge_out = ekfom_data.converge for the next pass; done_out = 1 when P_out (n x n)
- * holds the posterior and the loop ends (:665-718). */
-int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state_t *x,
+ * holds the posterior and the loop ends (:665-718); otherwise P_out receives the projected P_propagated of this
+ * iteration (the value of the reference's member P_ after :531-572): a loop that runs out on invalid passes leaves
+ * the filter with the one of its last valid iteration. limit: params.limit (0 = 0.001). */
+int malio_ieskf_step(int lid_num, int max_iteration, double limit, int iter_index, malio_state_t *x,
                      const malio_state_t *x_propagated, const double *P_propagated, const double *HtRinvH,
                      const double *HtRinvh, int *t_io, int *converge_out, int *done_out, double *P_out);
 

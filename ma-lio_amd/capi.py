@@ -23,7 +23,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
 ]
 
@@ -44,7 +44,7 @@ class Params(C.Structure):  # malio_params_t
                 ("plane_cov_max", C.c_double), ("plane_cov_min", C.c_double), ("localize_cov_max", C.c_double),
                 ("localize_cov_min", C.c_double), ("localize_thresh_max", C.c_double),
                 ("localize_thresh_min", C.c_double), ("filter_size_map", C.c_double), ("cell_size", C.c_float),
-                ("reserved", C.c_int32 * 3)]
+                ("reserved", C.c_int32), ("limit", C.c_double)]
 
 
 class State(C.Structure):  # malio_state_t
@@ -341,6 +341,12 @@ class Engine:
                                        _p(out["normvec"], C.c_float)), "malio_scan_get")
         return out
 
+    def set_pass_hook(self, fn):
+        """malio_set_pass_hook: fn(pass_number) runs on the host before every measurement pass of update_iterated."""
+        proto = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+        self._hook = proto(lambda k, _u: fn(k)) if fn else None
+        self._chk(lib().malio_set_pass_hook(self.h, self._hook if fn else C.cast(None, proto), None), "malio_set_pass_hook")
+
     def update_iterated(self, state_flat, P, R=0.001):
         s = state_from_flat(state_flat, self.L)
         P = np.ascontiguousarray(P, np.float64).copy()
@@ -466,7 +472,7 @@ class Engine:
                     HtRinvH=np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), HtRinvh=np.array(out.HtRinvh[:Cc]))
 
 
-def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh, t):
+def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh, t, limit=0.0):
     """malio_ieskf_step (pure host, no GPU). Returns (x_new_flat, t, converge, done, P_out)."""
     n = 17 + 6 * L
     x = state_from_flat(x_flat, L)
@@ -476,7 +482,7 @@ def ieskf_step(L, max_iteration, i, x_flat, xprop_flat, P_prop, HtRinvH, HtRinvh
     hv = np.ascontiguousarray(HtRinvh, np.float64)
     P_out = np.zeros((n, n), np.float64)
     t_io, conv, done = C.c_int(int(t)), C.c_int(0), C.c_int(0)
-    rc = lib().malio_ieskf_step(int(L), int(max_iteration), int(i), C.byref(x), C.byref(xp), _p(P_prop, C.c_double),
+    rc = lib().malio_ieskf_step(int(L), int(max_iteration), C.c_double(limit), int(i), C.byref(x), C.byref(xp), _p(P_prop, C.c_double),
                                 _p(H, C.c_double), _p(hv, C.c_double), C.byref(t_io), C.byref(conv), C.byref(done),
                                 _p(P_out, C.c_double))
     if rc != OK:

@@ -71,15 +71,23 @@ static void fold_entry(const malio_pose_t &p, UncEntry &e) {
   e.Q[5] = -0.5 * (Srr[1][2] + Srr[2][1]);
 }
 
+// Nearest_Points[i] in the caller's order: the five of the search pass where it found five inside sqrt(5) m, else the
+// unrestricted 5-NN (far_knn5) - ikdtree.Nearest_Search has no radius (ikd_Tree.cpp:426-461)
 __global__ void __launch_bounds__(BLK) k_gather_side(int N, const u32 *__restrict__ perm, const u32 *__restrict__ nbr,
-                                                     const float4 *__restrict__ map_pts, float4 *out_near /*[N][5]*/) {
+                                                     const u32 *__restrict__ far, const unsigned char *__restrict__ nfound,
+                                                     const float4 *__restrict__ map_pts, float4 *out_near /*[N][5]*/,
+                                                     int *out_cnt /*[N] caller's order*/) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= N) return;
   u32 o = perm[i];
+  const u32 *src = nfound[i] >= 5 ? nbr : far;
+  int cnt = 0;
   for (int k = 0; k < 5; k++) {
-    u32 j = nbr[(size_t)k * N + i];  // original map index
+    u32 j = src[(size_t)k * N + i];  // original map index
+    cnt += j != 0xFFFFFFFFu;
     out_near[(size_t)o * 5 + k] = (j != 0xFFFFFFFFu) ? map_pts[j] : make_float4(0, 0, 0, 0);
   }
+  out_cnt[o] = cnt;
 }
 
 }  // namespace malio
@@ -675,19 +683,31 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(plane.data(), c->d_plane, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
   std::vector<float4> near;
-  if (nearest && c->nbr_epoch != c->map_epoch) {
+  if ((nearest || nearest_count) && c->nbr_epoch != c->map_epoch) {
     c->err = "malio_scan_get: the map changed after the last search pass; read Nearest_Points before map_add/delete";
     return MALIO_ERR_BAD_ARG;
   }
-  if (nearest) {
+  std::vector<int> near_cnt;
+  if (nearest || nearest_count) {
+    if (int rcs = map_sync_search(c)) return rcs;
+    if (c->nbr_epoch != c->map_epoch) {  // (a rebuild renumbered the map)
+      c->err = "malio_scan_get: the map changed after the last search pass; read Nearest_Points before map_add/delete";
+      return MALIO_ERR_BAD_ARG;
+    }
+    ArenaScope sc(c->arena);
     float4 *d_near = nullptr;
-    MALIO_HIP(hipMalloc(&d_near, sizeof(float4) * 5 * (size_t)N));
-    hipLaunchKernelGGL(k_gather_side, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, N, c->d_perm, c->d_nbr,
-                       c->d_map_in, d_near);
-    near.resize((size_t)5 * N);
+    u32 *d_far = nullptr;
+    int *d_cnt = nullptr;
+    MALIO_HIP(sc.get(&d_near, 5 * (size_t)N));
+    MALIO_HIP(sc.get(&d_far, 5 * (size_t)N));
+    MALIO_HIP(sc.get(&d_cnt, (size_t)N));
+    if (int rcf = far_knn5(c, d_far)) return rcf;
+    hipLaunchKernelGGL(k_gather_side, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, N, c->d_perm, c->d_nbr, d_far,
+                       c->d_nfound, c->d_map_in, d_near, d_cnt);
+    near.resize((size_t)5 * N), near_cnt.resize(N);
     MALIO_HIP(hipMemcpyAsync(near.data(), d_near, sizeof(float4) * near.size(), hipMemcpyDeviceToHost, c->stream));
+    MALIO_HIP(hipMemcpyAsync(near_cnt.data(), d_cnt, sizeof(int) * N, hipMemcpyDeviceToHost, c->stream));
     MALIO_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_near);
   }
   MALIO_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < N; i++) {
@@ -698,7 +718,7 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
       bool untouched = (c->last_M <= 0) || (sel[i] && !c->prm.extrinsic_est_en);
       normal_y[o] = untouched ? ny[i] : (float)tr[i];
     }
-    if (nearest_count) nearest_count[o] = nf[i];
+    if (nearest_count) nearest_count[o] = near_cnt[o];
     if (selected) selected[o] = sel[i];
     if (res_last) res_last[o] = sel[i] ? fabsf(pd2[i]) : 0.f;
     if (world_xyz) world_xyz[3 * o] = world[i], world_xyz[3 * o + 1] = world[N + i], world_xyz[3 * o + 2] = world[2 * N + i];
@@ -733,13 +753,19 @@ int malio_debug_counters(malio_handle_t h, int *out8) {
   return MALIO_OK;
 }
 
-int malio_ieskf_step(int lid_num, int max_iteration, int iter_index, malio_state_t *x, const malio_state_t *x_propagated,
+int malio_set_pass_hook(malio_handle_t h, void (*fn)(int, void *), void *user) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  h->pass_hook = fn, h->pass_hook_user = user;
+  return MALIO_OK;
+}
+
+int malio_ieskf_step(int lid_num, int max_iteration, double limit, int iter_index, malio_state_t *x, const malio_state_t *x_propagated,
                      const double *P_propagated, const double *HtRinvH, const double *HtRinvh, int *t_io,
                      int *converge_out, int *done_out, double *P_out) {
   if (lid_num < 1 || lid_num > MALIO_MAX_LIDAR || !x || !x_propagated || !P_propagated || !HtRinvH || !HtRinvh ||
       !t_io || !converge_out || !done_out || !P_out)
     return MALIO_ERR_BAD_ARG;
-  return ieskf_step(lid_num, max_iteration, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
+  return ieskf_step(lid_num, max_iteration, limit, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
                     converge_out, done_out, P_out);
 }
 

@@ -258,6 +258,8 @@ struct Ctx {
   double *d_rows = nullptr;      // optional dense rows [N][C+2]
   size_t cap_rows = 0;
   size_t cap_partials = 0;
+  void (*pass_hook)(int, void *) = nullptr;  // malio_set_pass_hook
+  void *pass_hook_user = nullptr;
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -308,6 +310,7 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
 // measure.hip: PointToAdd / PointNoNeedDownsample membership + world points, all in ORIGINAL scan order
 int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
                     u32 *d_nonf, float4 *d_wp);
+int far_knn5(Ctx *c, u32 *d_far);  // measure.hip: unrestricted 5-NN of the queries with nfound < 5, [5][N] sorted order
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
@@ -358,7 +361,7 @@ constexpr double DEFER_SCORE_MIN = 64.0;
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
-int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
                int *done_out, double *P_out);
 

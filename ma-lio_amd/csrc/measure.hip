@@ -665,7 +665,11 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool pend = (q0 + lane < a.N) && s_nf[lane] == NF_PENDING;  // lane <-> query, the same in every wave
     unsigned long long todo = __ballot(pend);
-    if (todo) {  // workgroup-uniform: every wave reads the same flags
+    // every wave must have taken its snapshot of the flags before any wave rewrites one (the serving wave stores the
+    // final count, wave 0 stores NF_DEFERRED): a wave that read s_nf late would see a different `todo`, the round-robin
+    // assignment below would differ between waves and a query could be left NF_PENDING
+    __syncthreads();
+    if (todo) {  // workgroup-uniform: every wave took the same snapshot
       const int npend = __popcll(todo);
       PH_NOTE(3, npend);
       const bool heavy = npend > DEFER_MIN;
@@ -1106,21 +1110,32 @@ int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d
 // the query cell, until the best distance is inside the covered cube; then (rare) a scan of the whole map.
 constexpr int FAR_RMAX = 6;
 static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
+// K = 1: the nearest map point of the queries with an empty search ball (what :421-425 reads), far_idx[N].
+// K = 5: the unrestricted 5-NN of every query with fewer than five neighbours inside sqrt(5) m, far_idx[5][N] - what
+// ikdtree.Nearest_Search leaves in Nearest_Points[i] (ikd_Tree.cpp:426-461 has no radius), handed out by malio_scan_get.
+template <int K>
 __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__restrict__ world4,
                                                      const unsigned char *__restrict__ nfound, NlView nl,
                                                      const float4 *__restrict__ map_in, int map_n, u32 *far_idx) {
   const int qi = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (qi >= N) return;
-  if (nfound[qi] != 0) {
-    if (lane == 0) far_idx[qi] = INVALID;
+  if (K == 1 ? nfound[qi] != 0 : nfound[qi] >= 5) {
+    if (lane < K) far_idx[(size_t)lane * N + qi] = INVALID;
     return;
   }
   const float4 w = world4[qi];
   const float gx = w.x * nl.inv_cf, gy = w.y * nl.inv_cf, gz = w.z * nl.inv_cf;
   const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
   const float margin = 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
-  float bd = INFINITY;
-  u32 bo = INVALID;
+  // lane-local candidates under the total order (d2, map index); a deleted slot (x = +inf) is at infinite distance
+  Top5 t;
+#pragma unroll
+  for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
+  auto offer = [&](const float4 p, u32 og) {
+    float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
+    float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+    top5_insert(t, d2 < INFINITY ? top5_key(d2, og) : ~0ull);
+  };
   bool done = false;
   for (int r = 0; r <= FAR_RMAX && !done; r++) {
     const int side = 2 * r + 1, nblk = side * side * side;
@@ -1129,7 +1144,7 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
       u32 start = 0, count = 0;
       if (bi < nblk) {
         const int a = bi % side - r, b = (bi / side) % side - r, c = bi / (side * side) - r;
-        if (max(max(abs(a), abs(b)), abs(c)) == r) {  // only the new shell
+        if (max(max(abs(a), abs(b)), abs(c)) == r) {  // only the new shell (the blocks are disjoint: no duplicates)
           u64 key = cell_key_d(cx + 3 * a, cy + 3 * b, cz + 3 * c);
           u32 slot = hash_key_d(key) & nl.tmask;
           cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
@@ -1142,46 +1157,27 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
         const u32 s0 = __shfl(start, src), cn = __shfl(count, src);
         for (u32 j = (u32)lane; j < cn; j += 64) {
           const float4 p = nl.pts[(size_t)s0 + j];
-          float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
-          float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-          u32 og = __float_as_uint(p.w);
-          if (d2 < bd || (d2 == bd && og < bo)) bd = d2, bo = og;
+          offer(p, __float_as_uint(p.w));
         }
       }
     }
-    // best over the wave, (d2, index) order
-    unsigned long long kk = ((unsigned long long)__float_as_uint(bd) << 32) | bo;  // d2 >= 0: bit order == value order
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      unsigned long long other = __shfl_xor(kk, o);
-      kk = other < kk ? other : kk;
-    }
-    const float wd = __uint_as_float((u32)(kk >> 32));
-    const u32 wo = (u32)kk;
+    // best K over the wave; the merged list then lives in lane 0 only, so that a further shell cannot count it twice
+    merge_group<64>(t, INFINITY);
     // everything within (3r+1) cell edges of the query's cell has been seen
     const float reach = (float)(3 * r + 1) * nl.cf - margin;
-    if (wo != INVALID && wd <= reach * reach * 0.99999f) {
-      bd = wd, bo = wo;
-      done = true;
-    }
-  }
-  if (!done) {  // farther than ~40 m from every map point: scan the map
-    bd = INFINITY, bo = INVALID;
-    for (int j = lane; j < map_n; j += 64) {
-      const float4 p = map_in[j];
-      float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
-      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-      if (d2 < bd || (d2 == bd && (u32)j < bo)) bd = d2, bo = (u32)j;
-    }
-    unsigned long long kk = ((unsigned long long)__float_as_uint(bd) << 32) | bo;
+    if (t.og(K - 1) != INVALID && t.d(K - 1) <= reach * reach * 0.99999f) done = true;
+    if (!done && lane != 0) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      unsigned long long other = __shfl_xor(kk, o);
-      kk = other < kk ? other : kk;
+      for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
     }
-    bo = (u32)kk;
   }
-  if (lane == 0) far_idx[qi] = bo;
+  if (!done) {  // farther than ~40 m from every map point (or fewer than K points in the map): scan the map
+#pragma unroll
+    for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
+    for (int j = lane; j < map_n; j += 64) offer(map_in[j], (u32)j);
+    merge_group<64>(t, INFINITY);
+  }
+  if (lane < K) far_idx[(size_t)lane * N + qi] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
 }
 
 struct MapIncArgs {
@@ -1225,7 +1221,8 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
       const float my = (float)(floor((double)wy / a.fs) * a.fs + 0.5 * a.fs);
       const float mz = (float)(floor((double)wz / a.fs) * a.fs + 0.5 * a.fs);
       const float dist = ((wx - mx) * (wx - mx) + (wy - my) * (wy - my)) + (wz - mz) * (wz - mz);
-      const int nf = a.nfound[i];
+      int nf = a.nfound[i];
+      if (nf > 5) nf = 0;  // defence: only 0..5 are ever stored (a search marker must never index nbr[5][N])
       const u32 n0 = nf > 0 ? a.nbr[i] : a.far_idx[i];
       const float4 m0 = a.map_in[n0];
       if ((double)fabsf(m0.x - mx) > 0.5 * a.fs && (double)fabsf(m0.y - my) > 0.5 * a.fs &&
@@ -1248,6 +1245,15 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
   a.wp[o] = make_float4(wx, wy, wz, a.wny ? a.wny[o] : 0.f);
 }
 
+// Nearest_Points beyond the search radius (malio_scan_get): d_far [5][N], INVALID where the search pass found all five
+int far_knn5(Ctx *c, u32 *d_far) {
+  const long long th = (long long)c->N * 64;
+  hipLaunchKernelGGL(k_far_nearest<5>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, c->N, c->d_world4,
+                     c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
 int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
                     u32 *d_nonf, float4 *d_wp) {
   if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
@@ -1256,13 +1262,20 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
     c->err = "map_incremental: the map changed after the last search pass of this scan";
     return MALIO_ERR_BAD_ARG;
   }
+  // The re-add test of :426-435 looks at the neighbours the search pass kept (d2 <= 5). That equals the reference's
+  // unrestricted 5-NN only while a neighbour farther than sqrt(5) m cannot be closer to the voxel centre than the point
+  // itself, i.e. while the half diagonal of a voxel stays below sqrt(5)/2: filter_size_map < sqrt(5/3) m.
+  if (c->prm.filter_size_map >= 1.29) {
+    c->err = "map_incremental: filter_size_map >= 1.29 m is not supported (the cached neighbours inside sqrt(5) m no longer decide laserMapping.cpp:426-435)";
+    return MALIO_ERR_BAD_ARG;
+  }
   const int N = c->N;
   ArenaScope sc(c->arena);
   u32 *d_far = nullptr;
   MALIO_HIP(sc.get(&d_far, (size_t)N));
   if (c->map_n - c->map_dead > 0 && flg_EKF_inited) {
     long long th = (long long)N * 64;
-    hipLaunchKernelGGL(k_far_nearest, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
+    hipLaunchKernelGGL(k_far_nearest<1>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
                        c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
   }
   MapIncArgs a;

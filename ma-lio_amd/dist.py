@@ -332,8 +332,9 @@ def sharded_update_iterated(backend, state0, P0, group=None):
         M = out["M"]
         if M < n:
             raise NotImplementedError("M < n fallback (esekfom.hpp:574-582) is a single-GPU path")
-        x, t, converge, done, P_out = capi.ieskf_step(L, max_it, i, x, x_prop, P0, out["HtRinvH"], out["HtRinvh"], t)
+        x, t, converge, done, P_out = capi.ieskf_step(L, max_it, i, x, x_prop, P0, out["HtRinvH"], out["HtRinvh"], t,
+                                                        limit=float(backend.params.get("limit", 0.0)))
+        P = P_out  # the posterior when done, else the projected P_ the reference would be left with (esekfom.hpp:531-572)
         if done:
-            P = P_out
             break
     return dict(state=x, P=P, passes=passes, searches=searches, M=M, t=t)

@@ -139,7 +139,10 @@ using GainFn = std::function<int(const std::vector<double> &, std::vector<double
 //   t_io       in/out: number of converged iterations so far (esekfom.hpp:658)
 //   converge   out: ekfom_data.converge for the NEXT pass (:649-663)
 //   done       out: 1 when the posterior covariance was written to P_out and the loop must stop (:665-718)
-static int step_core(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+//   P_out      done: the posterior; otherwise the PROJECTED P_propagated of this iteration - what the reference's member
+//              P_ holds from :531-572 until the next valid iteration overwrites it, and therefore what the filter is
+//              left with when the loop runs out on invalid passes (`continue` at :514-517 restores nothing)
+static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                      const double *P_prop, const GainFn &gain, int *t_io, int *converge_out, int *done_out,
                      double *P_out) {
   const int n = 17 + 6 * L, C = 6 * (L + 1);
@@ -178,9 +181,9 @@ static int step_core(int L, int maximum_iter, int i, malio_state_t *x, const mal
     dx_[a] = s;
   }
   state_boxplus(x_, L, dx_.data());  // :646
-  bool converge = true;              // :649-657 (limit = 0.001 on every component, esekfom.hpp:160-163)
+  bool converge = true;              // :649-657 (limit[i] = 0.001 unless params.limit says otherwise, esekfom.hpp:160-163)
   for (int a = 0; a < n; a++)
-    if (std::fabs(dx_[a]) > 0.001) {
+    if (std::fabs(dx_[a]) > limit) {
       converge = false;
       break;
     }
@@ -219,6 +222,8 @@ static int step_core(int L, int maximum_iter, int i, malio_state_t *x, const mal
       for (int b = 0; b < n; b++) P_out[a * n + b] = L_[a * n + b] - acc[b];
     }
     *done_out = 1;
+  } else {
+    memcpy(P_out, P_.data(), sizeof(double) * (size_t)n * n);
   }
   return MALIO_OK;
 }
@@ -249,15 +254,16 @@ static GainFn normal_eq_gain(int L, const double *HtRinvH, const double *HtRinvh
   };
 }
 
-int ieskf_step(int L, int maximum_iter, int i, malio_state_t *x, const malio_state_t *x_propagated,
+int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
                int *done_out, double *P_out) {
-  return step_core(L, maximum_iter, i, x, x_propagated, P_prop, normal_eq_gain(L, HtRinvH, HtRinvh), t_io,
+  return step_core(L, maximum_iter, limit > 0 ? limit : 0.001, i, x, x_propagated, P_prop, normal_eq_gain(L, HtRinvH, HtRinvh), t_io,
                    converge_out, done_out, P_out);
 }
 
 int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
   const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
+  const double limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
   malio_state_t x_ = *xio;
   const malio_state_t x_propagated = x_;
   const Mat P_prop(Pio, Pio + (size_t)n * n);
@@ -268,6 +274,7 @@ int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, dou
   for (int i = -1; i < maximum_iter; i++) {  // esekfom.hpp:509
     memset(&mo, 0, sizeof(mo));
     searches += converge ? 1 : 0;
+    if (c->pass_hook) c->pass_hook(passes, c->pass_hook_user);
     // h_dyn_share: the fused pass over this GPU's scan, or - with an exchange - over the scan sharded across the node
     int rc = xchg ? malio_measure_node((malio_handle_t)c, xchg, &x_, converge, &mo, nullptr)
                   : malio_measure((malio_handle_t)c, &x_, converge, &mo);
@@ -326,12 +333,13 @@ int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, dou
       gain = normal_eq_gain(L, mo.HtRinvH, mo.HtRinvh);
     }
     int done = 0;
-    rc = step_core(L, maximum_iter, i, &x_, &x_propagated, P_prop.data(), gain, &t, &converge, &done, Pio);
+    rc = step_core(L, maximum_iter, limit, i, &x_, &x_propagated, P_prop.data(), gain, &t, &converge, &done, Pio);
     solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != MALIO_OK) return rc;
     if (done) break;
   }
-  // (when every pass was invalid the reference leaves x_ and P_ as propagated: Pio untouched)
+  // When the loop ran out without `done` (its last pass was invalid), Pio holds what the last VALID iteration left in
+  // the reference's member P_: the projected P_propagated (step_core); with no valid pass at all it is untouched.
   *xio = x_;
   if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
   if (solve_time) *solve_time += solve;

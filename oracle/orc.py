@@ -16,7 +16,7 @@ REF_SO = os.path.join(_HERE, "_ref", "libikd_ref.so")
 PARAM_ORDER = [
     "lid_num", "max_iteration", "extrinsic_est_en", "plane_th", "cov_threshold", "range_min", "range_max",
     "point_cov_max", "point_cov_min", "plane_cov_max", "plane_cov_min", "localize_cov_max", "localize_cov_min",
-    "localize_thresh_max", "localize_thresh_min", "filter_size_map",
+    "localize_thresh_max", "localize_thresh_min", "filter_size_map", "limit",
 ]
 
 
@@ -65,7 +65,7 @@ class Oracle:
     """One Scene (the globals h_share_model touches) plus its k-NN provider."""
 
     def __init__(self, params: dict, threads=1, use_ref=False):
-        prm = np.array([float(params[k]) for k in PARAM_ORDER], dtype=np.float64)
+        prm = np.array([float(params.get(k, 0.0)) for k in PARAM_ORDER], dtype=np.float64)  # limit: 0 = 0.001
         self.params = dict(params)
         self.L = int(params["lid_num"])
         self.C = 6 * (1 + self.L)
@@ -85,6 +85,22 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def set_replay(self, passes):
+        """passes: list of dict(valid, h_x [M,C], h [M], R [M]) handed back by successive h_share_model calls ([] = off)."""
+        n = len(passes)
+        valid = np.array([int(p["valid"]) for p in passes] or [0], np.int32)
+        M = np.array([p["h_x"].shape[0] for p in passes] or [0], np.int32)
+        hx = _f64(np.concatenate([p["h_x"] for p in passes])) if n else np.zeros((1, self.C))
+        hv = _f64(np.concatenate([p["h"] for p in passes])) if n else np.zeros(1)
+        Rv = _f64(np.concatenate([p["R"] for p in passes])) if n else np.zeros(1)
+        lib().orc_set_replay(self.h, n, _p(valid, C.c_int), _p(M, C.c_int), _p(hx, C.c_double), _p(hv, C.c_double),
+                             _p(Rv, C.c_double))
+
+    def set_pass_hook(self, fn):
+        """fn(pass_number) is called before every measurement pass of update_iterated (None removes it)."""
+        self._hook = C.CFUNCTYPE(None, C.c_int, C.c_void_p)(lambda k, _u: fn(k)) if fn else None
+        lib().orc_set_pass_hook(self.h, self._hook if fn else C.cast(None, C.CFUNCTYPE(None, C.c_int, C.c_void_p)), None)
 
     def set_threads(self, t):
         lib().orc_set_threads(self.h, int(t))

@@ -5,9 +5,9 @@
 //   point  : 12 floats, pcl::PointXYZINormal memory layout (x y z _ nx ny nz _ intensity curvature _ _)
 //   pose   : 59 doubles = q(x,y,z,w) t(3) T(16 row-major) cov(36 row-major)       (common_lib.h:57-63)
 //   state  : pos(3) rot(x,y,z,w) offset_R[L](4 each) offset_T[L](3 each) vel bg ba grav   = 19+7L doubles
-//   params : 16 doubles = lid_num max_iteration extrinsic_est_en plane_th cov_threshold range_min
+//   params : 17 doubles = lid_num max_iteration extrinsic_est_en plane_th cov_threshold range_min
 //            range_max point_cov_max point_cov_min plane_cov_max plane_cov_min localize_cov_max
-//            localize_cov_min localize_thresh_max localize_thresh_min filter_size_map
+//            localize_cov_min localize_thresh_max localize_thresh_min filter_size_map limit (0 = 0.001)
 #include <omp.h>
 #include "orc_core.hpp"
 #include "orc_spline.hpp"
@@ -68,6 +68,7 @@ void *orc_create(const double *prm, int threads, const char *ref_so) {
   p.point_cov_max = prm[7], p.point_cov_min = prm[8], p.plane_cov_max = prm[9], p.plane_cov_min = prm[10];
   p.localize_cov_max = prm[11], p.localize_cov_min = prm[12], p.localize_thresh_max = prm[13];
   p.localize_thresh_min = prm[14], p.filter_size_map = prm[15];
+  p.limit = prm[16] > 0 ? prm[16] : 0.001;
   h->sc.threads = threads < 1 ? 1 : threads;
   if (ref_so && ref_so[0]) {
     h->knn = make_ref_knn(ref_so, (float)p.filter_size_map);
@@ -81,6 +82,28 @@ void orc_destroy(void *hh) {
   Handle *h = (Handle *)hh;
   delete h->knn;
   delete h;
+}
+// Replay mode for the Eigen pin (oracle/ref_eigen): npass recorded measurement results, rows of pass k =
+// hx[off_k .. off_k + M_k) with off_k = sum of the earlier M; valid[k] == 0 -> ekfom_data.valid = false.
+void orc_set_replay(void *hh, int npass, const int *valid, const int *M, const double *hx, const double *hv, const double *Rv) {
+  Handle *h = (Handle *)hh;
+  const int C = 6 * (1 + h->sc.prm.lid_num);
+  h->sc.replay.clear(), h->sc.replay_pos = 0;
+  size_t off = 0;
+  for (int k = 0; k < npass; k++) {
+    DynShare d;
+    d.valid = valid[k] != 0;
+    d.h_x = Mat(M[k], C);
+    for (int r = 0; r < M[k]; r++)
+      for (int c = 0; c < C; c++) d.h_x(r, c) = hx[(off + r) * C + c];
+    d.h.assign(hv + off, hv + off + M[k]), d.R.assign(Rv + off, Rv + off + M[k]);
+    off += M[k];
+    h->sc.replay.push_back(d);
+  }
+}
+void orc_set_pass_hook(void *hh, void (*fn)(int, void *), void *user) {
+  Handle *h = (Handle *)hh;
+  h->sc.pass_hook = fn, h->sc.pass_hook_user = user;
 }
 int orc_is_ref(void *hh) { return ((Handle *)hh)->is_ref ? 1 : 0; }
 void orc_set_threads(void *hh, int t) { ((Handle *)hh)->sc.threads = t < 1 ? 1 : t; }

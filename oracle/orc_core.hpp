@@ -38,6 +38,7 @@ struct Params {
   double localize_cov_max = 2, localize_cov_min = 0.3;
   double localize_thresh_max = 0.7, localize_thresh_min = 0.2;
   double filter_size_map = 0.5;
+  double limit = 0.001;  // esekf::limit[i] (esekfom.hpp:160-163,894)
 };
 
 constexpr int MAXL = 4;
@@ -110,6 +111,14 @@ struct Scene {
   bool use_override = false;
   double override_minmax[4] = {0, 0, 0, 0};
   bool skip_loc_weight = false;  // leave h_x / h un-weighted by the localization weight (it is global too)
+  // test support: called before every h_dyn_share invocation of update_iterated with the pass number (0-based); the
+  // reference's hook is a plain function that may do anything, e.g. find its map changed under it
+  // test support (oracle/ref_eigen pin): when non-empty, call k of h_share_model hands back replay[k] instead of
+  // evaluating the scan - the same recorded rows are fed to the reference's esekf built against Eigen
+  std::vector<DynShare> replay;
+  int replay_pos = 0;
+  void (*pass_hook)(int pass, void *user) = nullptr;
+  void *pass_hook_user = nullptr;
   void set_scan(const std::vector<Pt> &body);
   // laserMapping.cpp:552-760
   void h_share_model(const State &s, DynShare &ekfom_data);

@@ -54,6 +54,12 @@ static void sym3_eig(double A[3][3], double ev[3]) {
 
 // laserMapping.cpp:552-760
 void Scene::h_share_model(const State &s, DynShare &ekfom_data) {
+  if (!replay.empty()) {
+    const DynShare &r = replay[replay_pos++ % replay.size()];
+    ekfom_data.valid = r.valid, ekfom_data.h_x = r.h_x, ekfom_data.h = r.h, ekfom_data.R = r.R;
+    effct_feat_num = r.h_x.r;
+    return;
+  }
   const int feats_down_size = (int)feats_down_body.size();
   const int lid_num = prm.lid_num;
   // extrinsic_update() (:291-308, :557): the void* state pointers alias the filter's live state,
@@ -393,6 +399,7 @@ void update_iterated(Scene &sc, State &x_, Mat &P_, double R, UpdateStats &st, s
   for (int i = -1; i < maximum_iter; i++) {  // :509
     dyn_share.valid = true;
     if (dyn_share.converge) st.searches++;
+    if (sc.pass_hook) sc.pass_hook(st.passes, sc.pass_hook_user);
     sc.h_share_model(x_, dyn_share);  // :512
     st.passes++;
     std::vector<double> R_dyn = dyn_share.R;
@@ -476,9 +483,9 @@ void update_iterated(Scene &sc, State &x_, Mat &P_, double R, UpdateStats &st, s
     boxplus(x_, dx_);  // :646
     if (trace_states) trace_states->push_back(x_);
 
-    dyn_share.converge = true;  // :649-657 (limit[i] = 0.001, esekfom.hpp:160-163)
+    dyn_share.converge = true;  // :649-657 (limit[i] = 0.001 unless the caller set another one, esekfom.hpp:160-163)
     for (int a = 0; a < n; a++)
-      if (std::fabs(dx_[a]) > 0.001) {
+      if (std::fabs(dx_[a]) > sc.prm.limit) {
         dyn_share.converge = false;
         break;
       }

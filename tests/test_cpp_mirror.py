@@ -32,7 +32,7 @@ def _dump(path, sc, orc_mod, wny):
     L = sc["L"]
     with open(path, "wb") as f:
         np.array([L, sc["N"], sc["Nmap"]], np.int32).tofile(f)
-        np.array([float(sc["params"][k]) for k in PARAM_ORDER], np.float64).tofile(f)
+        np.array([float(sc["params"][k]) for k in PARAM_ORDER[:16]], np.float64).tofile(f)
         np.asarray(sc["state0"], np.float64).tofile(f)
         np.asarray(sc["P0"], np.float64).tofile(f)
         np.ascontiguousarray(sc["map"], np.float32).tofile(f)

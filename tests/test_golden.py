@@ -17,7 +17,7 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "g
 
 def load(name, orc):
     z = np.load(os.path.join(HERE, "golden", name + ".npz"))
-    prm = {k: z["params"][i] for i, k in enumerate(orc.PARAM_ORDER)}
+    prm = {k: z["params"][i] for i, k in enumerate(orc.PARAM_ORDER) if i < len(z["params"])}  # older fixtures: no `limit`
     for k in ("lid_num", "max_iteration", "extrinsic_est_en"):
         prm[k] = int(prm[k])
     off = np.concatenate([[0], np.cumsum(z["table_len"])])

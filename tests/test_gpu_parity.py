@@ -37,8 +37,11 @@ def compare_pass(eng, o, state, converge, exact=True):
     assert np.array_equal(gs["normvec"][sel], os_["normvec"][sel])
     assert np.array_equal(gs["res_last"][sel], os_["res_last"][sel])
     if converge:
-        assert np.array_equal(gs["nearest"][sel][:, :, :3], os_["nearest"][sel][:, :, :3])
-        assert np.array_equal(gs["nearest"][sel][:, :, 5], os_["nearest"][sel][:, :, 5])  # normal_y of the map points
+        # Nearest_Points of EVERY point, accepted or not, inside the sqrt(5) m radius or not: the reference's search has
+        # no radius (ikd_Tree.cpp:426-461), map_incremental reads them (laserMapping.cpp:411-435)
+        assert np.array_equal(gs["nearest_cnt"], os_["nearest_cnt"])
+        assert np.array_equal(gs["nearest"][:, :, :3], os_["nearest"][:, :, :3])
+        assert np.array_equal(gs["nearest"][:, :, 5], os_["nearest"][:, :, 5])  # normal_y of the map points
     assert np.allclose(gs["normal_y"], os_["normal_y"], rtol=1e-6, atol=0)
     assert g["M"] == r["M"]
     sc = max(1.0, np.abs(r["h_x"]).max())
@@ -125,6 +128,56 @@ def test_no_effective_points(capi, orc, scenes):
     assert u["passes"] == v["passes"] and np.array_equal(u["state"], v["state"])
 
 
+def test_ten_pass_update_forced_search(capi, orc, scenes):
+    """esekf's `limit` (esekfom.hpp:160-163) tightened until no pass converges: max_iteration + 1 passes, the search
+    pass forced at i == maximum_iter - 2 (:660-663) and the posterior written at i == maximum_iter - 1 (:665)."""
+    sc = scenes.make_scene(seed=231, N=2500, Nmap=40000, L=3, kind="tunnel", det_range=500.0, max_iteration=9, limit=1e-30)
+    eng, o = make_pair(capi, orc, sc)
+    u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["searches"]) == (10, 2) == (v["passes"], v["searches"]) and u["t"] == 0 and u["M"] == v["M"]
+    assert np.abs(u["state"] - v["state"]).max() < 1e-8
+    assert_P_close(u["P"], v["P"])
+    sc3 = scenes.make_scene(seed=231, N=2500, Nmap=40000, L=3, kind="tunnel", det_range=500.0, max_iteration=9)
+    eng3 = capi.Engine(sc3["params"], device=0)
+    eng3.map_build(sc3["map"])
+    eng3.scan_set(sc3["scan"], sc3["tables"], sc3["temporal_comp"])
+    assert eng3.update_iterated(sc3["state0"], sc3["P0"])["passes"] < 10  # the reference's 1e-3 stops early
+
+
+def test_valid_then_invalid_passes_leave_projected_P(capi, orc, scenes):
+    """A loop that runs out on invalid passes after a valid one: the reference's member P_ keeps the PROJECTED
+    P_propagated of the last valid iteration (esekfom.hpp:514-531: `continue` restores nothing) and x_ the state after
+    that iteration. The map region under the scan is deleted between pass 0 and pass 1 - h_dyn_share is a plain
+    function in the reference, the hook stands for whatever made it find an empty neighbourhood."""
+    sc = scenes.make_scene(seed=232, N=2000, Nmap=30000, L=2, prior_dpos=0.0, prior_drot_deg=0.0, limit=0.05)  # pass 0 converges
+    eng, o = make_pair(capi, orc, sc)
+    c = sc["state_gt"][0:3]
+    box = np.array([[c[0] - 150, c[1] - 150, c[2] - 50, c[0] + 150, c[1] + 150, c[2] + 50]], np.float32)
+    far = np.abs(sc["map"][:, :3] - c[None, :].astype(np.float32)).max(1) >= 150
+    extra = sc["map"][:64].copy()  # something must stay in the map: a clump 5 km away
+    extra[:, 0] += 5000.0
+    both = np.concatenate([sc["map"], extra])
+    eng.map_build(both), o.map_build(both)
+
+    def g_hook(k):
+        if k == 1:
+            assert eng.map_delete_boxes(box) == sc["map"].shape[0] - int(far.sum())
+
+    def o_hook(k):
+        if k == 1:
+            o.map_build(np.concatenate([sc["map"][far], extra]))
+
+    eng.set_pass_hook(g_hook), o.set_pass_hook(o_hook)
+    u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
+    eng.set_pass_hook(None), o.set_pass_hook(None)
+    # pass 0 valid and converged (t = 1, hence a SEARCH pass next), passes 1..3 find nothing
+    assert (u["passes"], u["searches"], u["M"], u["t"]) == (4, 4, v["M"], 1) and (v["passes"], v["searches"]) == (4, 4)
+    assert np.abs(u["state"] - v["state"]).max() < 1e-9 and not np.array_equal(v["state"], sc["state0"])
+    assert not np.array_equal(v["P"], sc["P0"])  # projected, not the raw propagated covariance ...
+    assert np.abs(u["P"] - v["P"]).max() <= 1e-12 * np.abs(v["P"]).max()
+    assert np.abs(v["P"] - sc["P0"]).max() < 1e-3 * np.abs(sc["P0"]).max()  # ... and not a posterior either
+
+
 def test_tiny_map_and_small_M_fallback(capi, orc, scenes):
     """Fewer accepted points than state dimensions -> esekfom.hpp:574-582 (K via the M x M system)."""
     sc = scenes.make_scene(seed=213, N=400, Nmap=6000, L=1)
@@ -194,6 +247,8 @@ def test_full_size_configs(capi, orc, scenes, cfg):
     o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     u, v = eng.update_iterated(sc["state0"], sc["P0"]), o.update_iterated(sc["state0"], sc["P0"])
     assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    if cfg == 5:  # BASELINE config 5 = 10 IESKF passes: -1..8, the last one the search forced at i == maximum_iter - 2
+        assert (u["passes"], u["searches"], u["t"]) == (10, 2, 0)
     # Yardstick at full size: the reference algorithm's own sensitivity to summation order. K_x = P_inv * HtH
     # (esekfom.hpp:637) cancels ~11 digits at 1e5 points, and unobservable directions (tunnel axis) are only
     # held by the prior, so the oracle run on the SAME points in a different order already moves the state by

@@ -291,3 +291,32 @@ def test_localization_weight_branches(orc, scenes):
         assert r["weight"] == pytest.approx(want, rel=1e-9)
         if kind == "plain":
             assert ratio < p["localize_thresh_min"] and r["weight"] == p["localize_cov_min"]
+
+
+def test_update_limit_and_pass_hook(orc, scenes):
+    """esekf's `limit` (esekfom.hpp:160-163): tightened so that nothing converges the loop runs max_iteration + 1 passes
+    with the search forced at i == maximum_iter - 2 (:660-663); a pass hook that empties the map after pass 0 leaves
+    the state of pass 0 and the PROJECTED prior covariance (:514-531)."""
+    kw = dict(seed=231, N=600, Nmap=20000, L=3, kind="tunnel", det_range=500.0, max_iteration=9)
+    sc = scenes.make_scene(limit=1e-30, **kw)
+    o = orc.Oracle(sc["params"], threads=2)
+    o.map_build(sc["map"]), o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    v = o.update_iterated(sc["state0"], sc["P0"])
+    assert (v["passes"], v["searches"]) == (10, 2)
+    sc3 = scenes.make_scene(**kw)
+    o3 = orc.Oracle(sc3["params"], threads=2)
+    o3.map_build(sc3["map"]), o3.scan_set(sc3["scan"], sc3["tables"], sc3["temporal_comp"])
+    assert o3.update_iterated(sc3["state0"], sc3["P0"])["passes"] < 10
+
+    sc = scenes.make_scene(seed=232, N=600, Nmap=20000, L=2, prior_dpos=0.0, prior_drot_deg=0.0, limit=0.05)  # pass 0 converges
+    o = orc.Oracle(sc["params"], threads=2)
+    o.map_build(sc["map"]), o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    far = sc["map"][:64].copy()
+    far[:, 0] += 5000.0
+    seen = []
+    o.set_pass_hook(lambda k: (seen.append(k), o.map_build(far) if k == 1 else None))
+    w = o.update_iterated(sc["state0"], sc["P0"])
+    o.set_pass_hook(None)
+    assert seen == [0, 1, 2, 3] and w["passes"] == 4 and w["searches"] == 4
+    assert not np.array_equal(w["state"], sc["state0"]) and not np.array_equal(w["P"], sc["P0"])
+    assert np.abs(w["P"] - sc["P0"]).max() < 1e-3 * np.abs(sc["P0"]).max()  # the projection is close to the identity
