@@ -367,6 +367,24 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
 int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double *guess4, double *sums_out,
                       double *extrema4_out, double timeout_s);
 int malio_xchg_row(malio_xchg_t x); /* row_doubles the exchange was created with */
+/* The same exchange between the THREADS of one process (one per GPU: what the node handle below runs on): creates all
+ * `world` endpoints at once over a private block; endpoint r is used by thread r only. */
+int malio_xchg_create_local(int world, int row_doubles, malio_xchg_t *out_world);
+/* ... and over RCCL (xGMI between the GPUs of a node, the network beyond): the producing kernels leave the row in HBM
+ * (malio_xchg_device_row), ncclAllGather runs on the handle's stream right behind them, one copy brings all rows to
+ * pinned memory, ONE stream synchronisation per exchange; the rows are then added in rank order on the host like
+ * everywhere else, so every rank holds the same bits. unique_id128: MALIO_RCCL_ID_BYTES from malio_rccl_unique_id()
+ * on one rank, handed to the others by whatever launched them (torch.distributed / MPI / a file). Collective. */
+#define MALIO_RCCL_ID_BYTES 128
+int malio_rccl_unique_id(void *out128);
+int malio_xchg_create_rccl(const void *unique_id128, int rank, int world, int row_doubles, int device, malio_xchg_t *out);
+int malio_xchg_device_row(malio_xchg_t x, double **d_row);
+/* 0 = shared memory (processes), 1 = local (threads), 2 = RCCL */
+int malio_xchg_kind(malio_xchg_t x);
+/* malio_xchg_reduce for an RCCL exchange whose device row was filled by work queued on `stream`; own_words_out (may
+ * be NULL) receives this rank's own words after the four extrema. */
+int malio_xchg_reduce_stream(malio_xchg_t x, void *stream, int ns, const double *guess4, double *sums_out,
+                             double *extrema4_out, double *own_words_out);
 /* Creator only, once every rank has opened the segment: removes the name (the mappings stay), so that nothing is left
  * in /dev/shm however the job ends. */
 int malio_xchg_unlink(malio_xchg_t x);
@@ -386,6 +404,62 @@ int malio_node_stats(malio_handle_t h, int *stats2); /* the two counters of mali
  * (esekfom.hpp:574-582 needs the rows of every rank: not a sharded path). */
 int malio_update_iterated_node(malio_handle_t h, malio_xchg_t x, malio_state_t *state, double *P, double R, int *stats,
                                double *solve_time);
+
+/* ---- map sharded by space (BASELINE config 4) ------------------------------------------------ */
+/* Makes this handle shard `rank` of `world`: space is cut into cubic tiles of edge tile_m (0 = 16 m), a tile belongs to
+ * the shard its hashed coordinates name. Call before malio_map_build. From then on
+ *   - malio_map_build / malio_map_add are handed the WHOLE map / all new points on every shard and keep the points of
+ *     the shard's own tiles plus a 2.3 m halo (> sqrt(5) m, the radius beyond which laserMapping.cpp:587 rejects), by
+ *     whole down-sampling voxels; malio_map_delete_boxes deletes within the shard;
+ *   - malio_scan_set is handed the WHOLE scan on every shard; a SEARCH pass serves the points whose world point falls
+ *     into an own tile (every shard computes the same bits, hence the same owner), REUSE passes keep serving those;
+ *   - sums and extrema cover the served points: exchange them between the shards exactly as for a sharded scan
+ *     (malio_measure_node / the stage calls). No neighbour merge is needed: the halo makes every acceptable 5-NN local,
+ *     and results equal those of one handle holding the whole map (tests/test_partition.py).
+ * malio_scan_get then only holds values for the served points: malio_scan_owned tells which (1 = served here). */
+int malio_set_partition(malio_handle_t h, int rank, int world, float tile_m);
+int malio_scan_owned(malio_handle_t h, uint8_t *owned);
+
+/* ---- several GPUs behind ONE handle, called from ONE thread ("multi-GPU handled inside") ------------- */
+/* The reference drives the whole path from its single main thread (laserMapping.cpp:985-1060); malio_node_* is the
+ * same interface as the malio_* calls above for a caller that owns n_gpus GPUs of one node: one worker thread per GPU
+ * inside the library, the caller posts one call at a time. devices: HIP ordinals (NULL = 0 .. n_gpus-1; an ordinal may
+ * repeat - several shards on one GPU - except with RCCL). partition:
+ *   MALIO_PART_SCAN   map replicated on every GPU, the scan cut into n_gpus contiguous shards
+ *   MALIO_PART_TILES  map sharded by spatial tiles of edge tile_m (0 = 16 m) with a halo, every GPU is handed the whole
+ *                     scan and serves the points of its own tiles (malio_set_partition; BASELINE config 4)
+ * exchange: how the per-pass [sums | extrema] rows (2.4 KB per GPU) meet - MALIO_NODE_XCHG_HOST: through host memory (the
+ * rows are consumed by the host: the n x n filter algebra runs on the caller's thread), MALIO_NODE_XCHG_RCCL:
+ * ncclAllGather over xGMI on the GPUs' streams. Either way the rows are added in GPU order: results do not depend on
+ * timing, and equal those of one GPU given the whole scan and map up to the order of the final additions. */
+typedef struct malio_node *malio_node_t;
+enum { MALIO_PART_SCAN = 0, MALIO_PART_TILES = 1 };
+enum { MALIO_NODE_XCHG_HOST = 0, MALIO_NODE_XCHG_RCCL = 1 };
+int malio_node_create(const malio_params_t *params, int n_gpus, const int *devices, int partition, int exchange,
+                      float tile_m, malio_node_t *out);
+int malio_node_destroy(malio_node_t nd);
+const char *malio_node_last_error(malio_node_t nd);
+int malio_node_gpus(malio_node_t nd);
+int malio_node_handle(malio_node_t nd, int rank, malio_handle_t *out); /* the per-GPU handle (diagnostics, profiling) */
+/* == malio_map_build / malio_map_add / malio_map_delete_boxes on every GPU (a tile shard keeps its part);
+ * out arrays (optional) take one value per GPU */
+int malio_node_map_build(malio_node_t nd, const malio_point_t *pts, int n);
+int malio_node_map_size(malio_node_t nd, int *out_sizes);
+int malio_node_map_add(malio_node_t nd, const malio_point_t *pts, int n, int downsample_on, int *out_added);
+int malio_node_map_delete_boxes(malio_node_t nd, const malio_box_t *boxes, int nb, int *out_deleted);
+/* == malio_scan_set / malio_measure (no rows path) / malio_update_iterated / malio_scan_get / malio_set_pass_hook */
+int malio_node_scan_set(malio_node_t nd, const malio_point_t *feats_down_body, int n, const malio_pose_t *const *pose_unc,
+                        const int *pose_unc_len, const malio_pose_t *temporal_comp);
+int malio_node_measure(malio_node_t nd, const malio_state_t *s, int converge, malio_measure_out_t *out);
+int malio_node_update_iterated(malio_node_t nd, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+int malio_node_scan_get(malio_node_t nd, float *normal_y, malio_point_t *nearest, int *nearest_count, uint8_t *selected,
+                        float *res_last, float *world_xyz, float *normvec4);
+int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int pass, void *user), void *user);
+int malio_node_exchange_stats(malio_node_t nd, int *stats2); /* passes that needed one / two exchanges so far */
+/* shard geometry, host code (no GPU): which shard serves each of n world points (xyz [n][3]) / whether shard `rank`
+ * stores each of n map points */
+int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner);
+int malio_part_stores(const float *xyz, int n, int rank, int world, float tile_m, float filter_size_map, uint8_t *out_stores);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded

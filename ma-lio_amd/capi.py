@@ -23,9 +23,16 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
+    "malio_xchg_create_local", "malio_rccl_unique_id", "malio_xchg_create_rccl", "malio_xchg_device_row", "malio_xchg_kind",
+    "malio_xchg_reduce_stream", "malio_node_create", "malio_node_destroy", "malio_node_last_error", "malio_node_gpus",
+    "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
+    "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
+    "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
 ]
+PART_SCAN, PART_TILES = 0, 1
+XCHG_HOST, XCHG_RCCL = 0, 1
 
 
 class Point(C.Structure):  # malio_point_t == pcl::PointXYZINormal
@@ -64,10 +71,13 @@ _lib = None
 
 
 def _share_hip_runtime_with_torch():
-    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7,
-    looked up by FILE name `libamdhip64.so`); if /opt/rocm's copy is mapped first, torch later maps its own next
-    to it and its device init fails ("No HIP GPUs are available"). Mapping torch's copy first makes the loader
-    satisfy our DT_NEEDED libamdhip64.so.7 with it, in whichever order the two are used. No torch -> system HIP."""
+    """One HIP runtime and one RCCL per process. PyTorch-ROCm wheels bundle their own libamdhip64 (soname
+    libamdhip64.so.7) and librccl (librccl.so.1), looked up by FILE name; libmalio_hip.so links both by soname. If
+    /opt/rocm's copies are mapped first, torch later maps its own next to them and its device init fails ("No HIP GPUs
+    are available"). Mapping torch's copies first works for HIP alone, but with RCCL mapped before the rest of torch the
+    process dies in a static destructor at exit ("double free or corruption", MI355X box, r02b) - the only order that is
+    clean in every combination is torch's own: import it first when it is installed, and let the loader satisfy our
+    DT_NEEDED entries with what it mapped. No torch -> the system libraries (a C++ integration never meets this)."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -75,12 +85,17 @@ def _share_hip_runtime_with_torch():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        return
+    for name in ("libamdhip64.so", "librccl.so"):  # mapped by torch lazily in some builds: make sure before we load
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def lib():
@@ -145,6 +160,16 @@ def make_params(p: dict, cell_size=0.0):
 
 class MalioError(RuntimeError):
     pass
+
+
+def _scan_tables(L, pose_tables, temporal_comp):
+    """ctypes views of pose_unc[lid][k] / temporal_comp (+ the arrays that must outlive the call)."""
+    tabs = [np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1, 59)) for t in pose_tables]
+    ptrs = (C.POINTER(Pose) * L)(*[_p(t, Pose) for t in tabs])
+    lens = (C.c_int * L)(*[t.shape[0] for t in tabs])
+    tc = np.ascontiguousarray(np.asarray(temporal_comp, np.float64).reshape(-1, 59))
+    tcp = _p(tc, Pose) if L > 1 else None
+    return ptrs, lens, tcp, tabs, tc
 
 
 class Engine:
@@ -341,6 +366,15 @@ class Engine:
                                        _p(out["normvec"], C.c_float)), "malio_scan_get")
         return out
 
+    def set_partition(self, rank, world, tile_m=0.0):
+        """malio_set_partition: this handle becomes spatial shard `rank` of `world` (call before map_build)."""
+        self._chk(lib().malio_set_partition(self.h, int(rank), int(world), C.c_float(tile_m)), "malio_set_partition")
+
+    def scan_owned(self):
+        out = np.zeros(self.N, np.uint8)
+        self._chk(lib().malio_scan_owned(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8))), "malio_scan_owned")
+        return out.astype(bool)
+
     def set_pass_hook(self, fn):
         """malio_set_pass_hook: fn(pass_number) runs on the host before every measurement pass of update_iterated."""
         proto = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
@@ -526,6 +560,173 @@ class NodeExchange:
             self.close()
         except Exception:
             pass
+
+
+class RcclExchange(NodeExchange):
+    """malio_xchg_create_rccl: the same exchange over RCCL (one process or thread per GPU). unique_id: bytes from
+    rccl_unique_id() on one rank, distributed by the launcher (e.g. torch.distributed.broadcast_object_list)."""
+
+    def __init__(self, unique_id, rank, world, row_doubles, device):
+        self.h = C.c_void_p()
+        self.world, self.row, self.timeout = int(world), int(row_doubles), 60.0
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        rc = lib().malio_xchg_create_rccl(buf, int(rank), int(world), int(row_doubles), int(device), C.byref(self.h))
+        if rc != OK:
+            raise MalioError(f"malio_xchg_create_rccl rc={rc}")
+        self.out = np.zeros((self.world, self.row), np.float64)
+        self._fn = lib().malio_xchg_all_gather
+        self._out_p = _p(self.out, C.c_double)
+        self._to = C.c_double(self.timeout)
+
+    def unlink(self):
+        pass
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().malio_rccl_unique_id(buf)
+    if rc != OK:
+        raise MalioError(f"malio_rccl_unique_id rc={rc}")
+    return bytes(buf.raw)
+
+
+def part_owner(xyz, world, tile_m=0.0):
+    """malio_part_owner for an [n,3] float32 array: the shard that serves a world point."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros(xyz.shape[0], np.int32)
+    rc = lib().malio_part_owner(_p(xyz, C.c_float), xyz.shape[0], int(world), C.c_float(tile_m), _p(out, C.c_int))
+    assert rc == OK
+    return out
+
+
+def part_stores(xyz, rank, world, tile_m=0.0, filter_size_map=0.5):
+    """malio_part_stores for an [n,3] float32 array: whether shard `rank` keeps a map point (own tiles + halo)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros(xyz.shape[0], np.uint8)
+    rc = lib().malio_part_stores(_p(xyz, C.c_float), xyz.shape[0], int(rank), int(world), C.c_float(tile_m),
+                                 C.c_float(filter_size_map), _p(out, C.c_uint8))
+    assert rc == OK
+    return out.astype(bool)
+
+
+class Node:
+    """malio_node_*: several GPUs (or several shards on one GPU: devices=[0, 0, ...]) behind one handle."""
+
+    def __init__(self, params: dict, devices, partition=PART_SCAN, exchange=XCHG_HOST, tile_m=0.0, cell_size=0.0):
+        self.L = int(params["lid_num"])
+        self.C = 6 * (1 + self.L)
+        self.n = 17 + 6 * self.L
+        self.params = dict(params)
+        self._prm = make_params(params, cell_size)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self.G = len(devices)
+        self.h = C.c_void_p()
+        rc = lib().malio_node_create(C.byref(self._prm), self.G, devs, int(partition), int(exchange), C.c_float(tile_m),
+                                     C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise MalioError(f"malio_node_create rc={rc}")
+        self.N = 0
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            lib().malio_node_last_error.restype = C.c_char_p
+            lib().malio_node_last_error.argtypes = [C.c_void_p]
+            raise MalioError(f"{what} rc={rc}: {lib().malio_node_last_error(self.h).decode()}")
+        return rc
+
+    def close(self):
+        if self.h:
+            lib().malio_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def map_build(self, pts12):
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        self._chk(lib().malio_node_map_build(self.h, _p(pts12, Point), pts12.shape[0]), "malio_node_map_build")
+
+    def map_sizes(self):
+        out = (C.c_int * self.G)()
+        self._chk(lib().malio_node_map_size(self.h, out), "malio_node_map_size")
+        return list(out)
+
+    def map_delete_boxes(self, boxes6):
+        boxes6 = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+        out = (C.c_int * self.G)()
+        self._chk(lib().malio_node_map_delete_boxes(self.h, boxes6.ctypes.data_as(C.c_void_p), boxes6.shape[0], out),
+                  "malio_node_map_delete_boxes")
+        return list(out)
+
+    def map_add(self, pts12, downsample_on=True):
+        pts12 = np.ascontiguousarray(pts12, np.float32).reshape(-1, 12)
+        out = (C.c_int * self.G)()
+        self._chk(lib().malio_node_map_add(self.h, _p(pts12, Point), pts12.shape[0], int(bool(downsample_on)), out),
+                  "malio_node_map_add")
+        return list(out)
+
+    def scan_set(self, pts12, pose_tables, temporal_comp):
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        self.N = pts12.shape[0]
+        self._scan_keep = _scan_tables(self.L, pose_tables, temporal_comp)
+        ptrs, lens, tcp = self._scan_keep[:3]
+        self._chk(lib().malio_node_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_node_scan_set")
+
+    def measure(self, state_flat, converge=True):
+        s = state_from_flat(state_flat, self.L)
+        out = MeasureOut()
+        rc = self._chk(lib().malio_node_measure(self.h, C.byref(s), int(bool(converge)), C.byref(out)), "malio_node_measure")
+        Cc = self.C
+        return dict(rc=rc, valid=bool(out.valid), M=int(out.M), w_loc=float(out.w_loc),
+                    HtRinvH=np.array(out.HtRinvH[:Cc * Cc]).reshape(Cc, Cc), HtRinvh=np.array(out.HtRinvh[:Cc]),
+                    unit_cov_minmax=tuple(out.unit_cov_minmax), R_minmax=tuple(out.R_minmax))
+
+    def measure_fn(self, state_flat, converge=True):
+        """Pre-bound pass for timing loops: fn() -> rc."""
+        s = state_from_flat(state_flat, self.L)
+        out = MeasureOut()
+        f, h, sp, op, cv = lib().malio_node_measure, self.h, C.byref(s), C.byref(out), int(bool(converge))
+
+        def fn():
+            return f(h, sp, cv, op)
+        fn._keep = (s, out)
+        return fn, out
+
+    def update_iterated(self, state_flat, P, R=0.001):
+        s = state_from_flat(state_flat, self.L)
+        P = np.ascontiguousarray(P, np.float64).copy()
+        stats = (C.c_int * 4)()
+        st = C.c_double(0)
+        rc = self._chk(lib().malio_node_update_iterated(self.h, C.byref(s), _p(P, C.c_double), C.c_double(R), stats,
+                                                        C.byref(st)), "malio_node_update_iterated")
+        return dict(rc=rc, state=state_to_flat(s, self.L), P=P, passes=stats[0], searches=stats[1], M=stats[2], t=stats[3],
+                    solve_time=st.value)
+
+    def scan_get(self):
+        n = self.N
+        out = dict(normal_y=np.zeros(n, np.float32), nearest=np.zeros((n, 5, 12), np.float32),
+                   nearest_cnt=np.zeros(n, np.int32), selected=np.zeros(n, np.uint8),
+                   res_last=np.zeros(n, np.float32), world=np.zeros((n, 3), np.float32),
+                   normvec=np.zeros((n, 4), np.float32))
+        self._chk(lib().malio_node_scan_get(self.h, _p(out["normal_y"], C.c_float), _p(out["nearest"], Point),
+                                            _p(out["nearest_cnt"], C.c_int), _p(out["selected"], C.c_uint8),
+                                            _p(out["res_last"], C.c_float), _p(out["world"], C.c_float),
+                                            _p(out["normvec"], C.c_float)), "malio_node_scan_get")
+        return out
+
+    def exchange_stats(self):
+        st = (C.c_int * 2)()
+        lib().malio_node_exchange_stats(self.h, st)
+        return int(st[0]), int(st[1])
+
+    def set_pass_hook(self, fn):
+        proto = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+        self._hook = proto(lambda k, _u: fn(k)) if fn else None
+        self._chk(lib().malio_node_set_pass_hook(self.h, self._hook if fn else C.cast(None, proto), None), "malio_node_set_pass_hook")
 
 
 class PinnedArray:

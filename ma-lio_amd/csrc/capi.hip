@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(BLK) k_gather_side(int N, const u32 *__restric
 }  // namespace malio
 
 static int check(malio_handle_t h) { return h ? MALIO_OK : MALIO_ERR_BAD_ARG; }
+static int rc_dev_row(malio_xchg_t x, double **row) { return malio_xchg_device_row(x, row); }
 
 // pinned staging buffer of the upload paths, grown on demand and kept (hipHostMalloc/hipHostFree cost ~0.7 ms each)
 static int host_stage(malio::Ctx *c, size_t bytes, void **out) {
@@ -177,6 +178,32 @@ int malio_set_stream(malio_handle_t h, void *hip_stream, int external) {
   return MALIO_OK;
 }
 
+int malio_set_partition(malio_handle_t h, int rank, int world, float tile_m) {
+  if (check(h) || world < 1 || rank < 0 || rank >= world) return MALIO_ERR_BAD_ARG;
+  if (h->map_n > 0) {
+    h->err = "malio_set_partition: call before malio_map_build";
+    return MALIO_ERR_BAD_ARG;
+  }
+  if (!(tile_m > 0.f)) tile_m = 16.f;
+  if (tile_m < 4.f * (PART_HALO + 0.5f * (float)h->prm.filter_size_map)) return MALIO_ERR_BAD_ARG;  // part_touches: <= 8 tiles
+  h->part.rank = rank, h->part.world = world, h->part.inv_tile = 1.0f / tile_m;
+  return MALIO_OK;
+}
+
+int malio_scan_owned(malio_handle_t h, uint8_t *owned) {
+  if (check(h) || !owned) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
+  MALIO_HIP(hipSetDevice(c->device));
+  std::vector<u32> perm(c->N);
+  std::vector<unsigned char> nf(c->N);
+  MALIO_HIP(hipMemcpyAsync(perm.data(), c->d_perm, sizeof(u32) * c->N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->N; i++) owned[perm[i]] = nf[i] != 0xFD;  // NF_NOTMINE
+  return MALIO_OK;
+}
+
 int malio_set_profiling(malio_handle_t h, int on) {
   if (check(h)) return MALIO_ERR_BAD_ARG;
   h->profiling = on != 0;
@@ -200,8 +227,20 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   Ctx *c = h;
   MALIO_HIP(hipSetDevice(c->device));
   float4 *stage = nullptr;
-  if (int rcs = host_stage(c, sizeof(float4) * (size_t)n, (void **)&stage)) return rcs;
-  for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+  if (int rcs = host_stage(c, sizeof(float4) * (size_t)n + 16, (void **)&stage)) return rcs;
+  if (c->part.world > 1) {
+    // this shard's part of the map: own tiles + halo, in the caller's order (ties between equal distances are broken by
+    // map index, so the relative order must be the unsharded one)
+    const float fs = (float)c->prm.filter_size_map;
+    int m = 0;
+    for (int i = 0; i < n; i++)
+      if (part_stores(c->part, pts[i].x, pts[i].y, pts[i].z, fs)) stage[m++] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+    c->part_sentinel = m == 0;
+    if (m == 0) stage[m++] = make_float4(1e9f, 1e9f, 1e9f, 0.f);  // an empty shard still answers "no neighbours" for its tiles
+    n = m;
+  } else {
+    for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+  }
   if ((size_t)n > c->cap_map_in) {
     if (c->d_map_in) (void)hipFree(c->d_map_in);
     c->d_map_in = nullptr;
@@ -220,7 +259,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
 
 int malio_map_size(malio_handle_t h, int *out_size) {
   if (check(h) || !out_size) return MALIO_ERR_BAD_ARG;
-  *out_size = h->map_n - h->map_dead;
+  *out_size = h->map_n - h->map_dead - (h->part_sentinel ? 1 : 0);
   return MALIO_OK;
 }
 
@@ -274,9 +313,12 @@ int malio_nearest_search(malio_handle_t h, const malio_point_t *queries, int n, 
 
 int malio_map_add(malio_handle_t h, const malio_point_t *pts, int n, int downsample_on, int *out_added) {
   if (check(h) || n < 0 || (n > 0 && !pts)) return MALIO_ERR_BAD_ARG;
-  std::vector<float4> stage((size_t)n);
-  for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
-  return map_add(h, stage.data(), n, downsample_on, out_added);
+  std::vector<float4> stage;
+  stage.reserve((size_t)n);
+  const float fs = (float)h->prm.filter_size_map;
+  for (int i = 0; i < n; i++)  // a shard takes the points it stores (own tiles + halo, whole voxels): see part_stores
+    if (part_stores(h->part, pts[i].x, pts[i].y, pts[i].z, fs)) stage.push_back(make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y));
+  return map_add(h, stage.data(), (int)stage.size(), downsample_on, out_added);
 }
 
 int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, int *out_deleted) {
@@ -287,6 +329,10 @@ int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, i
 int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
                           const float *world_normal_y, int *out_counts3) {
   if (check(h) || !state_point) return MALIO_ERR_BAD_ARG;
+  if (h->part.world > 1) {
+    h->err = "malio_map_incremental: a map shard only knows the neighbours of its own points; the points to add must reach every shard (use the node handle, or malio_scan_get + malio_map_add on every shard)";
+    return MALIO_ERR_BAD_ARG;
+  }
   return map_incremental(h, state_point, flg_EKF_inited, world_normal_y, out_counts3);
 }
 
@@ -539,38 +585,51 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
     return MALIO_OK;
   };
   prof_begin(c);
+  // where the kernels leave [sums | extrema words]: the handle's pinned result buffer (the host exchanges it through
+  // shared memory), or the exchange's device row (RCCL gathers it on the stream, right behind the kernels)
+  double *row = c->d_res;
+  const bool dev_xchg = malio_xchg_kind(x) == 2;
+  if (dev_xchg && (rc_dev_row(x, &row) != MALIO_OK)) return MALIO_ERR_BAD_ARG;
+  double own[MALIO_MINMAX_LEN] = {0};
+  auto reduce = [&](const double *guess, double *Eout) -> int {  // one exchange: gather, true extrema, rank-ordered sum
+    if (dev_xchg) return malio_xchg_reduce_stream(x, c->stream, ns, guess, res, Eout, own + 4);
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    memcpy(own + 4, res + ns + 4, sizeof(double) * 4);
+    return malio_xchg_reduce(x, res, ns, guess, res, Eout, timeout_s);
+  };
   const bool spec = c->node_guess_valid;
-  int rc = pass_stage1(c, s, converge, spec ? nullptr : c->d_res + ns);
+  int rc = pass_stage1(c, s, converge, spec ? nullptr : row + ns);
   if (rc != MALIO_OK) return rc;
   double E[4];
   bool have_sums = false;
   if (spec) {
     if ((rc = upload(c->node_guess)) != MALIO_OK) return rc;
-    if ((rc = pass_stage2(c, c->d_node_mm, c->d_res + ns, c->d_res, false)) != MALIO_OK) return rc;
-    MALIO_HIP(hipStreamSynchronize(c->stream));
-    rc = malio_xchg_reduce(x, res, ns, c->node_guess, res, E, timeout_s);
+    if ((rc = pass_stage2(c, c->d_node_mm, row + ns, row, false)) != MALIO_OK) return rc;
+    rc = reduce(c->node_guess, E);
     if (rc < 0) return rc;
     have_sums = rc == MALIO_OK;
     if (have_sums) c->node_hits++;
   } else {
-    MALIO_HIP(hipStreamSynchronize(c->stream));
     const double nan4[4] = {NAN, NAN, NAN, NAN};  // never equal: only the extrema are wanted from this exchange
-    rc = malio_xchg_reduce(x, res, ns, nan4, res, E, timeout_s);
+    rc = reduce(nan4, E);
     if (rc < 0) return rc;
   }
   if (!have_sums) {  // first pass of a scan, or the extrema moved: weight the rows with the true extrema
     if (spec) c->node_misses++;
+    double keep[4];
+    memcpy(keep, own + 4, sizeof(keep));  // (this rank's own words come with the extrema: the second round has none)
     if ((rc = upload(E)) != MALIO_OK) return rc;
-    if ((rc = pass_stage2(c, c->d_node_mm, nullptr, c->d_res, false)) != MALIO_OK) return rc;
-    MALIO_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = pass_stage2(c, c->d_node_mm, nullptr, row, false)) != MALIO_OK) return rc;
     double E2[4];
-    rc = malio_xchg_reduce(x, res, ns, nullptr, res, E2, timeout_s);
+    rc = reduce(nullptr, E2);
     if (rc != MALIO_OK) return rc < 0 ? rc : MALIO_ERR_HIP;
+    memcpy(own + 4, keep, sizeof(keep));
   }
   prof_end(c);
   memcpy(c->node_guess, E, sizeof(E));
   c->node_guess_valid = true;
   memcpy(res + ns, E, sizeof(E));  // finish_host reads the global extrema here, then this rank's own words
+  memcpy(res + ns + 4, own + 4, sizeof(double) * 4);
   rc = finish_host(c, res, res + ns, out);
   c->last_M = out->M;
   if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/malio.h"
@@ -85,6 +86,50 @@ __device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (
   return h;
 }
 #endif
+
+// Spatial sharding of the map across `world` handles (BASELINE config 4): space is cut into cubic tiles,
+// a tile belongs to the shard its hashed coordinates name. A shard stores the map points of its own tiles plus a halo
+// (every point whose voxel box, grown by PART_HALO, touches an owned tile) and serves the scan points whose world point
+// of the SEARCH pass lies in an owned tile. PART_HALO > sqrt(5) m: every neighbour the reference can accept
+// (pointSearchSqDis[4] <= 5, laserMapping.cpp:587) of an owned query is in the shard, so its result equals the one an
+// unsharded engine gives; nothing needs merging. Same float arithmetic on host and device (-ffp-contract=off).
+constexpr float PART_HALO = 2.3f;
+struct PartView {
+  int rank = 0, world = 1;  // world <= 1: not partitioned
+  float inv_tile = 1.f / 16.f;
+};
+__host__ __device__ inline int tile_coord(float x, float inv_tile) { return (int)floorf(x * inv_tile); }
+__host__ __device__ inline u32 tile_owner(int tx, int ty, int tz, u32 world) {
+  u32 h = (u32)tx * 0x9E3779B1u ^ (u32)ty * 0x85EBCA77u ^ (u32)tz * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  return h % world;
+}
+__host__ __device__ inline bool part_owns(const PartView &p, float x, float y, float z) {
+  return p.world <= 1 ||
+         tile_owner(tile_coord(x, p.inv_tile), tile_coord(y, p.inv_tile), tile_coord(z, p.inv_tile), (u32)p.world) == (u32)p.rank;
+}
+// does the box [c - r, c + r] touch a tile of this shard? (at most 8 tiles while 2 r < tile edge)
+inline bool part_touches(const PartView &p, float cx, float cy, float cz, float r) {
+  if (p.world <= 1) return true;
+  const int x0 = tile_coord(cx - r, p.inv_tile), x1 = tile_coord(cx + r, p.inv_tile);
+  const int y0 = tile_coord(cy - r, p.inv_tile), y1 = tile_coord(cy + r, p.inv_tile);
+  const int z0 = tile_coord(cz - r, p.inv_tile), z1 = tile_coord(cz + r, p.inv_tile);
+  for (int z = z0; z <= z1; z++)
+    for (int y = y0; y <= y1; y++)
+      for (int x = x0; x <= x1; x++)
+        if (tile_owner(x, y, z, (u32)p.world) == (u32)p.rank) return true;
+  return false;
+}
+// a map point is stored by every shard its down-sampling voxel (edge fs; the point itself when fs <= 0) reaches: all
+// points of one voxel live on the same shards, so the per-voxel keeper rule of Add_Points sees complete voxels everywhere
+inline bool part_stores(const PartView &p, float x, float y, float z, float fs) {
+  if (p.world <= 1) return true;
+  if (!(fs > 0.f)) return part_touches(p, x, y, z, PART_HALO);
+  const float hx = (floorf(x / fs) + 0.5f) * fs, hy = (floorf(y / fs) + 0.5f) * fs, hz = (floorf(z / fs) + 0.5f) * fs;
+  return part_touches(p, hx, hy, hz, PART_HALO + 0.5f * fs);
+}
 
 // Per-LiDAR constants of one pass (all double; rotation matrices row-major).
 struct LidarConst {
@@ -186,6 +231,8 @@ struct Ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
   float cell = 1.125f, inv_cell = 1.f / 1.125f;
+  PartView part;  // malio_set_partition
+  bool part_sentinel = false;  // this shard's part of the map was empty: it holds one far-away placeholder point
 
   // map
   NlScratch nl_scratch;
@@ -361,6 +408,11 @@ constexpr double DEFER_SCORE_MIN = 64.0;
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+// the same loop over any measurement pass (host/node.cpp drives several GPUs through it); rows_pass == nullptr: no rows
+// path, fewer accepted points than states -> MALIO_SMALL_M_FALLBACK
+using PassFn = std::function<int(const malio_state_t *, int, malio_measure_out_t *)>;
+int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn *rows_pass, int Nscan, void (*hook)(int, void *),
+                    void *hook_user, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
 int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
                int *done_out, double *P_out);

@@ -110,6 +110,7 @@ struct Pass1Args {
   u32 *dq;         // [N] queries deferred to k_search_tail
   u32 *dq_ctl;     // [0..1] deferred count by pass parity, [2..3] workgroups with > DEFER_MIN uncertified queries
   int parity, defer;
+  PartView part;   // spatial shard this handle serves (world <= 1: everything)
   u32 *nbr;  // [5][N] ORIGINAL map indices (INVALID when fewer than 5 inside the radius)
   float4 *plane;
   float *pd2;
@@ -496,6 +497,7 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, 
 constexpr int NL1_G = 4;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
 constexpr unsigned char NF_PENDING = 0xFF;
 constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
+constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
 constexpr int TAIL_BLOCKS = 1024;  // k_search_tail: 4096 waves x 4 queries per sweep
 constexpr int TAIL_G = 16;         // lanes per deferred query (level-2 lists hold ~180..900 points)
 constexpr int DEFER_MIN = 8;                 // a workgroup serves up to this many uncertified queries itself
@@ -625,9 +627,13 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   const int q0 = blockIdx.x * SQ;
   // ---- phase A ----
   const int i = q0 + (int)threadIdx.x;  // meaningful for wave 0 only
-  const bool mine = threadIdx.x < SQ && i < a.N;
+  bool mine = threadIdx.x < SQ && i < a.N;
   PH(0, 0);
   PH_ENTER();
+  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
+    mm_reset_slot(a.mm_next, threadIdx.x);
+    if (threadIdx.x == 0) a.dq_ctl[a.parity ^ 1] = 0, a.dq_ctl[2 + (a.parity ^ 1)] = 0;
+  }
   if (threadIdx.x < SQ) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
@@ -637,9 +643,15 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       a.world4[i] = w;
       a.pbnorm[i] = nb;
       s_nb[threadIdx.x] = nb;
+      if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
+        mine = false;
+        a.nfound[i] = NF_NOTMINE, a.sel[i] = 0;
+        w = make_float4(3e9f, 3e9f, 3e9f, 0.f);  // far from every list: its search lanes find an empty cell
+      }
     }
     s_w[threadIdx.x] = w;
   }
+  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) return;  // a workgroup of somebody else's tiles
   __syncthreads();
   PH(0, 1);
   // ---- phase B ----
@@ -663,7 +675,8 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   // unmatched queries (map frontier, thinned map) costs 16 serial searches per wave instead of 64 in wave 0 ----
   {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool pend = (q0 + lane < a.N) && s_nf[lane] == NF_PENDING;  // lane <-> query, the same in every wave
+    // lane <-> query, the same in every wave (a point of another shard sits at 3e9 and is never searched further)
+    const bool pend = (q0 + lane < a.N) && s_nf[lane] == NF_PENDING && s_w[lane].x < 1e9f;
     unsigned long long todo = __ballot(pend);
     // every wave must have taken its snapshot of the flags before any wave rewrites one (the serving wave stores the
     // final count, wave 0 stores NF_DEFERRED): a wave that read s_nf late would see a different `todo`, the round-robin
@@ -728,10 +741,6 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
     const unsigned long long bal = __ballot(selected);
     if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, (u64)__popcll(bal));
-    if (blockIdx.x == 0) {
-      mm_reset_slot(a.mm_next, lane);  // MM_SLOTS == 64 lanes
-      if (lane == 0) a.dq_ctl[a.parity ^ 1] = 0, a.dq_ctl[2 + (a.parity ^ 1)] = 0;  // next pass' deferral counters
-    }
   }
   PH(0, 9);
   PH_EXIT();
@@ -784,7 +793,7 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
-  if (i < a.N) {
+  if (i < a.N && a.nfound[i] != NF_NOTMINE) {  // (a partitioned handle keeps serving the points of its last search pass)
     const float4 q = a.scan[i];
     const int packed = __float_as_int(q.w);
     const int lid = packed & 0xFF, tidx = packed >> 8;
@@ -1119,7 +1128,7 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
                                                      const float4 *__restrict__ map_in, int map_n, u32 *far_idx) {
   const int qi = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (qi >= N) return;
-  if (K == 1 ? nfound[qi] != 0 : nfound[qi] >= 5) {
+  if (K == 1 ? nfound[qi] != 0 : nfound[qi] >= 5) {  // (NF_NOTMINE included: another shard answers for that point)
     if (lane < K) far_idx[(size_t)lane * N + qi] = INVALID;
     return;
   }
@@ -1204,6 +1213,10 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
   const float4 q = a.scan[i];
   const int lid = (int)(__float_as_uint(q.w) & 0xFF);
   // feats_down_body[i].normal_y with the last pass' rewrite folded in (see commit_normal_y)
+  if (a.nfound[i] == NF_NOTMINE) {  // another shard classifies this point
+    a.addf[o] = 0u, a.nonf[o] = 0u, a.wp[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const bool untouched = !a.commit_prev || (a.sel[i] && !a.extrinsic_est_en);
   const float nyv = untouched ? a.ny[i] : (float)a.trace[i];
   u32 cls = 0;
@@ -1480,6 +1493,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
   a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
   a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.parity = c->dq_parity, a.defer = c->defer_enabled ? 1 : 0;
+  a.part = c->part;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;

@@ -262,8 +262,21 @@ int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, c
 }
 
 int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
-  const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
-  const double limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
+  // h_dyn_share: the fused pass over this GPU's scan, or - with an exchange - over the scan sharded across the node
+  PassFn pass = [c, xchg](const malio_state_t *s, int converge, malio_measure_out_t *mo) -> int {
+    return xchg ? malio_measure_node((malio_handle_t)c, xchg, s, converge, mo, nullptr) : malio_measure((malio_handle_t)c, s, converge, mo);
+  };
+  PassFn rows = [c](const malio_state_t *s, int converge, malio_measure_out_t *mo) -> int {
+    return malio_measure((malio_handle_t)c, s, converge, mo);
+  };
+  // the M x M form (esekfom.hpp:574-582) needs every rank's rows: not a sharded path
+  return ieskf_update_fn(c->prm, pass, xchg ? nullptr : &rows, c->N, c->pass_hook, c->pass_hook_user, xio, Pio, R, stats, solve_time);
+}
+
+int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn *rows_pass, int Nscan, void (*hook)(int, void *),
+                    void *hook_user, malio_state_t *xio, double *Pio, double R, int *stats, double *solve_time) {
+  const int L = prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = prm.max_iteration;
+  const double limit = prm.limit > 0 ? prm.limit : 0.001;
   malio_state_t x_ = *xio;
   const malio_state_t x_propagated = x_;
   const Mat P_prop(Pio, Pio + (size_t)n * n);
@@ -274,26 +287,24 @@ int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, dou
   for (int i = -1; i < maximum_iter; i++) {  // esekfom.hpp:509
     memset(&mo, 0, sizeof(mo));
     searches += converge ? 1 : 0;
-    if (c->pass_hook) c->pass_hook(passes, c->pass_hook_user);
-    // h_dyn_share: the fused pass over this GPU's scan, or - with an exchange - over the scan sharded across the node
-    int rc = xchg ? malio_measure_node((malio_handle_t)c, xchg, &x_, converge, &mo, nullptr)
-                  : malio_measure((malio_handle_t)c, &x_, converge, &mo);
+    if (hook) hook(passes, hook_user);
+    int rc = pass(&x_, converge, &mo);
     passes++;
     if (rc < 0) return rc;
     if (!mo.valid) continue;  // :514-517
     lastM = mo.M;
-    if (xchg && n > mo.M) return MALIO_SMALL_M_FALLBACK;  // the M x M form needs every rank's rows: not a sharded path
+    if (!rows_pass && n > mo.M) return MALIO_SMALL_M_FALLBACK;
     auto t0 = std::chrono::steady_clock::now();
     GainFn gain;
     if (n > mo.M) {
       // :574-582 small-M fallback: K = P H^T (H P H^T / R + I)^-1 / R with the scalar R, needs the rows.
       // Same state, converge = 0: the accept flags of the pass above stand, so these are its rows.
       const int M = mo.M;
-      rows_hx.assign((size_t)c->N * C, 0.0), rows_h.assign(c->N, 0.0), rows_R.assign(c->N, 0.0);
+      rows_hx.assign((size_t)Nscan * C, 0.0), rows_h.assign(Nscan, 0.0), rows_R.assign(Nscan, 0.0);
       malio_measure_out_t mr;
       memset(&mr, 0, sizeof(mr));
       mr.h_x = rows_hx.data(), mr.h = rows_h.data(), mr.R = rows_R.data();
-      rc = malio_measure((malio_handle_t)c, &x_, 0, &mr);
+      rc = (*rows_pass)(&x_, 0, &mr);
       if (rc < 0) return rc;
       gain = [&, M](const std::vector<double> &P_, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
         Mat S((size_t)M * M, 0.0), PHt((size_t)n * M, 0.0);

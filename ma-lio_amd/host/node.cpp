@@ -1,0 +1,322 @@
+// The node handle: several GPUs behind ONE handle, called from ONE thread - the shape of the reference's integration
+// (h_share_model and the ikd-Tree calls all come from laserMapping.cpp's single main thread, :985-1060) and of
+// SURVEY.md §8b ("multi-GPU handled inside").
+//
+// One worker thread per GPU owns that GPU's malio handle (a Ctx: map shard or replica, scan shard, stream); the caller's
+// thread posts one job at a time and waits for all workers. A measurement pass is malio_measure_node on every worker:
+// the workers exchange their [sums | extrema] rows among themselves - through a private block of memory (the 2.4 KB are
+// consumed by the host: the n x n filter algebra runs once, on the caller's thread) or through RCCL - and every worker
+// ends up with the same reduced normal equations, added in rank order. Two ways to split the work:
+//   MALIO_PART_SCAN   map replicated, scan cut into contiguous shards (every BASELINE map fits one GPU many times over)
+//   MALIO_PART_TILES  map sharded by spatial tiles with a halo, every worker sees the whole scan and serves the points
+//                     of its own tiles (BASELINE config 4; malio_set_partition)
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <sched.h>
+#include "../csrc/malio_internal.hpp"
+
+namespace {
+
+struct Worker {
+  int rank = 0, device = 0;
+  malio_handle_t h = nullptr;
+  malio_xchg_t x = nullptr;
+  std::thread th;
+  int rc = 0;
+  malio_measure_out_t out;
+  // scan shard (MALIO_PART_SCAN): points [lo, hi) of the caller's cloud
+  int lo = 0, hi = 0;
+};
+
+}  // namespace
+
+struct malio_node {
+  malio_params_t prm{};
+  int n = 0, partition = MALIO_PART_SCAN, exchange = MALIO_NODE_XCHG_HOST;
+  float tile_m = 0.f;
+  std::vector<Worker> w;
+  std::string err;
+  int N = 0;  // points of the current scan
+  // job hand-off: the caller bumps `seq` after storing `job`; a worker runs it when it sees a new value and bumps `done`
+  std::function<int(Worker &)> job;
+  std::atomic<uint64_t> seq{0};
+  std::atomic<int> done{0};
+  std::atomic<bool> quit{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> sleepers{0};
+  void (*pass_hook)(int, void *) = nullptr;
+  void *pass_hook_user = nullptr;
+
+  int run(const std::function<int(Worker &)> &j) {  // all workers, in parallel; first non-zero status wins (errors first)
+    job = j;
+    done.store(0, std::memory_order_relaxed);
+    seq.fetch_add(1, std::memory_order_release);
+    if (sleepers.load(std::memory_order_acquire) > 0) {
+      std::lock_guard<std::mutex> lk(mu);
+      cv.notify_all();
+    }
+    unsigned spins = 0;
+    while (done.load(std::memory_order_acquire) < n) {
+      if (++spins < 4096)
+        __builtin_ia32_pause();
+      else
+        spins = 0, sched_yield();
+    }
+    int rc = 0;
+    for (auto &k : w)
+      if (k.rc < 0) return k.rc;
+    for (auto &k : w)
+      if (k.rc > rc) rc = k.rc;
+    return rc;
+  }
+
+  void loop(Worker &me) {
+    (void)hipSetDevice(me.device);
+    uint64_t seen = 0;
+    while (true) {
+      // passes of one update follow each other within tens of microseconds: spin for a while, then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (seq.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_relaxed)) {
+        if (++spins < 2048) {
+          __builtin_ia32_pause();
+          continue;
+        }
+        spins = 0;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+          std::unique_lock<std::mutex> lk(mu);
+          sleepers.fetch_add(1, std::memory_order_acq_rel);
+          cv.wait_for(lk, std::chrono::milliseconds(50),
+                      [&] { return seq.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_relaxed); });
+          sleepers.fetch_sub(1, std::memory_order_acq_rel);
+        } else {
+          sched_yield();
+        }
+      }
+      if (quit.load(std::memory_order_relaxed) && seq.load(std::memory_order_acquire) == seen) return;
+      seen = seq.load(std::memory_order_acquire);
+      me.rc = job(me);
+      done.fetch_add(1, std::memory_order_release);
+    }
+  }
+};
+
+using malio::Ctx;
+
+extern "C" {
+
+int malio_node_create(const malio_params_t *params, int n_gpus, const int *devices, int partition, int exchange,
+                      float tile_m, malio_node_t *out) {
+  if (!params || !out || n_gpus < 1 || n_gpus > 64) return MALIO_ERR_BAD_ARG;
+  if (partition != MALIO_PART_SCAN && partition != MALIO_PART_TILES) return MALIO_ERR_BAD_ARG;
+  if (exchange != MALIO_NODE_XCHG_HOST && exchange != MALIO_NODE_XCHG_RCCL) return MALIO_ERR_BAD_ARG;
+  *out = nullptr;
+  malio_node *nd = new malio_node();
+  nd->prm = *params, nd->n = n_gpus, nd->partition = partition, nd->exchange = exchange, nd->tile_m = tile_m;
+  nd->w.resize(n_gpus);
+  const int row = params->lid_num * 97 + MALIO_MINMAX_LEN;
+  std::vector<malio_xchg_t> xs(n_gpus, nullptr);
+  if (exchange == MALIO_NODE_XCHG_HOST && malio_xchg_create_local(n_gpus, row, xs.data()) != MALIO_OK) {
+    delete nd;
+    return MALIO_ERR_ALLOC;
+  }
+  char uid[MALIO_RCCL_ID_BYTES];
+  if (exchange == MALIO_NODE_XCHG_RCCL && malio_rccl_unique_id(uid) != MALIO_OK) {
+    delete nd;
+    return MALIO_ERR_HIP;
+  }
+  for (int r = 0; r < n_gpus; r++) {
+    Worker &k = nd->w[r];
+    k.rank = r, k.device = devices ? devices[r] : r, k.x = xs[r];
+    k.th = std::thread([nd, r] { nd->loop(nd->w[r]); });
+  }
+  // handles (and RCCL communicators: ncclCommInitRank is collective) are created by the threads that will use them
+  const void *uidp = uid;
+  int rc = nd->run([nd, row, uidp](Worker &k) -> int {
+    int rc = malio_create(&nd->prm, k.device, &k.h);
+    if (rc != MALIO_OK) return rc;
+    if (nd->partition == MALIO_PART_TILES && (rc = malio_set_partition(k.h, k.rank, nd->n, nd->tile_m)) != MALIO_OK) return rc;
+    if (nd->exchange == MALIO_NODE_XCHG_RCCL) rc = malio_xchg_create_rccl(uidp, k.rank, nd->n, row, k.device, &k.x);
+    return rc;
+  });
+  if (rc != MALIO_OK) {
+    malio_node_destroy(nd);
+    return rc;
+  }
+  *out = nd;
+  return MALIO_OK;
+}
+
+int malio_node_destroy(malio_node_t nd) {
+  if (!nd) return MALIO_ERR_BAD_ARG;
+  nd->run([](Worker &k) -> int {
+    if (k.x) malio_xchg_destroy(k.x);
+    if (k.h) malio_destroy(k.h);
+    k.x = nullptr, k.h = nullptr;
+    return 0;
+  });
+  nd->quit.store(true);
+  {
+    std::lock_guard<std::mutex> lk(nd->mu);
+    nd->cv.notify_all();
+  }
+  for (auto &k : nd->w)
+    if (k.th.joinable()) k.th.join();
+  delete nd;
+  return MALIO_OK;
+}
+
+const char *malio_node_last_error(malio_node_t nd) {
+  if (!nd) return "null node";
+  for (auto &k : nd->w)
+    if (k.rc < 0 && k.h) return malio_last_error(k.h);
+  return nd->err.c_str();
+}
+
+int malio_node_gpus(malio_node_t nd) { return nd ? nd->n : 0; }
+
+int malio_node_handle(malio_node_t nd, int rank, malio_handle_t *out) {
+  if (!nd || !out || rank < 0 || rank >= nd->n) return MALIO_ERR_BAD_ARG;
+  *out = nd->w[rank].h;
+  return MALIO_OK;
+}
+
+int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int, void *), void *user) {
+  if (!nd) return MALIO_ERR_BAD_ARG;
+  nd->pass_hook = fn, nd->pass_hook_user = user;
+  return MALIO_OK;
+}
+
+// ---- map: every GPU is handed the whole call; a tile shard keeps its part (malio_set_partition) ----------------------
+int malio_node_map_build(malio_node_t nd, const malio_point_t *pts, int n) {
+  if (!nd || !pts || n <= 0) return MALIO_ERR_BAD_ARG;
+  return nd->run([=](Worker &k) { return malio_map_build(k.h, pts, n); });
+}
+
+int malio_node_map_size(malio_node_t nd, int *out_sizes /*[n_gpus]*/) {
+  if (!nd || !out_sizes) return MALIO_ERR_BAD_ARG;
+  for (int r = 0; r < nd->n; r++)
+    if (int rc = malio_map_size(nd->w[r].h, &out_sizes[r])) return rc;
+  return MALIO_OK;
+}
+
+int malio_node_map_add(malio_node_t nd, const malio_point_t *pts, int n, int downsample_on, int *out_added /*[n_gpus]*/) {
+  if (!nd || n < 0 || (n > 0 && !pts)) return MALIO_ERR_BAD_ARG;
+  return nd->run([=](Worker &k) { return malio_map_add(k.h, pts, n, downsample_on, out_added ? &out_added[k.rank] : nullptr); });
+}
+
+int malio_node_map_delete_boxes(malio_node_t nd, const malio_box_t *boxes, int nb, int *out_deleted /*[n_gpus]*/) {
+  if (!nd || nb < 0 || (nb > 0 && !boxes)) return MALIO_ERR_BAD_ARG;
+  return nd->run([=](Worker &k) { return malio_map_delete_boxes(k.h, boxes, nb, out_deleted ? &out_deleted[k.rank] : nullptr); });
+}
+
+// ---- scan -----------------------------------------------------------------------------------------------------------
+int malio_node_scan_set(malio_node_t nd, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
+                        const int *pose_unc_len, const malio_pose_t *temporal_comp) {
+  if (!nd || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
+  if (nd->partition == MALIO_PART_SCAN && n < nd->n) return MALIO_ERR_BAD_ARG;
+  nd->N = n;
+  for (int r = 0; r < nd->n; r++) {
+    Worker &k = nd->w[r];
+    if (nd->partition == MALIO_PART_SCAN)
+      k.lo = (int)((long long)n * r / nd->n), k.hi = (int)((long long)n * (r + 1) / nd->n);
+    else
+      k.lo = 0, k.hi = n;
+  }
+  return nd->run([=](Worker &k) { return malio_scan_set(k.h, body + k.lo, k.hi - k.lo, pose_unc, pose_unc_len, temporal_comp); });
+}
+
+int malio_node_measure(malio_node_t nd, const malio_state_t *s, int converge, malio_measure_out_t *out) {
+  if (!nd || !s || !out) return MALIO_ERR_BAD_ARG;
+  if (out->h_x || out->h || out->R) {
+    nd->err = "malio_node_measure: the rows path is a single-GPU path";
+    return MALIO_ERR_BAD_ARG;
+  }
+  const int rc = nd->run([=](Worker &k) {
+    memset(&k.out, 0, sizeof(k.out));
+    return malio_measure_node(k.h, k.x, s, converge, &k.out, nullptr);
+  });
+  if (rc < 0) return rc;
+  *out = nd->w[0].out;  // every worker holds the same reduced result, bit for bit
+  return rc;
+}
+
+int malio_node_update_iterated(malio_node_t nd, malio_state_t *x, double *P, double R, int *stats, double *solve_time) {
+  if (!nd || !x || !P) return MALIO_ERR_BAD_ARG;
+  if (solve_time) *solve_time = 0;
+  malio::PassFn pass = [nd](const malio_state_t *s, int converge, malio_measure_out_t *mo) -> int {
+    return malio_node_measure(nd, s, converge, mo);
+  };
+  return malio::ieskf_update_fn(nd->prm, pass, nullptr, nd->N, nd->pass_hook, nd->pass_hook_user, x, P, R, stats, solve_time);
+}
+
+int malio_node_exchange_stats(malio_node_t nd, int *stats2) {
+  if (!nd || !stats2) return MALIO_ERR_BAD_ARG;
+  return malio_node_stats(nd->w[0].h, stats2);
+}
+
+// Side effects in the caller's scan order, merged from the GPUs: a scan shard returns its own range, a tile shard the
+// points it served (malio_scan_owned).
+int malio_node_scan_get(malio_node_t nd, float *normal_y, malio_point_t *nearest, int *nearest_count, uint8_t *selected,
+                        float *res_last, float *world_xyz, float *normvec4) {
+  if (!nd) return MALIO_ERR_BAD_ARG;
+  if (nd->N <= 0) return MALIO_ERR_NO_SCAN;
+  if (nd->partition == MALIO_PART_SCAN)
+    return nd->run([=](Worker &k) {
+      const size_t o = (size_t)k.lo;
+      return malio_scan_get(k.h, normal_y ? normal_y + o : nullptr, nearest ? nearest + 5 * o : nullptr,
+                            nearest_count ? nearest_count + o : nullptr, selected ? selected + o : nullptr,
+                            res_last ? res_last + o : nullptr, world_xyz ? world_xyz + 3 * o : nullptr,
+                            normvec4 ? normvec4 + 4 * o : nullptr);
+    });
+  // tiles: every worker fills private arrays, then copies the entries of the points it served (disjoint between workers)
+  const int N = nd->N;
+  return nd->run([=](Worker &k) -> int {
+    std::vector<float> ny(normal_y ? N : 0), rl(res_last ? N : 0), wx(world_xyz ? 3 * (size_t)N : 0), nv(normvec4 ? 4 * (size_t)N : 0);
+    std::vector<malio_point_t> nr(nearest ? 5 * (size_t)N : 0);
+    std::vector<int> nc(nearest_count ? N : 0);
+    std::vector<uint8_t> sl(selected ? N : 0), own(N);
+    int rc = malio_scan_get(k.h, normal_y ? ny.data() : nullptr, nearest ? nr.data() : nullptr, nearest_count ? nc.data() : nullptr,
+                            selected ? sl.data() : nullptr, res_last ? rl.data() : nullptr, world_xyz ? wx.data() : nullptr,
+                            normvec4 ? nv.data() : nullptr);
+    if (rc != MALIO_OK) return rc;
+    if ((rc = malio_scan_owned(k.h, own.data())) != MALIO_OK) return rc;
+    for (int i = 0; i < N; i++) {
+      if (!own[i]) continue;
+      if (normal_y) normal_y[i] = ny[i];
+      if (nearest) memcpy(nearest + 5 * (size_t)i, nr.data() + 5 * (size_t)i, sizeof(malio_point_t) * 5);
+      if (nearest_count) nearest_count[i] = nc[i];
+      if (selected) selected[i] = sl[i];
+      if (res_last) res_last[i] = rl[i];
+      if (world_xyz) memcpy(world_xyz + 3 * (size_t)i, wx.data() + 3 * (size_t)i, sizeof(float) * 3);
+      if (normvec4) memcpy(normvec4 + 4 * (size_t)i, nv.data() + 4 * (size_t)i, sizeof(float) * 4);
+    }
+    return MALIO_OK;
+  });
+}
+
+// ---- shard geometry (host code: tests, and callers that want to know where a point lives) -------------------------
+int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner) {
+  if (!xyz || !out_owner || n < 0 || world < 1) return MALIO_ERR_BAD_ARG;
+  const float inv = 1.0f / (tile_m > 0.f ? tile_m : 16.f);
+  for (int i = 0; i < n; i++)
+    out_owner[i] = (int)malio::tile_owner(malio::tile_coord(xyz[3 * i], inv), malio::tile_coord(xyz[3 * i + 1], inv),
+                                          malio::tile_coord(xyz[3 * i + 2], inv), (unsigned)world);
+  return MALIO_OK;
+}
+int malio_part_stores(const float *xyz, int n, int rank, int world, float tile_m, float filter_size_map, uint8_t *out_stores) {
+  if (!xyz || !out_stores || n < 0 || world < 1 || rank < 0 || rank >= world) return MALIO_ERR_BAD_ARG;
+  malio::PartView p;
+  p.rank = rank, p.world = world, p.inv_tile = 1.0f / (tile_m > 0.f ? tile_m : 16.f);
+  for (int i = 0; i < n; i++) out_stores[i] = malio::part_stores(p, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], filter_size_map) ? 1 : 0;
+  return MALIO_OK;
+}
+
+}  // extern "C"

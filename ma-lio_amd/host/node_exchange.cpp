@@ -22,15 +22,31 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <memory>
 #include "../../include/malio.h"
 
+// Three carriers behind one interface (all_gather of one row per rank, rows back in rank order):
+//   SHM    ranks = processes of one node, rows in a POSIX shared-memory segment
+//   LOCAL  ranks = threads of one process (the node handle, host/node.cpp), rows in a heap block: same protocol
+//   RCCL   ranks = anything RCCL connects (one process per GPU over xGMI, or the threads of a node handle): the row is
+//          produced in HBM, ncclAllGather moves it on the handle's stream, one copy brings all rows to pinned memory
+enum { XCHG_SHM = 0, XCHG_LOCAL = 1, XCHG_RCCL = 2 };
+
 struct malio_xchg {
+  int kind = XCHG_SHM;
   int rank = 0, world = 0, row = 0;
   bool owner = false;
   size_t bytes = 0;
   char *base = nullptr;
+  std::shared_ptr<std::vector<char>> heap;  // LOCAL: the block all ranks share
   uint64_t epoch = 0;
   std::string name;
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int device = -1;
+  double *d_row = nullptr, *d_all = nullptr, *h_all = nullptr;  // [row], [world][row] in HBM, [world][row] pinned
   std::vector<double> all;  // [world][row] scratch of malio_xchg_reduce
   std::atomic<uint64_t> *seq(int r) const { return reinterpret_cast<std::atomic<uint64_t> *>(base + (size_t)r * 64); }
   double *data(int buf, int r) const {
@@ -83,8 +99,89 @@ int malio_xchg_create(const char *name, int rank, int world, int row_doubles, in
   return MALIO_OK;
 }
 
+int malio_xchg_create_local(int world, int row_doubles, malio_xchg_t *out_world) {
+  if (!out_world || world < 1 || row_doubles < 1) return MALIO_ERR_BAD_ARG;
+  const size_t bytes = (size_t)world * 64 + sizeof(double) * 2 * (size_t)world * row_doubles;
+  auto heap = std::make_shared<std::vector<char>>(bytes + 64, 0);
+  char *base = heap->data() + ((64 - (reinterpret_cast<uintptr_t>(heap->data()) & 63)) & 63);  // sequence words on own lines
+  for (int r = 0; r < world; r++) {
+    malio_xchg *x = new (std::nothrow) malio_xchg();
+    if (!x) {
+      for (int k = 0; k < r; k++) delete out_world[k];
+      return MALIO_ERR_ALLOC;
+    }
+    x->kind = XCHG_LOCAL, x->rank = r, x->world = world, x->row = row_doubles, x->bytes = bytes, x->base = base, x->heap = heap;
+    out_world[r] = x;
+  }
+  return MALIO_OK;
+}
+
+int malio_rccl_unique_id(void *out128) {
+  if (!out128) return MALIO_ERR_BAD_ARG;
+  static_assert(sizeof(ncclUniqueId) == MALIO_RCCL_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return MALIO_ERR_HIP;
+  std::memcpy(out128, &id, sizeof(id));
+  return MALIO_OK;
+}
+
+static int rccl_buffers(malio_xchg *x) {
+  const size_t rb = sizeof(double) * (size_t)x->row;
+  if (hipMalloc((void **)&x->d_row, rb) != hipSuccess || hipMalloc((void **)&x->d_all, rb * x->world) != hipSuccess ||
+      hipHostMalloc((void **)&x->h_all, rb * x->world, hipHostMallocDefault) != hipSuccess)
+    return MALIO_ERR_ALLOC;
+  (void)hipMemset(x->d_row, 0, rb);
+  return MALIO_OK;
+}
+
+int malio_xchg_create_rccl(const void *unique_id128, int rank, int world, int row_doubles, int device, malio_xchg_t *out) {
+  if (!unique_id128 || !out || world < 1 || rank < 0 || rank >= world || row_doubles < 1) return MALIO_ERR_BAD_ARG;
+  *out = nullptr;
+  if (hipSetDevice(device) != hipSuccess) return MALIO_ERR_NO_DEVICE;
+  malio_xchg *x = new (std::nothrow) malio_xchg();
+  if (!x) return MALIO_ERR_ALLOC;
+  x->kind = XCHG_RCCL, x->rank = rank, x->world = world, x->row = row_doubles, x->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id128, sizeof(id));
+  if (ncclCommInitRank(&x->comm, world, id, rank) != ncclSuccess) {
+    delete x;
+    return MALIO_ERR_HIP;
+  }
+  if (int rc = rccl_buffers(x)) {
+    malio_xchg_destroy(x);
+    return rc;
+  }
+  *out = x;
+  return MALIO_OK;
+}
+
+int malio_xchg_kind(malio_xchg_t x) { return x ? x->kind : -1; }
+
+int malio_xchg_device_row(malio_xchg_t x, double **d_row) {
+  if (!x || !d_row || x->kind != XCHG_RCCL) return MALIO_ERR_BAD_ARG;
+  *d_row = x->d_row;
+  return MALIO_OK;
+}
+
+// RCCL: all ranks' rows, gathered from x->d_row on `stream` (the stream the producing kernels were queued on: the
+// collective needs no host synchronisation before it), copied to pinned memory, ONE synchronisation at the end
+static int rccl_gather(malio_xchg *x, void *stream, double *out_all) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ncclAllGather(x->d_row, x->d_all, (size_t)x->row, ncclDouble, x->comm, st) != ncclSuccess) return MALIO_ERR_HIP;
+  const size_t bytes = sizeof(double) * (size_t)x->row * x->world;
+  if (hipMemcpyAsync(x->h_all, x->d_all, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return MALIO_ERR_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) return MALIO_ERR_HIP;
+  std::memcpy(out_all, x->h_all, bytes);
+  return MALIO_OK;
+}
+
 int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, double timeout_s) {
   if (!x || !in || !out_all) return MALIO_ERR_BAD_ARG;
+  if (x->kind == XCHG_RCCL) {  // host row in, host rows out (tests, bring-up): staged through the device row
+    if (hipSetDevice(x->device) != hipSuccess) return MALIO_ERR_HIP;
+    if (hipMemcpy(x->d_row, in, sizeof(double) * (size_t)x->row, hipMemcpyHostToDevice) != hipSuccess) return MALIO_ERR_HIP;
+    return rccl_gather(x, nullptr, out_all);
+  }
   const uint64_t e = ++x->epoch;
   const int buf = (int)(e & 1);
   std::memcpy(x->data(buf, x->rank), in, sizeof(double) * x->row);
@@ -108,12 +205,29 @@ int malio_xchg_all_gather(malio_xchg_t x, const double *in, double *out_all, dou
   return MALIO_OK;
 }
 
+static int reduce_gathered(malio_xchg *x, int ns, const double *guess4, double *sums_out, double *extrema4_out);
+
+int malio_xchg_reduce_stream(malio_xchg_t x, void *stream, int ns, const double *guess4, double *sums_out,
+                             double *extrema4_out, double *own_words_out) {
+  if (!x || x->kind != XCHG_RCCL || !sums_out || !extrema4_out || ns < 0 || ns + 4 > x->row) return MALIO_ERR_BAD_ARG;
+  x->all.resize((size_t)x->world * x->row);
+  int rc = rccl_gather(x, stream, x->all.data());
+  if (rc != MALIO_OK) return rc;
+  if (own_words_out)  // this rank's own words after the four extrema (count, search diagnostic, ...)
+    std::memcpy(own_words_out, &x->all[(size_t)x->rank * x->row + ns + 4], sizeof(double) * (size_t)(x->row - ns - 4));
+  return reduce_gathered(x, ns, guess4, sums_out, extrema4_out);
+}
+
 int malio_xchg_reduce(malio_xchg_t x, const double *row_in, int ns, const double *guess4, double *sums_out,
                       double *extrema4_out, double timeout_s) {
   if (!x || !row_in || !sums_out || !extrema4_out || ns < 0 || ns + 4 > x->row) return MALIO_ERR_BAD_ARG;
   x->all.resize((size_t)x->world * x->row);
   int rc = malio_xchg_all_gather(x, row_in, x->all.data(), timeout_s);
   if (rc != MALIO_OK) return rc;
+  return reduce_gathered(x, ns, guess4, sums_out, extrema4_out);
+}
+
+static int reduce_gathered(malio_xchg *x, int ns, const double *guess4, double *sums_out, double *extrema4_out) {
   double E[4];
   for (int k = 0; k < 4; k++) {
     E[k] = x->all[(size_t)ns + k];
@@ -146,7 +260,16 @@ int malio_xchg_unlink(malio_xchg_t x) {  // once every rank has opened the segme
 
 int malio_xchg_destroy(malio_xchg_t x) {
   if (!x) return MALIO_OK;
-  if (x->base) munmap(x->base, x->bytes);
+  if (x->kind == XCHG_RCCL) {
+    if (x->device >= 0) (void)hipSetDevice(x->device);
+    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->d_row) (void)hipFree(x->d_row);
+    if (x->d_all) (void)hipFree(x->d_all);
+    if (x->h_all) (void)hipHostFree(x->h_all);
+    delete x;
+    return MALIO_OK;
+  }
+  if (x->kind == XCHG_SHM && x->base) munmap(x->base, x->bytes);
   if (x->owner) shm_unlink(x->name.c_str());
   delete x;
   return MALIO_OK;
