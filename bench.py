@@ -8,13 +8,15 @@ over one fused multi-LiDAR scan that is already resident in HBM, against the res
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map.
-N > 1 (weak scaling): every rank holds the replicated map and its own 100k-point shard of an
-N x 100k-point scan; a pass exchanges the extrema and the 97 L sums of SURVEY.md §8(e) - 2.4 KB per rank that the
-HOST consumes - in one all-gather while the previous pass' extrema still hold, else in two exchanges
-(ma-lio_amd/dist.py). Between the ranks of one node (this contract) the rows travel through shared memory
-(malio_xchg_*); MALIO_EXCHANGE=collective sends them through the process group (RCCL) instead. Barriers and the
-max-over-ranks timing use the process group.
+N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map (the configuration the metric
+is quoted on).
+N > 1 (strong scaling): BASELINE.json configs[3] - ONE 200k-point 3-LiDAR scan vs ONE 8M-point map on N GPUs. Headline:
+the map sharded by spatial tiles with a halo (malio_set_partition), every rank serves the scan points of its own tiles,
+the [97 L sums | extrema] rows of SURVEY.md §8(e) all-gathered over RCCL inside the library (malio_measure_node on an
+RCCL exchange), added in rank order. The line also carries the three other combinations (exchange through node shared
+memory; map replicated + scan cut into N contiguous shards), the first (two-exchange) pass of a scan, the sharded
+iterated update, the load balance of the tiles and - rank 0 - the same job on one GPU. Barriers and the max-over-ranks
+timing use the process group (RCCL).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields). The CPU oracle is used only for
 the `cpu_baseline` leg (rank 0, N = 1), never inside the timed GPU region.
@@ -199,89 +201,16 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (1-based)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    ge.load_package()
-    from malio_amd import capi, scenes
-    from malio_amd import dist as mdist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # one rank per GPU (the driver's launch); MALIO_DIST_BACKEND=gloo lets several ranks share one GPU so that the
-    # multi-rank code path can be exercised on a single-GPU box (development only: gloo stages through the host)
-    backend = os.environ.get("MALIO_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE"
-
-    cfg = scenes.CONFIGS[args.config]
-    # same map (seed of the config) on every rank; the scan shard differs per rank (weak scaling)
-    sc = scenes.make_scene(cfg=args.config)
-    if distributed and rank > 0:
-        sc_r = scenes.make_scene(cfg=args.config, scan_seed=1000 + rank)
-        sc["scan"] = sc_r["scan"]
-    N, L = sc["N"], sc["L"]
-
-    eng = capi.Engine(sc["params"], device=dev_index)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.map_build(sc["map"])
-    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-    state = sc["state0"]
-
-    if distributed:
-        be = mdist.HipBackend(eng)
-        fast, fast_out = be.pass_fn(state, True)  # stage 1 -> all-reduce MAX -> stage 2 -> all-reduce SUM -> finish
-
-        def step():
-            rc = fast()
-            assert rc >= 0
-            return fast_out
-    else:
-        fast, fast_out = eng.measure_fn(state, True)  # ctypes call with pre-built structs: no Python in the loop
-
-        def step():
-            rc = fast()
-            assert rc >= 0
-            return fast_out
-
-    out = None
-    for _ in range(args.warmup):
-        out = step()
-
-    def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # The timed region is EXACTLY --steps steps between two fences, max over ranks. A step is ~50 us, so a region of a
-    # few dozen steps is ~1 ms and one scheduling hiccup moves it by percents: the region is therefore repeated (every
-    # repetition is the contract's measurement) until >= 400 steps have been timed, and the MEDIAN repetition is reported.
-    blocks = max(1, -(-400 // max(args.steps, 1)))
+def timed_blocks(step, steps, fence, distributed, dist, torch):
+    """EXACTLY `steps` steps between two fences (barrier + device sync), max over ranks - repeated until >= 400 steps
+    have been timed; returns (median seconds per region, all regions)."""
+    blocks = max(1, -(-400 // max(steps, 1)))
     dts = []
     for _ in range(blocks):
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for _ in range(steps):
+            step()
         fence()
         dt = time.perf_counter() - t0
         if distributed:
@@ -289,127 +218,331 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         dts.append(dt)
-    dt = float(np.median(dts))
-    ms_per_step = dt / args.steps * 1e3
-    value = (N * world) / (dt / args.steps)
+    return float(np.median(dts)), dts
 
-    # ---- the same pass with cold caches, and the first pass of a new scan (rank-local, single GPU) ----
-    cold = None
-    if not distributed:
-        flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")  # 4x the 256 MB Infinity Cache
-        tc = []
-        for k in range(12):
-            flush.add_(1)  # evicts the lists, the map array and the per-point state from L2 and the MALL
-            torch.cuda.synchronize()
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=0, help="BASELINE.json config number (1-based); default 2 at one GPU, 4 beyond")
+    ap.add_argument("--tile", type=float, default=16.0, help="tile edge [m] of the spatially sharded map (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    ge.load_package()
+    from malio_amd import capi, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # one rank per GPU (the driver's launch); MALIO_DIST_BACKEND=gloo lets several ranks share one GPU so that the
+    # multi-rank code path can be exercised on a single-GPU box (development only; RCCL needs one GPU per rank)
+    backend = os.environ.get("MALIO_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    distributed = "RANK" in os.environ and world > 1
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE"
+    if distributed:
+        return main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backend)
+
+    args.config = args.config or 2
+    cfg = scenes.CONFIGS[args.config]
+    sc = scenes.make_scene(cfg=args.config)
+    N, L = sc["N"], sc["L"]
+
+    eng = capi.Engine(sc["params"], device=dev_index)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    state = sc["state0"]
+    fast, fast_out = eng.measure_fn(state, True)  # ctypes call with pre-built structs: no Python in the loop
+
+    def step():
+        rc = fast()
+        assert rc >= 0
+        return fast_out
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+
+    def fence():
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # The timed region is EXACTLY --steps steps between two fences. A step is ~50 us, so a region of a few dozen steps is
+    # ~1 ms and one scheduling hiccup moves it by percents: the region is therefore repeated (every repetition is the
+    # contract's measurement) until >= 400 steps have been timed, and the MEDIAN repetition is reported.
+    dt, dts = timed_blocks(step, args.steps, fence, False, dist, torch)
+    blocks = len(dts)
+    ms_per_step = dt / args.steps * 1e3
+    value = N / (dt / args.steps)
+
+    # ---- the same pass with cold caches, and the first pass of a new scan ----
+    flush = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")  # 4x the 256 MB Infinity Cache
+    tc = []
+    for k in range(12):
+        flush.add_(1)  # evicts the lists, the map array and the per-point state from L2 and the MALL
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        step()
+        tc.append(time.perf_counter() - t)
+    tf = []
+    for k in range(6):
+        s2 = scenes.make_scene(cfg=args.config, scan_seed=900 + k)
+        eng.scan_set(s2["scan"], sc["tables"], sc["temporal_comp"])
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        step()  # first pass of a new scan: the once-per-scan spatial sort + a search over lists nobody touched yet
+        tf.append(time.perf_counter() - t)
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    step()
+    del flush
+    cold = {"cold_pass_ms": float(np.median(tc[2:]) * 1e3), "new_scan_first_pass_ms": float(np.median(tf[1:]) * 1e3),
+            "note": "cold: 1 GiB streamed through the GPU before every pass (L2 + Infinity Cache evicted); value/ms_per_step "
+                    "repeat one state on a warm cache"}
+
+    # ---- secondary metric: whole iterated update (ESKF iteration ms) ----
+    ts, passes, solve, searches = [], 0, [], 0
+    for _ in range(10):
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        eng.measure(state, True)  # per-scan spatial sort happens on the first pass; keep it out
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        u = eng.update_iterated(state, sc["P0"])
+        ts.append(time.perf_counter() - t)
+        passes, searches = u["passes"], u["searches"]
+        solve.append(u["solve_time"])
+    eskf = {"update_ms": float(np.median(ts) * 1e3), "passes": passes, "searches": searches,
+            "iter_ms": float(np.median(ts) * 1e3 / max(passes, 1)),
+            "host_algebra_ms": float(np.median(solve) * 1e3)}  # a11: the n x n filter algebra of all passes
+
+    roofline = roofline_block(eng, state, args, N)
+    secondary = secondary_figures(eng, sc, scenes, capi, args.config)
+    cpu = None if args.no_cpu_baseline else cpu_baseline(sc)
+    line = {
+        "metric": "points/sec through k-NN+residual step (100k-pt scan vs 1M-pt map); ESKF iter ms",
+        "value": value, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "timed_blocks": blocks,
+        "ms_per_step_minmax": [min(dts) / args.steps * 1e3, max(dts) / args.steps * 1e3],
+        "cold": cold, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
+        "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step" % (
+            cfg["name"], N, L, sc["Nmap"]), "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L,
+            "M_accepted": int(out.M), "seed": sc["seed"]},
+        "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_block(eng, state, args, n_points):
+    """Roofline of the dominant kernel: hipEvents on the engine's stream, same process, same workload."""
+    eng.set_profiling(True)
+    per = {}
+    for _ in range(min(50, max(10, args.steps))):
+        eng.measure(state, True)
+        for name, ms in eng.last_kernel_times():
+            per.setdefault(name, []).append(ms)
+    eng.set_profiling(False)
+    kt = {k: float(np.mean(v)) for k, v in per.items()}
+    dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
+    achieved = ALG_BYTES_SEARCH_PASS * n_points / (dom_ms * 1e-3) / 1e9
+    # PMC counters and rocprofv3's own kernel durations cannot be collected from inside this process: they come from
+    # the committed runs of this same command (profiles/README.md), and are labelled as such
+    traffic, traffic_src, rp_ms, rp_src = None, None, None, None
+    tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, PROFILE_TAG + "_pmc_traffic.json")
+    if args.config == 2 and os.path.exists(tj):
+        tjd = json.load(open(tj))
+        traffic, traffic_src = tjd["traffic_bytes_per_launch"], "committed PMC run " + os.path.relpath(tj, ROOT)
+        rp_ms, rp_src = tjd.get("rocprof_kernel_ms"), tjd.get("rocprof_source")
+    return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * n_points, "kernel_ms": dom_ms,
+            "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes the marker gap)",
+            "frac_rocprof": (ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rp_ms else None,
+            "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src, "kernel_event_ms": kt}
+
+
+def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backend):
+    """N > 1: BASELINE config 4 - ONE 200k-point 3-LiDAR scan against ONE 8M-point map on N GPUs (strong scaling: the
+    job is fixed, SURVEY.md §8e / BASELINE.md §3 iv). Headline: map sharded by spatial tiles with a halo, every rank serves
+    the scan points of its own tiles, normal equations exchanged over RCCL inside the library (malio_measure_node).
+    The other three combinations (exchange through node shared memory; map replicated + scan cut into N shards) are timed
+    the same way and reported next to it, as are the first (two-exchange) pass of a scan and, on rank 0, the same job on
+    one GPU."""
+    args.config = args.config or 4
+    cfg = scenes.CONFIGS[args.config]
+    sc = scenes.make_scene(cfg=args.config)  # the same seed on every rank: same map, same scan
+    N, L, state = sc["N"], sc["L"], sc["state0"]
+    ns_row = 97 * L + 8
+    use_rccl = backend == "nccl"
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def bcast(obj):
+        box = [obj]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def make_exchange(kind):
+        if kind == "rccl":
+            uid = bcast(capi.rccl_unique_id() if rank == 0 else None)
+            return capi.RcclExchange(uid, rank, world, ns_row, dev_index)
+        import uuid
+        name = bcast("/malio_%s" % uuid.uuid4().hex[:16] if rank == 0 else None)  # unique per job and per exchange
+        x = capi.NodeExchange(name, 0, world, ns_row, create=True) if rank == 0 else None
+        dist.barrier()  # the segment exists (and is zeroed) before anybody else opens it
+        if rank != 0:
+            x = capi.NodeExchange(name, rank, world, ns_row, create=False)
+        dist.barrier()
+        if rank == 0:
+            x.unlink()
+        return x
+
+    engines = {}
+
+    def engine(partition):
+        if partition not in engines:
+            e = capi.Engine(sc["params"], device=dev_index)
+            e.set_stream(torch.cuda.current_stream().cuda_stream)
+            if partition == "tiles":
+                e.set_partition(rank, world, args.tile)
+                e.map_build(sc["map"])
+                e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            else:
+                lo, hi = N * rank // world, N * (rank + 1) // world
+                e.map_build(sc["map"])
+                e.scan_set(sc["scan"][lo:hi], sc["tables"], sc["temporal_comp"])
+            engines[partition] = e
+        return engines[partition]
+
+    def rescan(partition):
+        e = engines[partition]
+        if partition == "tiles":
+            e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        else:
+            lo, hi = N * rank // world, N * (rank + 1) // world
+            e.scan_set(sc["scan"][lo:hi], sc["tables"], sc["temporal_comp"])
+
+    results, keep = {}, []
+    order = [("tiles", "rccl"), ("tiles", "shm"), ("scan", "rccl"), ("scan", "shm")]
+    if not use_rccl:
+        order = [o for o in order if o[1] == "shm"]
+    for partition, xk in order:
+        e = engine(partition)
+        x = make_exchange(xk)
+        keep.append(x)
+        fn, out = e.measure_node_fn(x, state, True)
+
+        def step():
+            rc = fn()
+            assert rc >= 0, rc
+        # first pass of a scan: the spatial sort, the extrema exchange, then the sums exchange
+        firsts = []
+        for _ in range(4):
+            rescan(partition)
+            fence()
             t = time.perf_counter()
             step()
-            tc.append(time.perf_counter() - t)
-        tf = []
-        for k in range(6):
-            s2 = scenes.make_scene(cfg=args.config, scan_seed=900 + k)
-            eng.scan_set(s2["scan"], sc["tables"], sc["temporal_comp"])
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            step()  # first pass of a new scan: the once-per-scan spatial sort + a search over lists nobody touched yet
-            tf.append(time.perf_counter() - t)
-        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-        step()
-        del flush
-        cold = {"cold_pass_ms": float(np.median(tc[2:]) * 1e3), "new_scan_first_pass_ms": float(np.median(tf[1:]) * 1e3),
-                "note": "cold: 1 GiB streamed through the GPU before every pass (L2 + Infinity Cache evicted); value/ms_per_step "
-                        "repeat one state on a warm cache"}
-
-    # ---- secondary metric: whole iterated update (ESKF iteration ms), single GPU only ----
-    eskf = None
-    if not distributed:
-        ts, passes, solve = [], 0, []
-        for _ in range(10):
-            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-            eng.measure(state, True)  # per-scan spatial sort happens on the first pass; keep it out
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            u = eng.update_iterated(state, sc["P0"])
-            ts.append(time.perf_counter() - t)
-            passes = u["passes"]
-            solve.append(u["solve_time"])
-        eskf = {"update_ms": float(np.median(ts) * 1e3), "passes": passes,
-                "iter_ms": float(np.median(ts) * 1e3 / max(passes, 1)),
-                "host_algebra_ms": float(np.median(solve) * 1e3)}  # a11: the n x n filter algebra of all passes
-
-    elif getattr(be, "xchg", None) is not None:   # the sharded update, one library call per rank (malio_update_iterated_node)
-        ts, passes = [], 0
-        for _ in range(10):
-            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-            step()                   # per-scan spatial sort happens on the first pass; keep it out
+            firsts.append(time.perf_counter() - t)
+        for _ in range(args.warmup):
+            step()
+        dt, dts = timed_blocks(step, args.steps, fence, True, dist, torch)
+        # whole iterated update over the sharded job (every rank runs the same n x n algebra on the same reduced sums)
+        ups, passes = [], 0
+        for _ in range(5):
+            rescan(partition)
+            step()
             fence()
             t = time.perf_counter()
-            u = eng.update_iterated_node(be.xchg, state, sc["P0"])
+            u = e.update_iterated_node(x, state, sc["P0"])
             fence()
-            ts.append(time.perf_counter() - t)
+            ups.append(time.perf_counter() - t)
             passes = u["passes"]
-        tmed = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+        tmed = torch.tensor([float(np.median(ups)), float(np.median(firsts[1:]))], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmed, op=dist.ReduceOp.MAX)
-        eskf = {"update_ms": float(tmed.item() * 1e3), "passes": passes, "iter_ms": float(tmed.item() * 1e3 / max(passes, 1)),
-                "sharded": True}
+        hits, misses = e.node_stats()
+        results[(partition, xk)] = {"ms_per_step": dt / args.steps * 1e3, "timed_blocks": len(dts),
+                                    "ms_per_step_minmax": [min(dts) / args.steps * 1e3, max(dts) / args.steps * 1e3],
+                                    "first_pass_ms": float(tmed[1].item() * 1e3), "update_ms": float(tmed[0].item() * 1e3),
+                                    "update_passes": passes, "M_accepted": int(out.M),
+                                    "one_exchange_passes": hits, "two_exchange_passes": misses}
+    head = order[0]
+    hres = results[head]
+    value = N / (hres["ms_per_step"] * 1e-3)
 
-    # ---- roofline of the dominant kernel: hipEvents on the engine's stream, same command ----
-    roofline = None
+    # load balance of the tile sharding: scan points served and map points stored per rank
+    et = engines["tiles"]
+    served = torch.tensor([float(et.scan_owned().sum()), float(et.map_size())], dtype=torch.float64, device="cuda")
+    allsv = [torch.zeros_like(served) for _ in range(world)]
+    dist.all_gather(allsv, served)
+    balance = {"scan_points_served": [int(v[0].item()) for v in allsv], "map_points_stored": [int(v[1].item()) for v in allsv]}
+
+    roofline = single = None
     if rank == 0:
-        eng.set_profiling(True)
-        per = {}
-        for _ in range(min(50, max(10, args.steps))):
-            eng.measure(state, True)  # same kernels as the sharded pass, without the collectives in between
-            for name, ms in eng.last_kernel_times():
-                per.setdefault(name, []).append(ms)
-        eng.set_profiling(False)
-        kt = {k: float(np.mean(v)) for k, v in per.items()}
-        dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
-        achieved = ALG_BYTES_SEARCH_PASS * N / (dom_ms * 1e-3) / 1e9
-        # PMC counters and rocprofv3's own kernel durations cannot be collected from inside this process: they come from
-        # the committed runs of this same command (profiles/README.md), and are labelled as such
-        traffic, traffic_src, rp_ms, rp_src = None, None, None, None
-        tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, PROFILE_TAG + "_pmc_traffic.json")
-        if args.config == 2 and os.path.exists(tj):
-            tjd = json.load(open(tj))
-            traffic, traffic_src = tjd["traffic_bytes_per_launch"], "committed PMC run " + os.path.relpath(tj, ROOT)
-            rp_ms, rp_src = tjd.get("rocprof_kernel_ms"), tjd.get("rocprof_source")
-        roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * N, "kernel_ms": dom_ms,
-                    "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes the marker gap)",
-                    "frac_rocprof": (ALG_BYTES_SEARCH_PASS * N / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rp_ms else None,
-                    "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src,
-                    "kernel_event_ms": kt}
-    # ---- secondary figures of the other rows of the path (rank 0, single GPU): undistortion kernel and map upkeep ----
-    secondary = None
-    if rank == 0 and not distributed:
-        secondary = secondary_figures(eng, sc, scenes, capi, args.config)
-    if distributed:
-        dist.barrier()
-
-    cpu = None
-    if rank == 0 and not distributed and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sc)
-
+        n_mine = balance["scan_points_served"][0]
+        roofline = roofline_block(et, state, args, n_mine)
+        roofline["note"] = "rank 0's shard: %d of %d scan points served" % (n_mine, N)
+    fence()
+    if rank == 0:  # the same job on ONE GPU (the strong-scaling baseline), outside everybody's timed regions
+        e1 = capi.Engine(sc["params"], device=dev_index)
+        e1.map_build(sc["map"])
+        e1.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        f1, _ = e1.measure_fn(state, True)
+        for _ in range(args.warmup + 1):
+            f1()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(200):
+            f1()
+        torch.cuda.synchronize()
+        single = {"ms_per_step": (time.perf_counter() - t) / 200 * 1e3}
+        single["speedup_at_n"] = single["ms_per_step"] / hres["ms_per_step"]
+    fence()
     if rank == 0:
         line = {
             "metric": "points/sec through k-NN+residual step (100k-pt scan vs 1M-pt map); ESKF iter ms",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "timed_blocks": blocks, "ms_per_step_minmax": [min(dts) / args.steps * 1e3, max(dts) / args.steps * 1e3],
-            "cold": cold, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": hres["ms_per_step"], "timed_blocks": hres["timed_blocks"],
+            "ms_per_step_minmax": hres["ms_per_step_minmax"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None,
             "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
-            "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step%s" % (
-                cfg["name"], N, L, sc["Nmap"], "" if not distributed else
-                "; scan sharded %d x %d pts, map replicated, one all-gather of [sums | extrema] per pass while the extrema of the previous pass still hold (else two exchanges), rows exchanged via %s" % (
-                    world, N, "node shared memory" if getattr(be, "spec_stats", {}).get("exchange") == "shm" else "the process group (%s)" % backend)),
-                "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L, "M_accepted": int(out["M"] if isinstance(out, dict) else out.M),
-                "seed": sc["seed"]},
-            "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": "%s: ONE %d-pt %d-LiDAR scan vs ONE %d-pt map on %d GPUs, one search pass (converge=1) per step; "
+                       "map sharded by %g m spatial tiles + 2.3 m halo, each rank serves the scan points of its tiles, "
+                       "[sums | extrema] rows all-gathered over %s inside the library (one exchange per pass while the extrema of the "
+                       "previous pass hold, else two), added in rank order" % (
+                           cfg["name"], N, L, sc["Nmap"], world, args.tile, "RCCL" if head[1] == "rccl" else "node shared memory"),
+                       "partition": head[0], "exchange": head[1], "total_points": N, "map_points": sc["Nmap"], "lidars": L,
+                       "M_accepted": hres["M_accepted"], "seed": sc["seed"], "tile_m": args.tile},
+            "eskf": {"update_ms": hres["update_ms"], "passes": hres["update_passes"], "sharded": True,
+                     "iter_ms": hres["update_ms"] / max(hres["update_passes"], 1)},
+            "first_pass_ms": hres["first_pass_ms"],
+            "variants": {"%s+%s" % k: v for k, v in results.items()},
+            "balance": balance, "single_gpu_same_job": single, "roofline": roofline, "cpu_baseline": None,
         }
         print(json.dumps(line), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    for x in keep:
+        x.close()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -83,8 +83,8 @@ def _share_hip_runtime_with_torch():
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
+    if spec is None or not spec.submodule_search_locations or os.environ.get("MALIO_TORCH_FIRST", "1") == "0":
+        return  # (MALIO_TORCH_FIRST=0: a process that will never import torch, e.g. the host-only exchange workers)
     try:
         import torch  # noqa: F401
     except Exception:
@@ -455,6 +455,17 @@ class Engine:
     def scan_order(self, mode):
         """malio_scan_order: 0 auto (host scans sorted, resident scans as they are), 1 always sort, 2 never sort."""
         self._chk(lib().malio_scan_order(self.h, int(mode)), "malio_scan_order")
+
+    def measure_node_fn(self, xchg, state_flat, converge=True):
+        """Pre-bound malio_measure_node (one pass over a scan / map sharded across ranks): fn() -> rc, out struct."""
+        s = state_from_flat(state_flat, self.L)
+        out = MeasureOut()
+        f, h, xh, sp, op, cv = lib().malio_measure_node, self.h, xchg.h, C.byref(s), C.byref(out), int(bool(converge))
+
+        def fn():
+            return f(h, xh, sp, cv, op, None)
+        fn._keep = (s, out, xchg)
+        return fn, out
 
     def update_iterated_node(self, xchg, state_flat, P, R=0.001):
         """malio_update_iterated_node: the iterated update over a scan sharded across the ranks of one node."""

@@ -5,6 +5,7 @@ import time
 
 import numpy as np
 
+os.environ["MALIO_TORCH_FIRST"] = "0"  # host-only process: never imports torch (see capi._share_hip_runtime_with_torch)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
