@@ -443,9 +443,11 @@ def test_call_order_errors(capi, scenes):
 
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
-    """The N > 1 code path of bench.py (scan sharded over ranks, MAX + SUM all-reduce per pass, C finish) with two
-    ranks on the one GPU a test box has: MALIO_DIST_BACKEND=gloo (RCCL refuses two ranks per device). The global
-    count of accepted points must be the sum of what each shard accepts on its own."""
+    """The N > 1 code path of bench.py (ONE scan against ONE map on N ranks, strong scaling: map sharded by spatial tiles,
+    rows exchanged inside the library, C finish) with two ranks on the one GPU a test box has: MALIO_DIST_BACKEND=gloo
+    keeps the process group off RCCL (which refuses two ranks per device), so the shared-memory exchange is the headline
+    and the replicated-map / sharded-scan variant rides along. Both partitionings are exact: the global count of accepted
+    points must equal what ONE engine accepts on the whole scan."""
     import json
     import os
     import subprocess
@@ -458,16 +460,17 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     js = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
-    assert js["n_gpus"] == 2 and js["scaling"] == "weak" and js["value"] > 0
-    Ms = []
+    assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["value"] > 0
+    assert js["config"]["partition"] == "tiles" and js["config"]["exchange"] == "shm"
     sc = scenes.make_scene(cfg=3)
-    for r in range(2):   # bench.py: same map / tables / prior on every rank, the scan shard differs
-        scan = sc["scan"] if r == 0 else scenes.make_scene(cfg=3, scan_seed=1000 + r)["scan"]
-        eng = capi.Engine(sc["params"])
-        eng.map_build(sc["map"])
-        eng.scan_set(scan, sc["tables"], sc["temporal_comp"])
-        Ms.append(eng.measure(sc["state0"], True)["M"])
-    assert js["config"]["M_accepted"] == sum(Ms)
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    M = eng.measure(sc["state0"], True)["M"]
+    assert js["config"]["M_accepted"] == M
+    assert set(js["variants"]) == {"tiles+shm", "scan+shm"}
+    assert all(v["M_accepted"] == M and v["first_pass_ms"] > 0 for v in js["variants"].values())
+    assert sum(js["balance"]["scan_points_served"]) == sc["N"]
 
 
 @pytest.mark.gpu

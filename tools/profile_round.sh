@@ -12,5 +12,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_stdout.txt 2> $OUT/rocprof_stderr.txt
 bash $ROOT/tools/pmc_run.sh $TAG/pmc > $OUT/pmc_run_stdout.txt 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/${TAG}_pmc_summary.txt 2>&1
+python $ROOT/tools/pmc_traffic.py $OUT $TAG > /dev/null 2>&1
 ls $OUT
 tail -c 600 $OUT/${TAG}_bench_stdout.txt
