@@ -244,6 +244,21 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
 int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats,
                           double *solve_time);
 
+/* How malio_update_iterated drives its loop (same arithmetic in all three).
+ * MALIO_UPDATE_GATED (default): every pass of the loop is enqueued ahead of the GPU; between two passes a one-workgroup
+ *   gate kernel announces the finished pass' sums (stored by the kernels in pinned memory) through a sequence word, polls
+ *   a second word until the calling thread has published the next pass' control block - state, search / reuse, or stop -
+ *   and copies it to where the pass kernels read it. The n x n algebra of esekfom.hpp:521-720 stays on the calling thread
+ *   (half of it runs while the GPU is busy with the pass); what disappears is the synchronise / launch round trip per pass.
+ * MALIO_UPDATE_HOST: one pass at a time - launch, synchronise, algebra, launch (what a pass hook, per-pass profiling,
+ *   the node-sharded update and the M < n rows path use). Bit-identical to GATED.
+ * MALIO_UPDATE_DEVICE: the algebra too on the GPU (one workgroup after every pass, which also decides what the next pass
+ *   is): ONE chain the host waits for once. The serial 35-step eliminations are latency-bound on a GPU - measured 3x the
+ *   time of the other two - so this is the mode for a host that must not be in the loop, not the fast one; differs from
+ *   the others by the device's libm (sin/cos/atan, <= 2 ulp), i.e. ~1e-9 in the state at 1e5 points. */
+enum { MALIO_UPDATE_DEVICE = 0, MALIO_UPDATE_HOST = 1, MALIO_UPDATE_GATED = 2 };
+int malio_set_update_mode(malio_handle_t h, int mode);
+
 /* h_dyn_share is a plain function in the reference (esekfom.hpp:130,512): whatever it does - tracing, or finding the
  * map changed under it - happens once per pass on the calling thread. fn(pass, user) is called before every
  * measurement pass of malio_update_iterated[_node] with the 0-based pass number; NULL removes it. */

@@ -30,6 +30,7 @@ EXPORTS = [
     "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
     "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
+    "malio_set_update_mode",
 ]
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
@@ -209,6 +210,11 @@ class Engine:
 
     def set_profiling(self, on=True):
         self._chk(lib().malio_set_profiling(self.h, int(on)), "malio_set_profiling")
+
+    def set_update_mode(self, mode):
+        """"device" (default): update_iterated is one enqueued chain of kernels with the filter algebra on the GPU;
+        "host": one pass at a time, algebra on the calling thread."""
+        self._chk(lib().malio_set_update_mode(self.h, {"device": 0, "host": 1, "gated": 2}[mode]), "malio_set_update_mode")
 
     def last_kernel_times(self):
         names = (C.c_char_p * 16)()

@@ -151,6 +151,7 @@ int malio_destroy(malio_handle_t h) {
   free_nlist(c->nl2);
   free_nl_scratch(c->nl_scratch);
   free_grid(c->gnew);
+  free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
@@ -800,7 +801,21 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
 int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double R, int *stats, double *solve_time) {
   if (check(h) || !x || !P) return MALIO_ERR_BAD_ARG;
   MALIO_HIP_H(hipSetDevice(h->device));
+  // The whole loop as one enqueued chain with the filter algebra on the device (csrc/ieskf_dev.hip), unless something
+  // needs the host between passes: a pass hook, profiling of single passes, or - found out by the first valid pass -
+  // fewer accepted points than states (the M x M form of esekfom.hpp:574-582 works on rows).
+  if (h->update_mode != MALIO_UPDATE_HOST && !h->pass_hook && !h->profiling) {
+    if (solve_time) *solve_time = 0;
+    const int rc = h->update_mode == MALIO_UPDATE_GATED ? ieskf_update_gated(h, x, P, stats, solve_time) : ieskf_update_device(h, x, P, stats);
+    if (rc != MALIO_SMALL_M_FALLBACK) return rc;
+  }
   return ieskf_update(h, nullptr, x, P, R, stats, solve_time);
+}
+
+int malio_set_update_mode(malio_handle_t h, int mode) {
+  if (check(h) || (mode != MALIO_UPDATE_DEVICE && mode != MALIO_UPDATE_HOST && mode != MALIO_UPDATE_GATED)) return MALIO_ERR_BAD_ARG;
+  h->update_mode = mode;
+  return MALIO_OK;
 }
 
 // Diagnostics (not part of the reference interface): {level-1 directory cells, map points, level-2 directory cells}.

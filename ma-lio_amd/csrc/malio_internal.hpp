@@ -148,6 +148,53 @@ struct WeightConst {
   double plane_cov_max, plane_cov_min, point_cov_max, point_cov_min, range_min, range_max;
 };
 
+// Quaternion form of the state of one pass (stage 1: world transform in Eigen's quaternion * vector order)
+struct D3 {
+  double x, y, z;
+};
+struct Q4 {
+  double x, y, z, w;
+};
+struct QuatConst {
+  Q4 rot;
+  D3 pos;
+  Q4 q0;
+  D3 t0;
+  Q4 ql[MALIO_MAX_LIDAR];
+  D3 tl[MALIO_MAX_LIDAR];
+  Q4 qtc[MALIO_MAX_LIDAR];  // index lid (0 unused)
+  D3 ttc[MALIO_MAX_LIDAR];
+};
+
+// Device-resident state of the iterated update (csrc/ieskf_dev.hip): with it a whole update_iterated is ONE chain of
+// kernels the host enqueues up front and waits for once. The pass kernels (DEV = true instantiations) read the state
+// and the control words from here instead of from their kernel arguments; k_ieskf_step - one workgroup running the
+// n x n filter algebra of esekfom.hpp:521-720 after every pass - is the only writer.
+constexpr int DEV_NMAX = 17 + 6 * MALIO_MAX_LIDAR;  // 41
+struct DevLoop {
+  int done;         // the loop is over (or was never started): every remaining kernel of the chain exits at once
+  int converge;     // ekfom_data.converge of the NEXT pass: 1 = search, 0 = reuse (esekfom.hpp:649-663)
+  int i;            // loop index of the NEXT pass (esekfom.hpp:509: -1 .. maximum_iter - 1)
+  int t;            // converged iterations so far (:658)
+  int passes, searches, lastM;
+  int status;       // MALIO_OK, MALIO_SMALL_M_FALLBACK (n > M: the host redoes the update on the rows path) or < 0
+  int mm_parity;    // extrema slot set the NEXT pass accumulates into (the other one is cleared by it)
+  int dq_parity;    // deferral counter set of the NEXT search pass
+  int commit_prev;  // the previous pass was valid: its (sel, trace) are folded into normal_y by the next one
+  int valid_any;    // a pass was valid: P_proj of the last valid iteration is what a loop that runs out leaves behind
+  int heavy;        // deferral score of the last search pass (steers the host's k_search_tail switch)
+  int lastM_valid;  // accepted points of the last VALID pass (stats[2])
+  int maximum_iter, L, extrinsic_est_en;
+  double limit;
+  double tcq[MALIO_MAX_LIDAR][4], tct[MALIO_MAX_LIDAR][3];  // temporal compensation of this scan (index lid - 1)
+  malio_state_t x, x_prop;
+  QuatConst qc;  // x in the forms the pass kernels read
+  PassConst pc;
+  // localization-weight parameters (laserMapping.cpp:749-756)
+  double loc_thresh_min, loc_thresh_max, loc_cov_min, loc_cov_max;
+  long long stamps[16];  // developer aid: wall_clock64 (100 MHz) at the phase boundaries of the last step kernel
+};
+
 // Uncertainty-table entry folded for trace(Sigma_p) (associate_uct.hpp:153-175):
 // p' = T (0.05 p, 1);  trace = k0 + lin . p' + p'^T Q p'
 struct alignas(16) UncEntry {
@@ -302,6 +349,17 @@ struct Ctx {
   double *h_sums = nullptr;      // pinned
   double *h_res = nullptr, *d_res = nullptr;  // pinned + its device-visible alias: results stored by the kernels
   double *h_minmax = nullptr;    // pinned [5]
+  // device-resident iterated update (csrc/ieskf_dev.hip)
+  DevLoop *d_loop = nullptr;     // control block + state
+  double *d_loopbuf = nullptr;   // P_prop | P_proj | P_projinv | dx_new | scratch (see ieskf_dev.hip)
+  char *h_loop_in = nullptr;     // pinned: what one update uploads (DevLoop + P_prop)
+  char *h_loop_out = nullptr;    // pinned, device-mapped: what the last step kernel stores (DevLoop + P)
+  char *d_loop_out = nullptr;    // ... its device alias
+  char *h_gate = nullptr, *d_gate = nullptr;  // pinned + device alias: control block and sequence words of the gated loop
+  int gate_epoch = 1;
+  double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
+  int gate_trace_n = 0;
+  int update_mode = MALIO_UPDATE_GATED;  // malio_set_update_mode
   double *d_rows = nullptr;      // optional dense rows [N][C+2]
   size_t cap_rows = 0;
   size_t cap_partials = 0;
@@ -408,6 +466,17 @@ constexpr double DEFER_SCORE_MIN = 64.0;
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);
 // host/ieskf.cpp
 int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
+// csrc/ieskf_dev.hip: the same update as ONE enqueued chain of kernels with the n x n algebra on the device; returns
+// MALIO_SMALL_M_FALLBACK untouched inputs when a pass accepted fewer points than there are states (rows path: host loop)
+int ieskf_update_device(Ctx *c, malio_state_t *x, double *P, int *stats);
+void free_dev_loop(Ctx *c);
+int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
+// measure.hip: the pass kernels of one iteration of the device loop (k_search/k_reuse by the control block's converge
+// flag, [k_search_tail], k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
+int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out);
+int prepare_scan_dev(Ctx *c, const malio_state_t *s);  // map lists in sync, scan sorted
+void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
+void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc);
 // the same loop over any measurement pass (host/node.cpp drives several GPUs through it); rows_pass == nullptr: no rows
 // path, fewer accepted points than states -> MALIO_SMALL_M_FALLBACK
 using PassFn = std::function<int(const malio_state_t *, int, malio_measure_out_t *)>;
@@ -416,6 +485,17 @@ int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn 
 int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                const double *P_prop, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out,
                int *done_out, double *P_out);
+// the same iteration in two halves: what depends on the iterate alone (dx, the projected P_propagated and its inverse) and
+// what needs the pass' normal equations
+struct StepPre {
+  std::vector<double> P_, Pinv, dx, dx_new;
+  int inv_state = 0;  // 0: Pinv not computed, 1: valid, -1: P_ is singular
+};
+void ieskf_step_pre(int L, const malio_state_t *x, const malio_state_t *x_propagated, const double *P_prop, StepPre &pre,
+                    bool with_inverse);
+int ieskf_step_post(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
+                    StepPre &pre, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out, int *done_out,
+                    double *P_out);
 
 // profiling helpers
 void prof_begin(Ctx *c);

@@ -11,6 +11,7 @@
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
 #include "malio_internal.hpp"
+#include "../host/manifold.hpp"
 #include <hipcub/hipcub.hpp>
 
 namespace malio {
@@ -49,12 +50,6 @@ __device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pe
 #define PH_EXIT()
 #endif
 
-struct D3 {
-  double x, y, z;
-};
-struct Q4 {
-  double x, y, z, w;
-};
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 cross(D3 a, D3 b) {
@@ -78,17 +73,7 @@ __device__ __forceinline__ D3 mulRt(const double *R, D3 v) {
           R[2] * v.x + R[5] * v.y + R[8] * v.z};
 }
 
-struct QuatConst {
-  Q4 rot;
-  D3 pos;
-  Q4 q0;
-  D3 t0;
-  Q4 ql[MALIO_MAX_LIDAR];
-  D3 tl[MALIO_MAX_LIDAR];
-  Q4 qtc[MALIO_MAX_LIDAR];  // index lid (0 unused)
-  D3 ttc[MALIO_MAX_LIDAR];
-};
-
+constexpr int MM_SLOTS = 64;  // extrema slots (see mm_publish)
 struct Pass1Args {
   int N;
   const float4 *scan;
@@ -121,7 +106,27 @@ struct Pass1Args {
   unsigned char *nfound;
   float *ny;        // [N] feats_down_body[i].normal_y as the reference would hold it (committed lazily)
   int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
+  // device loop (DEV = true instantiations): state, parities and commit_prev come from *dl, the slot sets from mm_base
+  const DevLoop *dl;
+  u64 *mm_base;     // [2 parities][MM_SLOTS][5]
 };
+// what a DEV kernel reads from the control block instead of from its arguments
+struct PassDyn {
+  int commit_prev, parity;
+  u64 *mm_cur, *mm_next;
+};
+template <bool DEV>
+__device__ __forceinline__ PassDyn pass_dyn(const Pass1Args &a) {
+  PassDyn d;
+  if (DEV) {
+    const int mp = a.dl->mm_parity;
+    d.commit_prev = a.dl->commit_prev, d.parity = a.dl->dq_parity;
+    d.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, d.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
+  } else {
+    d.commit_prev = a.commit_prev, d.parity = a.parity, d.mm_cur = a.mm_cur, d.mm_next = a.mm_next;
+  }
+  return d;
+}
 
 __device__ __forceinline__ u64 cell_key_d(int ix, int iy, int iz) {
   const long long B = 1ll << 20;
@@ -412,8 +417,8 @@ __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, 
 // rewrites it with trace(Sigma_p), except for accepted points when extrinsic_est_en is off (:681).
 // A pass that bailed out with no effective points (:635-639) rewrites nothing, which is only known on the
 // host after the pass - so the fold happens at the start of the NEXT pass (or in malio_scan_get).
-__device__ __forceinline__ void commit_normal_y(const Pass1Args &a, int i) {
-  if (!a.commit_prev) return;
+__device__ __forceinline__ void commit_normal_y(const Pass1Args &a, int commit_prev, int i) {
+  if (!commit_prev) return;
   if (a.sel[i] && !a.extrinsic_est_en) return;
   a.ny[i] = (float)a.trace[i];
 }
@@ -424,7 +429,6 @@ __device__ __forceinline__ void commit_normal_y(const Pass1Args &a, int i) {
 // folded by one wave of the consumer. Slot layout: [MM_SLOTS][5] u64 = max_u, min_u, max_R, min_R (doubles under
 // an order-preserving encoding), count. Two parities alternate between passes; a stage-1 kernel accumulates into
 // one and resets the other, so no separate clearing launch is needed.
-constexpr int MM_SLOTS = 64;
 __device__ __forceinline__ u64 mm_enc(double x) {
   u64 b = (u64)__double_as_longlong(x);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
@@ -461,7 +465,7 @@ __device__ __forceinline__ void mm_fold_wave(const u64 *slots, int extrinsic_est
 }
 
 // workgroup-wide version for the thread-per-point kernels (k_reuse)
-__device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, double ucov, double tr) {
+__device__ __forceinline__ void block_minmax(const Pass1Args &a, const PassDyn &dy, bool selected, double ucov, double tr) {
   __shared__ double sm[BLK / 64][5];
   double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
   bool rsel = selected && a.extrinsic_est_en;
@@ -480,9 +484,9 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, bool selected, 
       r0 = fmax(r0, sm[w][0]), r1 = fmin(r1, sm[w][1]), r2 = fmax(r2, sm[w][2]), r3 = fmin(r3, sm[w][3]);
       r4 += sm[w][4];
     }
-    mm_publish(a.mm_cur, r0, r1, r2, r3, (u64)r4);
+    mm_publish(dy.mm_cur, r0, r1, r2, r3, (u64)r4);
   }
-  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(a.mm_next, threadIdx.x);
+  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
 }
 
 // a2: ikdtree.Nearest_Search (laserMapping.cpp:586) on neighbour lists. ONE directory probe + one contiguous
@@ -545,14 +549,14 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
 
 // a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
-__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, const float4 w, double nb, const u32 og[5], int nf,
-                                            bool &selected, double &ucov, double &tr) {
+__device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev, int i, const float4 w, double nb,
+                                            const u32 og[5], int nf, bool &selected, double &ucov, double &tr) {
   selected = false, ucov = 0.0, tr = 0.0;
 #pragma unroll
   for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
   a.nfound[i] = (unsigned char)nf;
   a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
-  commit_normal_y(a, i);
+  commit_normal_y(a, commit_prev, i);
   if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
     // ---- esti_plane<float> (common_lib.h:144-190) ----
     float A[5][3], W[5];
@@ -603,6 +607,45 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, const flo
   a.trace[i] = tr;
 }
 
+// REUSE pass of one point (ekfom_data.converge == false, laserMapping.cpp:583-595): neighbours, plane and flag are kept; the
+// residual and the range gate are re-evaluated at the new state.
+__device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst &qc, int commit_prev, int i, bool &selected,
+                                            double &ucov, double &tr) {
+  selected = false, ucov = 0.0, tr = 0.0;
+  if (i >= a.N || a.nfound[i] == NF_NOTMINE) return;  // (a partitioned handle keeps serving the points of its last search pass)
+  const float4 q = a.scan[i];
+  const int packed = __float_as_int(q.w);
+  const int lid = packed & 0xFF, tidx = packed >> 8;
+  float wx, wy, wz;
+  double nb;
+  world_point(qc, q, lid, wx, wy, wz, nb);
+  a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
+  commit_normal_y(a, commit_prev, i);
+  if (a.sel[i]) {
+    const float4 pl = a.plane[i];
+    const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
+    ucov = a.ucov[i];
+    float pd2;
+    if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
+      selected = true;
+      a.pd2[i] = pd2;
+    }
+  }
+  a.sel[i] = selected ? 1 : 0;
+  tr = trace_for(a, q, lid, tidx, selected);
+  a.trace[i] = tr;
+}
+
+// a4 over one wave's 64 points: extrema of unit_cov / R and the count of accepted points -> one slot
+__device__ __forceinline__ void wave_minmax_publish(const Pass1Args &a, u64 *mm_cur, bool selected, double ucov, double tr) {
+  double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
+  const bool rsel = selected && a.extrinsic_est_en;
+  double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
+  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
+  const unsigned long long bal = __ballot(selected);
+  if ((threadIdx.x & 63) == 0) mm_publish(mm_cur, mxu, mnu, mxr, mnr, (u64)__popcll(bal));
+}
+
 // ---- SEARCH pass, one kernel (laserMapping.cpp:563-612 + the rejected-point trace of :725-743) ----------------
 // A workgroup owns SQ = 64 consecutive sorted queries and runs three phases:
 //   A  wave 0, lane = query: a1 world transform (double, Eigen's operation order) -> LDS, world4, |p'|
@@ -619,27 +662,43 @@ constexpr int KS_WAVES = KS_BLK / 64;
 #ifndef KS_WPE
 #define KS_WPE 7
 #endif
+// DEV = true: one pass of the device-resident update loop (DevLoop): exits when the loop is over, runs the REUSE pass on
+// its first wave when the control block asks for one (a reuse pass then costs one launch of this grid, no second
+// kernel that would have to be enqueued and skipped), and takes state, parities and commit_prev from the block.
+template <bool DEV>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ float4 s_w[SQ];
   __shared__ u32 s_og[5][SQ];
   __shared__ unsigned char s_nf[SQ];
   __shared__ double s_nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
+  if (DEV && a.dl->done) return;
+  const QuatConst &qc = DEV ? a.dl->qc : a.qc;
+  const PassDyn dy = pass_dyn<DEV>(a);
   const int q0 = blockIdx.x * SQ;
   // ---- phase A ----
   const int i = q0 + (int)threadIdx.x;  // meaningful for wave 0 only
+  if (DEV && !a.dl->converge) {  // REUSE pass: wave 0, lane = point
+    if (threadIdx.x >= SQ) return;
+    bool selected;
+    double ucov, tr;
+    reuse_point(a, qc, dy.commit_prev, i, selected, ucov, tr);
+    wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);
+    if (blockIdx.x == 0) mm_reset_slot(dy.mm_next, threadIdx.x);
+    return;
+  }
   bool mine = threadIdx.x < SQ && i < a.N;
   PH(0, 0);
   PH_ENTER();
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
-    mm_reset_slot(a.mm_next, threadIdx.x);
-    if (threadIdx.x == 0) a.dq_ctl[a.parity ^ 1] = 0, a.dq_ctl[2 + (a.parity ^ 1)] = 0;
+    mm_reset_slot(dy.mm_next, threadIdx.x);
+    if (threadIdx.x == 0) a.dq_ctl[dy.parity ^ 1] = 0, a.dq_ctl[2 + (dy.parity ^ 1)] = 0;
   }
   if (threadIdx.x < SQ) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
       const float4 q = a.scan[i];
       double nb;
-      world_point(a.qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
+      world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
       a.pbnorm[i] = nb;
       s_nb[threadIdx.x] = nb;
@@ -688,12 +747,12 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       const bool heavy = npend > DEFER_MIN;
       // steers the host's defer switch (DEFER_SCORE_MIN): a workgroup more than half full of uncertified queries
       // would take tens of microseconds longer on its own and counts as 64, a mildly loaded one as 1
-      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + a.parity], npend > 32 ? 64u : 1u);
+      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + dy.parity], npend > 32 ? 64u : 1u);
       if (heavy && a.defer) {
         // too many for this workgroup: hand them to k_search_tail, which spreads them one per wave over the GPU
         if (wave == 0) {
           u32 base = 0;
-          if (lane == 0) base = atomicAdd(&a.dq_ctl[a.parity], (u32)npend);
+          if (lane == 0) base = atomicAdd(&a.dq_ctl[dy.parity], (u32)npend);
           base = __shfl(base, 0);
           if (pend) {
             a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)(q0 + lane);
@@ -732,16 +791,9 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   PH(0, 3);
   bool selected = false;
   double ucov = 0.0, tr = 0.0;
-  if (mine && nf != NF_DEFERRED) point_phase(a, i, s_w[lane], s_nb[lane], og, nf, selected, ucov, tr);
+  if (mine && nf != NF_DEFERRED) point_phase(a, dy.commit_prev, i, s_w[lane], s_nb[lane], og, nf, selected, ucov, tr);
   PH(0, 8);
-  {  // a4 over this wave's 64 queries
-    double mxu = selected ? ucov : -INFINITY, mnu = selected ? ucov : INFINITY;
-    const bool rsel = selected && a.extrinsic_est_en;
-    double mxr = rsel ? tr : -INFINITY, mnr = rsel ? tr : INFINITY;
-    mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
-    const unsigned long long bal = __ballot(selected);
-    if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, (u64)__popcll(bal));
-  }
+  wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);  // a4 over this wave's 64 queries
   PH(0, 9);
   PH_EXIT();
 }
@@ -749,11 +801,14 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
 // Deferred level-2 work of k_search: 16 lanes per query on the level-2 list, then the first lane of each group runs
 // the point phase. Workgroups whose queries are mostly unmatched - the map frontier, a thinned map - would otherwise serialise
 // 16 such searches per wave while the rest of the GPU idles.
+template <bool DEV>
 __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
+  if (DEV && (a.dl->done || !a.dl->converge)) return;  // the loop is over, or this pass is a reuse pass
+  const PassDyn dy = pass_dyn<DEV>(a);
   // 16 lanes per query: 4 queries per wave search concurrently, then their first lanes run the point phase together
   const int lane = threadIdx.x & 63, sub = threadIdx.x & (TAIL_G - 1);
   const u32 grp = (blockIdx.x * BLK + threadIdx.x) / TAIL_G, ngrp = (gridDim.x * BLK) / TAIL_G;
-  const u32 cnt = a.dq_ctl[a.parity];
+  const u32 cnt = a.dq_ctl[dy.parity];
   double mxu = -INFINITY, mnu = INFINITY, mxr = -INFINITY, mnr = INFINITY;
   u64 nsel = 0;
   const u32 sweeps = (cnt + ngrp - 1) / ngrp;
@@ -772,7 +827,7 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
       bool selected;
       double ucov, tr;
       const u32 og5[5] = {t.og(0), t.og(1), t.og(2), t.og(3), t.og(4)};
-      point_phase(a, i, w, a.pbnorm[i], og5, nf, selected, ucov, tr);
+      point_phase(a, dy.commit_prev, i, w, a.pbnorm[i], og5, nf, selected, ucov, tr);
       if (selected) {
         nsel++;
         mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -784,39 +839,17 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
   mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) nsel += __shfl_xor(nsel, d);
-  if (lane == 0) mm_publish(a.mm_cur, mxu, mnu, mxr, mnr, nsel);
+  if (lane == 0) mm_publish(dy.mm_cur, mxu, mnu, mxr, mnr, nsel);
 }
 
-// REUSE pass (ekfom_data.converge == false, :583-595): neighbours, plane and flag are kept; the
-// residual and the range gate are re-evaluated at the new state.
+// REUSE pass of the host-driven path, thread per point (the device loop runs it inside k_search<true>).
 __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
-  bool selected = false;
-  double ucov = 0.0, tr = 0.0;
-  if (i < a.N && a.nfound[i] != NF_NOTMINE) {  // (a partitioned handle keeps serving the points of its last search pass)
-    const float4 q = a.scan[i];
-    const int packed = __float_as_int(q.w);
-    const int lid = packed & 0xFF, tidx = packed >> 8;
-    float wx, wy, wz;
-    double nb;
-    world_point(a.qc, q, lid, wx, wy, wz, nb);
-    a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
-    commit_normal_y(a, i);
-    if (a.sel[i]) {
-      const float4 pl = a.plane[i];
-      const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
-      ucov = a.ucov[i];
-      float pd2;
-      if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
-        selected = true;
-        a.pd2[i] = pd2;
-      }
-    }
-    a.sel[i] = selected ? 1 : 0;
-    tr = trace_for(a, q, lid, tidx, selected);
-    a.trace[i] = tr;
-  }
-  block_minmax(a, selected, ucov, tr);
+  const PassDyn dy = pass_dyn<false>(a);
+  bool selected;
+  double ucov, tr;
+  reuse_point(a, a.qc, dy.commit_prev, i, selected, ucov, tr);
+  block_minmax(a, dy, selected, ucov, tr);
 }
 
 __global__ void k_mm_init(u64 *slots) { mm_reset_slot(slots, threadIdx.x); }
@@ -853,11 +886,15 @@ struct Pass2Args {
   double *partials;       // [NSUM][pstride]: entry-major, so the final sum reads each entry's partials contiguously
   int pstride;
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
+  // device loop (DEV = true): the matrix form of the state, the slot parity and the deferral parity come from *dl
+  const DevLoop *dl;
+  const u64 *mm_base;     // [2 parities][MM_SLOTS][5]
+  const u32 *dq_ctl;      // deferral counters ([2 + parity]: the search kernel's heavy-workgroup score)
 };
 
 // a5 + a7: weights and the 12 non-zero entries of the (c_i-scaled) Jacobian row of one accepted point
-__device__ __forceinline__ void point_row(const Pass2Args &a, const double mm[4], int i, int lid, double u[12],
-                                          double &hs, double &r) {
+__device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &pc, const double mm[4], int i, int lid,
+                                          double u[12], double &hs, double &r) {
   const float4 q = a.scan[i];
   const float4 pl = a.plane[i];
   const double max_u = mm[0], min_u = -mm[1], max_c = mm[2], min_c = -mm[3];
@@ -871,24 +908,24 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const double mm[4]
     cp = 1 / ((a.wc.plane_cov_max - a.wc.plane_cov_min) * (cp - min_u) / (max_u - min_u) + a.wc.plane_cov_min);
   // geometry (:658-693)
   D3 p{(double)q.x, (double)q.y, (double)q.z};
-  const LidarConst &lc = a.pc.lid[lid];
+  const LidarConst &lc = pc.lid[lid];
   D3 X;  // q0 * p_be + t0  == point_this (IMU frame at LiDAR-0 scan end)
   D3 p_be;
   if (lid == 0) {
     p_be = p;
-    X = mulR(a.pc.R0, p) + D3{a.pc.t0[0], a.pc.t0[1], a.pc.t0[2]};
+    X = mulR(pc.R0, p) + D3{pc.t0[0], pc.t0[1], pc.t0[2]};
   } else {
     D3 y = mulR(lc.Rl, p) + D3{lc.tl[0], lc.tl[1], lc.tl[2]};
     X = mulR(lc.Rtc, y) + D3{lc.ttc[0], lc.ttc[1], lc.ttc[2]};
     p_be = p;  // unused for lid != 0
   }
   D3 n{(double)pl.x, (double)pl.y, (double)pl.z};
-  D3 Cv = mulRt(a.pc.Rw, n);  // s.rot.conjugate() * norm_vec (:676)
+  D3 Cv = mulRt(pc.Rw, n);  // s.rot.conjugate() * norm_vec (:676)
   D3 A = cross(X, Cv);        // point_crossmat * C (:677)
   D3 B{0, 0, 0}, Cb{0, 0, 0};
   if (a.extrinsic_est_en) {
     if (lid == 0) {
-      B = cross(p_be, mulRt(a.pc.R0, Cv));  // :684
+      B = cross(p_be, mulRt(pc.R0, Cv));  // :684
       Cb = Cv;
     } else {
       Cb = mulRt(lc.Rtc, Cv);            // :689
@@ -915,11 +952,16 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const double mm[4]
 
 // One workgroup = 256 consecutive sorted points of ONE LiDAR. Rows go to LDS, each wave turns its 64 rows into a
 // 16x16 block of sums with 16 f64 MFMAs, the 4 wave blocks are added in a fixed order.
+template <bool DEV>
 __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __shared__ double SA[BLK][17];  // a_p: u / r (r clamped as esekfom.hpp:624-626), u[0..2], 0   (+1 pad)
   __shared__ double SB[BLK][17];  // b_p: u, hs, 0 0 0                                           (+1 pad)
   __shared__ double DW[BLK / 64][16][16];
   __shared__ double mm_s[5];
+  if (DEV && a.dl->done) return;
+  const u64 *mmslots = DEV ? a.mm_base + (size_t)a.dl->mm_parity * MM_SLOTS * 5 : a.mmslots;
+  const u32 *heavy = DEV ? a.dq_ctl + 2 + a.dl->dq_parity : a.heavy;
+  const PassConst &pc = DEV ? a.dl->pc : a.pc;
   PH(1, 0);
   // ---- a4 fold: the first wave of every workgroup folds the 64 extrema slots of stage 1 (2.5 KB from L2) ----
   if (a.minmax4) {
@@ -928,23 +970,23 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       // staged path with the extrema supplied by the caller (a guess, or all-reduced): this shard's own extrema are
       // still wanted - the caller verifies its guess against them - and are folded here instead of by a separate launch
       double o5[5];
-      mm_fold_wave(a.mmslots, a.extrinsic_est_en, o5);
+      mm_fold_wave(mmslots, a.extrinsic_est_en, o5);
       if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
-        a.mm_out[5] = (double)*a.heavy;
+        a.mm_out[5] = (double)*heavy;
       }
     }
   } else if (threadIdx.x < 64) {
     double o5[5];
-    mm_fold_wave(a.mmslots, a.extrinsic_est_en, o5);
+    mm_fold_wave(mmslots, a.extrinsic_est_en, o5);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) mm_s[k] = o5[k];
       if (blockIdx.x == 0 && a.mm_out) {
 #pragma unroll
         for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
-        a.mm_out[5] = (double)*a.heavy;
+        a.mm_out[5] = (double)*heavy;
       }
     }
   }
@@ -961,7 +1003,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   double u[12], hs = 0, r = 1;
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
-  if (selected) point_row(a, mm, i, lid, u, hs, r);
+  if (selected) point_row(a, pc, mm, i, lid, u, hs, r);
   PH(1, 2);
   if (a.rows && in) {
     double *row = a.rows + (size_t)i * 14;
@@ -1051,7 +1093,8 @@ struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
 __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
-                                                      int L, double *out) {
+                                                      int L, double *out, const DevLoop *dl /* device loop, or null */) {
+  if (dl && dl->done) return;
   const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (w >= L * NSUM) return;  // wave-uniform
   const int lid = w / NSUM, e = w - lid * NSUM;
@@ -1118,7 +1161,6 @@ int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d
 // exactly for the queries whose search ball was empty: shells of 3x3x3-cell blocks of the level-2 lists around
 // the query cell, until the best distance is inside the covered cube; then (rare) a scan of the whole map.
 constexpr int FAR_RMAX = 6;
-static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
 // K = 1: the nearest map point of the queries with an empty search ball (what :421-425 reads), far_idx[N].
 // K = 5: the unrestricted 5-NN of every query with fewer than five neighbours inside sqrt(5) m, far_idx[5][N] - what
 // ikdtree.Nearest_Search leaves in Nearest_Points[i] (ikd_Tree.cpp:426-461 has no radius), handed out by malio_scan_get.
@@ -1307,15 +1349,7 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
 }
 
 // ---- host side of a pass -------------------------------------------------------------------------
-static void q_to_R(const double q[4], double R[9]) {  // (x,y,z,w) -> row-major, Eigen toRotationMatrix
-  double x = q[0], y = q[1], z = q[2], w = q[3];
-  double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
-         tzz = tz * z;
-  R[0] = 1 - (tyy + tzz), R[1] = txy - twz, R[2] = txz + twy;
-  R[3] = txy + twz, R[4] = 1 - (txx + tzz), R[5] = tyz - twx;
-  R[6] = txz - twy, R[7] = tyz + twx, R[8] = 1 - (txx + tyy);
-}
+static void q_to_R(const double q[4], double R[9]) { mf::quat_R_eigen(q, R); }
 
 int sums_len(const Ctx *c) { return c->prm.lid_num * NSUM; }
 
@@ -1419,7 +1453,7 @@ __global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict
   plane[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-static void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
+void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
   auto Q = [](const double q[4]) { return Q4{q[0], q[1], q[2], q[3]}; };
   auto V = [](const double t[3]) { return D3{t[0], t[1], t[2]}; };
   qc.rot = Q(s->rot), qc.pos = V(s->pos);
@@ -1472,16 +1506,9 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   return MALIO_OK;
 }
 
-int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
-  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
-  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
-  if (int rc = map_sync_search(c)) return rc;
-  Pass1Args a;
-  fill_quat_const(c, s, a.qc);
-  if (!c->scan_sorted) {
-    int rc = sort_scan(c, a.qc);
-    if (rc != MALIO_OK) return rc;
-  }
+// everything of Pass1Args that does not depend on the pass (state, parities and commit_prev are filled by the caller,
+// or read from the device loop's control block)
+static void fill_pass1_static(Ctx *c, Pass1Args &a) {
   a.N = c->N;
   a.scan = c->d_scan;
   a.map_in = c->d_map_in;
@@ -1489,40 +1516,17 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
   a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm;
-  c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
-  a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
-  a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
-  a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.parity = c->dq_parity, a.defer = c->defer_enabled ? 1 : 0;
+  a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.defer = c->defer_enabled ? 1 : 0;
   a.part = c->part;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
-  a.ny = c->d_ny, a.commit_prev = c->last_M > 0 ? 1 : 0;
-  c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
-  const int nb = (c->N + BLK - 1) / BLK;
-  c->last_pass_search = converge != 0;
-  if (converge) {
-    c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
-    a.parity = c->dq_parity;
-    c->nbr_epoch = c->map_epoch;
-    hipLaunchKernelGGL(k_search, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
-                       view_of(c->nl2));
-    prof_mark(c, "k_search");
-    if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
-      hipLaunchKernelGGL(k_search_tail, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
-      prof_mark(c, "k_search_tail");
-    }
-  } else {
-    hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
-    prof_mark(c, "k_reuse");
-  }
-  if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
-    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en,
-                       (const u32 *)(c->d_dq_ctl + 2 + c->dq_parity), d_minmax4_out);
-    prof_mark(c, "k_minmax_reduce");
-  }
-  MALIO_HIP(hipGetLastError());
-  // matrix form of the same state for stage 2
-  PassConst &pc = c->pc;
+  a.ny = c->d_ny;
+  a.mm_base = c->d_mmslots;
+  a.dl = nullptr, a.mm_cur = a.mm_next = nullptr, a.parity = 0, a.commit_prev = 0;
+}
+
+// matrix form of a state for stage 2 (a5: rotation matrices of the pose, the extrinsics and the temporal compensation)
+void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
   q_to_R(s->rot, pc.Rw);
   q_to_R(s->offset_R[0], pc.R0);
   for (int k = 0; k < 3; k++) pc.pw[k] = s->pos[k], pc.t0[k] = s->offset_T[0][k];
@@ -1541,24 +1545,73 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   }
   pc.L = c->prm.lid_num, pc.extrinsic_est_en = c->prm.extrinsic_est_en;
   pc.plane_th = c->prm.plane_th, pc.cov_threshold = c->prm.cov_threshold;
+}
+
+int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
+  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  if (int rc = map_sync_search(c)) return rc;
+  Pass1Args a;
+  fill_quat_const(c, s, a.qc);
+  if (!c->scan_sorted) {
+    int rc = sort_scan(c, a.qc);
+    if (rc != MALIO_OK) return rc;
+  }
+  fill_pass1_static(c, a);
+  c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
+  a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
+  a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
+  a.parity = c->dq_parity;
+  a.commit_prev = c->last_M > 0 ? 1 : 0;
+  c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
+  const int nb = (c->N + BLK - 1) / BLK;
+  c->last_pass_search = converge != 0;
+  if (converge) {
+    c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
+    a.parity = c->dq_parity;
+    c->nbr_epoch = c->map_epoch;
+    hipLaunchKernelGGL(k_search<false>, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
+                       view_of(c->nl2));
+    prof_mark(c, "k_search");
+    if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
+      hipLaunchKernelGGL(k_search_tail<false>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
+      prof_mark(c, "k_search_tail");
+    }
+  } else {
+    hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
+    prof_mark(c, "k_reuse");
+  }
+  if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
+    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en,
+                       (const u32 *)(c->d_dq_ctl + 2 + c->dq_parity), d_minmax4_out);
+    prof_mark(c, "k_minmax_reduce");
+  }
+  MALIO_HIP(hipGetLastError());
+  fill_pass_const(c, s, c->pc);  // matrix form of the same state for stage 2
   return MALIO_OK;
 }
 
-int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows) {
-  Pass2Args a;
+static int fill_pass2_static(Ctx *c, Pass2Args &a) {
   a.N = c->N, a.L = c->prm.lid_num, a.extrinsic_est_en = c->prm.extrinsic_est_en;
   a.scan = c->d_scan, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.ucov = c->d_ucov, a.trace = c->d_trace, a.sel = c->d_sel;
   int nb = nblocks_total(c, a.seg_block0);
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) a.seg_start[l] = c->seg_start[l < c->prm.lid_num ? l : c->prm.lid_num];
-  a.pc = c->pc;
   a.wc.plane_cov_max = c->prm.plane_cov_max, a.wc.plane_cov_min = c->prm.plane_cov_min;
   a.wc.point_cov_max = c->prm.point_cov_max, a.wc.point_cov_min = c->prm.point_cov_min;
   a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
+  a.partials = c->d_partials, a.pstride = (int)c->cap_partials;
+  a.rows = nullptr, a.minmax4 = nullptr, a.mmslots = nullptr, a.heavy = nullptr, a.mm_out = nullptr;
+  a.dl = nullptr, a.mm_base = c->d_mmslots, a.dq_ctl = c->d_dq_ctl;
+  return nb;
+}
+
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows) {
+  Pass2Args a;
+  const int nb = fill_pass2_static(c, a);
+  a.pc = c->pc;
   a.minmax4 = d_minmax4_in;
   a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
   a.heavy = c->d_dq_ctl + 2 + c->dq_parity;
-  a.partials = c->d_partials, a.pstride = (int)c->cap_partials;
-  a.rows = nullptr;
   if (want_rows) {
     size_t need = (size_t)c->N * 14;
     if (need > c->cap_rows) {
@@ -1568,42 +1621,49 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
     }
     a.rows = c->d_rows;
   }
-  hipLaunchKernelGGL(k_rows_reduce, dim3(nb), dim3(BLK), 0, c->stream, a);
+  hipLaunchKernelGGL(k_rows_reduce<false>, dim3(nb), dim3(BLK), 0, c->stream, a);
   prof_mark(c, "k_rows_reduce");
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
   hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out);
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr);
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
 
-// 3x3 symmetric eigenvalues by cyclic Jacobi (sigma_3/sigma_1 of h_x[:,0:3] = sqrt(l_min/l_max) of N^T N)
-static void sym3_eig_host(double a[3][3], double ev[3]) {
-  for (int sweep = 0; sweep < 64; sweep++) {
-    double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    if (off < 1e-300) break;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++) {
-        if (a[p][q] == 0) continue;
-        double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-        double cs = 1 / sqrt(t * t + 1), sn = t * cs;
-        for (int k = 0; k < 3; k++) {
-          double akp = a[k][p], akq = a[k][q];
-          a[k][p] = cs * akp - sn * akq, a[k][q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < 3; k++) {
-          double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = cs * apk - sn * aqk, a[q][k] = sn * apk + cs * aqk;
-        }
-      }
+// Device loop (csrc/ieskf_dev.hip): sort the scan (once per scan) with the state the loop starts from
+int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
+  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  if (int rc = map_sync_search(c)) return rc;
+  if (!c->scan_sorted) {
+    QuatConst qc;
+    fill_quat_const(c, s, qc);
+    if (int rc = sort_scan(c, qc)) return rc;
   }
-  ev[0] = a[0][0], ev[1] = a[1][1], ev[2] = a[2][2];
-  if (ev[0] > ev[1]) std::swap(ev[0], ev[1]);
-  if (ev[1] > ev[2]) std::swap(ev[1], ev[2]);
-  if (ev[0] > ev[1]) std::swap(ev[0], ev[1]);
+  return MALIO_OK;
+}
+
+// One pass of the device loop: the same kernels, every pass-dependent input read from c->d_loop. Nothing here depends
+// on what the pass will turn out to be: a search pass, a reuse pass (inside k_search<true>) or nothing (loop over).
+int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out) {
+  Pass1Args a;
+  fill_pass1_static(c, a);
+  a.dl = c->d_loop;
+  hipLaunchKernelGGL(k_search<true>, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
+                     view_of(c->nl2));
+  if (a.defer) hipLaunchKernelGGL(k_search_tail<true>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
+  Pass2Args b;
+  const int nb = fill_pass2_static(c, b);
+  b.dl = c->d_loop, b.mm_out = d_mm_out;
+  hipLaunchKernelGGL(k_rows_reduce<true>, dim3(nb), dim3(BLK), 0, c->stream, b);
+  SegBlocks sb;
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = b.seg_block0[l];
+  hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)c->d_loop);
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
 }
 
 // Assemble the C x C normal equations from the per-LiDAR 12 x 12 blocks, apply the localization
@@ -1640,17 +1700,9 @@ int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure
     return MALIO_NO_EFFECTIVE_POINTS;
   }
   out->valid = 1;
-  double ev[3];
-  sym3_eig_host(NtN, ev);
-  double weight = sqrt(ev[0] > 0 ? ev[0] : 0.0) / sqrt(ev[2]);
-  if (weight > c->prm.localize_thresh_max)
-    weight = c->prm.localize_cov_max;
-  else if (weight < c->prm.localize_thresh_min)
-    weight = c->prm.localize_cov_min;
-  else
-    weight = (c->prm.localize_cov_max - c->prm.localize_cov_min) * (weight - c->prm.localize_thresh_min) /
-                 (c->prm.localize_thresh_max - c->prm.localize_thresh_min) +
-             c->prm.localize_cov_min;
+  const double weight = mf::localize_weight(NtN[0][0], NtN[1][1], NtN[2][2], NtN[0][1], NtN[0][2], NtN[1][2],
+                                            c->prm.localize_thresh_min, c->prm.localize_thresh_max,
+                                            c->prm.localize_cov_min, c->prm.localize_cov_max);
   out->w_loc = weight;
   const double w2 = weight * weight;
   for (int k = 0; k < C * C; k++) out->HtRinvH[k] *= w2;

@@ -52,8 +52,9 @@ void state_boxminus(const malio_state_t &x, const malio_state_t &o, int L, doubl
 
 // ---- dense helpers (row-major, n <= 41) -----------------------------------------------------------------
 using Mat = std::vector<double>;
-// in-place inverse by LU with partial pivoting (what Eigen's inverse() does for n > 4)
-bool invert(Mat &A, int n) {
+// First w columns of A^-1 (n x w, row-major) by LU with partial pivoting - what Eigen's inverse() does for n > 4 - with
+// all right-hand sides advanced together. A is destroyed. w = n: the whole inverse.
+bool invert_cols(Mat &A, int n, int w, Mat &X) {
   std::vector<int> piv(n);
   for (int i = 0; i < n; i++) piv[i] = i;
   for (int k = 0; k < n; k++) {
@@ -75,28 +76,35 @@ bool invert(Mat &A, int n) {
   }
   // A^-1 = U^-1 L^-1 P with ALL right-hand sides advanced together, one row operation at a time (row-major, so the
   // inner loops run over contiguous columns and vectorise without reassociation). Every entry sees exactly the
-  // operations, in exactly the order, of a column-by-column forward/back substitution: same bits, ~5x faster -
+  // operations, in exactly the order, of a column-oriented forward/back substitution (csrc/ieskf_dev.hip lds_invert
+  // runs the same sequence on the GPU): same bits, ~5x faster than column by column -
   // at 60 us per GPU pass the 35 x 35 algebra between passes is no longer negligible.
-  Mat X((size_t)n * n, 0.0);
-  for (int i = 0; i < n; i++) X[(size_t)i * n + piv[i]] = 1.0;
+  X.assign((size_t)n * w, 0.0);
+  for (int i = 0; i < n; i++)
+    if (piv[i] < w) X[(size_t)i * w + piv[i]] = 1.0;
   for (int i = 0; i < n; i++) {
-    double *xi = &X[(size_t)i * n];
+    double *xi = &X[(size_t)i * w];
     for (int j = 0; j < i; j++) {
       const double l = A[i * n + j];
-      const double *xj = &X[(size_t)j * n];
-      for (int c = 0; c < n; c++) xi[c] -= l * xj[c];
+      const double *xj = &X[(size_t)j * w];
+      for (int c = 0; c < w; c++) xi[c] -= l * xj[c];
     }
   }
   for (int i = n - 1; i >= 0; i--) {
-    double *xi = &X[(size_t)i * n];
-    for (int j = i + 1; j < n; j++) {
-      const double u = A[i * n + j];
-      const double *xj = &X[(size_t)j * n];
-      for (int c = 0; c < n; c++) xi[c] -= u * xj[c];
+    double *xi = &X[(size_t)i * w];
+    for (int j = n - 1; j > i; j--) {  // j descending: the order of a column-oriented sweep (finished rows are
+      const double u = A[i * n + j];   // subtracted from all earlier ones as they complete) - what the device loop runs
+      const double *xj = &X[(size_t)j * w];
+      for (int c = 0; c < w; c++) xi[c] -= u * xj[c];
     }
     const double d = A[i * n + i];
-    for (int c = 0; c < n; c++) xi[c] /= d;
+    for (int c = 0; c < w; c++) xi[c] /= d;
   }
+  return true;
+}
+bool invert(Mat &A, int n) {  // in place
+  Mat X;
+  if (!invert_cols(A, n, n, X)) return false;
   A.swap(X);
   return true;
 }
@@ -131,32 +139,24 @@ void cols_applyT(Mat &P, int n, int idx, int d, const double *B) {
 namespace malio {
 
 // gain(P_projected, K_h, K_x): fills K_h (n) and K_x[:, 0:C] (n x n, rest zero) for the current pass.
-using GainFn = std::function<int(const std::vector<double> &, std::vector<double> &, std::vector<double> &)>;
+using GainFn = std::function<int(StepPre &, std::vector<double> &, std::vector<double> &)>;
 
-// One iteration of esekfom.hpp:509-720 AFTER the measurement pass. Pure host code.
-//   i          loop index of esekfom.hpp:509 (-1 .. max_iteration-1)
-//   x          in: state the pass was evaluated at; out: x boxplus dx
-//   t_io       in/out: number of converged iterations so far (esekfom.hpp:658)
-//   converge   out: ekfom_data.converge for the NEXT pass (:649-663)
-//   done       out: 1 when the posterior covariance was written to P_out and the loop must stop (:665-718)
-//   P_out      done: the posterior; otherwise the PROJECTED P_propagated of this iteration - what the reference's member
-//              P_ holds from :531-572 until the next valid iteration overwrites it, and therefore what the filter is
-//              left with when the loop runs out on invalid passes (`continue` at :514-517 restores nothing)
-static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
-                     const double *P_prop, const GainFn &gain, int *t_io, int *converge_out, int *done_out,
-                     double *P_out) {
-  const int n = 17 + 6 * L, C = 6 * (L + 1);
-  malio_state_t &x_ = *x;
-  Mat P_(P_prop, P_prop + (size_t)n * n);
-  std::vector<int> so3_idx;
-  so3_idx.push_back(3);
-  for (int l = 0; l < L; l++) so3_idx.push_back(6 + 3 * l);
+// First half of one iteration of esekfom.hpp:509-720: everything that depends on the iterate alone (:526-572, and the
+// first of the two inversions of :621) - a caller that has the GPU busy with the measurement pass of this very iterate
+// runs it meanwhile (ieskf_update_gated).
+void ieskf_step_pre(int L, const malio_state_t *x, const malio_state_t *x_propagated, const double *P_prop, StepPre &pre,
+                    bool with_inverse) {
+  const int n = 17 + 6 * L;
+  const malio_state_t &x_ = *x;
+  Mat &P_ = pre.P_;
+  P_.assign(P_prop, P_prop + (size_t)n * n);
+  std::vector<double> &dx = pre.dx, &dx_new = pre.dx_new;
+  dx.assign(n, 0.0);
   const int s2_idx = 15 + 6 * L;
-  std::vector<double> dx(n), dx_new(n), dx_(n), K_h(n);
-  Mat K_x((size_t)n * n, 0.0);
   state_boxminus(x_, *x_propagated, L, dx.data());  // :526
   dx_new = dx;
-  for (int idx : so3_idx) {  // :534-549
+  for (int b = 0; b <= L; b++) {  // :534-549
+    const int idx = b == 0 ? 3 : 6 + 3 * (b - 1);
     double B[9];
     A_matrix_T(&dx[idx], B);
     double tmp[3];
@@ -173,7 +173,32 @@ static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t
     rows_apply(P_, P_, n, s2_idx, 2, B, n);
     cols_applyT(P_, n, s2_idx, 2, B);
   }
-  int rc = gain(P_, K_h, K_x);  // :574-640
+  pre.inv_state = 0;
+  if (with_inverse) {
+    pre.Pinv = P_;
+    pre.inv_state = invert(pre.Pinv, n) ? 1 : -1;
+  }
+}
+
+// Second half, AFTER the measurement pass. Pure host code.
+//   i          loop index of esekfom.hpp:509 (-1 .. max_iteration-1)
+//   x          in: state the pass was evaluated at; out: x boxplus dx
+//   t_io       in/out: number of converged iterations so far (esekfom.hpp:658)
+//   converge   out: ekfom_data.converge for the NEXT pass (:649-663)
+//   done       out: 1 when the posterior covariance was written to P_out and the loop must stop (:665-718)
+//   P_out      done: the posterior; otherwise the PROJECTED P_propagated of this iteration - what the reference's member
+//              P_ holds from :531-572 until the next valid iteration overwrites it, and therefore what the filter is
+//              left with when the loop runs out on invalid passes (`continue` at :514-517 restores nothing)
+static int step_post(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
+                     StepPre &pre, const GainFn &gain, int *t_io, int *converge_out, int *done_out, double *P_out) {
+  const int n = 17 + 6 * L, C = 6 * (L + 1);
+  malio_state_t &x_ = *x;
+  Mat &P_ = pre.P_;
+  const std::vector<double> &dx_new = pre.dx_new;
+  const int s2_idx = 15 + 6 * L;
+  std::vector<double> dx_(n), K_h(n);
+  Mat K_x((size_t)n * n, 0.0);
+  int rc = gain(pre, K_h, K_x);  // :574-640
   if (rc != MALIO_OK) return rc;
   for (int a = 0; a < n; a++) {  // :642
     double s = K_h[a];
@@ -195,7 +220,8 @@ static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t
   *done_out = 0;
   if (t > 1 || i == maximum_iter - 1) {  // :665-718
     Mat L_(P_);
-    for (int idx : so3_idx) {
+    for (int b = 0; b <= L; b++) {
+      const int idx = b == 0 ? 3 : 6 + 3 * (b - 1);
       double B[9];
       A_matrix_T(&dx_[idx], B);
       rows_apply(L_, P_, n, idx, 3, B, n);
@@ -228,30 +254,50 @@ static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t
   return MALIO_OK;
 }
 
+static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
+                     const double *P_prop, const GainFn &gain, int *t_io, int *converge_out, int *done_out,
+                     double *P_out) {
+  StepPre pre;
+  ieskf_step_pre(L, x, x_propagated, P_prop, pre, false);
+  return step_post(L, maximum_iter, limit, i, x, x_propagated, pre, gain, t_io, converge_out, done_out, P_out);
+}
+
 // esekfom.hpp:621-637 on the reduced normal equations: P_inv = (P^-1 + blk(HtRinvH))^-1,
-// K_h = P_inv[:, 0:C] HtRinvh, K_x[:, 0:C] = P_inv[:, 0:C] HtRinvH
+// K_h = P_inv[:, 0:C] HtRinvh, K_x[:, 0:C] = P_inv[:, 0:C] HtRinvH. Only the first C columns of P_inv are used, so only
+// they are solved for (every column of an inverse is an independent right-hand side: same values).
 static GainFn normal_eq_gain(int L, const double *HtRinvH, const double *HtRinvh) {
-  return [=](const std::vector<double> &P_, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
+  return [=](StepPre &pre, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
     const int n = 17 + 6 * L, C = 6 * (L + 1);
-    Mat Pt(P_);
-    if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+    if (pre.inv_state == 0) {
+      pre.Pinv = pre.P_;
+      pre.inv_state = invert(pre.Pinv, n) ? 1 : -1;
+    }
+    if (pre.inv_state < 0) return MALIO_ERR_BAD_ARG;
+    Mat &Pt = pre.Pinv, Pc;
     for (int a = 0; a < C; a++)
       for (int b = 0; b < C; b++) Pt[a * n + b] += HtRinvH[a * C + b];
-    if (!invert(Pt, n)) return MALIO_ERR_BAD_ARG;
+    if (!invert_cols(Pt, n, C, Pc)) return MALIO_ERR_BAD_ARG;
     for (int a = 0; a < n; a++) {
       double s = 0;
-      for (int b = 0; b < C; b++) s += Pt[a * n + b] * HtRinvh[b];
+      for (int b = 0; b < C; b++) s += Pc[a * C + b] * HtRinvh[b];
       K_h[a] = s;
       double *kx = &K_x[(size_t)a * n];
       for (int b = 0; b < C; b++) kx[b] = 0.0;
       for (int k = 0; k < C; k++) {  // k ascending per entry, as a dot product would; contiguous in b
-        const double p = Pt[a * n + k];
+        const double p = Pc[a * C + k];
         const double *hk = &HtRinvH[(size_t)k * C];
         for (int b = 0; b < C; b++) kx[b] += p * hk[b];
       }
     }
     return MALIO_OK;
   };
+}
+
+int ieskf_step_post(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
+                    StepPre &pre, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out, int *done_out,
+                    double *P_out) {
+  return step_post(L, maximum_iter, limit > 0 ? limit : 0.001, i, x, x_propagated, pre, normal_eq_gain(L, HtRinvH, HtRinvh), t_io,
+                   converge_out, done_out, P_out);
 }
 
 int ieskf_step(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
@@ -306,7 +352,8 @@ int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn 
       mr.h_x = rows_hx.data(), mr.h = rows_h.data(), mr.R = rows_R.data();
       rc = (*rows_pass)(&x_, 0, &mr);
       if (rc < 0) return rc;
-      gain = [&, M](const std::vector<double> &P_, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
+      gain = [&, M](StepPre &pre, std::vector<double> &K_h, std::vector<double> &K_x) -> int {
+        const Mat &P_ = pre.P_;
         Mat S((size_t)M * M, 0.0), PHt((size_t)n * M, 0.0);
         for (int a = 0; a < n; a++)
           for (int m = 0; m < M; m++) {

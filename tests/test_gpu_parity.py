@@ -105,6 +105,42 @@ def test_pass_and_update_parity(capi, orc, scenes, kw):
     assert np.allclose(gs["normal_y"], os_["normal_y"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("kw", [CASES[0], CASES[1], CASES[3], CASES[4], CASES[8], CASES[9]], ids=lambda k: "s%d" % k["seed"])
+def test_update_modes_agree(capi, scenes, kw):
+    """The three ways malio_update_iterated can drive its loop (include/malio.h):
+      gated  (default) - every pass enqueued ahead, k_gate between passes, the n x n algebra on the calling thread;
+      host             - one pass at a time: launch, synchronise, algebra, launch;
+      device           - the algebra in a one-workgroup kernel, the whole update one chain the host waits for once.
+    gated and host run the same host code on the same sums: bit-identical. The device loop follows the same operation
+    order but with the device's libm in the manifold maps (a few ulp per sin / cos / atan), which the conditioning of the
+    reference's covariance formula amplifies (assert_P_close): compared like the oracle is."""
+    kw = dict(kw)
+    kw.pop("yardstick", None)
+    sc = scenes.make_scene(**kw)
+    res = {}
+    for mode in ("gated", "host", "device"):
+        eng = capi.Engine(sc["params"], device=0)
+        eng.set_update_mode(mode)
+        eng.map_build(sc["map"])
+        out = []
+        for rep in range(2):   # a second scan on the same handle: parities, normal_y fold and defer switch carried over
+            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            u = eng.update_iterated(sc["state0"], sc["P0"])
+            out.append((u, eng.scan_get()))
+        res[mode] = out
+    for (u, gs), (v, hs), (w, ds) in zip(res["gated"], res["host"], res["device"]):
+        assert (u["passes"], u["searches"], u["M"], u["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
+        assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"])
+        for k in ("selected", "res_last", "normal_y", "nearest", "world", "normvec"):
+            assert np.array_equal(gs[k], hs[k]), k
+        assert (w["passes"], w["searches"], w["M"], w["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
+        assert np.abs(w["state"] - v["state"]).max() < 1e-8
+        assert_P_close(w["P"], v["P"])
+        assert np.array_equal(ds["selected"], hs["selected"]) and np.array_equal(ds["nearest"], hs["nearest"])
+        assert np.allclose(ds["res_last"], hs["res_last"], rtol=1e-5, atol=1e-7)
+        assert np.allclose(ds["normal_y"], hs["normal_y"], rtol=1e-6, atol=0)
+
+
 def test_table_index_clamps(capi, orc, scenes):
     """normal_x outside the table / negative: the two different clamps of laserMapping.cpp:694-696 vs :737-739."""
     sc = scenes.make_scene(seed=211, N=1500, Nmap=30000, L=3, n_table=6)
