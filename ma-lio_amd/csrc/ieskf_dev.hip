@@ -482,6 +482,8 @@ void free_dev_loop(Ctx *c) {
   if (c->h_loop_in) (void)hipHostFree(c->h_loop_in);
   if (c->h_loop_out) (void)hipHostFree(c->h_loop_out);
   if (c->h_gate) (void)hipHostFree(c->h_gate);
+  if (c->d_gate_ticket) (void)hipFree(c->d_gate_ticket);
+  c->d_gate_ticket = nullptr;
   c->h_gate = c->d_gate = nullptr;
   c->d_loopbuf = nullptr, c->d_loop = nullptr, c->h_loop_in = nullptr, c->h_loop_out = nullptr, c->d_loop_out = nullptr;
 }
@@ -565,38 +567,9 @@ namespace malio {
 // the forms the kernels read, converge flag, parities, or `done`), and (3) copies that block into the DevLoop the pass
 // kernels read. GPU -> host and host -> GPU each cost one PCIe latency instead of a completion signal plus a doorbell
 // plus dispatch. A gate gives up after GATE_TIMEOUT_US (the host died or returned): the chain then drains as on `done`.
-struct GateArgs {
-  DevLoop *dl;
-  const double *cmd;   // pinned: the host's control block, DevLoop layout (rounded up to 256 B) ...
-  const int *cmd_seq;  // ... and the word the host stores LAST (release)
-  int *msg_seq;        // pinned: sequence word the GPU publishes
-  int publish, wait_for, first, ndoubles;
-};
-constexpr long long GATE_TIMEOUT_US = 200000;
-__global__ void __launch_bounds__(256) k_gate(GateArgs g) {
-  __shared__ int s_ok;
-  if (!g.first && g.dl->done) return;  // the loop ended at an earlier gate: nothing to publish, nobody to wait for
-  if (threadIdx.x == 0) {
-    if (g.publish) {
-      __threadfence_system();
-      __hip_atomic_store(g.msg_seq, g.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const long long t0 = wall_clock64();
-    int ok = 1;
-    while (__hip_atomic_load(g.cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != g.wait_for) {
-      if (wall_clock64() - t0 > GATE_TIMEOUT_US * 100) {  // 100 MHz
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    s_ok = ok;
-    if (!ok) g.dl->done = 1, g.dl->status = MALIO_ERR_TIMEOUT;
-  }
-  __syncthreads();
-  if (!s_ok) return;
-  double *dst = reinterpret_cast<double *>(g.dl);
-  for (int e = threadIdx.x; e < g.ndoubles; e += 256) dst[e] = g.cmd[e];
+__global__ void __launch_bounds__(256) k_gate(GateArgs g) {  // the gate before the first pass (nothing to ride on)
+  if (!g.first && g.dl->done) return;
+  gate_body(g);
 }
 
 int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, double *solve_time) {
@@ -610,6 +583,10 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     MALIO_HIP(hipHostMalloc((void **)&c->h_loop_in, sizeof(double) * (hdr + nn), hipHostMallocMapped));
     MALIO_HIP(hipHostMalloc((void **)&c->h_loop_out, OUT_P_OFF + sizeof(double) * nn, hipHostMallocMapped | hipHostMallocCoherent));
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_loop_out, c->h_loop_out, 0));
+  }
+  if (!c->d_gate_ticket) {
+    MALIO_HIP(hipMalloc(&c->d_gate_ticket, 256));
+    MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
   }
   if (!c->h_gate) {
     MALIO_HIP(hipHostMalloc((void **)&c->h_gate, sizeof(double) * hdr + 256, hipHostMallocMapped | hipHostMallocCoherent));
@@ -648,7 +625,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     __atomic_store_n(const_cast<int *>(cmd_seq), base + p + 1, __ATOMIC_RELEASE);
   };
   publish(0, false);  // before the chain exists: gate 0 finds it at once
-  // ---- the chain: gate 0, then units of [pass p | gate p + 1], enqueued one pass ahead of the GPU (the launches of unit
+  // ---- the chain: gate 0, then units of [pass p | gate p + 1] (the gate is the last workgroup of the pass' last kernel), enqueued one pass ahead of the GPU (the launches of unit
   // p + 1 and the first half of iteration p's algebra run on this thread while the GPU is busy with pass p; a loop that
   // ends early leaves at most one unit of kernels behind, which exit at once) ----
   GateArgs g;
@@ -656,16 +633,14 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   g.cmd_seq = reinterpret_cast<const int *>(c->d_gate + sizeof(double) * hdr);
   g.msg_seq = reinterpret_cast<int *>(c->d_gate + sizeof(double) * hdr + 128);
   g.ndoubles = (int)hdr;
-  auto enqueue_gate = [&](int p) {
-    g.first = p == 0, g.publish = p == 0 ? 0 : base + p, g.wait_for = base + p + 1;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, c->stream, g);
+  g.ticket = c->d_gate_ticket;
+  auto set_gate = [&](int p) { g.first = p == 0, g.publish = p == 0 ? 0 : base + p, g.wait_for = base + p + 1; };
+  auto enqueue_unit = [&](int p) -> int {  // pass p; gate p + 1 is the last workgroup of its last kernel
+    set_gate(p + 1);
+    return enqueue_pass_dev(c, c->d_res, c->d_res + ns_, &g);
   };
-  auto enqueue_unit = [&](int p) -> int {
-    if (int rc = enqueue_pass_dev(c, c->d_res, c->d_res + ns_)) return rc;
-    enqueue_gate(p + 1);
-    return MALIO_OK;
-  };
-  enqueue_gate(0);
+  set_gate(0);
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, c->stream, g);
   if (int rc = enqueue_unit(0)) return rc;
   // ---- the loop (esekfom.hpp:509) ----
   int rc_out = MALIO_OK;

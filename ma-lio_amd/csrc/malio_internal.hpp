@@ -204,6 +204,46 @@ struct alignas(16) UncEntry {
   double Q[6];  // xx yy zz xy xz yz
 };
 
+// Gate between two passes of the gated update loop (csrc/ieskf_dev.hip): announce the finished pass to the host, wait for
+// the control block of the next one, copy it into the DevLoop the pass kernels read.
+struct GateArgs {
+  DevLoop *dl;
+  const double *cmd;   // pinned: the host's control block, DevLoop layout (rounded up to 256 B) ...
+  const int *cmd_seq;  // ... and the word the host stores LAST (release)
+  int *msg_seq;        // pinned: sequence word the GPU publishes
+  u32 *ticket;         // device counter of the kernel the gate rides on (k_final_reduce: its last workgroup is the gate)
+  int publish, wait_for, first, ndoubles;
+};
+#if defined(__HIP__)
+constexpr long long GATE_TIMEOUT_US = 200000;
+// called by every thread of ONE workgroup (256 threads); a gate gives up after GATE_TIMEOUT_US (the host died or
+// returned): the rest of the chain then drains as on `done`
+__device__ inline void gate_body(const GateArgs &g) {
+  __shared__ int s_gate_ok;
+  if (threadIdx.x == 0) {
+    if (g.publish) {
+      __threadfence_system();
+      __hip_atomic_store(g.msg_seq, g.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(g.cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != g.wait_for) {
+      if (wall_clock64() - t0 > GATE_TIMEOUT_US * 100) {  // 100 MHz
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    s_gate_ok = ok;
+    if (!ok) g.dl->done = 1, g.dl->status = MALIO_ERR_TIMEOUT;
+  }
+  __syncthreads();
+  if (!s_gate_ok) return;
+  double *dst = reinterpret_cast<double *>(g.dl);
+  for (int e = threadIdx.x; e < g.ndoubles; e += blockDim.x) dst[e] = g.cmd[e];
+}
+#endif
+
 // Per-call device scratch: one block that grows to the largest call seen, handed out by a bump pointer and released
 // in stack order (hipMalloc/hipFree cost ~0.1 ms each and a map update needs a dozen temporaries).
 struct Arena {
@@ -355,6 +395,7 @@ struct Ctx {
   char *h_loop_in = nullptr;     // pinned: what one update uploads (DevLoop + P_prop)
   char *h_loop_out = nullptr;    // pinned, device-mapped: what the last step kernel stores (DevLoop + P)
   char *d_loop_out = nullptr;    // ... its device alias
+  u32 *d_gate_ticket = nullptr;  // (word 3 of d_dq_ctl's allocation is not used: own word, zeroed once)
   char *h_gate = nullptr, *d_gate = nullptr;  // pinned + device alias: control block and sequence words of the gated loop
   int gate_epoch = 1;
   double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
@@ -473,7 +514,7 @@ void free_dev_loop(Ctx *c);
 int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
 // measure.hip: the pass kernels of one iteration of the device loop (k_search/k_reuse by the control block's converge
 // flag, [k_search_tail], k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
-int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out);
+int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate = nullptr);  // gate: rides on the last kernel
 int prepare_scan_dev(Ctx *c, const malio_state_t *s);  // map lists in sync, scan sorted
 void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
 void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc);

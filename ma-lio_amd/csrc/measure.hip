@@ -1092,25 +1092,40 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_s
 struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
+// With a gate (gated update loop): the workgroup that finishes last - a ticket counter - announces the sums to the host,
+// waits for the next pass' control block and installs it (gate_body): the gate costs no launch of its own.
 __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
-                                                      int L, double *out, const DevLoop *dl /* device loop, or null */) {
+                                                      int L, double *out, const DevLoop *dl /* device loop, or null */,
+                                                      GateArgs gate /* gate.dl == null: none */) {
   if (dl && dl->done) return;
   const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-  if (w >= L * NSUM) return;  // wave-uniform
-  const int lid = w / NSUM, e = w - lid * NSUM;
-  const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
-  const double *row = partials + (size_t)e * pstride;
-  double acc = 0;
-  for (int b = b0 + lane; b < b1; b += 64 * 4) {
-    double v[4];
+  if (w < L * NSUM) {  // wave-uniform
+    const int lid = w / NSUM, e = w - lid * NSUM;
+    const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
+    const double *row = partials + (size_t)e * pstride;
+    double acc = 0;
+    for (int b = b0 + lane; b < b1; b += 64 * 4) {
+      double v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = (b + 64 * u < b1) ? row[b + 64 * u] : 0.0;
+      for (int u = 0; u < 4; u++) v[u] = (b + 64 * u < b1) ? row[b + 64 * u] : 0.0;
 #pragma unroll
-    for (int u = 0; u < 4; u++) acc += v[u];
+      for (int u = 0; u < 4; u++) acc += v[u];
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+    if (lane == 0) out[lid * NSUM + e] = acc;
   }
-#pragma unroll
-  for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
-  if (lane == 0) out[lid * NSUM + e] = acc;
+  if (!gate.dl) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();  // this workgroup's sums (pinned host memory) before its ticket
+    const u32 t = atomicAdd(gate.ticket, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) *gate.ticket = 0u;  // for the next kernel that carries a gate (stream-ordered)
+  }
+  __syncthreads();
+  if (s_last) gate_body(gate);
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
@@ -1626,7 +1641,7 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
   hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr);
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr, GateArgs{});
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
@@ -1647,7 +1662,7 @@ int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
 
 // One pass of the device loop: the same kernels, every pass-dependent input read from c->d_loop. Nothing here depends
 // on what the pass will turn out to be: a search pass, a reuse pass (inside k_search<true>) or nothing (loop over).
-int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out) {
+int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate) {
   Pass1Args a;
   fill_pass1_static(c, a);
   a.dl = c->d_loop;
@@ -1661,7 +1676,8 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out) {
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = b.seg_block0[l];
   hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)c->d_loop);
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)c->d_loop,
+                     gate ? *gate : GateArgs{});
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
