@@ -152,6 +152,35 @@ struct Top5 {
   __device__ __forceinline__ u32 og(int i) const { return (u32)k[i]; }
 };
 __device__ __forceinline__ u64 top5_key(float d2, u32 og) { return ((u64)__float_as_uint(d2) << 32) | (u64)og; }
+// the largest key anybody inserts ("no candidate"): low word INVALID; as an f64 bit pattern it is the largest finite
+// double, NOT a NaN (see the f64 form of the insertion)
+constexpr u64 TOP5_MAXKEY = 0x7FEFFFFFFFFFFFFFull;
+#ifndef KS_U64KEY
+// Keys are >= +0 as integers with the sign bit clear and - d2 being a finite float - never carry an all-ones f64
+// exponent: read as DOUBLES they are positive finite numbers (denormals included, which the f64 units handle at full
+// speed) that order exactly like the integers. A sorted insertion is then five min/max pairs on the f64 pipe: 10
+// half-rate instructions instead of 5 64-bit compares and 18 selects.
+__device__ __forceinline__ double f64_min_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double f64_max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
+  double x = __longlong_as_double((long long)key);
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const double cur = __longlong_as_double((long long)t.k[k]);
+    const double lo = f64_min_raw(cur, x);
+    x = f64_max_raw(cur, x);
+    t.k[k] = (u64)__double_as_longlong(lo);
+  }
+}
+#else
 __device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
   // The list is sorted, so the five comparisons against the key are independent of each other (no compare-exchange
   // chain) and every slot is a two-way select on them: slot k takes its left neighbour when the key sorts before
@@ -163,6 +192,7 @@ __device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
   t.k[1] = c0 ? t.k[0] : (c1 ? key : t.k[1]);
   t.k[0] = c0 ? key : t.k[0];
 }
+#endif
 
 // One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
 __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 tmask, u64 key, Cell first, u32 slot,
@@ -370,6 +400,40 @@ __device__ __forceinline__ double point_trace(const UncEntry &e, float px, float
          (e.Q[0] * a * a + e.Q[1] * b * b + e.Q[2] * c * c + 2.0 * (e.Q[3] * a * b + e.Q[4] * a * c + e.Q[5] * b * c));
 }
 
+// Wave-wide extrema on DPP row operations (quad_perm, row_half_mirror, row_mirror inside the 16-lane rows, row_bcast
+// 15 / 31 across them, lane 63 read back): six dependent steps of ~20 cycles. The xor-shuffle form (ds_bpermute: an
+// LDS-crossbar round trip per step and per 32-bit half) cost ~1 us for the four reductions at the end of k_search's
+// phase C, on every workgroup's critical path.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane63_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+#ifndef KS_NO_DPP
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_f64<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_f64<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_f64<0x141, 0xF>(v));  // row_half_mirror
+  v = fmax(v, dpp_f64<0x140, 0xF>(v));  // row_mirror
+  v = fmax(v, dpp_f64<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+  v = fmax(v, dpp_f64<0x143, 0xC>(v));  // row_bcast:31 into rows 2 and 3
+  return readlane63_f64(v);
+}
+__device__ __forceinline__ double wave_min(double v) {
+  v = fmin(v, dpp_f64<0xB1, 0xF>(v));
+  v = fmin(v, dpp_f64<0x4E, 0xF>(v));
+  v = fmin(v, dpp_f64<0x141, 0xF>(v));
+  v = fmin(v, dpp_f64<0x140, 0xF>(v));
+  v = fmin(v, dpp_f64<0x142, 0xA>(v));
+  v = fmin(v, dpp_f64<0x143, 0xC>(v));
+  return readlane63_f64(v);
+}
+#else
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d));
@@ -380,6 +444,7 @@ __device__ __forceinline__ double wave_min(double v) {
   for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_xor(v, d));
   return v;
 }
+#endif
 
 // ---- a1: p' (LiDAR-0 frame) and the world point, double -> float (laserMapping.cpp:569-578) --------
 __device__ __forceinline__ void world_point(const QuatConst &qc, const float4 q, int lid, float &wx, float &wy,
@@ -498,7 +563,10 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, const PassDyn &
 //   level 2 (FINAL = true, cf2 >= sqrt 5): guaranteed radius >= cf2 covers the reference's acceptance radius
 //   (`pointSearchSqDis[4] > 5` rejects, :587), so whatever it finds inside d2 <= 5 is final.
 // Squared distances are computed as ikd_Tree.cpp:1697 without FMA; candidates with d2 > limit2 are dropped.
-constexpr int NL1_G = 4;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
+#ifndef KS_G
+#define KS_G 4
+#endif
+constexpr int NL1_G = KS_G;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
 constexpr unsigned char NF_PENDING = 0xFF;
 constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
@@ -534,7 +602,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
       // d2 <= limit2 <=> key < sentinel key, which the list is padded with: no separate range test. A slot past the
       // end of the list (its load was clamped to the last entry) gets the largest key and sorts after everything.
       const u64 key = top5_key(d2, __float_as_uint(m[u].w));
-      top5_insert(t, j + (u32)(u * G) < count ? key : ~0ull);
+      top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
     }
   }
   if (G > 1) merge_group<G>(t, sentinel);
@@ -674,26 +742,42 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   if (DEV && a.dl->done) return;
   const QuatConst &qc = DEV ? a.dl->qc : a.qc;
   const PassDyn dy = pass_dyn<DEV>(a);
+  // query of local slot l (one per lane of the control wave)
+#ifdef KS_CHUNKS
+  // balance: the four 16-query chunks of a workgroup come from four distant places of the sorted scan (one per search
+  // wave, so a wave's list reads stay coherent), instead of 64 consecutive queries that share a dense or a sparse region
+  const int nchunk_wg = (int)gridDim.x;
+  auto qidx = [&](int l) { return (((int)blockIdx.x + (l >> 4) * nchunk_wg) << 4) + (l & 15); };
+#else
   const int q0 = blockIdx.x * SQ;
+  auto qidx = [&](int l) { return q0 + l; };
+#endif
+#ifdef KS_CW
+  const int cw = (int)(blockIdx.x & (KS_WAVES - 1));  // the wave that runs the per-query phases A and C
+#else
+  const int cw = 0;
+#endif
+  const int lane_ = (int)(threadIdx.x & 63);
+  const bool cwave = (int)(threadIdx.x >> 6) == cw;
   // ---- phase A ----
-  const int i = q0 + (int)threadIdx.x;  // meaningful for wave 0 only
+  const int i = qidx(lane_);  // meaningful for the control wave only
   if (DEV && !a.dl->converge) {  // REUSE pass: wave 0, lane = point
     if (threadIdx.x >= SQ) return;
     bool selected;
     double ucov, tr;
-    reuse_point(a, qc, dy.commit_prev, i, selected, ucov, tr);
+    reuse_point(a, qc, dy.commit_prev, (int)(blockIdx.x * SQ + threadIdx.x), selected, ucov, tr);
     wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);
     if (blockIdx.x == 0) mm_reset_slot(dy.mm_next, threadIdx.x);
     return;
   }
-  bool mine = threadIdx.x < SQ && i < a.N;
+  bool mine = cwave && i < a.N;
   PH(0, 0);
   PH_ENTER();
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
     mm_reset_slot(dy.mm_next, threadIdx.x);
     if (threadIdx.x == 0) a.dq_ctl[dy.parity ^ 1] = 0, a.dq_ctl[2 + (dy.parity ^ 1)] = 0;
   }
-  if (threadIdx.x < SQ) {
+  if (cwave) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
       const float4 q = a.scan[i];
@@ -701,14 +785,14 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
       a.pbnorm[i] = nb;
-      s_nb[threadIdx.x] = nb;
+      s_nb[lane_] = nb;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
         mine = false;
         a.nfound[i] = NF_NOTMINE, a.sel[i] = 0;
         w = make_float4(3e9f, 3e9f, 3e9f, 0.f);  // far from every list: its search lanes find an empty cell
       }
     }
-    s_w[threadIdx.x] = w;
+    s_w[lane_] = w;
   }
   if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) return;  // a workgroup of somebody else's tiles
   __syncthreads();
@@ -735,7 +819,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lane <-> query, the same in every wave (a point of another shard sits at 3e9 and is never searched further)
-    const bool pend = (q0 + lane < a.N) && s_nf[lane] == NF_PENDING && s_w[lane].x < 1e9f;
+    const bool pend = (qidx(lane) < a.N) && s_nf[lane] == NF_PENDING && s_w[lane].x < 1e9f;
     unsigned long long todo = __ballot(pend);
     // every wave must have taken its snapshot of the flags before any wave rewrites one (the serving wave stores the
     // final count, wave 0 stores NF_DEFERRED): a wave that read s_nf late would see a different `todo`, the round-robin
@@ -755,7 +839,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
           if (lane == 0) base = atomicAdd(&a.dq_ctl[dy.parity], (u32)npend);
           base = __shfl(base, 0);
           if (pend) {
-            a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)(q0 + lane);
+            a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)qidx(lane);
             s_nf[lane] = NF_DEFERRED;
           }
         }
@@ -781,9 +865,9 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       __syncthreads();
     }
   }
-  if (threadIdx.x >= SQ) return;
-  // ---- phase C (wave 0) ----
-  const int lane = threadIdx.x;
+  if (!cwave) return;
+  // ---- phase C (control wave) ----
+  const int lane = lane_;
   u32 og[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) og[k] = s_og[k][lane];
@@ -1196,11 +1280,11 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
   // lane-local candidates under the total order (d2, map index); a deleted slot (x = +inf) is at infinite distance
   Top5 t;
 #pragma unroll
-  for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
+  for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
   auto offer = [&](const float4 p, u32 og) {
     float ddx = w.x - p.x, ddy = w.y - p.y, ddz = w.z - p.z;
     float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-    top5_insert(t, d2 < INFINITY ? top5_key(d2, og) : ~0ull);
+    top5_insert(t, d2 < INFINITY ? top5_key(d2, og) : TOP5_MAXKEY);
   };
   bool done = false;
   for (int r = 0; r <= FAR_RMAX && !done; r++) {
@@ -1234,12 +1318,12 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
     if (t.og(K - 1) != INVALID && t.d(K - 1) <= reach * reach * 0.99999f) done = true;
     if (!done && lane != 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
+      for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
     }
   }
   if (!done) {  // farther than ~40 m from every map point (or fewer than K points in the map): scan the map
 #pragma unroll
-    for (int k = 0; k < 5; k++) t.k[k] = ~0ull;
+    for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
     for (int j = lane; j < map_n; j += 64) offer(map_in[j], (u32)j);
     merge_group<64>(t, INFINITY);
   }
