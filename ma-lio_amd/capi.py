@@ -328,6 +328,25 @@ class Engine:
         self._keep = (tabs, tc)
         self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
 
+    def scan_set_fn(self, pts12, pose_tables, temporal_comp):
+        """malio_scan_set with every ctypes argument built beforehand: returns a zero-argument callable (bench.py times
+        the C call, not the marshalling of ~30 pose-table entries in Python)."""
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        n = pts12.shape[0]
+        tabs = [np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1, 59)) for t in pose_tables]
+        ptrs = (C.POINTER(Pose) * self.L)(*[_p(t, Pose) for t in tabs])
+        lens = (C.c_int * self.L)(*[t.shape[0] for t in tabs])
+        tc = np.ascontiguousarray(np.asarray(temporal_comp, np.float64).reshape(-1, 59))
+        tcp = _p(tc, Pose) if self.L > 1 else None
+        p = _p(pts12, Point)
+        fn = lib().malio_scan_set
+
+        def call():
+            self.N = n
+            self._keep = (tabs, tc, pts12)
+            self._chk(fn(self.h, p, n, ptrs, lens, tcp), "malio_scan_set")
+        return call
+
     def measure(self, state_flat, converge=True, want_rows=False):
         s = state_from_flat(state_flat, self.L)
         out = MeasureOut()
@@ -359,6 +378,30 @@ class Engine:
             return f(h, sp, cv, op)
         fn._keep = keep
         return fn, out
+
+    def update_iterated_fn(self, state_flat, P, R=0.001):
+        """Pre-bound malio_update_iterated for timing loops: returns (fn, result); fn() restores the prior (state, P) and
+        runs the update - two small memcpys and the C call, no Python conversions; result() builds the dict afterwards."""
+        s0 = state_from_flat(state_flat, self.L)
+        s = state_from_flat(state_flat, self.L)
+        P0 = np.ascontiguousarray(P, np.float64).copy()
+        Pw = P0.copy()
+        stats = (C.c_int * 4)()
+        st = C.c_double(0)
+        f = lib().malio_update_iterated
+        h, sp, pp, stp, Rc = self.h, C.byref(s), _p(Pw, C.c_double), C.byref(st), C.c_double(R)
+        ssz, s0p, psz, p0p, pwp = C.sizeof(s), C.addressof(s0), P0.nbytes, P0.ctypes.data, Pw.ctypes.data
+
+        def fn():
+            C.memmove(C.addressof(s), s0p, ssz)
+            C.memmove(pwp, p0p, psz)
+            return f(h, sp, pp, Rc, stats, stp)
+
+        def result():
+            return dict(state=state_to_flat(s, self.L), P=Pw.copy(), passes=stats[0], searches=stats[1], M=stats[2],
+                        t=stats[3], solve_time=st.value)
+        fn._keep = (s0, s, P0, Pw, stats, st)
+        return fn, result
 
     def scan_get(self):
         n = self.N

@@ -155,7 +155,7 @@ int malio_destroy(malio_handle_t h) {
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
-  fr(c->d_map_alt);
+  fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
@@ -427,6 +427,41 @@ static int scan_reset(Ctx *c) {
   return MALIO_OK;
 }
 
+namespace malio {
+// The caller's 48-byte points, already in HBM (copied there from page-locked memory by the DMA engine), packed to the
+// 20-byte upload record; what the host loop of malio_scan_set does while it packs - counting the points of each LiDAR
+// slot, validating the slot, noticing whether the slots come in ascending blocks - is left in info[] for the first pass:
+// info[l] = points of slot l, info[8] = points with a slot outside [0, L), info[9] = descents of the slot sequence.
+__global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw12, int n, int L, UploadRec *upload, u32 *info) {
+  __shared__ u32 s_cnt[10];
+  if (threadIdx.x < 10) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) {
+    const float *p = raw12 + (size_t)i * 12;
+    const float4 a = *reinterpret_cast<const float4 *>(p);      // x y z _
+    const float2 b = *reinterpret_cast<const float2 *>(p + 4);  // normal_x normal_y
+    const int lid = (int)p[8];                                  // laserMapping.cpp:570
+    int idx = (int)b.x;                                         // int(laser_p.normal_x), laserMapping.cpp:694,737
+    if (idx > 0x3FFFFF) idx = 0x3FFFFF;
+    if (idx < -0x3FFFFF) idx = -0x3FFFFF;
+    const bool bad = lid < 0 || lid >= L;
+    UploadRec r;
+    r.x = a.x, r.y = a.y, r.z = a.z;
+    r.w = ((unsigned)idx << 8) | (unsigned)(bad ? 0 : lid);
+    r.ny = b.y;
+    upload[i] = r;
+    if (bad)
+      atomicAdd(&s_cnt[8], 1u);
+    else
+      atomicAdd(&s_cnt[lid], 1u);
+    if (i > 0 && (int)p[8 - 12] > lid) atomicAdd(&s_cnt[9], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 10 && s_cnt[threadIdx.x]) atomicAdd(&info[threadIdx.x], s_cnt[threadIdx.x]);
+}
+}  // namespace malio
+
 int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
                    const int *pose_unc_len, const malio_pose_t *temporal_comp) {
   if (check(h) || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
@@ -440,6 +475,31 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   c->N = n;
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
+  c->seg_pending = false;
+  {
+    // A cloud in page-locked memory (malio_host_alloc, or any hipHostMalloc / hipHostRegister'ed buffer) is not touched
+    // by this thread at all: one DMA copy of the 48-byte points and a kernel that packs them; the per-slot counts come
+    // back with the first pass (resolve_scan_segments). A pageable cloud would be staged by the runtime page by page
+    // (~0.7 ms per 10 MB): it is packed here instead, in one pass over it.
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (pinned) {
+      if ((size_t)n > c->cap_raw) {
+        if (c->d_raw) (void)hipFree(c->d_raw);
+        c->d_raw = nullptr, c->cap_raw = (size_t)n + (size_t)n / 8 + 1024;
+        MALIO_HIP(hipMalloc(&c->d_raw, sizeof(float) * 12 * c->cap_raw));
+      }
+      if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
+      MALIO_HIP(hipMemcpyAsync(c->d_raw, body, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+      MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
+      hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_raw, n, L, c->d_upload, c->d_packinfo);
+      MALIO_HIP(hipGetLastError());
+      c->seg_pending = true;
+      c->scan_keep_order = false;  // decided when the counts arrive
+      return scan_reset(c);
+    }
+  }
   UploadRec *stage = nullptr;
   if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n, (void **)&stage)) return rcs;
   int cnt[MALIO_MAX_LIDAR] = {0};

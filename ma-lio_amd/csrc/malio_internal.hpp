@@ -354,6 +354,11 @@ struct Ctx {
   bool scan_keep_order = false;  // this scan is used in its upload order (no spatial sort), see malio_scan_order
   int scan_order_mode = 0;       // MALIO_SCAN_ORDER_*
   UploadRec *d_upload = nullptr;  // [N] scan as uploaded, caller's order (see UploadRec)
+  float *d_raw = nullptr;         // [N][12] the caller's page-locked cloud as copied (malio_scan_set, pinned path)
+  size_t cap_raw = 0;
+  u32 *d_packinfo = nullptr;      // k_pack_raw: per-slot counts, bad slots, descents
+  u32 *d_sort_cnt = nullptr;      // scan grouping: bucket counts + offsets (measure.hip sort_scan)
+  bool seg_pending = false;       // seg_start[] not known yet: the counts are still on the device
   float4 *d_scan = nullptr;     // [N] sorted
   u32 *d_perm = nullptr;        // [N] sorted -> original index
   int last_M = -1;
@@ -516,6 +521,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *
 // flag, [k_search_tail], k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
 int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate = nullptr);  // gate: rides on the last kernel
 int prepare_scan_dev(Ctx *c, const malio_state_t *s);  // map lists in sync, scan sorted
+int resolve_scan_segments(Ctx *c);  // the per-LiDAR segments of a scan that was packed on the device
 void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
 void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc);
 // the same loop over any measurement pass (host/node.cpp drives several GPUs through it); rows_pass == nullptr: no rows

@@ -12,7 +12,6 @@
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
 #include "malio_internal.hpp"
 #include "../host/manifold.hpp"
-#include <hipcub/hipcub.hpp>
 
 namespace malio {
 
@@ -1514,14 +1513,24 @@ int measure_alloc(Ctx *c) {
   return MALIO_OK;
 }
 
-// Sort key of a scan point: (LiDAR slot, level-1 cell of its world position under the first pass' state). Float is
-// enough for the position (ordering only). The cell coordinates enter modulo 1024 (1152 m at the default edge, more
-// than twice any det_range the reference ships): a scan wider than that would merely interleave two far-apart cells,
-// which costs locality, not correctness. One 32-bit key for the whole scan - the slot in the top bits makes the LiDAR
-// segments contiguous and ordered, whatever the upload order - so ONE stable radix sort of 4 digit passes does all
-// the grouping; ties keep the upload order.
-__global__ void __launch_bounds__(BLK) k_scan_keys(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
-                                                   u32 *keys, u32 *vals) {
+// ---- once-per-scan grouping of the scan -------------------------------------------------------------------------------
+// What the search pass wants from the order of the scan: the points of one LiDAR slot contiguous, slots ascending
+// (k_rows_reduce works on per-slot blocks), queries of the same level-1 map cell adjacent (their list reads coalesce and
+// hit L1) - and an order that is the same in every run, because every fixed-order reduction over the scan inherits it.
+// A full sort delivers that and more (it was one stable radix sort of 32-bit keys: 10 launches of rocprim's merge sort,
+// ~0.1 ms for 100 k points, as much as two search passes); nothing needs the cells themselves ordered. So: a bucket
+// grouping. key = (slot, cell of the world point under the first pass' state, coordinates modulo 1024: a scan wider
+// than 1152 m merely interleaves two far-apart cells); bucket = (slot, 12-bit hash of the cell);
+//   k_sort_count    key, bucket, arrival rank inside the bucket (atomic: arbitrary)
+//   k_sort_scan     exclusive scan of the bucket counts (one workgroup; clears the counts for the next scan)
+//   k_sort_scatter  points to their bucket's segment in arrival order
+//   k_sort_place    every point ranks itself inside its segment under (key, index in the caller's cloud) - segments
+//                   hold a few points - and goes to segment start + rank: deterministic, same-cell points adjacent;
+//                   the kernel writes the sorted scan and resets the per-point state a new scan starts from.
+constexpr int SORT_NBK = 4096;                           // buckets per LiDAR slot (100 k points: ~8 per bucket)
+constexpr int SORT_NB = SORT_NBK * MALIO_MAX_LIDAR;      // 16384
+__global__ void __launch_bounds__(BLK) k_sort_count(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
+                                                    u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   const UploadRec q = in[i];
@@ -1531,25 +1540,93 @@ __global__ void __launch_bounds__(BLK) k_scan_keys(const UploadRec *__restrict__
   D3 pg = qrot(qc.rot, X) + qc.pos;
   const u32 cx = (u32)(int)floorf((float)pg.x * inv_cf) & 1023u, cy = (u32)(int)floorf((float)pg.y * inv_cf) & 1023u,
             cz = (u32)(int)floorf((float)pg.z * inv_cf) & 1023u;
-  keys[i] = ((u32)lid << 30) | (cz << 20) | (cy << 10) | cx;
-  vals[i] = (u32)i;
+  const u32 cell = (cz << 20) | (cy << 10) | cx;
+  const u32 b = (u32)lid * SORT_NBK + ((cell * 0x9E3779B1u) >> 20);
+  keys[i] = cell;
+  bkt[i] = b;
+  rnk[i] = atomicAdd(&cnt[b], 1u);
 }
-// the sorted scan + the per-scan state every new scan starts from (nothing reads these arrays before the first pass)
-__global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict__ in, const u32 *__restrict__ src, int n,
-                                                     float4 *out_scan, u32 *out_perm, float *out_ny, unsigned char *sel,
-                                                     unsigned char *nfound, u32 *nbr, float *pd2, float4 *plane) {
+// one workgroup: 1024 threads x 16 consecutive buckets; thread sums -> wave scan (shuffles) -> scan of the 16 wave totals
+__global__ void __launch_bounds__(1024) k_sort_scan(u32 *cnt, u32 *offs) {  // offs[SORT_NB + 1]
+  __shared__ u32 s_wave[16];
+  constexpr int PER = SORT_NB / 1024;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  uint4 *c4 = reinterpret_cast<uint4 *>(cnt + (size_t)t * PER);
+  uint4 v[PER / 4];
+  u32 sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER / 4; k++) {
+    v[k] = c4[k];
+    sum += v[k].x + v[k].y + v[k].z + v[k].w;
+    c4[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  u32 inc = sum;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  u32 base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) base += w < wv ? s_wave[w] : 0u;
+  u32 run = base + inc - sum;
+  u32 *o = offs + (size_t)t * PER;
+#pragma unroll
+  for (int k = 0; k < PER / 4; k++) {
+    o[4 * k] = run, run += v[k].x;
+    o[4 * k + 1] = run, run += v[k].y;
+    o[4 * k + 2] = run, run += v[k].z;
+    o[4 * k + 3] = run, run += v[k].w;
+  }
+  if (t == 1023) offs[SORT_NB] = run;
+}
+__global__ void __launch_bounds__(BLK) k_sort_scatter(int n, const u32 *__restrict__ keys, const u32 *__restrict__ bkt,
+                                                      const u32 *__restrict__ rnk, const u32 *__restrict__ offs, u32 *tkey,
+                                                      u32 *tidx, u32 *tbkt) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  const u32 s = src[i];  // index in the caller's cloud
-  const UploadRec r = in[s];
-  out_scan[i] = make_float4(r.x, r.y, r.z, __uint_as_float(r.w));
-  out_perm[i] = s;
-  out_ny[i] = r.ny;
-  sel[i] = 0, nfound[i] = 0;
+  const u32 b = bkt[i], pos = offs[b] + rnk[i];
+  tkey[pos] = keys[i], tidx[pos] = (u32)i, tbkt[pos] = b;
+}
+// the sorted scan + the per-scan state every new scan starts from (nothing reads these arrays before the first pass)
+__device__ __forceinline__ void scan_install(const UploadRec *__restrict__ in, u32 src, int dst, int n, float4 *out_scan,
+                                             u32 *out_perm, float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
+                                             float *pd2, float4 *plane) {
+  const UploadRec r = in[src];  // src: index in the caller's cloud
+  out_scan[dst] = make_float4(r.x, r.y, r.z, __uint_as_float(r.w));
+  out_perm[dst] = src;
+  out_ny[dst] = r.ny;
+  sel[dst] = 0, nfound[dst] = 0;
 #pragma unroll
-  for (int k = 0; k < 5; k++) nbr[(size_t)k * n + i] = 0xFFFFFFFFu;
-  pd2[i] = 0.f;
-  plane[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < 5; k++) nbr[(size_t)k * n + dst] = 0xFFFFFFFFu;
+  pd2[dst] = 0.f;
+  plane[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(BLK) k_sort_place(const UploadRec *__restrict__ in, int n, const u32 *__restrict__ tkey,
+                                                    const u32 *__restrict__ tidx, const u32 *__restrict__ tbkt,
+                                                    const u32 *__restrict__ offs, float4 *out_scan, u32 *out_perm,
+                                                    float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
+                                                    float *pd2, float4 *plane) {
+  int j = blockIdx.x * BLK + threadIdx.x;
+  if (j >= n) return;
+  const u32 b = tbkt[j], s0 = offs[b], s1 = offs[b + 1];
+  const u32 mk = tkey[j], mi = tidx[j];
+  u32 rank = 0;
+  for (u32 m = s0; m < s1; m++) {
+    const u32 k = tkey[m], i = tidx[m];
+    rank += (k < mk || (k == mk && i < mi)) ? 1u : 0u;
+  }
+  scan_install(in, mi, (int)(s0 + rank), n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane);
+}
+// the upload order kept (malio_scan_order): install only
+__global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict__ in, int n, float4 *out_scan, u32 *out_perm,
+                                                     float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
+                                                     float *pd2, float4 *plane) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  scan_install(in, (u32)i, i, n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane);
 }
 
 void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
@@ -1568,39 +1645,57 @@ void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
   }
 }
 
-// Spatial sort of the scan, once per scan, with the first pass' state (coherence only, not results).
-__global__ void __launch_bounds__(BLK) k_scan_iota(u32 *p, int n) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n) p[i] = (u32)i;
+// A scan packed on the device (malio_scan_set with a page-locked cloud): its per-slot counts arrive here, once, before the
+// first pass sorts it. By now the pack kernel finished long ago; the read-back is one small blocking copy.
+int resolve_scan_segments(Ctx *c) {
+  if (!c->seg_pending) return MALIO_OK;
+  u32 info[16];
+  MALIO_HIP(hipMemcpyAsync(info, c->d_packinfo, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  c->seg_pending = false;
+  const int L = c->prm.lid_num;
+  if (info[8]) {  // int(intensity) outside [0, lid_num): what malio_scan_set rejects on the spot for a pageable cloud
+    c->N = 0;
+    c->err = "malio_scan_set: a point's LiDAR slot int(intensity) is outside [0, lid_num)";
+    return MALIO_ERR_BAD_ARG;
+  }
+  c->seg_start[0] = 0;
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? (int)info[l] : 0);
+  c->scan_keep_order = c->scan_order_mode == MALIO_SCAN_ORDER_KEEP && info[9] == 0;
+  return MALIO_OK;
 }
+
+// Grouping of the scan, once per scan, with the first pass' state (coherence only, not results).
 static int sort_scan(Ctx *c, const QuatConst &qc) {
   // The temporaries live in the arena and are handed back when this returns, with the kernels still queued: every
   // arena user enqueues on c->stream, so the stream's order is the only synchronisation needed.
   ArenaScope sc(c->arena);
   const int N = c->N;
-  u32 *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
-  void *d_tmp = nullptr;
-  size_t tmp_bytes = 0;
-  MALIO_HIP(sc.get(&d_keys, (size_t)N));
-  MALIO_HIP(sc.get(&d_keys2, (size_t)N));
-  MALIO_HIP(sc.get(&d_vals, (size_t)N));
-  MALIO_HIP(sc.get(&d_vals2, (size_t)N));
-  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, N, 0, 32, c->stream));
-  MALIO_HIP(sc.get((char **)&d_tmp, tmp_bytes ? tmp_bytes : 16));
   const dim3 grid((N + BLK - 1) / BLK);
   if (c->scan_keep_order) {  // malio_scan_order: the upload order is kept (it is grouped by LiDAR slot)
-    hipLaunchKernelGGL(k_scan_iota, grid, dim3(BLK), 0, c->stream, d_vals2, N);
-    hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, d_vals2, N, c->d_scan, c->d_perm, c->d_ny,
+    hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, N, c->d_scan, c->d_perm, c->d_ny,
                        c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
     c->scan_sorted = true;
     return MALIO_OK;
   }
-  hipLaunchKernelGGL(k_scan_keys, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, d_keys, d_vals);
-  // A stable radix sort: unlike a counting sort on atomic ranks, the resulting order - and with it every fixed-order
-  // reduction over the sorted scan - is identical in every run.
-  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d_vals2, N, 0, 32, c->stream));
-  hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, d_vals2, N, c->d_scan, c->d_perm, c->d_ny,
-                     c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
+  if (!c->d_sort_cnt) {  // bucket counts (left at zero by every scan) + offsets
+    MALIO_HIP(hipMalloc(&c->d_sort_cnt, sizeof(u32) * (2 * SORT_NB + 16)));
+    MALIO_HIP(hipMemsetAsync(c->d_sort_cnt, 0, sizeof(u32) * (2 * SORT_NB + 16), c->stream));
+  }
+  u32 *cnt = c->d_sort_cnt, *offs = c->d_sort_cnt + SORT_NB;
+  u32 *keys = nullptr, *bkt = nullptr, *rnk = nullptr, *tkey = nullptr, *tidx = nullptr, *tbkt = nullptr;
+  MALIO_HIP(sc.get(&keys, (size_t)N));
+  MALIO_HIP(sc.get(&bkt, (size_t)N));
+  MALIO_HIP(sc.get(&rnk, (size_t)N));
+  MALIO_HIP(sc.get(&tkey, (size_t)N));
+  MALIO_HIP(sc.get(&tidx, (size_t)N));
+  MALIO_HIP(sc.get(&tbkt, (size_t)N));
+  hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, keys, bkt, rnk, cnt);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs);
+  hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkey, tidx, tbkt);
+  hipLaunchKernelGGL(k_sort_place, grid, dim3(BLK), 0, c->stream, c->d_upload, N, tkey, tidx, tbkt, offs, c->d_scan, c->d_perm,
+                     c->d_ny, c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
+  MALIO_HIP(hipGetLastError());
   c->scan_sorted = true;
   return MALIO_OK;
 }
@@ -1653,6 +1748,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
   if (!c->scan_sorted) {
+    if (int rc = resolve_scan_segments(c)) return rc;
     int rc = sort_scan(c, a.qc);
     if (rc != MALIO_OK) return rc;
   }
@@ -1737,6 +1833,7 @@ int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   if (int rc = map_sync_search(c)) return rc;
   if (!c->scan_sorted) {
+    if (int rc = resolve_scan_segments(c)) return rc;
     QuatConst qc;
     fill_quat_const(c, s, qc);
     if (int rc = sort_scan(c, qc)) return rc;
