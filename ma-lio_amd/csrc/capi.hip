@@ -882,6 +882,7 @@ int malio_set_update_mode(malio_handle_t h, int mode) {
 int malio_debug_counters(malio_handle_t h, int *out8) {
   if (check(h) || !out8) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
+  if (int rc = map_apply_finish(c)) return rc;
   out8[0] = (int)c->nl1.ncells, out8[1] = (int)(c->nl1.entries / 27), out8[2] = (int)c->nl2.ncells;
   out8[3] = c->n_rebuilds, out8[4] = c->n_inplace, out8[5] = c->map_dead, out8[6] = c->nl_tomb, out8[7] = c->map_n;
   return MALIO_OK;

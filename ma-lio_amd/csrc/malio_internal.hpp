@@ -337,6 +337,7 @@ struct Ctx {
                                              // by kernels or copies; one stream sync serves all
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
+  bool apply_pending = false;  // an in-place list update is queued, its verdict (fitted / overflowed) not read yet
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
@@ -465,6 +466,7 @@ int far_knn5(Ctx *c, u32 *d_far);  // measure.hip: unrestricted 5-NN of the quer
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now
 int map_sync_search(Ctx *c);     // ... only if a mutator left them stale (called by every search entry point)
+int map_apply_finish(Ctx *c);    // read the verdict of a queued in-place list update (map_update.hip)
 
 // decode.hip
 int decode_livox(Ctx *c, const unsigned char *rec, int n_rec, int n_scans, int pfn, double blind, int eof_point,

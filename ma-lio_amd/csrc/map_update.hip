@@ -248,13 +248,38 @@ __global__ void __launch_bounds__(BLK) k_iota_u32(u32 *p, int n) {
 
 }  // namespace
 
+// An in-place list update reports through two state words (cells in use, overflow) whether it fitted. map_apply leaves
+// that check - the only thing its caller would wait for - to whoever needs the lists next: the mutators return with the
+// list maintenance kernels still queued, and the host gets on with the next scan's front end meanwhile.
+int map_apply_finish(Ctx *c) {
+  if (!c->apply_pending) return MALIO_OK;
+  c->apply_pending = false;
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  MALIO_HIP(hipGetLastError());
+  u32 *mb = nullptr;
+  MALIO_HIP(mbox(c, &mb));
+  const u32 *st1 = mb + 16, *st2 = mb + 20;
+  c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
+  bool in_place = !(st1[1] || st2[1]);  // a list or the tail region overflowed
+  // probing stays short below load 0.7; past it the next search rebuilds with a larger directory
+  if ((size_t)st1[2] * 10 > (size_t)(c->nl1.tmask + 1) * 7 || (size_t)st2[2] * 10 > (size_t)(c->nl2.tmask + 1) * 7)
+    in_place = false;
+  if (!in_place)
+    c->search_dirty = true;
+  else
+    c->n_inplace++;
+  return MALIO_OK;
+}
+
 int map_sync_search(Ctx *c) {
+  if (int rc = map_apply_finish(c)) return rc;
   if (!c->search_dirty) return MALIO_OK;
   return map_rebuild_search(c);
 }
 
 // Full rebuild: sweep the deleted slots out of the map array (indices change), then both list levels from scratch.
 int map_rebuild_search(Ctx *c) {
+  if (int rc = map_apply_finish(c)) return rc;
   c->search_dirty = false;
   if (c->map_dead > 0 && c->map_n > 0) {
     ArenaScope sc(c->arena);
@@ -311,6 +336,7 @@ __global__ void k_publish_states(const u32 *__restrict__ s1, const u32 *__restri
 // too many tombstones have piled up.
 static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, const u32 *keep, const u32 *rank,
                      int m, u32 nadd) {
+  if (int rcf = map_apply_finish(c)) return rcf;  // (the previous batch's verdict decides whether this one goes in place)
   const int hw = c->map_n;
   bool in_place = !c->search_dirty && hw > 0;
   // in place only while the directory is comfortably loaded and tombstones stay below a fifth of the live points
@@ -338,23 +364,16 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
       nl_append(c, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
       u32 *mb = nullptr, *mbd = nullptr;
       MALIO_HIP(mbox(c, &mb, &mbd));
-      u32 *st1 = mb + 16, *st2 = mb + 20;
       hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, c->stream, c->nl1.state, c->nl2.state, mbd + 16);
-      MALIO_HIP(hipStreamSynchronize(c->stream));
-      c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
-      if (st1[1] || st2[1]) in_place = false;  // a list or the tail region overflowed
-      // probing stays short below load 0.7; past it the next search rebuilds with a larger directory
-      if ((size_t)st1[2] * 10 > (size_t)(c->nl1.tmask + 1) * 7 || (size_t)st2[2] * 10 > (size_t)(c->nl2.tmask + 1) * 7)
-        in_place = false;
+      c->apply_pending = true;  // verdict read by map_apply_finish
     }
     c->map_n = hw + (int)nadd;
   }
-  MALIO_HIP(hipStreamSynchronize(c->stream));
   MALIO_HIP(hipGetLastError());
   if ((ndel || nadd)) {
     c->map_epoch++;  // neighbour ids handed out before this call may now name a dead slot
     if (!in_place) c->search_dirty = true;
-    else c->n_inplace++;
+    else if (!c->apply_pending) c->n_inplace++;
   }
   return MALIO_OK;
 }

