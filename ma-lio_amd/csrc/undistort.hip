@@ -7,8 +7,20 @@
 // Also emits, per point, how many IMU stamps lie strictly above its time (D_i); a suffix-min scan turns that into
 // the reference's single-step `if` counter (:484-494, the uncertainty-interval index written to `intensity`).
 // Algorithmic bytes: 16 B read + 16 B written per raw point.
+//
+// The kernel is bound by f64 issue (half rate on gfx950), so it is written to need few instructions rather than to
+// mirror the reference's expression tree (the acceptance bar is <= 1 float ulp on xyz, tests/test_undistort.py):
+//   * per knot interval the host precomputes the twist's angle, unit axis k and k k^T - I (= K^2 of the unit skew matrix):
+//     exp(b xi) = I + sin(b th) K + (1 - cos(b th)) K^2 then costs one sincos, 18 multiply/adds for R and as many for V,
+//     no matrix product K K and no division by th^2 (quat_ops.h:206-217 forms A, B, C and wskew * wskew per point);
+//   * the rotations of :498-503 are applied as matrices (the two constant ones prepared on the host) instead of going
+//     through Eigen's matrix -> quaternion conversion and four quaternion-vector products;
+//   * the knot times, IMU stamps and interval tables of the scan live in LDS (both binary searches were chains of
+//     dependent global loads).
 #include <algorithm>
+#include <cmath>
 #include "malio_internal.hpp"
+#include "../host/manifold.hpp"
 #include <hipcub/hipcub.hpp>
 
 namespace malio {
@@ -27,7 +39,11 @@ struct UndArgs {
   int n_imu, cov_pointer0;
   double eq[4], et[3];  // extrinsic of this LiDAR (q: x,y,z,w)
   double lq[4], lt[3];  // IMU pose at this LiDAR's scan end
+  const double *ivl;    // [K-1][UND_IVL] per-interval twist in axis-angle form (see k_undistort)
+  double Re[9], RlT[9];  // rotation matrices of eq and of lq^-1 (row-major)
 };
+constexpr int UND_IVL = 13;   // theta, k[3], K2 = k k^T - I as xx yy zz xy xz yz, translational part v[3]
+constexpr int UND_KMAX = 96;  // knots / IMU stamps the LDS tables hold (a 0.1 s scan has ~15 of each)
 
 struct D3u {
   double x, y, z;
@@ -87,7 +103,9 @@ __device__ __forceinline__ void se3_mul_d(double R[9], double t[3], const double
   for (int i = 0; i < 3; i++) t[i] = tn[i];
 }
 
-__global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
+// general-size fallback (more knots or stamps than the LDS tables hold): tables in global memory, the reference's
+// expression tree
+__global__ void __launch_bounds__(BLK) k_undistort_big(UndArgs a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= a.n) return;
   const float *pin = a.in12 + (size_t)i * 12;
@@ -185,6 +203,102 @@ __global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
   a.out[i] = make_float4((float)x.x, (float)x.y, (float)x.z, 1.f);
 }
 
+__device__ __forceinline__ void mat3_apply(const double *R, double &x, double &y, double &z) {
+  const double a = R[0] * x + R[1] * y + R[2] * z, b = R[3] * x + R[4] * y + R[5] * z, c = R[6] * x + R[7] * y + R[8] * z;
+  x = a, y = b, z = c;
+}
+__device__ __forceinline__ void mat3T_apply(const double *R, double &x, double &y, double &z) {
+  const double a = R[0] * x + R[3] * y + R[6] * z, b = R[1] * x + R[4] * y + R[7] * z, c = R[2] * x + R[5] * y + R[8] * z;
+  x = a, y = b, z = c;
+}
+__global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
+  // the two search tables in LDS (the binary searches are chains of dependent reads); the pose and twist rows of the
+  // interval found are read once per point from global memory - neighbouring points share them, they stay in L1
+  __shared__ double s_kt[UND_KMAX], s_it[UND_KMAX];
+  for (int e = threadIdx.x; e < a.K; e += BLK) s_kt[e] = a.knot_t[e];
+  for (int e = threadIdx.x; e < a.n_imu; e += BLK) s_it[e] = a.imu_t[e];
+  __syncthreads();
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= a.n) return;
+  const float *pin = a.in12 + (size_t)i * 12;
+  const float4 p = make_float4(pin[0], pin[1], pin[2], pin[9]);
+  const double point_t = (double)p.w / 1000.0 + a.lidar_beg_time;  // :482
+  {  // D_i: stamps imu_t[k], k <= cov_pointer0, that are > point_t (imu_t ascending)
+    int lo = 0, hi = a.cov_pointer0 + 1;
+    if (hi > a.n_imu) hi = a.n_imu;
+    const int top = hi;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_it[mid] > point_t)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    a.D[i] = top - lo;
+  }
+  int lo = 0, hi = a.K;  // i1 = (number of knots <= t) - 1; needs i1 - 1 and i1 + 2 (BsplineSE3.cpp:173-230)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (s_kt[mid] <= point_t)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int i1 = lo - 1;
+  if (i1 < 1 || i1 + 2 >= a.K || i == 0) {  // i == 0: the reference's loop stops before begin() (:475-476)
+    a.out[i] = make_float4(p.x, p.y, p.z, 0.f);
+    return;
+  }
+  const double t1 = s_kt[i1], t2 = s_kt[i1 + 1];
+  const double u = (point_t - t1) / (t2 - t1);
+  const double bb[3] = {1.0 / 6.0 * (5 + 3 * u - 3 * u * u + u * u * u), 1.0 / 6.0 * (1 + 3 * u + 3 * u * u - 2 * u * u * u),
+                        1.0 / 6.0 * (u * u * u)};
+  // :498-503 with the pose never formed: P_compensate = Re^T (Rl^T (T_i (Re P_i + te) - t_l) - te), where
+  // T_i = T0 A0 A1 A2 (:111) is applied to the point factor by factor, innermost first. For a unit axis k,
+  // exp(th k) x = x + sin(th) (k x x) + (1 - cos th) (k (k.x) - x), and the translation of exp_se3 is the same form on
+  // the twist's translational part with ((1 - cos th) / th, (th - sin th) / th).
+  double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  mat3_apply(a.Re, x, y, z);
+  x += a.et[0], y += a.et[1], z += a.et[2];
+#pragma unroll
+  for (int k = 2; k >= 0; k--) {
+    const double *iv = a.ivl + (size_t)(i1 - 1 + k) * UND_IVL;
+    const double th = bb[k] * iv[0];
+    double pa, pb, qa, qb;
+    if (th < 1e-7) {  // quat_ops.h:201-204
+      pa = th, pb = 0.5 * th * th, qa = 0.5 * th, qb = th * th * (1.0 / 6.0);
+    } else {
+      double sn, cs;
+      sincos(th, &sn, &cs);
+      const double r = 1.0 / th;
+      pa = sn, pb = 1 - cs, qa = pb * r, qb = (th - sn) * r;
+    }
+    const double kx = iv[1], ky = iv[2], kz = iv[3];
+    const double ux = bb[k] * iv[10], uy = bb[k] * iv[11], uz = bb[k] * iv[12];
+    // rotation of the point
+    const double cx = ky * z - kz * y, cy = kz * x - kx * z, cz = kx * y - ky * x;
+    const double dt = kx * x + ky * y + kz * z;
+    const double dx = kx * dt - x, dy = ky * dt - y, dz = kz * dt - z;
+    // translation V u
+    const double ex = ky * uz - kz * uy, ey = kz * ux - kx * uz, ez = kx * uy - ky * ux;
+    const double du = kx * ux + ky * uy + kz * uz;
+    const double fx = kx * du - ux, fy = ky * du - uy, fz = kz * du - uz;
+    x = (x + pa * cx + pb * dx) + (ux + qa * ex + qb * fx);
+    y = (y + pa * cy + pb * dy) + (uy + qa * ey + qb * fy);
+    z = (z + pa * cz + pb * dz) + (uz + qa * ez + qb * fz);
+  }
+  {
+    const double *T0 = a.knot_T + (size_t)(i1 - 1) * 12;
+    const double nx = T0[0] * x + T0[1] * y + T0[2] * z + T0[3], ny = T0[4] * x + T0[5] * y + T0[6] * z + T0[7],
+                 nz = T0[8] * x + T0[9] * y + T0[10] * z + T0[11];
+    x = nx - a.lt[0], y = ny - a.lt[1], z = nz - a.lt[2];
+  }
+  mat3_apply(a.RlT, x, y, z);
+  x -= a.et[0], y -= a.et[1], z -= a.et[2];
+  mat3T_apply(a.Re, x, y, z);
+  a.out[i] = make_float4((float)x, (float)y, (float)z, 1.f);
+}
+
 int spline_interval(const double *times, int n, double ts);
 void spline_interval_logs(const double *poses16, int n, double *logs6);
 
@@ -241,7 +355,20 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   int *d_D = nullptr, *d_rev = nullptr, *d_brev = nullptr, *d_entry = nullptr, *d_ne = nullptr;
   double *d_tab = nullptr;
   char *d_tmp = nullptr;
-  const size_t ntab = (size_t)n_knots + T12.size() + logs.size() + (size_t)n_imu;
+  // the same twists in axis-angle form (k_undistort): angle, unit axis k, K^2 = k k^T - I, translational part
+  std::vector<double> ivl((size_t)(n_knots - 1) * UND_IVL, 0.0);
+  for (int k = 0; k + 1 < n_knots; k++) {
+    const double *lg = &logs[(size_t)k * 6];
+    double *iv = &ivl[(size_t)k * UND_IVL];
+    const double th = std::sqrt(lg[0] * lg[0] + lg[1] * lg[1] + lg[2] * lg[2]);
+    double kx = 0, ky = 0, kz = 0;
+    if (th > 1e-300) kx = lg[0] / th, ky = lg[1] / th, kz = lg[2] / th;
+    iv[0] = th, iv[1] = kx, iv[2] = ky, iv[3] = kz;
+    iv[4] = -(ky * ky + kz * kz), iv[5] = -(kx * kx + kz * kz), iv[6] = -(kx * kx + ky * ky);  // (unit axis: k k^T - I)
+    iv[7] = kx * ky, iv[8] = kx * kz, iv[9] = ky * kz;
+    iv[10] = lg[3], iv[11] = lg[4], iv[12] = lg[5];
+  }
+  const size_t ntab = (size_t)n_knots + T12.size() + logs.size() + (size_t)n_imu + ivl.size();
   const int entry_cap = n_imu + 4;
   MALIO_HIP(sc.get(&d_und, (size_t)n));
   MALIO_HIP(sc.get(&d_D, (size_t)n));
@@ -257,6 +384,7 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   tab.insert(tab.end(), T12.begin(), T12.end());
   tab.insert(tab.end(), logs.begin(), logs.end());
   tab.insert(tab.end(), imu_stamps, imu_stamps + n_imu);
+  tab.insert(tab.end(), ivl.begin(), ivl.end());
   MALIO_HIP(hipMemcpyAsync(d_tab, tab.data(), sizeof(double) * ntab, hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipMemsetAsync(d_ne, 0, sizeof(int), c->stream));
   UndArgs a;
@@ -265,9 +393,20 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   a.imu_t = d_tab + n_knots + T12.size() + logs.size(), a.n_imu = n_imu, a.cov_pointer0 = cov_pointer0;
   for (int k = 0; k < 4; k++) a.eq[k] = ext_q[k], a.lq[k] = end_q[k];
   for (int k = 0; k < 3; k++) a.et[k] = ext_t[k], a.lt[k] = end_t[k];
+  a.ivl = a.imu_t + n_imu;
+  mf::quat_R_eigen(ext_q, a.Re);
+  {
+    double Rl[9];
+    mf::quat_R_eigen(end_q, Rl);
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) a.RlT[r * 3 + cc] = Rl[cc * 3 + r];
+  }
   const int nb = (n + BLK - 1) / BLK;
   prof_begin(c);
-  hipLaunchKernelGGL(k_undistort, dim3(nb), dim3(BLK), 0, c->stream, a);
+  if (n_knots <= UND_KMAX && n_imu <= UND_KMAX)
+    hipLaunchKernelGGL(k_undistort, dim3(nb), dim3(BLK), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(k_undistort_big, dim3(nb), dim3(BLK), 0, c->stream, a);
   prof_mark(c, "k_undistort");
   hipLaunchKernelGGL(k_und_rev, dim3(nb), dim3(BLK), 0, c->stream, d_D, n, d_rev);
   size_t tmp_bytes = 0;
