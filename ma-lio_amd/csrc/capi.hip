@@ -154,7 +154,7 @@ int malio_destroy(malio_handle_t h) {
   free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
@@ -793,6 +793,8 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   std::vector<double> tr(N);
   std::vector<float> ny(N);
   std::vector<float> pd2(N), world((size_t)3 * N);
+  std::vector<float4> world4;  // feats_down_world after a search pass (the search kernel keeps one copy of it)
+  const bool from_search = c->last_pass_search;
   std::vector<float4> plane(N);
   MALIO_HIP(hipMemcpyAsync(perm.data(), c->d_perm, sizeof(u32) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(sel.data(), c->d_sel, N, hipMemcpyDeviceToHost, c->stream));
@@ -800,7 +802,12 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
   MALIO_HIP(hipMemcpyAsync(tr.data(), c->d_trace, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(ny.data(), c->d_ny, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipMemcpyAsync(pd2.data(), c->d_pd2, sizeof(float) * N, hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+  if (from_search) {
+    world4.resize(N);
+    MALIO_HIP(hipMemcpyAsync(world4.data(), c->d_world4, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    MALIO_HIP(hipMemcpyAsync(world.data(), c->d_world, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, c->stream));
+  }
   MALIO_HIP(hipMemcpyAsync(plane.data(), c->d_plane, sizeof(float4) * N, hipMemcpyDeviceToHost, c->stream));
   std::vector<float4> near;
   if ((nearest || nearest_count) && c->nbr_epoch != c->map_epoch) {
@@ -841,7 +848,12 @@ int malio_scan_get(malio_handle_t h, float *normal_y, malio_point_t *nearest, in
     if (nearest_count) nearest_count[o] = near_cnt[o];
     if (selected) selected[o] = sel[i];
     if (res_last) res_last[o] = sel[i] ? fabsf(pd2[i]) : 0.f;
-    if (world_xyz) world_xyz[3 * o] = world[i], world_xyz[3 * o + 1] = world[N + i], world_xyz[3 * o + 2] = world[2 * N + i];
+    if (world_xyz) {
+      if (from_search)
+        world_xyz[3 * o] = world4[i].x, world_xyz[3 * o + 1] = world4[i].y, world_xyz[3 * o + 2] = world4[i].z;
+      else
+        world_xyz[3 * o] = world[i], world_xyz[3 * o + 1] = world[N + i], world_xyz[3 * o + 2] = world[2 * N + i];
+    }
     if (normvec4) {
       normvec4[4 * o] = plane[i].x, normvec4[4 * o + 1] = plane[i].y, normvec4[4 * o + 2] = plane[i].z;
       normvec4[4 * o + 3] = pd2[i];

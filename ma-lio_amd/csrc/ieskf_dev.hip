@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(ST_BLK) k_ieskf_step(StepArgs g) {
     dl->passes += 1;
     dl->searches += was_search ? 1 : 0;
     if (was_search) dl->heavy = (int)g.mm[5];
+    dl->last_search = was_search ? 1 : 0;
     dl->commit_prev = M > 0 ? 1 : 0;
     dl->lastM = M;
     if (valid) {
@@ -538,7 +539,7 @@ int ieskf_update_device(Ctx *c, malio_state_t *xio, double *Pio, int *stats) {
   // ---- results ----
   const DevLoop *o = reinterpret_cast<const DevLoop *>(c->h_loop_out);
   c->mm_parity = o->mm_parity, c->dq_parity = o->dq_parity;
-  c->last_pass_search = true;
+  c->last_pass_search = o->last_search != 0;
   c->defer_enabled = (double)o->heavy >= DEFER_SCORE_MIN;
   if (o->status == MALIO_SMALL_M_FALLBACK) {
     c->last_M = -1;  // the pass that ran folded the previous results already; the host loop starts this scan's update over

@@ -184,6 +184,7 @@ struct DevLoop {
   int valid_any;    // a pass was valid: P_proj of the last valid iteration is what a loop that runs out leaves behind
   int heavy;        // deferral score of the last search pass (steers the host's k_search_tail switch)
   int lastM_valid;  // accepted points of the last VALID pass (stats[2])
+  int last_search;  // the last pass that ran was a search pass (feats_down_world then lives in world4)
   int maximum_iter, L, extrinsic_est_en;
   double limit;
   double tcq[MALIO_MAX_LIDAR][4], tct[MALIO_MAX_LIDAR][3];  // temporal compensation of this scan (index lid - 1)
@@ -376,7 +377,6 @@ struct Ctx {
   float *d_pd2 = nullptr;      // [N]
   float *d_world = nullptr;    // [3][N]
   float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_search phase A; k_search_tail, k_far_nearest)
-  double *d_pbnorm = nullptr;  // [N]
   float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
   double *d_ucov = nullptr;    // [N] unit_cov
   double *d_trace = nullptr;   // [N] trace(Sigma_p) (clamp rule by selected flag)

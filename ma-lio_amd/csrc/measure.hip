@@ -88,7 +88,6 @@ struct Pass1Args {
   const float4 *map_in;  // [map slots] x y z normal_y (index = map id)
   // per-point outputs (sorted order)
   float4 *world4;  // [N] world point of the search pass
-  double *pbnorm;  // [N] |p'| (double), range gate :599
   u64 *mm_cur;     // extrema slots this pass accumulates into (MmSlots)
   u64 *mm_next;    // the other parity: reset here for the next pass
   u32 *dq;         // [N] queries deferred to k_search_tail
@@ -621,8 +620,7 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev,
   selected = false, ucov = 0.0, tr = 0.0;
 #pragma unroll
   for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
-  a.nfound[i] = (unsigned char)nf;
-  a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+  a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
   commit_normal_y(a, commit_prev, i);
   if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
     // ---- esti_plane<float> (common_lib.h:144-190) ----
@@ -783,7 +781,6 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
-      a.pbnorm[i] = nb;
       s_nb[lane_] = nb;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
         mine = false;
@@ -888,6 +885,7 @@ template <bool DEV>
 __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
   if (DEV && (a.dl->done || !a.dl->converge)) return;  // the loop is over, or this pass is a reuse pass
   const PassDyn dy = pass_dyn<DEV>(a);
+  const QuatConst &qc = DEV ? a.dl->qc : a.qc;
   // 16 lanes per query: 4 queries per wave search concurrently, then their first lanes run the point phase together
   const int lane = threadIdx.x & 63, sub = threadIdx.x & (TAIL_G - 1);
   const u32 grp = (blockIdx.x * BLK + threadIdx.x) / TAIL_G, ngrp = (gridDim.x * BLK) / TAIL_G;
@@ -910,7 +908,13 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
       bool selected;
       double ucov, tr;
       const u32 og5[5] = {t.og(0), t.og(1), t.og(2), t.og(3), t.og(4)};
-      point_phase(a, dy.commit_prev, i, w, a.pbnorm[i], og5, nf, selected, ucov, tr);
+      double nb;  // |p'| of the range gate: recomputed for the few deferred queries instead of stored for all
+      {
+        const float4 q = a.scan[i];
+        float wx, wy, wz;
+        world_point(qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
+      }
+      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, selected, ucov, tr);
       if (selected) {
         nsel++;
         mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -1468,7 +1472,7 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_dq), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_pbnorm), fr(c->d_ny);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
     MALIO_HIP(hipMalloc(&c->d_upload, sizeof(UploadRec) * K));
@@ -1484,7 +1488,6 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_sel, K));
     MALIO_HIP(hipMalloc(&c->d_nfound, K));
     MALIO_HIP(hipMalloc(&c->d_world4, sizeof(float4) * K));
-    MALIO_HIP(hipMalloc(&c->d_pbnorm, sizeof(double) * K));
     MALIO_HIP(hipMalloc(&c->d_ny, sizeof(float) * K));
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
@@ -1709,7 +1712,7 @@ static void fill_pass1_static(Ctx *c, Pass1Args &a) {
   a.unc = c->d_unc;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
-  a.world4 = c->d_world4, a.pbnorm = c->d_pbnorm;
+  a.world4 = c->d_world4;
   a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.defer = c->defer_enabled ? 1 : 0;
   a.part = c->part;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;

@@ -162,8 +162,12 @@ class HipBackend:
         if mode == "shm":
             # every rank derives the same segment name (the calls are collective, so the counters agree); rank 0 creates
             # and zeroes it, the first agreement doubles as "it exists before anybody else opens it"
-            tag = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "run") if ch.isalnum())[:24]
-            name = "/malio_%s_%s_%d_%d" % (tag, os.environ.get("MASTER_PORT", "0"), W, next(_xchg_ids))
+            # the name carries a random token rank 0 draws and broadcasts: two independent jobs on one node (same W, no
+            # TORCHELASTIC_RUN_ID / MASTER_PORT to tell them apart) can never meet in - or unlink - each other's segment
+            import uuid
+            box = [uuid.uuid4().hex[:16] if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            name = "/malio_%s_%d_%d" % (box[0], W, next(_xchg_ids))
             ok = True
             if rank == 0:
                 try:                                                            # no /dev/shm, no space: use the group

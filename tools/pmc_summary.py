@@ -4,7 +4,7 @@ d = sys.argv[1]
 for f in sorted(glob.glob(d + "/*counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-40:] + " g" + r["Grid_Size"]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[-40:] + " g" + r["Grid_Size"]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", f.split("/")[-1])
     for k, cs in acc.items():

@@ -9,12 +9,12 @@ d, tag = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else "k_search"
 vals = {}
 for line in open(os.path.join(d, tag + "_pmc_summary.txt")):
-    m = re.match(r"\s+malio::(\w+) g\d+\s+(\{.*\})", line)
-    if m and m.group(1) == kernel:
-        vals.update(ast.literal_eval(m.group(2)))
+    m = re.match(r"\s+malio::(\w+)(<\w+>)? g\d+\s+(\{.*\})", line)
+    if m and m.group(1) == kernel and m.group(2) in (None, "<false>"):
+        vals.update(ast.literal_eval(m.group(3)))
 avg_ns = calls = None
 for r in csv.DictReader(open(os.path.join(d, tag + "_bench_kernel_stats.csv"))):
-    if r["Name"].startswith("malio::%s(" % kernel):
+    if r["Name"].replace("void ", "").startswith(("malio::%s(" % kernel, "malio::%s<false>(" % kernel)):
         avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
 out = {
     "kernel": kernel, "workload": "city3_100k_1M, one launch",
