@@ -734,9 +734,34 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   if (rc != MALIO_OK) return rc;
   // The two result kernels store straight into pinned, device-mapped host memory (2.4 KB over PCIe): no copy kernel
   // between the last kernel and the host (worth ~1 us per pass).
-  rc = pass_stage2(c, nullptr, c->d_res + ns, c->d_res, want_rows);
+  // How the call learns that the pass is over: the last workgroup of the last kernel stores a sequence word into pinned
+  // memory (after the sums, which go there too) and this thread polls it - the results are in hand ~2 us before the
+  // queue's completion signal would have woken a hipStreamSynchronize. (Profiling and the rows path keep the sync.)
+  volatile int *h_msg = nullptr;
+  GateArgs gate{};
+  const bool poll = !c->profiling && !want_rows;
+  if (poll) {
+    int *d_msg = nullptr;
+    if ((rc = gate_words(c, &h_msg, &d_msg)) != MALIO_OK) return rc;
+    c->gate_epoch = c->gate_epoch >= (1 << 30) ? 1 : c->gate_epoch + 1;
+    gate.msg_seq = d_msg, gate.ticket = c->d_gate_ticket, gate.publish = c->gate_epoch;
+  }
+  rc = pass_stage2(c, nullptr, c->d_res + ns, c->d_res, want_rows, poll ? &gate : nullptr);
   if (rc != MALIO_OK) return rc;
-  MALIO_HIP(hipStreamSynchronize(c->stream));
+  if (poll) {
+    long long spins = 0;
+    while (__atomic_load_n(const_cast<int *>(h_msg), __ATOMIC_ACQUIRE) != gate.publish) {
+      if ((++spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+        if (__atomic_load_n(const_cast<int *>(h_msg), __ATOMIC_ACQUIRE) == gate.publish) break;
+        MALIO_HIP(hipStreamSynchronize(c->stream));  // surfaces the error that ended the queue early
+        c->err = "malio_measure: the pass ended without announcing its result";
+        return MALIO_ERR_HIP;
+      }
+      __builtin_ia32_pause();
+    }
+  } else {
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+  }
   prof_end(c);
   const double *res = c->h_res;
   rc = finish_host(c, res, res + ns, out);

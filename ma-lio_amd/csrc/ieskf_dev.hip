@@ -573,6 +573,27 @@ __global__ void __launch_bounds__(256) k_gate(GateArgs g) {  // the gate before 
   gate_body(g);
 }
 
+int ensure_gate_buffers(Ctx *c) {
+  const size_t hdr = loop_block_doubles();
+  if (!c->d_gate_ticket) {
+    MALIO_HIP(hipMalloc(&c->d_gate_ticket, 256));
+    MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
+  }
+  if (!c->h_gate) {
+    MALIO_HIP(hipHostMalloc((void **)&c->h_gate, sizeof(double) * hdr + 256, hipHostMallocMapped | hipHostMallocCoherent));
+    MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_gate, c->h_gate, 0));
+    memset(c->h_gate, 0, sizeof(double) * hdr + 256);
+  }
+  return MALIO_OK;
+}
+int gate_words(Ctx *c, volatile int **host_msg, int **dev_msg) {  // the GPU -> host sequence word
+  if (int rc = ensure_gate_buffers(c)) return rc;
+  const size_t off = sizeof(double) * loop_block_doubles() + 128;
+  *host_msg = reinterpret_cast<volatile int *>(c->h_gate + off);
+  *dev_msg = reinterpret_cast<int *>(c->d_gate + off);
+  return MALIO_OK;
+}
+
 int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, double *solve_time) {
   const int L = c->prm.lid_num, n = 17 + 6 * L, maximum_iter = c->prm.max_iteration;
   const double limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
@@ -585,15 +606,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     MALIO_HIP(hipHostMalloc((void **)&c->h_loop_out, OUT_P_OFF + sizeof(double) * nn, hipHostMallocMapped | hipHostMallocCoherent));
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_loop_out, c->h_loop_out, 0));
   }
-  if (!c->d_gate_ticket) {
-    MALIO_HIP(hipMalloc(&c->d_gate_ticket, 256));
-    MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
-  }
-  if (!c->h_gate) {
-    MALIO_HIP(hipHostMalloc((void **)&c->h_gate, sizeof(double) * hdr + 256, hipHostMallocMapped | hipHostMallocCoherent));
-    MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_gate, c->h_gate, 0));
-    memset(c->h_gate, 0, sizeof(double) * hdr + 256);
-  }
+  if (int rcg = ensure_gate_buffers(c)) return rcg;
   // pinned layout: [DevLoop block | cmd_seq (int) ... msg_seq (int at +128)]
   DevLoop *blk = reinterpret_cast<DevLoop *>(c->h_gate);
   volatile int *cmd_seq = reinterpret_cast<volatile int *>(c->h_gate + sizeof(double) * hdr);

@@ -485,7 +485,10 @@ int measure_alloc(Ctx *c);
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out);
 // d_minmax4_in: all-reduced extrema (multi-GPU) or null (single GPU: folded inside k_rows_reduce and published
 // to d_mm_out)
-int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows);
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows,
+                const GateArgs *gate = nullptr);  // gate: the last kernel announces its completion (see k_final_reduce)
+int ensure_gate_buffers(Ctx *c);  // ieskf_dev.hip: pinned sequence words + control block, ticket counter
+int gate_words(Ctx *c, volatile int **host_msg, int **dev_msg);
 int sums_len(const Ctx *c);
 int finish_host(Ctx *c, const double *sums, const double *minmax4, malio_measure_out_t *out);
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx /*original map index*/, float *d_d2, int *d_cnt);

@@ -1179,8 +1179,9 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_s
 struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
-// With a gate (gated update loop): the workgroup that finishes last - a ticket counter - announces the sums to the host,
-// waits for the next pass' control block and installs it (gate_body): the gate costs no launch of its own.
+// With a gate (gate.msg_seq set): the workgroup that finishes last - a ticket counter - announces the sums to the host
+// through a sequence word in pinned memory and, in the gated update loop (gate.dl set), waits for the next pass' control
+// block and installs it (gate_body): the gate costs no launch of its own.
 __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
                                                       int L, double *out, const DevLoop *dl /* device loop, or null */,
                                                       GateArgs gate /* gate.dl == null: none */) {
@@ -1202,7 +1203,7 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
     for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
     if (lane == 0) out[lid * NSUM + e] = acc;
   }
-  if (!gate.dl) return;
+  if (!gate.msg_seq) return;
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1212,7 +1213,13 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
     if (s_last) *gate.ticket = 0u;  // for the next kernel that carries a gate (stream-ordered)
   }
   __syncthreads();
-  if (s_last) gate_body(gate);
+  if (!s_last) return;
+  if (gate.dl) {
+    gate_body(gate);
+  } else if (threadIdx.x == 0) {  // announcement only (malio_measure polls this word instead of waiting for the queue's signal)
+    __threadfence_system();
+    __hip_atomic_store(gate.msg_seq, gate.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
@@ -1803,7 +1810,7 @@ static int fill_pass2_static(Ctx *c, Pass2Args &a) {
   return nb;
 }
 
-int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows) {
+int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows, const GateArgs *gate) {
   Pass2Args a;
   const int nb = fill_pass2_static(c, a);
   a.pc = c->pc;
@@ -1824,7 +1831,8 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
   hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
-                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr, GateArgs{});
+                     c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr,
+                     gate ? *gate : GateArgs{});
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
