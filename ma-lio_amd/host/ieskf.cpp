@@ -52,6 +52,36 @@ void state_boxminus(const malio_state_t &x, const malio_state_t &o, int L, doubl
 
 // ---- dense helpers (row-major, n <= 41) -----------------------------------------------------------------
 using Mat = std::vector<double>;
+// Forward and back substitution on all right-hand sides at once, one row operation at a time (see invert_cols). W > 0:
+// the row width is a compile-time constant and the row being built lives in registers across its j loop (one store per
+// row instead of one per (i, j)); same operations on every entry, in the same order.
+template <int W>
+static void solve_rows(const double *__restrict A, int n, double *__restrict X, int w_runtime = 0) {
+  const int w = W > 0 ? W : w_runtime;
+  double acc[W > 0 ? W : 64];
+  for (int i = 0; i < n; i++) {
+    double *xi = X + (size_t)i * w;
+    for (int c = 0; c < w; c++) acc[c] = xi[c];
+    for (int j = 0; j < i; j++) {
+      const double l = A[i * n + j];
+      const double *xj = X + (size_t)j * w;
+      for (int c = 0; c < w; c++) acc[c] -= l * xj[c];
+    }
+    for (int c = 0; c < w; c++) xi[c] = acc[c];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double *xi = X + (size_t)i * w;
+    for (int c = 0; c < w; c++) acc[c] = xi[c];
+    for (int j = n - 1; j > i; j--) {  // j descending: the order of a column-oriented sweep (finished rows are
+      const double u = A[i * n + j];   // subtracted from all earlier ones as they complete) - what the device loop runs
+      const double *xj = X + (size_t)j * w;
+      for (int c = 0; c < w; c++) acc[c] -= u * xj[c];
+    }
+    const double d = A[i * n + i];
+    for (int c = 0; c < w; c++) xi[c] = acc[c] / d;
+  }
+}
+
 // First w columns of A^-1 (n x w, row-major) by LU with partial pivoting - what Eigen's inverse() does for n > 4 - with
 // all right-hand sides advanced together. A is destroyed. w = n: the whole inverse.
 bool invert_cols(Mat &A, int n, int w, Mat &X) {
@@ -82,23 +112,16 @@ bool invert_cols(Mat &A, int n, int w, Mat &X) {
   X.assign((size_t)n * w, 0.0);
   for (int i = 0; i < n; i++)
     if (piv[i] < w) X[(size_t)i * w + piv[i]] = 1.0;
-  for (int i = 0; i < n; i++) {
-    double *xi = &X[(size_t)i * w];
-    for (int j = 0; j < i; j++) {
-      const double l = A[i * n + j];
-      const double *xj = &X[(size_t)j * w];
-      for (int c = 0; c < w; c++) xi[c] -= l * xj[c];
-    }
-  }
-  for (int i = n - 1; i >= 0; i--) {
-    double *xi = &X[(size_t)i * w];
-    for (int j = n - 1; j > i; j--) {  // j descending: the order of a column-oriented sweep (finished rows are
-      const double u = A[i * n + j];   // subtracted from all earlier ones as they complete) - what the device loop runs
-      const double *xj = &X[(size_t)j * w];
-      for (int c = 0; c < w; c++) xi[c] -= u * xj[c];
-    }
-    const double d = A[i * n + i];
-    for (int c = 0; c < w; c++) xi[c] /= d;
+  switch (w) {  // the row width as a compile-time constant: a row of X stays in registers across its j loop
+    case 12: solve_rows<12>(A.data(), n, X.data()); break;
+    case 18: solve_rows<18>(A.data(), n, X.data()); break;
+    case 24: solve_rows<24>(A.data(), n, X.data()); break;
+    case 30: solve_rows<30>(A.data(), n, X.data()); break;
+    case 23: solve_rows<23>(A.data(), n, X.data()); break;
+    case 29: solve_rows<29>(A.data(), n, X.data()); break;
+    case 35: solve_rows<35>(A.data(), n, X.data()); break;
+    case 41: solve_rows<41>(A.data(), n, X.data()); break;
+    default: solve_rows<0>(A.data(), n, X.data(), w); break;
   }
   return true;
 }
@@ -180,6 +203,21 @@ void ieskf_step_pre(int L, const malio_state_t *x, const malio_state_t *x_propag
   }
 }
 
+template <int N>
+static void posterior_rows(const double *__restrict L_, const double *__restrict K_x, const double *__restrict P_, int C,
+                           double *__restrict P_out) {
+  double acc[N];
+  for (int a = 0; a < N; a++) {
+    for (int b = 0; b < N; b++) acc[b] = 0.0;
+    for (int k = 0; k < C; k++) {
+      const double kx = K_x[a * N + k];
+      const double *pk = P_ + (size_t)k * N;
+      for (int b = 0; b < N; b++) acc[b] += kx * pk[b];
+    }
+    for (int b = 0; b < N; b++) P_out[a * N + b] = L_[a * N + b] - acc[b];
+  }
+}
+
 // Second half, AFTER the measurement pass. Pure host code.
 //   i          loop index of esekfom.hpp:509 (-1 .. max_iteration-1)
 //   x          in: state the pass was evaluated at; out: x boxplus dx
@@ -237,15 +275,11 @@ static int step_post(int L, int maximum_iter, double limit, int i, malio_state_t
       cols_applyT(L_, n, s2_idx, 2, B);
       cols_applyT(P_, n, s2_idx, 2, B);
     }
-    std::vector<double> acc(n);
-    for (int a = 0; a < n; a++) {  // :714, P = L - K_x[:, 0:C] P[0:C, :]  (k ascending per entry, row-wise axpy)
-      for (int b = 0; b < n; b++) acc[b] = 0.0;
-      for (int k = 0; k < C; k++) {
-        const double kx = K_x[a * n + k];
-        const double *pk = &P_[(size_t)k * n];
-        for (int b = 0; b < n; b++) acc[b] += kx * pk[b];
-      }
-      for (int b = 0; b < n; b++) P_out[a * n + b] = L_[a * n + b] - acc[b];
+    switch (n) {  // :714, P = L - K_x[:, 0:C] P[0:C, :]  (k ascending per entry, row-wise axpy, the row in registers)
+      case 23: posterior_rows<23>(L_.data(), K_x.data(), P_.data(), C, P_out); break;
+      case 29: posterior_rows<29>(L_.data(), K_x.data(), P_.data(), C, P_out); break;
+      case 35: posterior_rows<35>(L_.data(), K_x.data(), P_.data(), C, P_out); break;
+      default: posterior_rows<41>(L_.data(), K_x.data(), P_.data(), C, P_out); break;
     }
     *done_out = 1;
   } else {
@@ -260,6 +294,22 @@ static int step_core(int L, int maximum_iter, double limit, int i, malio_state_t
   StepPre pre;
   ieskf_step_pre(L, x, x_propagated, P_prop, pre, false);
   return step_post(L, maximum_iter, limit, i, x, x_propagated, pre, gain, t_io, converge_out, done_out, P_out);
+}
+
+// K_x[:, 0:C] = Pc (n x C) * HtRinvH (C x C): per entry k ascending, as a dot product would; a row at a time, in registers
+template <int C>
+static void gain_rows(const double *__restrict Pc, const double *__restrict H, int n, double *__restrict K_x) {
+  double acc[C];
+  for (int a = 0; a < n; a++) {
+    for (int b = 0; b < C; b++) acc[b] = 0.0;
+    for (int k = 0; k < C; k++) {
+      const double p = Pc[a * C + k];
+      const double *hk = H + (size_t)k * C;
+      for (int b = 0; b < C; b++) acc[b] += p * hk[b];
+    }
+    double *kx = K_x + (size_t)a * n;
+    for (int b = 0; b < C; b++) kx[b] = acc[b];
+  }
 }
 
 // esekfom.hpp:621-637 on the reduced normal equations: P_inv = (P^-1 + blk(HtRinvH))^-1,
@@ -281,13 +331,12 @@ static GainFn normal_eq_gain(int L, const double *HtRinvH, const double *HtRinvh
       double s = 0;
       for (int b = 0; b < C; b++) s += Pc[a * C + b] * HtRinvh[b];
       K_h[a] = s;
-      double *kx = &K_x[(size_t)a * n];
-      for (int b = 0; b < C; b++) kx[b] = 0.0;
-      for (int k = 0; k < C; k++) {  // k ascending per entry, as a dot product would; contiguous in b
-        const double p = Pc[a * C + k];
-        const double *hk = &HtRinvH[(size_t)k * C];
-        for (int b = 0; b < C; b++) kx[b] += p * hk[b];
-      }
+    }
+    switch (C) {  // (row of K_x in registers across its k loop: compile-time width)
+      case 12: gain_rows<12>(Pc.data(), HtRinvH, n, K_x.data()); break;
+      case 18: gain_rows<18>(Pc.data(), HtRinvH, n, K_x.data()); break;
+      case 24: gain_rows<24>(Pc.data(), HtRinvH, n, K_x.data()); break;
+      default: gain_rows<30>(Pc.data(), HtRinvH, n, K_x.data()); break;
     }
     return MALIO_OK;
   };
