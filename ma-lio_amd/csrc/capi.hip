@@ -96,7 +96,7 @@ static int check(malio_handle_t h) { return h ? MALIO_OK : MALIO_ERR_BAD_ARG; }
 static int rc_dev_row(malio_xchg_t x, double **row) { return malio_xchg_device_row(x, row); }
 
 // pinned staging buffer of the upload paths, grown on demand and kept (hipHostMalloc/hipHostFree cost ~0.7 ms each)
-static int host_stage(malio::Ctx *c, size_t bytes, void **out) {
+int malio::host_stage(malio::Ctx *c, size_t bytes, void **out) {
   if (c->stage_pending) {  // malio_scan_set returns with its upload still in flight
     MALIO_HIP(hipStreamSynchronize(c->stream));
     c->stage_pending = false;

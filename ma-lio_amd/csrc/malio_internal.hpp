@@ -453,6 +453,8 @@ void nl_append(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 
 void nl_tombstone(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
 void free_nl_scratch(NlScratch &s);
 
+// capi.hip: the handle's pinned upload staging buffer (waits for an upload still in flight out of it)
+int host_stage(Ctx *c, size_t bytes, void **out);
 // map_update.hip
 int map_add(Ctx *c, const float4 *h_pts, int n, int downsample_on, int *out_added);
 int map_add_dev(Ctx *c, const float4 *d_pts, int n, int downsample_on, int *out_added);  // d_pts: device memory

@@ -501,8 +501,14 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   MALIO_HIP(sc.get(&tiles2, (size_t)(N + 1 + 1023) / 1024 + 2));
   MALIO_HIP(sc.get(&wp, (size_t)N));
   if (h_world_normal_y) {
+    // through the pinned staging buffer: a copy out of the caller's pageable array would be staged by the runtime and
+    // block this thread for it (~0.1 ms for 100 k floats)
     MALIO_HIP(sc.get(&d_wny, (size_t)N));
-    MALIO_HIP(hipMemcpyAsync(d_wny, h_world_normal_y, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    void *stage = nullptr;
+    if (int rcs = host_stage(c, sizeof(float) * (size_t)N, &stage)) return rcs;
+    memcpy(stage, h_world_normal_y, sizeof(float) * (size_t)N);
+    MALIO_HIP(hipMemcpyAsync(d_wny, stage, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    c->stage_pending = true;
   }
   u32 *mb = nullptr, *mbd = nullptr;
   MALIO_HIP(mbox(c, &mb, &mbd));

@@ -980,13 +980,19 @@ struct Pass2Args {
 };
 
 // a5 + a7: weights and the 12 non-zero entries of the (c_i-scaled) Jacobian row of one accepted point
-__device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &pc, const double mm[4], int i, int lid,
+// what point_row reads of one point (loaded before the workgroup waits for the extrema, see k_rows_reduce)
+struct RowIn {
+  float4 q, pl;
+  double ucov, trace;
+  float pd2;
+};
+__device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &pc, const double mm[4], const RowIn &in, int lid,
                                           double u[12], double &hs, double &r) {
-  const float4 q = a.scan[i];
-  const float4 pl = a.plane[i];
+  const float4 q = in.q;
+  const float4 pl = in.pl;
   const double max_u = mm[0], min_u = -mm[1], max_c = mm[2], min_c = -mm[3];
   // plane weight c_i (laserMapping.cpp:651-656)
-  double cp = a.ucov[i];
+  double cp = in.ucov;
   if (cp == 0)
     cp = 1;
   else if (max_u == min_u)
@@ -1023,9 +1029,9 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &p
   u[3] = A.x * cp, u[4] = A.y * cp, u[5] = A.z * cp;
   u[6] = B.x * cp, u[7] = B.y * cp, u[8] = B.z * cp;
   u[9] = Cb.x * cp, u[10] = Cb.y * cp, u[11] = Cb.z * cp;
-  hs = (-1.0) * (double)a.pd2[i] * cp;  // :707,715
+  hs = (-1.0) * (double)in.pd2 * cp;  // :707,715
   // point noise R_i by FIC (:716-721)
-  double R = a.extrinsic_est_en ? a.trace[i] : 0.0;
+  double R = a.extrinsic_est_en ? in.trace : 0.0;
   const double lo = min_c + (max_c - min_c) * a.wc.range_min, hi = min_c + (max_c - min_c) * a.wc.range_max;
   if (R < lo)
     R = a.wc.point_cov_min;
@@ -1050,6 +1056,18 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   const u32 *heavy = DEV ? a.dq_ctl + 2 + a.dl->dq_parity : a.heavy;
   const PassConst &pc = DEV ? a.dl->pc : a.pc;
   PH(1, 0);
+  // this thread's point: its loads are issued before the extrema fold and the barrier behind it (nothing below needs
+  // them until then: a kernel this short is one memory round trip deep, and this puts it under the fold)
+  int lid = 0;
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (l < a.L && (int)blockIdx.x >= a.seg_block0[l]) lid = l;
+  const int i = a.seg_start[lid] + ((int)blockIdx.x - a.seg_block0[lid]) * BLK + threadIdx.x;
+  const bool in = i < a.seg_start[lid + 1];
+  const bool selected = in && a.sel[i] != 0;
+  RowIn rin;
+  rin.q = make_float4(0.f, 0.f, 0.f, 0.f), rin.pl = rin.q, rin.ucov = 0, rin.trace = 0, rin.pd2 = 0.f;
+  if (selected) rin.q = a.scan[i], rin.pl = a.plane[i], rin.ucov = a.ucov[i], rin.trace = a.trace[i], rin.pd2 = a.pd2[i];
   // ---- a4 fold: the first wave of every workgroup folds the 64 extrema slots of stage 1 (2.5 KB from L2) ----
   if (a.minmax4) {
     if (threadIdx.x < 4) mm_s[threadIdx.x] = a.minmax4[threadIdx.x];
@@ -1080,17 +1098,10 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __syncthreads();
   PH(1, 1);
   const double mm[4] = {mm_s[0], mm_s[1], mm_s[2], mm_s[3]};
-  int lid = 0;
-#pragma unroll
-  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
-    if (l < a.L && (int)blockIdx.x >= a.seg_block0[l]) lid = l;
-  const int i = a.seg_start[lid] + ((int)blockIdx.x - a.seg_block0[lid]) * BLK + threadIdx.x;
-  const bool in = i < a.seg_start[lid + 1];
-  const bool selected = in && a.sel[i] != 0;
   double u[12], hs = 0, r = 1;
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
-  if (selected) point_row(a, pc, mm, i, lid, u, hs, r);
+  if (selected) point_row(a, pc, mm, rin, lid, u, hs, r);
   PH(1, 2);
   if (a.rows && in) {
     double *row = a.rows + (size_t)i * 14;
