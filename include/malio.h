@@ -264,6 +264,12 @@ int malio_set_update_mode(malio_handle_t h, int mode);
  * measurement pass of malio_update_iterated[_node] with the 0-based pass number; NULL removes it. */
 int malio_set_pass_hook(malio_handle_t h, void (*fn)(int pass, void *user), void *user);
 
+/* The localization weight of laserMapping.cpp:745-756 from N^T N = sum c_i^2 n_i n_i^T (3 x 3 symmetric, given as
+ * xx yy zz xy xz yz): w = sigma_3 / sigma_1 of h_x[:, 0:3] = sqrt(lambda_min / lambda_max), mapped onto
+ * [localize_cov_min, localize_cov_max] between the two thresholds and clamped outside - what malio_measure applies
+ * (as w^2) to the reduced normal equations. Pure host code (the device-resident update loop runs the same function). */
+double malio_localize_weight(const double NtN6[6], double thresh_min, double thresh_max, double cov_min, double cov_max);
+
 /* One iteration of the update loop AFTER its measurement pass (esekfom.hpp:521-720, the M >= n branch
  * :621-637), on the reduced normal equations. Pure host code, needs no handle and no GPU: a multi-GPU
  * driver calls it between its collectives. iter_index = loop index i of esekfom.hpp:509 (-1 ...

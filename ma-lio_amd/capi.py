@@ -30,7 +30,7 @@ EXPORTS = [
     "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
     "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
-    "malio_set_update_mode",
+    "malio_set_update_mode", "malio_localize_weight",
 ]
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
@@ -111,6 +111,8 @@ def lib():
         _lib.malio_version.restype = C.c_char_p
         _lib.malio_last_error.restype = C.c_char_p
         _lib.malio_last_error.argtypes = [C.c_void_p]
+        _lib.malio_localize_weight.restype = C.c_double
+        _lib.malio_localize_weight.argtypes = [C.POINTER(C.c_double)] + [C.c_double] * 4
         for name in EXPORTS:
             getattr(_lib, name)  # AttributeError if an include/malio.h symbol is not exported
     return _lib

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include "malio_internal.hpp"
+#include "../host/manifold.hpp"
 
 using namespace malio;
 
@@ -939,6 +940,11 @@ int malio_ieskf_step(int lid_num, int max_iteration, double limit, int iter_inde
     return MALIO_ERR_BAD_ARG;
   return ieskf_step(lid_num, max_iteration, limit, iter_index, x, x_propagated, P_propagated, HtRinvH, HtRinvh, t_io,
                     converge_out, done_out, P_out);
+}
+
+double malio_localize_weight(const double NtN6[6], double thresh_min, double thresh_max, double cov_min, double cov_max) {
+  if (!NtN6) return 0.0;
+  return mf::localize_weight(NtN6[0], NtN6[1], NtN6[2], NtN6[3], NtN6[4], NtN6[5], thresh_min, thresh_max, cov_min, cov_max);
 }
 
 int malio_result_buffer(malio_handle_t h, double **host, double **dev, int *len_doubles) {

@@ -141,6 +141,29 @@ def test_update_modes_agree(capi, scenes, kw):
         assert np.allclose(ds["normal_y"], hs["normal_y"], rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("max_iteration", [0, 1])
+def test_short_loops_all_modes(capi, orc, scenes, max_iteration):
+    """NUM_MAX_ITERATIONS = 0 / 1: the loop of esekfom.hpp:509 runs one / two passes, the posterior is written by the
+    `i == maximum_iter - 1` branch (:665) on the last of them - in every update mode, against the oracle. (The gated and
+    the device-resident loop enqueue maximum_iter + 1 passes ahead: the shortest chains there are.)"""
+    sc = scenes.make_scene(seed=251, N=1800, Nmap=25000, L=2, max_iteration=max_iteration)
+    o = orc.Oracle(sc["params"], threads=4)
+    o.map_build(sc["map"])
+    o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    v = o.update_iterated(sc["state0"], sc["P0"])
+    assert v["passes"] == max_iteration + 1
+    for mode in ("gated", "host", "device"):
+        eng = capi.Engine(sc["params"], device=0)
+        eng.set_update_mode(mode)
+        eng.map_build(sc["map"])
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        u = eng.update_iterated(sc["state0"], sc["P0"])
+        assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"]), mode
+        assert np.abs(u["state"] - v["state"]).max() < 1e-8, mode
+        assert_P_close(u["P"], v["P"])
+        assert np.array_equal(eng.scan_get()["selected"], o.scan_get()["selected"])
+
+
 def test_table_index_clamps(capi, orc, scenes):
     """normal_x outside the table / negative: the two different clamps of laserMapping.cpp:694-696 vs :737-739."""
     sc = scenes.make_scene(seed=211, N=1500, Nmap=30000, L=3, n_table=6)
