@@ -312,6 +312,16 @@ int malio_host_free(void *p);
 int malio_predict(int lid_num, malio_state_t *x, double *P, double dt, const double *Q, const double *acc,
                   const double *gyro);
 
+/* Chains of malio_predict steps on the device, up to four independent tracks side by side (one workgroup each, state and
+ * covariance resident from the first step to the last): what ImuProcess::UndistortPcl runs one after the other per scan -
+ * kf.predict on (x_, P_), predict_cont on (x_cont, P_unc_), back_predict on (x_unc, P_unc_)
+ * (IMU_Processing.hpp:332,345,364,386,399) - is three tracks here. Track t starts from x[t] (in: start, out: end) and
+ * P + t * n * n (in/out; P == NULL: states only) and takes K[t] steps whose dt / acc[3] / gyro[3] are concatenated in
+ * track order; out_states (may be NULL) receives the state after every step in the same order (sum of K entries). Same
+ * arithmetic as malio_predict (to the device's libm); lid_num is the handle's. */
+int malio_predict_chain(malio_handle_t h, int n_tracks, malio_state_t *x, double *P, const int *K, const double *dt,
+                        const double *acc, const double *gyro, const double *Q, malio_state_t *out_states);
+
 /* ---- undistortion (IMU_Processing.hpp:475-507 + BsplineSE3.cpp:84-118) --------------------- */
 /* Per-raw-point SE(3) cubic B-spline pose + rigid compensation into the LiDAR's own scan-end frame.
  * pts (in/out, sorted by curvature as :229-233): x,y,z rewritten, intensity <- uncertainty-interval

@@ -30,7 +30,7 @@ EXPORTS = [
     "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
     "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
-    "malio_set_update_mode", "malio_localize_weight",
+    "malio_set_update_mode", "malio_localize_weight", "malio_predict_chain",
 ]
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
@@ -329,6 +329,30 @@ class Engine:
         tcp = _p(tc, Pose) if self.L > 1 else None
         self._keep = (tabs, tc)
         self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
+
+    def predict_chain(self, xs_flat, Ps, dts, accs, gyros, Q, want_states=True):
+        """malio_predict_chain: tracks = len(xs_flat); dts/accs/gyros: per track arrays (K_t, K_t x 3, K_t x 3).
+        Returns (end states flat, end P list or None, per-step states list per track)."""
+        nt = len(xs_flat)
+        X = (State * nt)(*[state_from_flat(x, self.L) for x in xs_flat])
+        n = 17 + 6 * self.L
+        P = None if Ps is None else np.ascontiguousarray(np.stack([np.asarray(p, np.float64) for p in Ps]))
+        K = (C.c_int * nt)(*[len(d) for d in dts])
+        dt = np.ascontiguousarray(np.concatenate([np.asarray(d, np.float64) for d in dts]))
+        acc = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64).reshape(-1, 3) for a in accs]))
+        gy = np.ascontiguousarray(np.concatenate([np.asarray(g, np.float64).reshape(-1, 3) for g in gyros]))
+        Qc = np.ascontiguousarray(Q, np.float64)
+        tot = int(dt.shape[0])
+        out = (State * max(tot, 1))() if want_states else None
+        self._chk(lib().malio_predict_chain(self.h, nt, X, None if P is None else _p(P, C.c_double), K, _p(dt, C.c_double),
+                                            _p(acc, C.c_double), _p(gy, C.c_double), _p(Qc, C.c_double), out),
+                  "malio_predict_chain")
+        ends = [state_to_flat(X[t], self.L) for t in range(nt)]
+        steps, o = [], 0
+        for t in range(nt):
+            steps.append([state_to_flat(out[o + k], self.L) for k in range(K[t])] if want_states else None)
+            o += K[t]
+        return ends, (None if P is None else [P[t].reshape(n, n) for t in range(nt)]), steps
 
     def scan_set_fn(self, pts12, pose_tables, temporal_comp):
         """malio_scan_set with every ctypes argument built beforehand: returns a zero-argument callable (bench.py times

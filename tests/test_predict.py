@@ -285,3 +285,37 @@ def test_golden_chain(capi, orc):
             assert np.allclose(Pg, z["P_10"], rtol=1e-10, atol=1e-18)
     assert np.array_equal(Po, z["P_50"])
     assert np.allclose(Pg, z["P_50"], rtol=1e-10, atol=1e-18)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1, 3, 4])
+def test_device_chain_equals_host_chain(capi, scenes, L):
+    """malio_predict_chain (row f-3 on the device): three tracks of different lengths side by side - what
+    ImuProcess::UndistortPcl runs one after the other as kf.predict / predict_cont / back_predict - against the same
+    steps taken one by one with the host's malio_predict: the state after EVERY step and the final covariance. Same
+    operation order; the device's sin / cos may differ from glibc's in the last place."""
+    rng = np.random.default_rng(40 + L)
+    n = 17 + 6 * L
+    sc = scenes.make_scene(seed=12, N=200, Nmap=3000, L=L)
+    eng = capi.Engine(sc["params"], device=0)
+    Ks = [40, 17, 1]
+    xs = [rnd_state(scenes, rng, L, small_bias=(t == 1)) for t in range(3)]
+    Ps = [rnd_cov(rng, n, [1e-4, 1e-2, 1.0][t]) for t in range(3)]
+    Q = rnd_Q(rng)
+    dts, accs, gyros = [], [], []
+    for t, K in enumerate(Ks):
+        tt = np.arange(K) * 0.005
+        dts.append(np.full(K, [0.005, 0.01, 0.0025][t]))
+        accs.append(np.stack([np.sin(tt) * 2, np.cos(2 * tt), 9.8 + 0.3 * np.sin(3 * tt)], 1))
+        gyros.append(np.stack([0.3 * np.cos(tt), 0.2 * np.sin(2 * tt), np.full(K, 0.5 if t != 2 else 0.0)], 1))
+    ends, Pe, steps = eng.predict_chain(xs, Ps, dts, accs, gyros, Q)
+    for t, K in enumerate(Ks):
+        x, P = xs[t], Ps[t]
+        for k in range(K):
+            x, P = capi.predict(L, x, P, dts[t][k], Q, accs[t][k], gyros[t][k])
+            assert np.allclose(steps[t][k], x, rtol=0, atol=1e-12 * max(1.0, np.abs(x).max())), (t, k)
+        assert np.allclose(ends[t], x, rtol=0, atol=1e-12 * max(1.0, np.abs(x).max()))
+        assert np.allclose(Pe[t], P, rtol=1e-10, atol=1e-18 + 1e-13 * np.abs(P).max())
+    # states only (P == NULL), one track
+    e2, none, s2 = eng.predict_chain(xs[:1], None, dts[:1], accs[:1], gyros[:1], Q)
+    assert none is None and np.allclose(e2[0], ends[0], rtol=0, atol=1e-12 * max(1.0, np.abs(ends[0]).max()))
