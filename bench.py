@@ -174,6 +174,32 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
         out["front_end"] = {"raw_points": n, "host_chain_ms": float(np.median(th) * 1e3),
                             "resident_chain_ms": float(np.median(tr) * 1e3),
                             "resident_chain_pinned_ms": float(np.median(tp) * 1e3)}
+    # row f-3 on the device: the three IMU tracks of a scan (predict / predict_cont / back_predict), 40 steps each, one call
+    try:
+        import ctypes as C
+        Lc, Kc = sc["L"], 40
+        tt = np.arange(Kc) * 0.005
+        accs = np.ascontiguousarray(np.tile(np.stack([np.sin(tt) * 2, np.cos(2 * tt), 9.8 + 0.3 * np.sin(3 * tt)], 1), (3, 1)))
+        gys = np.ascontiguousarray(np.tile(np.stack([0.3 * np.cos(tt), 0.2 * np.sin(2 * tt), np.full(Kc, 0.5)], 1), (3, 1)))
+        dts = np.full(3 * Kc, 0.005)
+        Xc = (capi.State * 3)(*[capi.state_from_flat(sc["state0"], Lc) for _ in range(3)])
+        Pc = np.ascontiguousarray(np.stack([sc["P0"]] * 3))
+        Qc = np.ascontiguousarray(np.eye(12) * 1e-4)
+        Kv = (C.c_int * 3)(Kc, Kc, Kc)
+        outc = (capi.State * (3 * Kc))()
+        f = capi.lib().malio_predict_chain
+        tsc = []
+        for _ in range(12):
+            t = time.perf_counter()
+            rc = f(eng.h, 3, Xc, capi._p(Pc, C.c_double), Kv, capi._p(dts, C.c_double), capi._p(accs, C.c_double),
+                   capi._p(gys, C.c_double), capi._p(Qc, C.c_double), outc)
+            tsc.append(time.perf_counter() - t)
+            assert rc == 0
+        out["predict_chain"] = {"tracks": 3, "steps_per_track": Kc, "device_ms": float(np.median(tsc[2:]) * 1e3),
+                                "note": "malio_predict_chain, upload and download included; one host core takes 2.6 us per step "
+                                        "(DESIGN.md 4e): 0.31 ms for the same 120 steps"}
+    except Exception as e:  # (a secondary figure must not take the headline down)
+        out["predict_chain"] = {"error": str(e)}
     # one whole turn of the mapping loop on the bench workload, as the integration calls it (laserMapping.cpp:985-1060):
     # scan upload + tables, iterated update (includes the once-per-scan spatial sort), map_incremental at the posterior
     wny = np.full(sc["N"], 0.001, np.float32)
