@@ -48,6 +48,40 @@ def test_esti_plane_vs_lstsq(orc, origin, tol):
         assert pcov == pytest.approx((((0.5 - Wd) / cs) ** 2 * Wd).sum(), rel=1e-12)
 
 
+@pytest.mark.parametrize("origin", [(0, 0, 0), (100, -50, 3), (1000, 800, 10)])
+def test_esti_plane_vs_lapack_pivoted_qr_float32(orc, origin):
+    """A second, independent implementation of the SAME algorithm class in the SAME precision: LAPACK's sgeqp3
+    (Householder QR with column pivoting on the remaining column norms - what Eigen's ColPivHouseholderQR is) solving
+    A x = -1 in float32. Agreement here is at float rounding x conditioning, an order of magnitude tighter than the
+    double-precision lstsq check above allows far from the origin - it pins the restatement's pivoting / reflector
+    arithmetic against an implementation that was not written from the same reading of Eigen."""
+    from scipy.linalg import qr, solve_triangular
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for _ in range(300):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        c = np.asarray(origin, float) + rng.normal(size=3)
+        b1 = np.cross(n, rng.normal(size=3))
+        b1 /= np.linalg.norm(b1)
+        b2 = np.cross(n, b1)
+        uv = rng.uniform(-1, 1, (5, 2))
+        P32 = (c + uv[:, :1] * b1 + uv[:, 1:] * b2 + rng.normal(0, 0.01, (5, 1)) * n).astype(np.float32)
+        ok, pabcd, _ = orc.esti_plane(pts12(P32), 1e9, 0.5)
+        Q, R, piv = qr(P32, mode="economic", pivoting=True)          # float32 in, float32 LAPACK
+        assert Q.dtype == np.float32
+        y = solve_triangular(R, Q.T @ np.full(5, -1, np.float32)).astype(np.float32)
+        x = np.zeros(3, np.float32)
+        x[piv] = y
+        nn = np.float32(np.linalg.norm(x))
+        ref = np.concatenate([x / nn, [np.float32(1) / nn]])
+        # error scale of a float32 least-squares solve: eps * cond(A); compare relative to it
+        cond = np.linalg.cond(P32.astype(np.float64))
+        err = np.abs(pabcd[:3] - ref[:3]).max()
+        worst = max(worst, err / (6e-8 * cond))
+    assert worst < 8.0, worst
+
+
 def test_esti_plane_flags(orc):
     # a non-planar neighbourhood must be rejected (any residual > plane_th), W[0] <= 1e-5 gives plane_cov 0
     P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0.5, 0.5, 3.0]], np.float32) + 5
