@@ -584,6 +584,7 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
   *out_n = n;
   if (n <= 0) return MALIO_ERR_NO_SCAN;
   c->N = n;
+  c->seg_pending = false;  // (a page-locked malio_scan_set nobody ran a pass on may have left its counts pending)
   c->seg_start[0] = 0;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? m[l] : 0);
   int rc = measure_alloc(c);
