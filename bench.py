@@ -438,7 +438,8 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
     sc = scenes.make_scene(cfg=args.config)  # the same seed on every rank: same map, same scan
     N, L, state = sc["N"], sc["L"], sc["state0"]
     ns_row = 97 * L + 8
-    use_rccl = backend == "nccl"
+    # (MALIO_BENCH_FORCE_RCCL=1: tests drive the RCCL leg's failure handling with several gloo ranks on one GPU)
+    use_rccl = backend == "nccl" or os.environ.get("MALIO_BENCH_FORCE_RCCL") == "1"
 
     def fence():
         dist.barrier()
@@ -490,10 +491,10 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
             e.scan_set(sc["scan"][lo:hi], sc["tables"], sc["temporal_comp"])
 
     results, keep = {}, []
-    order = [("tiles", "rccl"), ("tiles", "shm"), ("scan", "rccl"), ("scan", "shm")]
-    if not use_rccl:
-        order = [o for o in order if o[1] == "shm"]
-    for partition, xk in order:
+    extras = {"balance": None, "roofline": None, "single": None}
+    rccl_note = [None]
+
+    def run_variant(partition, xk):
         e = engine(partition)
         x = make_exchange(xk)
         keep.append(x)
@@ -532,42 +533,19 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
                                     "first_pass_ms": float(tmed[1].item() * 1e3), "update_ms": float(tmed[0].item() * 1e3),
                                     "update_passes": passes, "M_accepted": int(out.M),
                                     "one_exchange_passes": hits, "two_exchange_passes": misses}
-    head = order[0]
-    hres = results[head]
-    value = N / (hres["ms_per_step"] * 1e-3)
 
-    # load balance of the tile sharding: scan points served and map points stored per rank
-    et = engines["tiles"]
-    served = torch.tensor([float(et.scan_owned().sum()), float(et.map_size())], dtype=torch.float64, device="cuda")
-    allsv = [torch.zeros_like(served) for _ in range(world)]
-    dist.all_gather(allsv, served)
-    balance = {"scan_points_served": [int(v[0].item()) for v in allsv], "map_points_stored": [int(v[1].item()) for v in allsv]}
-
-    roofline = single = None
-    if rank == 0:
-        n_mine = balance["scan_points_served"][0]
-        roofline = roofline_block(et, state, args, n_mine)
-        roofline["note"] = "rank 0's shard: %d of %d scan points served" % (n_mine, N)
-    fence()
-    if rank == 0:  # the same job on ONE GPU (the strong-scaling baseline), outside everybody's timed regions
-        e1 = capi.Engine(sc["params"], device=dev_index)
-        e1.map_build(sc["map"])
-        e1.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-        f1, _ = e1.measure_fn(state, True)
-        for _ in range(args.warmup + 1):
-            f1()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(200):
-            f1()
-        torch.cuda.synchronize()
-        single = {"ms_per_step": (time.perf_counter() - t) / 200 * 1e3}
-        single["speedup_at_n"] = single["ms_per_step"] / hres["ms_per_step"]
-    fence()
-    if rank == 0:
+    def emit():
+        """rank 0's JSON line from whatever has been measured: RCCL tiles when that variant completed, else the
+        shared-memory exchange (same sharding, same arithmetic) with the reason."""
+        head = ("tiles", "rccl") if ("tiles", "rccl") in results else ("tiles", "shm")
+        hres = results[head]
+        single = extras["single"]
+        if single:
+            single = dict(single, speedup_at_n=single["ms_per_step"] / hres["ms_per_step"])
         line = {
             "metric": "points/sec through k-NN+residual step (100k-pt scan vs 1M-pt map); ESKF iter ms",
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": N / (hres["ms_per_step"] * 1e-3), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup,
             "ms_per_step": hres["ms_per_step"], "timed_blocks": hres["timed_blocks"],
             "ms_per_step_minmax": hres["ms_per_step_minmax"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
@@ -583,9 +561,80 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
                      "iter_ms": hres["update_ms"] / max(hres["update_passes"], 1)},
             "first_pass_ms": hres["first_pass_ms"],
             "variants": {"%s+%s" % k: v for k, v in results.items()},
-            "balance": balance, "single_gpu_same_job": single, "roofline": roofline, "cpu_baseline": None,
+            "balance": extras["balance"], "single_gpu_same_job": single, "roofline": extras["roofline"], "cpu_baseline": None,
         }
+        if rccl_note[0]:
+            line["rccl_note"] = rccl_note[0]
         print(json.dumps(line), flush=True)
+
+    # 1. the sharded job over the shared-memory exchange: needs nothing but the node's memory, so there is always a line
+    run_variant("tiles", "shm")
+
+    # load balance of the tile sharding: scan points served and map points stored per rank
+    et = engines["tiles"]
+    served = torch.tensor([float(et.scan_owned().sum()), float(et.map_size())], dtype=torch.float64, device="cuda")
+    allsv = [torch.zeros_like(served) for _ in range(world)]
+    dist.all_gather(allsv, served)
+    extras["balance"] = {"scan_points_served": [int(v[0].item()) for v in allsv],
+                         "map_points_stored": [int(v[1].item()) for v in allsv]}
+    if rank == 0:
+        n_mine = extras["balance"]["scan_points_served"][0]
+        extras["roofline"] = roofline_block(et, state, args, n_mine)
+        extras["roofline"]["note"] = "rank 0's shard: %d of %d scan points served" % (n_mine, N)
+    fence()
+    if rank == 0:  # the same job on ONE GPU (the strong-scaling baseline), outside everybody's timed regions
+        e1 = capi.Engine(sc["params"], device=dev_index)
+        e1.map_build(sc["map"])
+        e1.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        f1, _ = e1.measure_fn(state, True)
+        for _ in range(args.warmup + 1):
+            f1()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(200):
+            f1()
+        torch.cuda.synchronize()
+        extras["single"] = {"ms_per_step": (time.perf_counter() - t) / 200 * 1e3}
+        del e1
+    fence()
+
+    # 2. the same job with the rows moved by RCCL (the headline when it completes). This library's own communicator has
+    # only ever met one-rank worlds on the development boxes, so the leg runs under a watchdog: if a rank fails to join
+    # or a collective stalls, every rank reports what step 1 measured and leaves instead of hanging the node.
+    if use_rccl:
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("MALIO_RCCL_LEG_TIMEOUT_S", "240"))
+
+        def watchdog():
+            if done.wait(limit):
+                return
+            rccl_note[0] = "the RCCL leg did not complete within %.0f s (variants done: %s); headline from the shm exchange" % (
+                limit, ", ".join("%s+%s" % k for k in results))
+            if rank == 0:
+                emit()
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        ok = 1
+        try:
+            run_variant("tiles", "rccl")
+        except Exception as ex:  # (a rank that throws before its collective leaves the others to the watchdog)
+            ok, rccl_note[0] = 0, "tiles+rccl failed on rank %d: %r" % (rank, ex)
+            results.pop(("tiles", "rccl"), None)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            results.pop(("tiles", "rccl"), None)
+            rccl_note[0] = rccl_note[0] or "tiles+rccl failed on another rank"
+        else:
+            run_variant("scan", "rccl")
+        done.set()
+    # 3. map replicated, scan cut into N shards, over shared memory
+    run_variant("scan", "shm")
+    fence()
+    if rank == 0:
+        emit()
     dist.barrier()
     for x in keep:
         x.close()

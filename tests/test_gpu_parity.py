@@ -562,6 +562,29 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
 
 
 @pytest.mark.gpu
+def test_bench_rccl_leg_failure_still_prints_the_line():
+    """bench.py --gpus N measures the shared-memory exchange first and runs the RCCL leg under a watchdog. Two ranks on
+    ONE GPU make RCCL refuse the communicator (or stall): either way the run must end with exit code 0 and a line whose
+    headline is the shm exchange, carrying the reason."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29637", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "2", "--config", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MALIO_DIST_BACKEND="gloo", MALIO_BENCH_FORCE_RCCL="1",
+               MALIO_RCCL_LEG_TIMEOUT_S="60")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    js = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert js["n_gpus"] == 2 and js["config"]["exchange"] == "shm" and js["value"] > 0
+    assert "rccl_note" in js and "tiles+rccl" not in js["variants"]
+    assert js["roofline"] and js["single_gpu_same_job"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["shm", "collective"])
 def test_two_rank_sharded_pass_equals_single_engine(tmp_path, capi, scenes, exchange):
     """dist.HipBackend.pass_fn with two ranks (gloo, sharing the GPU): plain two-exchange sequence and the
