@@ -211,39 +211,61 @@ __device__ __forceinline__ void mat3T_apply(const double *R, double &x, double &
   const double a = R[0] * x + R[3] * y + R[6] * z, b = R[1] * x + R[4] * y + R[7] * z, c = R[2] * x + R[5] * y + R[8] * z;
   x = a, y = b, z = c;
 }
-__global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
+// sin and cos of an angle in [0, pi/4] without the argument reduction of the library's sincos (three calls per point,
+// ~80 f64 instructions each, were a quarter of k_undistort): the classical minimax kernels on that interval (odd
+// polynomial of degree 13 / even of degree 14, the coefficient set of fdlibm's k_sin.c / k_cos.c; error below one ulp
+// as written, without fused multiply-adds). Larger angles - a spline whose knots are more than 45 degrees apart - take the
+// library call.
+__device__ __forceinline__ void sincos_small(double x, double *sn, double *cs) {
+  const double z = x * x;
+  {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    *sn = x + v * (S1 + z * r);
+  }
+  {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    // 1 - (z/2 - z r), with a quarter of x moved out of the subtraction above 0.3 so that it stays exact (k_cos.c)
+    const double qx = x < 0.3 ? 0.0 : (x > 0.78125 ? 0.28125 : __hiloint2double(__double2hiint(x) - 0x00200000, 0));
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    *cs = a - (hz - z * r);
+  }
+}
+#ifndef UND_BLK
+#define UND_BLK 64
+#endif
+__global__ void __launch_bounds__(UND_BLK) k_undistort(UndArgs a) {
   // the two search tables in LDS (the binary searches are chains of dependent reads); the pose and twist rows of the
   // interval found are read once per point from global memory - neighbouring points share them, they stay in L1
+  // (all tables in LDS: every workgroup then copies 13 doubles per knot first - slower from ~30 knots on)
   __shared__ double s_kt[UND_KMAX], s_it[UND_KMAX];
-  for (int e = threadIdx.x; e < a.K; e += BLK) s_kt[e] = a.knot_t[e];
-  for (int e = threadIdx.x; e < a.n_imu; e += BLK) s_it[e] = a.imu_t[e];
+  for (int e = threadIdx.x; e < a.K; e += UND_BLK) s_kt[e] = a.knot_t[e];
+  for (int e = threadIdx.x; e < a.n_imu; e += UND_BLK) s_it[e] = a.imu_t[e];
   __syncthreads();
-  const int i = blockIdx.x * BLK + threadIdx.x;
+  const int i = blockIdx.x * UND_BLK + threadIdx.x;
   if (i >= a.n) return;
   const float *pin = a.in12 + (size_t)i * 12;
   const float4 p = make_float4(pin[0], pin[1], pin[2], pin[9]);
   const double point_t = (double)p.w / 1000.0 + a.lidar_beg_time;  // :482
-  {  // D_i: stamps imu_t[k], k <= cov_pointer0, that are > point_t (imu_t ascending)
-    int lo = 0, hi = a.cov_pointer0 + 1;
-    if (hi > a.n_imu) hi = a.n_imu;
-    const int top = hi;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s_it[mid] > point_t)
-        hi = mid;
-      else
-        lo = mid + 1;
-    }
-    a.D[i] = top - lo;
+  // Two upper bounds (both tables ascending): D_i counts the stamps imu_t[k], k <= cov_pointer0, that are > point_t;
+  // i1 = (number of knots <= point_t) - 1, and the spline needs i1 - 1 and i1 + 2 (BsplineSE3.cpp:173-230). The two
+  // binary searches advance in lock-step, branch-free, so that their dependent LDS reads overlap (7 halvings: <= 127).
+  const int top = min(a.cov_pointer0 + 1, a.n_imu);
+  int lo1 = 0, n1 = top, lo = 0, n2 = a.K;
+#pragma unroll
+  for (int it = 0; it < 7; it++) {
+    const int h1 = n1 >> 1, h2 = n2 >> 1;
+    const double v1 = s_it[min(lo1 + h1, UND_KMAX - 1)], v2 = s_kt[min(lo + h2, UND_KMAX - 1)];
+    const bool g1 = n1 > 0 && v1 <= point_t, g2 = n2 > 0 && v2 <= point_t;
+    lo1 = g1 ? lo1 + h1 + 1 : lo1, n1 = g1 ? n1 - h1 - 1 : h1;
+    lo = g2 ? lo + h2 + 1 : lo, n2 = g2 ? n2 - h2 - 1 : h2;
   }
-  int lo = 0, hi = a.K;  // i1 = (number of knots <= t) - 1; needs i1 - 1 and i1 + 2 (BsplineSE3.cpp:173-230)
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (s_kt[mid] <= point_t)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
+  a.D[i] = top - lo1;
   const int i1 = lo - 1;
   if (i1 < 1 || i1 + 2 >= a.K || i == 0) {  // i == 0: the reference's loop stops before begin() (:475-476)
     a.out[i] = make_float4(p.x, p.y, p.z, 0.f);
@@ -269,7 +291,10 @@ __global__ void __launch_bounds__(BLK) k_undistort(UndArgs a) {
       pa = th, pb = 0.5 * th * th, qa = 0.5 * th, qb = th * th * (1.0 / 6.0);
     } else {
       double sn, cs;
-      sincos(th, &sn, &cs);
+      if (th <= 0.785398163397448279)
+        sincos_small(th, &sn, &cs);
+      else
+        sincos(th, &sn, &cs);
       const double r = 1.0 / th;
       pa = sn, pb = 1 - cs, qa = pb * r, qb = (th - sn) * r;
     }
@@ -404,7 +429,7 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   const int nb = (n + BLK - 1) / BLK;
   prof_begin(c);
   if (n_knots <= UND_KMAX && n_imu <= UND_KMAX)
-    hipLaunchKernelGGL(k_undistort, dim3(nb), dim3(BLK), 0, c->stream, a);
+    hipLaunchKernelGGL(k_undistort, dim3((n + UND_BLK - 1) / UND_BLK), dim3(UND_BLK), 0, c->stream, a);
   else
     hipLaunchKernelGGL(k_undistort_big, dim3(nb), dim3(BLK), 0, c->stream, a);
   prof_mark(c, "k_undistort");
