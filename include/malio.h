@@ -245,10 +245,11 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
                           double *solve_time);
 
 /* How malio_update_iterated drives its loop (same arithmetic in all three).
- * MALIO_UPDATE_GATED (default): every pass of the loop is enqueued ahead of the GPU; between two passes a one-workgroup
- *   gate kernel announces the finished pass' sums (stored by the kernels in pinned memory) through a sequence word, polls
- *   a second word until the calling thread has published the next pass' control block - state, search / reuse, or stop -
- *   and copies it to where the pass kernels read it. The n x n algebra of esekfom.hpp:521-720 stays on the calling thread
+ * MALIO_UPDATE_GATED (default): every pass of the loop is enqueued ahead of the GPU; between two passes a gate - the last
+ *   workgroup of the pass' last kernel - announces the finished pass' sums (stored by the kernels in pinned memory) through
+ *   a sequence word, polls a second word until the calling thread has published the next pass' control block - state,
+ *   search / reuse, or stop; written straight into device memory when the BAR allows it - and copies it to where the pass
+ *   kernels read it. The n x n algebra of esekfom.hpp:521-720 stays on the calling thread
  *   (half of it runs while the GPU is busy with the pass); what disappears is the synchronise / launch round trip per pass.
  * MALIO_UPDATE_HOST: one pass at a time - launch, synchronise, algebra, launch (what a pass hook, per-pass profiling,
  *   the node-sharded update and the M < n rows path use). Bit-identical to GATED.

@@ -13,6 +13,7 @@
 // esekfom.hpp line numbers as in host/ieskf.cpp.
 #include <chrono>
 #include "malio_internal.hpp"
+#include <immintrin.h>
 #include "../host/manifold.hpp"
 
 namespace malio {
@@ -484,7 +485,8 @@ void free_dev_loop(Ctx *c) {
   if (c->h_loop_out) (void)hipHostFree(c->h_loop_out);
   if (c->h_gate) (void)hipHostFree(c->h_gate);
   if (c->d_gate_ticket) (void)hipFree(c->d_gate_ticket);
-  c->d_gate_ticket = nullptr;
+  if (c->d_cmd) (void)hipFree(c->d_cmd);
+  c->d_gate_ticket = nullptr, c->d_cmd = nullptr;
   c->h_gate = c->d_gate = nullptr;
   c->d_loopbuf = nullptr, c->d_loop = nullptr, c->h_loop_in = nullptr, c->h_loop_out = nullptr, c->d_loop_out = nullptr;
 }
@@ -562,16 +564,16 @@ namespace malio {
 // ---- gated loop: the chain of passes enqueued up front, the n x n algebra on the calling thread --------------------------
 // MALIO_UPDATE_GATED. The host-driven loop pays, per pass, a stream synchronisation, the host algebra and the launch of
 // the next pass' kernels before the GPU has anything to do again (~12 us of round trip around ~18 us of algebra). Here
-// every pass of the loop is already in the queue; between two passes sits k_gate, one workgroup that (1) tells the host -
-// a sequence word in pinned memory - that the previous pass' sums are complete (they are stored by the kernels straight
-// into pinned memory), (2) polls a second word until the host has published the control block of the next pass (state in
-// the forms the kernels read, converge flag, parities, or `done`), and (3) copies that block into the DevLoop the pass
-// kernels read. GPU -> host and host -> GPU each cost one PCIe latency instead of a completion signal plus a doorbell
-// plus dispatch. A gate gives up after GATE_TIMEOUT_US (the host died or returned): the chain then drains as on `done`.
-__global__ void __launch_bounds__(256) k_gate(GateArgs g) {  // the gate before the first pass (nothing to ride on)
-  if (!g.first && g.dl->done) return;
-  gate_body(g);
-}
+// every pass of the loop is already in the queue; between two passes sits a gate - the last workgroup of the pass' last
+// kernel (k_final_reduce, a ticket counter) - that (1) tells the host, through a sequence word in pinned memory, that the
+// pass' sums are complete (they are stored by the kernels straight into pinned memory), (2) polls a second word until the
+// host has published the control block of the next pass (state in the forms the kernels read, converge flag, parities,
+// or `done`), and (3) copies that block into the DevLoop the pass kernels read. GPU -> host costs one PCIe latency
+// instead of a completion signal; host -> GPU is a posted write: under a large BAR the block and its word live in
+// (fine-grained) device memory, which the host stores into directly and the gate polls locally (-2 us per pass against
+// polling pinned memory across PCIe). The first pass needs no gate: the state it starts from is known when the update
+// is called, so it is launched the way the host-driven loop launches a pass (arguments by value), with gate 1 riding on
+// it. A gate gives up after GATE_TIMEOUT_US (the host died or returned): the chain then drains as on `done`.
 
 int ensure_gate_buffers(Ctx *c) {
   const size_t hdr = loop_block_doubles();
@@ -583,6 +585,20 @@ int ensure_gate_buffers(Ctx *c) {
     MALIO_HIP(hipHostMalloc((void **)&c->h_gate, sizeof(double) * hdr + 256, hipHostMallocMapped | hipHostMallocCoherent));
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_gate, c->h_gate, 0));
     memset(c->h_gate, 0, sizeof(double) * hdr + 256);
+    // host -> GPU direction in device memory when the CPU can store there (MALIO_GATE_PINNED=1 keeps it in pinned memory)
+    int large_bar = 0;
+    const char *env = getenv("MALIO_GATE_PINNED");
+    if (!(env && env[0] == '1') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess &&
+        large_bar) {
+      if (hipExtMallocWithFlags((void **)&c->d_cmd, sizeof(double) * hdr + 256, hipDeviceMallocFinegrained) == hipSuccess) {
+        MALIO_HIP(hipMemset(c->d_cmd, 0, sizeof(double) * hdr + 256));
+        MALIO_HIP(hipDeviceSynchronize());
+      } else {
+        (void)hipGetLastError();
+        c->d_cmd = nullptr;
+      }
+    }
+    c->gate_stage.assign(hdr, 0.0);
   }
   return MALIO_OK;
 }
@@ -607,9 +623,10 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_loop_out, c->h_loop_out, 0));
   }
   if (int rcg = ensure_gate_buffers(c)) return rcg;
-  // pinned layout: [DevLoop block | cmd_seq (int) ... msg_seq (int at +128)]
-  DevLoop *blk = reinterpret_cast<DevLoop *>(c->h_gate);
-  volatile int *cmd_seq = reinterpret_cast<volatile int *>(c->h_gate + sizeof(double) * hdr);
+  // layout (pinned, and device memory under a large BAR): [DevLoop block | cmd_seq (int) ... msg_seq (int at +128, pinned only)]
+  DevLoop *blk = reinterpret_cast<DevLoop *>(c->gate_stage.data());
+  char *cmd_home = c->d_cmd ? c->d_cmd : c->h_gate;  // where the gate reads the block and its sequence word
+  volatile int *cmd_seq = reinterpret_cast<volatile int *>(cmd_home + sizeof(double) * hdr);
   volatile int *msg_seq = reinterpret_cast<volatile int *>(c->h_gate + sizeof(double) * hdr + 128);
   const int base = c->gate_epoch;
   c->gate_epoch += maximum_iter + 4;
@@ -618,7 +635,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
 
   malio_state_t x_ = *xio;
   const malio_state_t x_prop = x_;
-  std::vector<double> P_prop(Pio, Pio + (size_t)n * n);
+  std::vector<double> P_prop;  // (copied once pass 0 is on its way)
   int converge = 1, t = 0, passes = 0, searches = 0, lastM = 0;
   bool done = false;
   double solve = 0;
@@ -636,26 +653,36 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       fill_quat_const(c, &x_, blk->qc);
       fill_pass_const(c, &x_, blk->pc);
     }
+    // the block in one piece, then - behind a store fence: the BAR mapping is write-combining - its sequence word
+    // (only what the pass kernels read: the control words and the two forms of the state - x, x_prop and the rest of the
+    // block belong to the device-resident loop)
+    memcpy(cmd_home, blk, offsetof(DevLoop, tcq));
+    memcpy(cmd_home + offsetof(DevLoop, qc), reinterpret_cast<const char *>(blk) + offsetof(DevLoop, qc),
+           offsetof(DevLoop, loc_thresh_min) - offsetof(DevLoop, qc));
+    _mm_sfence();
     __atomic_store_n(const_cast<int *>(cmd_seq), base + p + 1, __ATOMIC_RELEASE);
+    _mm_sfence();
   };
-  publish(0, false);  // before the chain exists: gate 0 finds it at once
-  // ---- the chain: gate 0, then units of [pass p | gate p + 1] (the gate is the last workgroup of the pass' last kernel), enqueued one pass ahead of the GPU (the launches of unit
-  // p + 1 and the first half of iteration p's algebra run on this thread while the GPU is busy with pass p; a loop that
-  // ends early leaves at most one unit of kernels behind, which exit at once) ----
+  // ---- the chain: pass 0 with its arguments by value, then units of [pass p | gate p + 1] (the gate is the last workgroup
+  // of the pass' last kernel) enqueued one pass ahead of the GPU: the launches of unit p + 1 and the first half of
+  // iteration p's algebra run on this thread while the GPU is busy with pass p; a loop that ends early leaves at most
+  // one unit of kernels behind, which exit at once ----
   GateArgs g;
-  g.dl = c->d_loop, g.cmd = reinterpret_cast<const double *>(c->d_gate);
-  g.cmd_seq = reinterpret_cast<const int *>(c->d_gate + sizeof(double) * hdr);
+  const char *cmd_dev = c->d_cmd ? c->d_cmd : c->d_gate;
+  g.dl = c->d_loop, g.cmd = reinterpret_cast<const double *>(cmd_dev);
+  g.cmd_seq = reinterpret_cast<const int *>(cmd_dev + sizeof(double) * hdr);
   g.msg_seq = reinterpret_cast<int *>(c->d_gate + sizeof(double) * hdr + 128);
   g.ndoubles = (int)hdr;
   g.ticket = c->d_gate_ticket;
-  auto set_gate = [&](int p) { g.first = p == 0, g.publish = p == 0 ? 0 : base + p, g.wait_for = base + p + 1; };
-  auto enqueue_unit = [&](int p) -> int {  // pass p; gate p + 1 is the last workgroup of its last kernel
+  auto set_gate = [&](int p) { g.publish = base + p, g.wait_for = base + p + 1; };
+  auto enqueue_unit = [&](int p) -> int {  // pass p >= 1; gate p + 1 is the last workgroup of its last kernel
     set_gate(p + 1);
     return enqueue_pass_dev(c, c->d_res, c->d_res + ns_, &g);
   };
-  set_gate(0);
-  hipLaunchKernelGGL(k_gate, dim3(1), dim3(256), 0, c->stream, g);
-  if (int rc = enqueue_unit(0)) return rc;
+  set_gate(1);
+  if (int rc = pass_stage1(c, &x_, 1, nullptr)) return rc;
+  if (int rc = pass_stage2(c, nullptr, c->d_res + ns_, c->d_res, false, &g)) return rc;
+  P_prop.assign(Pio, Pio + (size_t)n * n);
   // ---- the loop (esekfom.hpp:509) ----
   int rc_out = MALIO_OK;
   malio_measure_out_t mo;

@@ -209,11 +209,11 @@ struct alignas(16) UncEntry {
 // the control block of the next one, copy it into the DevLoop the pass kernels read.
 struct GateArgs {
   DevLoop *dl;
-  const double *cmd;   // pinned: the host's control block, DevLoop layout (rounded up to 256 B) ...
+  const double *cmd;   // pinned, or device memory the host stores into: the control block, DevLoop layout (rounded up to 256 B) ...
   const int *cmd_seq;  // ... and the word the host stores LAST (release)
   int *msg_seq;        // pinned: sequence word the GPU publishes
   u32 *ticket;         // device counter of the kernel the gate rides on (k_final_reduce: its last workgroup is the gate)
-  int publish, wait_for, first, ndoubles;
+  int publish, wait_for, ndoubles;
 };
 #if defined(__HIP__)
 constexpr long long GATE_TIMEOUT_US = 200000;
@@ -403,6 +403,10 @@ struct Ctx {
   char *d_loop_out = nullptr;    // ... its device alias
   u32 *d_gate_ticket = nullptr;  // (word 3 of d_dq_ctl's allocation is not used: own word, zeroed once)
   char *h_gate = nullptr, *d_gate = nullptr;  // pinned + device alias: control block and sequence words of the gated loop
+  // Large BAR: the host stores the control block and its sequence word straight into (fine-grained) device memory, so the
+  // gate polls and copies local memory instead of reading pinned host memory across PCIe (null: no large BAR, pinned path)
+  char *d_cmd = nullptr;
+  std::vector<double> gate_stage;  // the block as the host composes it, before it goes out in one piece
   int gate_epoch = 1;
   double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
   int gate_trace_n = 0;

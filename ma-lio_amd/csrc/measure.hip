@@ -758,13 +758,14 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   const bool cwave = (int)(threadIdx.x >> 6) == cw;
   // ---- phase A ----
   const int i = qidx(lane_);  // meaningful for the control wave only
-  if (DEV && !a.dl->converge) {  // REUSE pass: wave 0, lane = point
-    if (threadIdx.x >= SQ) return;
+  if (DEV && !a.dl->converge) {  // REUSE pass: thread = point, so the first quarter of the grid does all of it
+    const int base = (int)(blockIdx.x * KS_BLK);
+    if (base >= a.N) return;
     bool selected;
     double ucov, tr;
-    reuse_point(a, qc, dy.commit_prev, (int)(blockIdx.x * SQ + threadIdx.x), selected, ucov, tr);
+    reuse_point(a, qc, dy.commit_prev, base + (int)threadIdx.x, selected, ucov, tr);
     wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);
-    if (blockIdx.x == 0) mm_reset_slot(dy.mm_next, threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
     return;
   }
   bool mine = cwave && i < a.N;
