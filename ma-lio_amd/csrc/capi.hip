@@ -157,6 +157,7 @@ int malio_destroy(malio_handle_t h) {
   for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt);
+  if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
   fr(c->d_sums), fr(c->d_rows);
@@ -433,7 +434,10 @@ namespace malio {
 // 20-byte upload record; what the host loop of malio_scan_set does while it packs - counting the points of each LiDAR
 // slot, validating the slot, noticing whether the slots come in ascending blocks - is left in info[] for the first pass:
 // info[l] = points of slot l, info[8] = points with a slot outside [0, L), info[9] = descents of the slot sequence.
-__global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw12, int n, int L, UploadRec *upload, u32 *info) {
+// The block that finishes last (ticket in info[12]) publishes info[0..9] and the scan's sequence number to pinned memory:
+// the first pass picks the counts up from there without a copy or a stream synchronisation (resolve_scan_segments).
+__global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw12, int n, int L, UploadRec *upload, u32 *info,
+                                                  u32 *pub, u32 seq) {
   __shared__ u32 s_cnt[10];
   if (threadIdx.x < 10) s_cnt[threadIdx.x] = 0;
   __syncthreads();
@@ -460,6 +464,16 @@ __global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw1
   }
   __syncthreads();
   if (threadIdx.x < 10 && s_cnt[threadIdx.x]) atomicAdd(&info[threadIdx.x], s_cnt[threadIdx.x]);
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&info[12], 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 10) pub[threadIdx.x] = __hip_atomic_load(&info[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&pub[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace malio
 
@@ -494,7 +508,14 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
       if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
       MALIO_HIP(hipMemcpyAsync(c->d_raw, body, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
       MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
-      hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_raw, n, L, c->d_upload, c->d_packinfo);
+      if (!c->h_packinfo) {
+        MALIO_HIP(hipHostMalloc((void **)&c->h_packinfo, sizeof(u32) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+        MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_packinfo_pub, c->h_packinfo, 0));
+        memset(c->h_packinfo, 0, sizeof(u32) * 16);
+      }
+      if (++c->pack_seq == 0) c->pack_seq = 1;
+      hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_raw, n, L, c->d_upload, c->d_packinfo,
+                         c->d_packinfo_pub, c->pack_seq);
       MALIO_HIP(hipGetLastError());
       c->seg_pending = true;
       c->scan_keep_order = false;  // decided when the counts arrive

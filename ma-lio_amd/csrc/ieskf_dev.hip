@@ -494,6 +494,7 @@ void free_dev_loop(Ctx *c) {
 int ieskf_update_device(Ctx *c, malio_state_t *xio, double *Pio, int *stats) {
   const int L = c->prm.lid_num, n = 17 + 6 * L, C = 6 * (L + 1), maximum_iter = c->prm.max_iteration;
   if (int rc = prepare_scan_dev(c, xio)) return rc;
+  if (int rc = resolve_scan_segments(c)) return rc;  // the chain's stage-2 kernels are launched per LiDAR segment
   const size_t hdr = loop_block_doubles(), nn = (size_t)DEV_NMAX * DEV_NMAX;
   if (!c->d_loopbuf) {
     MALIO_HIP(hipMalloc(&c->d_loopbuf, sizeof(double) * (hdr + 2 * nn)));

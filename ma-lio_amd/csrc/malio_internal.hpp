@@ -359,6 +359,8 @@ struct Ctx {
   float *d_raw = nullptr;         // [N][12] the caller's page-locked cloud as copied (malio_scan_set, pinned path)
   size_t cap_raw = 0;
   u32 *d_packinfo = nullptr;      // k_pack_raw: per-slot counts, bad slots, descents
+  u32 *h_packinfo = nullptr, *d_packinfo_pub = nullptr;  // pinned copy (+ sequence word [15]) the last block of k_pack_raw stores
+  u32 pack_seq = 0;
   u32 *d_sort_cnt = nullptr;      // scan grouping: bucket counts + offsets (measure.hip sort_scan)
   bool seg_pending = false;       // seg_start[] not known yet: the counts are still on the device
   float4 *d_scan = nullptr;     // [N] sorted

@@ -1669,13 +1669,27 @@ void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
   }
 }
 
-// A scan packed on the device (malio_scan_set with a page-locked cloud): its per-slot counts arrive here, once, before the
-// first pass sorts it. By now the pack kernel finished long ago; the read-back is one small blocking copy.
+// A scan packed on the device (malio_scan_set with a page-locked cloud): its per-slot counts arrive here, once, with the
+// first pass - AFTER that pass has queued the grouping and its search kernel, which need none of them: the pack kernel's
+// last block left the counts and the scan's sequence number in pinned memory, so this neither copies nor waits for the
+// stream (a blocking read-back here used to keep the GPU idle for ~40 us between the upload and the grouping).
 int resolve_scan_segments(Ctx *c) {
   if (!c->seg_pending) return MALIO_OK;
+  volatile u32 *pub = c->h_packinfo;
+  unsigned long long spins = 0;
+  while (__atomic_load_n(const_cast<u32 *>(&pub[15]), __ATOMIC_ACQUIRE) != c->pack_seq) {
+    if ((++spins & 0x3FFF) == 0) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipErrorNotReady && __atomic_load_n(const_cast<u32 *>(&pub[15]), __ATOMIC_ACQUIRE) != c->pack_seq) {
+        MALIO_HIP(q);  // the stream failed; if it merely drained without the word, something is badly wrong
+        c->err = "malio_scan_set: the pack kernel ended without publishing its counts";
+        return MALIO_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+  }
   u32 info[16];
-  MALIO_HIP(hipMemcpyAsync(info, c->d_packinfo, sizeof(info), hipMemcpyDeviceToHost, c->stream));
-  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 10; k++) info[k] = pub[k];
   c->seg_pending = false;
   const int L = c->prm.lid_num;
   if (info[8]) {  // int(intensity) outside [0, lid_num): what malio_scan_set rejects on the spot for a pageable cloud
@@ -1772,7 +1786,9 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
   if (!c->scan_sorted) {
-    if (int rc = resolve_scan_segments(c)) return rc;
+    // (the grouping needs the counts only to decide whether the caller's order can be kept)
+    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
+      if (int rc = resolve_scan_segments(c)) return rc;
     int rc = sort_scan(c, a.qc);
     if (rc != MALIO_OK) return rc;
   }
@@ -1807,7 +1823,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   }
   MALIO_HIP(hipGetLastError());
   fill_pass_const(c, s, c->pc);  // matrix form of the same state for stage 2
-  return MALIO_OK;
+  return resolve_scan_segments(c);  // stage 2 is launched per LiDAR segment
 }
 
 static int fill_pass2_static(Ctx *c, Pass2Args &a) {
@@ -1858,12 +1874,13 @@ int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   if (int rc = map_sync_search(c)) return rc;
   if (!c->scan_sorted) {
-    if (int rc = resolve_scan_segments(c)) return rc;
+    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
+      if (int rc = resolve_scan_segments(c)) return rc;
     QuatConst qc;
     fill_quat_const(c, s, qc);
     if (int rc = sort_scan(c, qc)) return rc;
   }
-  return MALIO_OK;
+  return MALIO_OK;  // (the segments are resolved by whoever launches a stage 2: pass_stage1, or the device loop)
 }
 
 // One pass of the device loop: the same kernels, every pass-dependent input read from c->d_loop. Nothing here depends
