@@ -15,6 +15,6 @@ python tools/probe_devloop.py 2 5 2>/dev/null | grep -vE "Rebuild|Multi" >> $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/loop -o loop -- python $ROOT/tools/time_mapinc.py > $OUT/loop_stdout.txt 2>&1
 ( echo "# one turn of the mapping loop (scan_set -> update_iterated -> map_incremental), config 2"
-  echo "# rocprofv3 --kernel-trace --memory-copy-trace -- python tools/time_mapinc.py ; python tools/loop_timeline.py <kernel csv> <copy csv> 6"
-  python $ROOT/tools/loop_timeline.py $OUT/loop/loop_kernel_trace.csv $OUT/loop/loop_memory_copy_trace.csv 6 ) > $OUT/${TAG}_loop_timeline.txt 2>&1
+  echo "# rocprofv3 --kernel-trace --memory-copy-trace -- python tools/time_mapinc.py ; python tools/loop_timeline.py <kernel csv> <copy csv> 7"
+  python $ROOT/tools/loop_timeline.py $OUT/loop/loop_kernel_trace.csv $OUT/loop/loop_memory_copy_trace.csv 7 ) > $OUT/${TAG}_loop_timeline.txt 2>&1
 cat $OUT/${TAG}_gputest.txt; tail -3 $OUT/${TAG}_loop_timeline.txt
