@@ -108,7 +108,9 @@ def test_pass_and_update_parity(capi, orc, scenes, kw):
 @pytest.mark.parametrize("kw", [CASES[0], CASES[1], CASES[3], CASES[4], CASES[8], CASES[9]], ids=lambda k: "s%d" % k["seed"])
 def test_update_modes_agree(capi, scenes, kw):
     """The three ways malio_update_iterated can drive its loop (include/malio.h):
-      gated  (default) - every pass enqueued ahead, k_gate between passes, the n x n algebra on the calling thread;
+      gated  (default) - every pass enqueued ahead, a gate (last workgroup of the pass' last kernel) between passes, the
+                         n x n algebra on the calling thread; the host -> GPU control block either stored through the BAR
+                         into device memory (large-BAR boxes) or read by the gate from pinned memory (MALIO_GATE_PINNED=1);
       host             - one pass at a time: launch, synchronise, algebra, launch;
       device           - the algebra in a one-workgroup kernel, the whole update one chain the host waits for once.
     gated and host run the same host code on the same sums: bit-identical. The device loop follows the same operation
@@ -117,22 +119,30 @@ def test_update_modes_agree(capi, scenes, kw):
     kw = dict(kw)
     kw.pop("yardstick", None)
     sc = scenes.make_scene(**kw)
+    import os
     res = {}
-    for mode in ("gated", "host", "device"):
-        eng = capi.Engine(sc["params"], device=0)
-        eng.set_update_mode(mode)
-        eng.map_build(sc["map"])
-        out = []
-        for rep in range(2):   # a second scan on the same handle: parities, normal_y fold and defer switch carried over
-            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-            u = eng.update_iterated(sc["state0"], sc["P0"])
-            out.append((u, eng.scan_get()))
-        res[mode] = out
+    for mode in ("gated", "gated_pinned", "host", "device"):
+        if mode == "gated_pinned":
+            os.environ["MALIO_GATE_PINNED"] = "1"  # read when the handle allocates its gate buffers (first update)
+        try:
+            eng = capi.Engine(sc["params"], device=0)
+            eng.set_update_mode(mode.split("_")[0])
+            eng.map_build(sc["map"])
+            out = []
+            for rep in range(2):   # a second scan on the same handle: parities, normal_y fold and defer switch carried over
+                eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+                u = eng.update_iterated(sc["state0"], sc["P0"])
+                out.append((u, eng.scan_get()))
+            res[mode] = out
+        finally:
+            os.environ.pop("MALIO_GATE_PINNED", None)
+    for gated in ("gated", "gated_pinned"):
+        for (u, gs), (v, hs) in zip(res[gated], res["host"]):
+            assert (u["passes"], u["searches"], u["M"], u["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
+            assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"])
+            for k in ("selected", "res_last", "normal_y", "nearest", "world", "normvec"):
+                assert np.array_equal(gs[k], hs[k]), k
     for (u, gs), (v, hs), (w, ds) in zip(res["gated"], res["host"], res["device"]):
-        assert (u["passes"], u["searches"], u["M"], u["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
-        assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"])
-        for k in ("selected", "res_last", "normal_y", "nearest", "world", "normvec"):
-            assert np.array_equal(gs[k], hs[k]), k
         assert (w["passes"], w["searches"], w["M"], w["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
         assert np.abs(w["state"] - v["state"]).max() < 1e-8
         assert_P_close(w["P"], v["P"])
