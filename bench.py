@@ -202,17 +202,21 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
         out["predict_chain"] = {"error": str(e)}
     # one whole turn of the mapping loop on the bench workload, as the integration calls it (laserMapping.cpp:985-1060):
     # scan upload + tables, iterated update (includes the once-per-scan spatial sort), map_incremental at the posterior
-    wny = np.full(sc["N"], 0.001, np.float32)
+    # (world_normal_y = NULL: feats_down_world is a freshly resized cloud on the caller's side, its normal_y zeros - the
+    # common case of include/malio.h; map_incremental_with_wny_ms passes an explicit [N] array through the staging buffer)
     upd, upd_result = eng.update_iterated_fn(sc["state0"], sc["P0"])
+    minc, minc_counts = eng.map_incremental_fn(None, True)
+    minc_w, _ = eng.map_incremental_fn(np.full(sc["N"], 0.001, np.float32), True)
     loop = {"scan_set_ms": [], "update_ms": [], "map_incremental_ms": []}
+    with_wny = []
     added = 0
     # the caller's cloud in page-locked memory (malio_host_alloc: INTEGRATION.md): scan_set is then one DMA copy and a
     # pack kernel this thread does not wait for; scan_set_pageable_ms is the same call on an ordinary (cold) buffer
     pin = capi.PinnedArray(sc["scan"].shape, np.float32)
     pageable = []
-    for k in range(6):
+    for k in range(7):
         s2 = scenes.make_scene(cfg=cfg_index, scan_seed=500 + k)  # a new scan of the same scene every turn
-        if k >= 4:
+        if k >= 5:
             call = eng.scan_set_fn(s2["scan"], sc["tables"], sc["temporal_comp"])  # (arguments marshalled beforehand)
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -228,17 +232,21 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
         t1 = time.perf_counter()
         assert upd() == 0
         t2 = time.perf_counter()
-        u = upd_result()
-        na, nn, _ = eng.map_incremental(u["state"], True, wny)
+        st = capi.state_from_flat(upd_result()["state"], sc["L"])  # (Python-side marshalling, outside the timed calls)
         t3 = time.perf_counter()
-        if k:  # the first turn pays one-time allocations
+        (minc_w if k == 4 else minc)(st)
+        t4 = time.perf_counter()
+        if k == 4:
+            with_wny.append((t4 - t3) * 1e3)
+        elif k:  # the first turn pays one-time allocations
             loop["scan_set_ms"].append((t1 - t) * 1e3), loop["update_ms"].append((t2 - t1) * 1e3)
-            loop["map_incremental_ms"].append((t3 - t2) * 1e3)
-        added = int(na + nn)
+            loop["map_incremental_ms"].append((t4 - t3) * 1e3)
+        added = int(minc_counts[0] + minc_counts[1])
     dbg = eng.debug_counters()
     out["scan_loop"] = {k: float(np.median(v)) for k, v in loop.items()}
     out["scan_loop"]["total_ms"] = float(sum(out["scan_loop"].values()))
     out["scan_loop"]["scan_set_pageable_ms"] = float(np.median(pageable))
+    out["scan_loop"]["map_incremental_with_wny_ms"] = float(np.median(with_wny)) if with_wny else None
     out["scan_loop"].update(map_points=eng.map_size(), added_per_scan=added,
                             lists_updated_in_place=bool(dbg["inplace"] > 0 and dbg["rebuilds"] <= 1))
     return out

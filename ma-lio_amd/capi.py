@@ -264,6 +264,20 @@ class Engine:
                                               cnt), "malio_map_incremental")
         return cnt[0], cnt[1], cnt[2]
 
+    def map_incremental_fn(self, world_normal_y=None, flg_EKF_inited=True):
+        """malio_map_incremental with its ctypes arguments built beforehand: returns (call, counts) where call(state_struct)
+        is the bare C call (bench.py times the call, not Python's marshalling) and counts the int[3] it fills."""
+        cnt = (C.c_int * 3)()
+        wny = None if world_normal_y is None else np.ascontiguousarray(world_normal_y, np.float32)
+        wp = _p(wny, C.c_float)
+        fn = lib().malio_map_incremental
+        flg = int(bool(flg_EKF_inited))
+
+        def call(state_struct):
+            self._keep_wny = wny
+            return self._chk(fn(self.h, C.byref(state_struct), flg, wp, cnt), "malio_map_incremental")
+        return call, cnt
+
     def map_get(self):
         """ikdtree.flatten: [n, 12] valid map points (x, y, z, normal_y populated)."""
         n = self.map_size()

@@ -442,32 +442,44 @@ __global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw1
   if (threadIdx.x < 10) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int i = blockIdx.x * BLK + threadIdx.x;
+  int lid = -1;  // -1: no point; MALIO_MAX_LIDAR: a slot outside [0, L)
+  bool descent = false;
   if (i < n) {
     const float *p = raw12 + (size_t)i * 12;
     const float4 a = *reinterpret_cast<const float4 *>(p);      // x y z _
     const float2 b = *reinterpret_cast<const float2 *>(p + 4);  // normal_x normal_y
-    const int lid = (int)p[8];                                  // laserMapping.cpp:570
+    lid = (int)p[8];                                            // laserMapping.cpp:570
     int idx = (int)b.x;                                         // int(laser_p.normal_x), laserMapping.cpp:694,737
     if (idx > 0x3FFFFF) idx = 0x3FFFFF;
     if (idx < -0x3FFFFF) idx = -0x3FFFFF;
+    descent = i > 0 && (int)p[8 - 12] > lid;
     const bool bad = lid < 0 || lid >= L;
     UploadRec r;
     r.x = a.x, r.y = a.y, r.z = a.z;
     r.w = ((unsigned)idx << 8) | (unsigned)(bad ? 0 : lid);
     r.ny = b.y;
     upload[i] = r;
-    if (bad)
-      atomicAdd(&s_cnt[8], 1u);
-    else
-      atomicAdd(&s_cnt[lid], 1u);
-    if (i > 0 && (int)p[8 - 12] > lid) atomicAdd(&s_cnt[9], 1u);
+    if (bad) lid = MALIO_MAX_LIDAR;
+  }
+  // counted per wave (a wave's points nearly always share one slot: 64 same-address LDS atomics otherwise)
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) {
+    const unsigned long long m = __ballot(lid == l);
+    if (m && lane == 0) atomicAdd(&s_cnt[l == MALIO_MAX_LIDAR ? 8 : l], (u32)__popcll(m));
+  }
+  {
+    const unsigned long long m = __ballot(descent);
+    if (m && lane == 0) atomicAdd(&s_cnt[9], (u32)__popcll(m));
   }
   __syncthreads();
   if (threadIdx.x < 10 && s_cnt[threadIdx.x]) atomicAdd(&info[threadIdx.x], s_cnt[threadIdx.x]);
   __shared__ int s_last;
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&info[12], 1u) == gridDim.x - 1;
+  if (threadIdx.x == 0) {
+    __threadfence();  // this block's counts before its ticket
+    s_last = atomicAdd(&info[12], 1u) == gridDim.x - 1;
+  }
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x < 10) pub[threadIdx.x] = __hip_atomic_load(&info[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

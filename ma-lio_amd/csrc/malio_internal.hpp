@@ -360,7 +360,7 @@ struct Ctx {
   size_t cap_raw = 0;
   u32 *d_packinfo = nullptr;      // k_pack_raw: per-slot counts, bad slots, descents
   u32 *h_packinfo = nullptr, *d_packinfo_pub = nullptr;  // pinned copy (+ sequence word [15]) the last block of k_pack_raw stores
-  u32 pack_seq = 0;
+  u32 pack_seq = 0, apply_seq = 0;
   u32 *d_sort_cnt = nullptr;      // scan grouping: bucket counts + offsets (measure.hip sort_scan)
   bool seg_pending = false;       // seg_start[] not known yet: the counts are still on the device
   float4 *d_scan = nullptr;     // [N] sorted
@@ -515,6 +515,7 @@ inline hipError_t mbox(Ctx *c, u32 **out, u32 **dev = nullptr) {
   if (dev) *dev = c->d_mbox;
   return hipSuccess;
 }
+constexpr int MBOX_APPLY_SEQ = 14;  // sequence word of k_publish_states (map_apply_finish waits for it, not for the stream)
 
 // k_search_tail costs ~17 us even for a handful of queries (launch + one dependent chain): it is only worth launching
 // when at least this many workgroups were loaded with uncertified queries (each counts 1, or 64 when more than half of

@@ -254,10 +254,25 @@ __global__ void __launch_bounds__(BLK) k_iota_u32(u32 *p, int n) {
 int map_apply_finish(Ctx *c) {
   if (!c->apply_pending) return MALIO_OK;
   c->apply_pending = false;
-  MALIO_HIP(hipStreamSynchronize(c->stream));
-  MALIO_HIP(hipGetLastError());
   u32 *mb = nullptr;
   MALIO_HIP(mbox(c, &mb));
+  // the verdict's sequence word, not the stream: by now the scan upload of the next turn is usually queued behind the list
+  // maintenance, and waiting for that too would leave the GPU idle until this thread has launched the scan's grouping
+  {
+    const volatile u32 *word = mb + MBOX_APPLY_SEQ;
+    unsigned long long spins = 0;
+    while (__atomic_load_n(const_cast<const u32 *>(word), __ATOMIC_ACQUIRE) != c->apply_seq) {
+      if ((++spins & 0x3FFF) == 0) {
+        hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipErrorNotReady && __atomic_load_n(const_cast<const u32 *>(word), __ATOMIC_ACQUIRE) != c->apply_seq) {
+          MALIO_HIP(q);
+          c->err = "map update: the list maintenance ended without publishing its verdict";
+          return MALIO_ERR_HIP;
+        }
+      }
+      __builtin_ia32_pause();
+    }
+  }
   const u32 *st1 = mb + 16, *st2 = mb + 20;
   c->nl1.ncells = st1[2], c->nl2.ncells = st2[2];
   bool in_place = !(st1[1] || st2[1]);  // a list or the tail region overflowed
@@ -325,8 +340,10 @@ static int map_reserve(Ctx *c, size_t extra) {
 }
 
 // the two list-state words the host looks at after an in-place update, into the host's mapped buffer
-__global__ void k_publish_states(const u32 *__restrict__ s1, const u32 *__restrict__ s2, u32 *out) {
-  out[threadIdx.x] = threadIdx.x < 4 ? s1[threadIdx.x] : s2[threadIdx.x - 4];
+__global__ void k_publish_states(const u32 *__restrict__ s1, const u32 *__restrict__ s2, u32 *out, u32 *seq_word, u32 seq) {
+  out[threadIdx.x] = threadIdx.x < 4 ? s1[threadIdx.x] : s2[threadIdx.x - 4];  // (8 threads: one wave)
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Apply one batch of changes to the map array and, when they fit, to the neighbour lists in place:
@@ -364,7 +381,9 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
       nl_append(c, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
       u32 *mb = nullptr, *mbd = nullptr;
       MALIO_HIP(mbox(c, &mb, &mbd));
-      hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, c->stream, c->nl1.state, c->nl2.state, mbd + 16);
+      if (++c->apply_seq == 0) c->apply_seq = 1;
+      hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, c->stream, c->nl1.state, c->nl2.state, mbd + 16,
+                         mbd + MBOX_APPLY_SEQ, c->apply_seq);
       c->apply_pending = true;  // verdict read by map_apply_finish
     }
     c->map_n = hw + (int)nadd;

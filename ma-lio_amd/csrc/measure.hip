@@ -1464,8 +1464,7 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   a.cov_threshold = c->prm.cov_threshold, a.fs = c->prm.filter_size_map;
   a.addf = d_addf, a.nonf = d_nonf, a.wp = d_wp;
   hipLaunchKernelGGL(k_mapinc_classify, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, a);
-  MALIO_HIP(hipStreamSynchronize(c->stream));
-  MALIO_HIP(hipGetLastError());
+  MALIO_HIP(hipGetLastError());  // (no wait: the caller's scans are queued behind it, d_far goes back to the arena in stream order)
   return MALIO_OK;
 }
 
