@@ -109,12 +109,14 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
     u32 cand[8];  // stored points inside the box (a 0.5 m voxel rarely holds more than two)
     int nc = 0;
     bool cand_overflow = false;
-    for (u32 j0 = 0; j0 < ec; j0 += 4) {  // 4 independent loads in flight: the list is ~45 entries from L2/HBM
-      float4 q4[4];
+    constexpr int VB = 16;  // independent loads in flight: the list is ~45 entries from L2/HBM, one voxel per thread and few
+                            // threads, so the kernel is as long as its chain of load round trips (4 at a time: 32 us)
+    for (u32 j0 = 0; j0 < ec; j0 += VB) {
+      float4 q4[VB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) q4[u] = lpts[(size_t)es + min(j0 + (u32)u, ec - 1)];
+      for (int u = 0; u < VB; u++) q4[u] = lpts[(size_t)es + min(j0 + (u32)u, ec - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < VB; u++) {
         const float4 q = q4[u];  // x = +inf for a tombstone: fails the box test
         // Search_by_range / Delete_by_range leaf test (ikd_Tree.cpp:1263-1274, :807): min <= q < max
         if (j0 + (u32)u >= ec ||
