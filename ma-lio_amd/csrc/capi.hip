@@ -156,7 +156,7 @@ int malio_destroy(malio_handle_t h) {
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
   fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
-  fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt);
+  fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt), fr(c->d_del);
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);

@@ -344,6 +344,8 @@ struct Ctx {
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
   float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
   size_t cap_map_in = 0, cap_map_alt = 0;
+  unsigned char *d_del = nullptr;  // per-slot "deleted by this batch" marks of the voxel update; all zero between calls (k_map_kill_list clears what it kills)
+  size_t cap_del = 0;
   int map_dead = 0;  // slots of d_map_in[0, map_n) that hold a deleted point (x = +inf)
   int nl_tomb = 0;   // tombstoned points in the lists since the last full build
   int n_rebuilds = 0, n_inplace = 0;  // diagnostics: full list builds / map changes applied to the lists in place
@@ -450,6 +452,8 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
                   float div_cell = 0.f);  // div_cell > 0: cell index = floor(x / div_cell) (ikd-Tree voxel rule)
 int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n, u32 *total_out = nullptr,
                        const u32 *fwd = nullptr, int nfwd = 0);  // d_tiles: [(n+1023)/1024 + 1]
+int exclusive_scan_u32_pair(Ctx *c, const u32 *inA, u32 *outA, u32 *tilesA, u32 *totalA, const u32 *inB, u32 *outB,
+                            u32 *tilesB, u32 *totalB, int n);  // two scans of one length in one pair of launches
 void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl);
 void free_nlist(NList &nl);

@@ -194,9 +194,123 @@ __global__ void k_publish_total(const u32 *__restrict__ last, const u32 *__restr
   if ((int)threadIdx.x < nfwd) total_out[1 + threadIdx.x] = fwd[threadIdx.x];
 }
 
+// A small scan (n <= 16 K: the per-scan cell tables and keep flags of the map upkeep) in ONE launch of one workgroup:
+// 1024 threads x up to 16 consecutive elements, wave scans by shuffles, 16 wave totals through LDS.
+constexpr int SCAN_SMALL_MAX = 16384;
+__global__ void __launch_bounds__(1024) k_scan_small(const u32 *__restrict__ in, u32 *out, int n, u32 *total_out,
+                                                     const u32 *__restrict__ fwd, int nfwd) {
+  __shared__ u32 wsum[16];
+  const int per = (n + 1023) / 1024;  // <= 16
+  const int base = threadIdx.x * per;
+  u32 v[16];
+  u32 t = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    v[k] = (k < per && base + k < n) ? in[base + k] : 0u;
+    t += v[k];
+  }
+  u32 incl = t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 woff = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) woff += w < wave ? wsum[w] : 0u;
+  u32 excl = woff + incl - t;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (k < per && base + k < n) {
+      out[base + k] = excl;
+      if (total_out && base + k == n - 1) total_out[0] = excl;  // (callers scan m + 1 flags with a zero at the end)
+    }
+    excl += v[k];
+  }
+  if (total_out && (int)threadIdx.x < nfwd) total_out[1 + threadIdx.x] = fwd[threadIdx.x];
+}
+
+// Two scans of the same length in one pair of launches (blockIdx.y picks the array): map_incremental's two flag arrays.
+struct ScanPair {
+  const u32 *in[2];
+  u32 *out[2], *tiles[2], *total[2];
+};
+__global__ void __launch_bounds__(BLK) k_scan_tiles2(ScanPair p, int n) {
+  __shared__ u32 wsum[BLK / 64];
+  const u32 *in = p.in[blockIdx.y];
+  u32 *out = p.out[blockIdx.y];
+  int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  u32 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+  u32 t = v[0] + v[1] + v[2] + v[3];
+  u32 incl = t;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (int w = 0; w < wave; w++) woff += wsum[w];
+  u32 excl = woff + incl - t;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k < n) out[base + k] = excl;
+    excl += v[k];
+  }
+  if (threadIdx.x == BLK - 1) p.tiles[blockIdx.y][blockIdx.x] = woff + incl;
+}
+__global__ void __launch_bounds__(BLK) k_scan_add_fused2(ScanPair p, int n) {
+  __shared__ u32 wsum[BLK / 64];
+  u32 *out = p.out[blockIdx.y];
+  const u32 *tile_sums = p.tiles[blockIdx.y];
+  u32 *total_out = p.total[blockIdx.y];
+  u32 part = 0;
+  for (int t = threadIdx.x; t < (int)blockIdx.x; t += BLK) part += tile_sums[t];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  u32 off = 0;
+#pragma unroll
+  for (int w = 0; w < BLK / 64; w++) off += wsum[w];
+  const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (base + k < n) {
+      const u32 v = out[base + k] + off;
+      out[base + k] = v;
+      if (total_out && base + k == n - 1) total_out[0] = v;
+    }
+}
+int exclusive_scan_u32_pair(Ctx *c, const u32 *inA, u32 *outA, u32 *tilesA, u32 *totalA, const u32 *inB, u32 *outB,
+                            u32 *tilesB, u32 *totalB, int n) {
+  const int ntiles = (n + 1023) / 1024;
+  if (ntiles > 1024) {  // (beyond a million flags: two ordinary scans)
+    exclusive_scan_u32(c, inA, outA, tilesA, n, totalA);
+    return exclusive_scan_u32(c, inB, outB, tilesB, n, totalB);
+  }
+  ScanPair p;
+  p.in[0] = inA, p.in[1] = inB, p.out[0] = outA, p.out[1] = outB, p.tiles[0] = tilesA, p.tiles[1] = tilesB;
+  p.total[0] = totalA, p.total[1] = totalB;
+  hipLaunchKernelGGL(k_scan_tiles2, dim3(ntiles, 2), dim3(BLK), 0, c->stream, p, n);
+  hipLaunchKernelGGL(k_scan_add_fused2, dim3(ntiles, 2), dim3(BLK), 0, c->stream, p, n);
+  return MALIO_OK;
+}
+
 // total_out (optional, device-visible, e.g. the mapped mailbox): receives out[n - 1] and then fwd[0 .. nfwd)
 int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n, u32 *total_out, const u32 *fwd,
                        int nfwd) {
+  if (n <= SCAN_SMALL_MAX) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, c->stream, d_in, d_out, n, total_out, fwd, nfwd);
+    return MALIO_OK;
+  }
   int ntiles = (n + 1023) / 1024;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(BLK), 0, c->stream, d_in, d_out, d_tiles, n);
   if (ntiles <= 1024) {

@@ -208,9 +208,20 @@ __global__ void __launch_bounds__(BLK) k_box_delete(const float4 *__restrict__ m
   if (hit) dlist[base + __popcll(m & ((1ull << lane) - 1))] = (u32)i;
 }
 
-__global__ void __launch_bounds__(BLK) k_map_kill_list(float4 *mapp, const u32 *__restrict__ dlist, int ndel) {
+__global__ void __launch_bounds__(BLK) k_map_kill_list(float4 *mapp, const u32 *__restrict__ dlist, int ndel, unsigned char *del,
+                                                       u32 del_n) {
   int d = blockIdx.x * BLK + threadIdx.x;
-  if (d < ndel) mapp[dlist[d]].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
+  if (d < ndel) {
+    const u32 mi = dlist[d];
+    mapp[mi].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
+    if (mi < del_n) del[mi] = 0;  // the voxel update's mark: the array is all zero again when the batch is through
+  }
+}
+// keep flags of one Add_Points pair: [0, m_ds) decided by k_vox_add (0), [m_ds, m) kept (1), then a zero and the kernel's
+// two counters
+__global__ void __launch_bounds__(BLK) k_init_addf(u32 *addf, int m_ds, int m) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < m + 3) addf[i] = (i >= m_ds && i < m) ? 1u : 0u;
 }
 
 __global__ void __launch_bounds__(BLK) k_compact(const float4 *__restrict__ src, const u32 *__restrict__ flag,
@@ -218,6 +229,19 @@ __global__ void __launch_bounds__(BLK) k_compact(const float4 *__restrict__ src,
                                                  float4 *dst) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i < n && flag[i]) dst[(base ? *base : 0u) + pos[i]] = src[i];
+}
+
+// two stable compactions of one source in one launch (blockIdx.y): map_incremental's PointToAdd | PointNoNeedDownsample
+__global__ void __launch_bounds__(BLK) k_compact2(const float4 *__restrict__ src, const u32 *__restrict__ flagA,
+                                                  const u32 *__restrict__ posA, float4 *dstA, const u32 *__restrict__ flagB,
+                                                  const u32 *__restrict__ posB, float4 *dstB, int n) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  if (blockIdx.y == 0) {
+    if (flagA[i]) dstA[posA[i]] = src[i];
+  } else {
+    if (flagB[i]) dstB[posB[i]] = src[i];
+  }
 }
 
 int ensure_alt(Ctx *c, size_t need) {
@@ -370,7 +394,7 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
       nl_tombstone(c, c->nl1, c->nl2, c->d_map_in, dlist, (int)ndel);
     }
     hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, dlist,
-                       (int)ndel);
+                       (int)ndel, c->d_del, (u32)(c->d_del ? c->cap_del : 0));
     c->map_dead += (int)ndel, c->nl_tomb += (int)ndel;
   }
   if (nadd) {
@@ -447,17 +471,21 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   CellGrid &gnew = c->gnew;
   rc = group_by_cell(c, d_new, m_ds, 1.f / ds, gnew, nullptr, ds);
   if (rc != MALIO_OK) return rc;
-  unsigned char *del = nullptr;
+  // the "deleted by this batch" marks live in a persistent array that is all zero between calls (the kill kernel of
+  // map_apply clears the marks it consumes): no megabyte-sized clear per scan
+  if ((size_t)hw + 1 > c->cap_del) {
+    if (c->d_del) (void)hipFree(c->d_del);
+    c->d_del = nullptr, c->cap_del = c->cap_map_in + 1024;
+    MALIO_HIP(hipMalloc(&c->d_del, c->cap_del));
+    MALIO_HIP(hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream));
+  }
+  unsigned char *del = c->d_del;
   u32 *dlist = nullptr, *mb = nullptr, *mbd = nullptr;
-  hipError_t e = sc.get(&del, (size_t)hw + 1);
-  if (e == hipSuccess) e = sc.get(&dlist, (size_t)hw + 1);
+  hipError_t e = sc.get(&dlist, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
   if (e == hipSuccess) e = mbox(c, &mb, &mbd);
-  if (e == hipSuccess) e = hipMemsetAsync(del, 0, (size_t)hw + 1, c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(addf, 0, sizeof(u32) * ((size_t)m + 1 + 2), c->stream);
   MALIO_HIP(e);
-  if (m_plain > 0)
-    hipLaunchKernelGGL(k_fill_u32, dim3((m_plain + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf + m_ds, 1u, m_plain);
+  hipLaunchKernelGGL(k_init_addf, dim3((m + 3 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf, m_ds, m);
   const u32 ntsize = gnew.tmask + 1;
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
                      d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
@@ -536,16 +564,13 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   int rc = mapinc_classify(c, state_point, flg_EKF_inited, d_wny, addf, nonf, wp);  // also zeroes addf[N], nonf[N]
   if (rc != MALIO_OK) return rc;
   // the two list lengths go straight from the scans' last kernels into the host's mapped buffer: no copy launches
-  exclusive_scan_u32(c, addf, apos, tiles, N + 1, mbd + 0);
-  exclusive_scan_u32(c, nonf, npos, tiles2, N + 1, mbd + 2);
+  exclusive_scan_u32_pair(c, addf, apos, tiles, mbd + 0, nonf, npos, tiles2, mbd + 2, N + 1);
   MALIO_HIP(hipStreamSynchronize(c->stream));
   const int na = (int)mb[0], nn = (int)mb[2];
   MALIO_HIP(sc.get(&d_add, (size_t)na + (size_t)nn));  // PointToAdd | PointNoNeedDownsample, back to back
   d_non = d_add + na;
-  hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, addf, apos, N,
-                     (const u32 *)nullptr, d_add);
-  hipLaunchKernelGGL(k_compact, dim3((N + BLK - 1) / BLK), dim3(BLK), 0, c->stream, wp, nonf, npos, N,
-                     (const u32 *)nullptr, d_non);
+  hipLaunchKernelGGL(k_compact2, dim3((N + BLK - 1) / BLK, 2), dim3(BLK), 0, c->stream, wp, addf, apos, d_add, nonf, npos,
+                     d_non, N);
   int added = 0;
   // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)   (:443-444)
   if ((float)c->prm.filter_size_map > 0.f)
