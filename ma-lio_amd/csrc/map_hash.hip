@@ -149,6 +149,18 @@ __global__ void __launch_bounds__(BLK) k_clear_table(Cell *t, u32 n) {
   }
 }
 
+// group_by_cell's three clears in one launch: scratch keys <- EMPTY, counters [tbig + 1] <- 0, compact table <- empty cells
+__global__ void __launch_bounds__(BLK) k_gbc_prepare(u64 *keys, u32 *cnt, u32 tbig, Cell *table, u32 tsize) {
+  const u32 i = blockIdx.x * BLK + threadIdx.x;
+  if (i < tbig) keys[i] = EMPTY_KEY;
+  if (i <= tbig) cnt[i] = 0u;
+  if (i < tsize) {
+    Cell c;
+    c.key = EMPTY_KEY, c.start = 0, c.count = 0;
+    table[i] = c;
+  }
+}
+
 static u32 next_pow2(u32 v) {
   u32 p = 1;
   while (p < v) p <<= 1;
@@ -341,8 +353,18 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   MALIO_HIP(sc.get(&slot_of, (size_t)n));
   MALIO_HIP(sc.get(&rank_of, (size_t)n));
   MALIO_HIP(sc.get(&tiles, (size_t)ntiles + 1));
-  hipLaunchKernelGGL(k_fill_u64, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, EMPTY_KEY, (size_t)tbig);
-  MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * ((size_t)tbig + 1), c->stream));
+  // the compact table is sized for the worst case (every point in its own cell) instead of reading the cell count
+  // back: this runs once per scan on ~2 k points, where a host round trip costs more than clearing a few KB
+  u32 tsize = next_pow2(std::max(1024u, 4u * (u32)n));
+  if ((size_t)tsize > g.cap_table) {
+    if (g.table) (void)hipFree(g.table);
+    g.table = nullptr;
+    g.cap_table = tsize;
+    MALIO_HIP(hipMalloc(&g.table, sizeof(Cell) * g.cap_table));
+  }
+  // scratch keys, counters (+ the cell counter) and the compact table cleared by ONE launch
+  hipLaunchKernelGGL(k_gbc_prepare, dim3((std::max(tbig + 1, tsize) + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt,
+                     tbig, g.table, tsize);
   int nb = (n + BLK - 1) / BLK;
   hipLaunchKernelGGL(k_gbc_insert, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, inv_cell, div_cell, keys, cnt, tbig - 1,
                      slot_of, rank_of, ncells);
@@ -357,16 +379,6 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
   }
   hipLaunchKernelGGL(k_gbc_scatter, dim3(nb), dim3(BLK), 0, c->stream, d_in, d_in_orig, n, slot_of, rank_of, start,
                      g.pts, g.orig);
-  // the compact table is sized for the worst case (every point in its own cell) instead of reading the cell count
-  // back: this runs once per scan on ~2 k points, where a host round trip costs more than clearing a few KB
-  u32 tsize = next_pow2(std::max(1024u, 4u * (u32)n));
-  if ((size_t)tsize > g.cap_table) {
-    if (g.table) (void)hipFree(g.table);
-    g.table = nullptr;
-    g.cap_table = tsize;
-    MALIO_HIP(hipMalloc(&g.table, sizeof(Cell) * g.cap_table));
-  }
-  hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, g.table, tsize);
   hipLaunchKernelGGL(k_gbc_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, tbig,
                      g.table, tsize - 1);
   g.tmask = tsize - 1;
