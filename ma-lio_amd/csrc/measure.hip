@@ -1282,6 +1282,7 @@ int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d
 // exactly for the queries whose search ball was empty: shells of 3x3x3-cell blocks of the level-2 lists around
 // the query cell, until the best distance is inside the covered cube; then (rare) a scan of the whole map.
 constexpr int FAR_RMAX = 6;
+constexpr int FAR_GROUP = 16;  // scan points per wave and stride of k_far_nearest (a map frontier full of empty balls still fills the GPU)
 // K = 1: the nearest map point of the queries with an empty search ball (what :421-425 reads), far_idx[N].
 // K = 5: the unrestricted 5-NN of every query with fewer than five neighbours inside sqrt(5) m, far_idx[5][N] - what
 // ikdtree.Nearest_Search leaves in Nearest_Points[i] (ikd_Tree.cpp:426-461 has no radius), handed out by malio_scan_get.
@@ -1289,12 +1290,24 @@ template <int K>
 __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__restrict__ world4,
                                                      const unsigned char *__restrict__ nfound, NlView nl,
                                                      const float4 *__restrict__ map_in, int map_n, u32 *far_idx) {
-  const int qi = (blockIdx.x * BLK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (qi >= N) return;
-  if (K == 1 ? nfound[qi] != 0 : nfound[qi] >= 5) {  // (NF_NOTMINE included: another shard answers for that point)
-    if (lane < K) far_idx[(size_t)lane * N + qi] = INVALID;
-    return;
+  // A grid of waves strides over the scan FAR_GROUP points at a time: one coalesced look at the flags, INVALID for the
+  // points that need nothing (nearly all of them), then the few that do are served one after the other by the whole wave.
+  // (One wave per scan point - 25 k workgroups that return at once - cost 10 us for a handful of searches.)
+  const int lane = threadIdx.x & 63;
+  const int wave0 = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * BLK) >> 6);
+  for (int base = wave0 * FAR_GROUP; base < N; base += nwaves * FAR_GROUP) {
+  const int ql = base + lane;
+  const bool mine = lane < FAR_GROUP && ql < N;
+  // (NF_NOTMINE counts as served: another shard answers for that point)
+  const bool needy = mine && (K == 1 ? nfound[ql] == 0 : nfound[ql] < 5);
+  if (mine && !needy) {
+#pragma unroll
+    for (int k = 0; k < K; k++) far_idx[(size_t)k * N + ql] = INVALID;
   }
+  unsigned long long todo = __ballot(needy);
+  while (todo) {
+  const int qi = base + __ffsll((long long)todo) - 1;
+  todo &= todo - 1;
   const float4 w = world4[qi];
   const float gx = w.x * nl.inv_cf, gy = w.y * nl.inv_cf, gz = w.z * nl.inv_cf;
   const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
@@ -1350,6 +1363,8 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
     merge_group<64>(t, INFINITY);
   }
   if (lane < K) far_idx[(size_t)lane * N + qi] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
+  }  // needy queries of this group of 64
+  }  // groups of 64 points
 }
 
 struct MapIncArgs {
@@ -1423,8 +1438,8 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
 
 // Nearest_Points beyond the search radius (malio_scan_get): d_far [5][N], INVALID where the search pass found all five
 int far_knn5(Ctx *c, u32 *d_far) {
-  const long long th = (long long)c->N * 64;
-  hipLaunchKernelGGL(k_far_nearest<5>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, c->N, c->d_world4,
+  const long long th = ((long long)c->N + FAR_GROUP - 1) / FAR_GROUP * 64;
+  hipLaunchKernelGGL(k_far_nearest<5>, dim3((unsigned)std::min<long long>((th + BLK - 1) / BLK, 2048)), dim3(BLK), 0, c->stream, c->N, c->d_world4,
                      c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
@@ -1450,8 +1465,8 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   u32 *d_far = nullptr;
   MALIO_HIP(sc.get(&d_far, (size_t)N));
   if (c->map_n - c->map_dead > 0 && flg_EKF_inited) {
-    long long th = (long long)N * 64;
-    hipLaunchKernelGGL(k_far_nearest<1>, dim3((unsigned)((th + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, N, c->d_world4,
+    long long th = ((long long)N + FAR_GROUP - 1) / FAR_GROUP * 64;
+    hipLaunchKernelGGL(k_far_nearest<1>, dim3((unsigned)std::min<long long>((th + BLK - 1) / BLK, 2048)), dim3(BLK), 0, c->stream, N, c->d_world4,
                        c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
   }
   MapIncArgs a;
