@@ -434,10 +434,11 @@ namespace malio {
 // 20-byte upload record; what the host loop of malio_scan_set does while it packs - counting the points of each LiDAR
 // slot, validating the slot, noticing whether the slots come in ascending blocks - is left in info[] for the first pass:
 // info[l] = points of slot l, info[8] = points with a slot outside [0, L), info[9] = descents of the slot sequence.
-// The block that finishes last (ticket in info[12]) publishes info[0..9] and the scan's sequence number to pinned memory:
-// the first pass picks the counts up from there without a copy or a stream synchronisation (resolve_scan_segments).
-__global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw12, int n, int L, UploadRec *upload, u32 *info,
-                                                  u32 *pub, u32 seq) {
+// info[0..9] and the scan's sequence number reach pinned memory from a LATER kernel of the same stream (the first
+// workgroup of the grouping's first kernel, or k_publish_pack when the caller's order is to be kept and the counts are
+// needed before that): the first pass picks them up there without a copy or a stream synchronisation
+// (resolve_scan_segments), and the pack kernel does not end on a ticket and a write across PCIe.
+__global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw12, int n, int L, UploadRec *upload, u32 *info) {
   __shared__ u32 s_cnt[10];
   // The block's 256 points (12 KB) come in with fully coalesced 16-byte loads - every byte of the source is read exactly
   // once, which is what makes reading the caller's page-locked cloud in place (across PCIe, uncached) as fast as a DMA
@@ -489,18 +490,6 @@ __global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw1
   }
   __syncthreads();
   if (threadIdx.x < 10 && s_cnt[threadIdx.x]) atomicAdd(&info[threadIdx.x], s_cnt[threadIdx.x]);
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();  // this block's counts before its ticket
-    s_last = atomicAdd(&info[12], 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x < 10) pub[threadIdx.x] = __hip_atomic_load(&info[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&pub[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace malio
 
@@ -545,8 +534,9 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
         memset(c->h_packinfo, 0, sizeof(u32) * 16);
       }
       if (++c->pack_seq == 0) c->pack_seq = 1;
-      hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, src, n, L, c->d_upload, c->d_packinfo,
-                         c->d_packinfo_pub, c->pack_seq);
+      hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, src, n, L, c->d_upload, c->d_packinfo);
+      c->pack_publish_pending = true;
+      if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP) publish_pack_now(c);
       MALIO_HIP(hipGetLastError());
       c->seg_pending = true;
       c->scan_keep_order = false;  // decided when the counts arrive

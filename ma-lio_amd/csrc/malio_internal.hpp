@@ -361,8 +361,9 @@ struct Ctx {
   float *d_raw = nullptr;         // [N][12] the caller's page-locked cloud as copied (malio_scan_set, pinned path)
   size_t cap_raw = 0;
   u32 *d_packinfo = nullptr;      // k_pack_raw: per-slot counts, bad slots, descents
-  u32 *h_packinfo = nullptr, *d_packinfo_pub = nullptr;  // pinned copy (+ sequence word [15]) the last block of k_pack_raw stores
+  u32 *h_packinfo = nullptr, *d_packinfo_pub = nullptr;  // pinned copy (+ sequence word [15]) of k_pack_raw's counts
   u32 pack_seq = 0, apply_seq = 0;
+  bool pack_publish_pending = false;  // the counts of k_pack_raw still have to be stored to pinned memory by a later kernel
   u32 *d_sort_cnt = nullptr;      // scan grouping: bucket counts + offsets (measure.hip sort_scan)
   bool seg_pending = false;       // seg_start[] not known yet: the counts are still on the device
   float4 *d_scan = nullptr;     // [N] sorted
@@ -539,6 +540,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *
 // flag, [k_search_tail], k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
 int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate = nullptr);  // gate: rides on the last kernel
 int prepare_scan_dev(Ctx *c, const malio_state_t *s);  // map lists in sync, scan sorted
+void publish_pack_now(Ctx *c);  // a one-wave kernel that publishes k_pack_raw's counts (when no grouping kernel will)
 int resolve_scan_segments(Ctx *c);  // the per-LiDAR segments of a scan that was packed on the device
 void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc);
 void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc);

@@ -1565,8 +1565,23 @@ int measure_alloc(Ctx *c) {
 //                   the kernel writes the sorted scan and resets the per-point state a new scan starts from.
 constexpr int SORT_NBK = 4096;                           // buckets per LiDAR slot (100 k points: ~8 per bucket)
 constexpr int SORT_NB = SORT_NBK * MALIO_MAX_LIDAR;      // 16384
+// counts of k_pack_raw (finished: same stream) -> pinned memory, then the scan's sequence number; called by ONE workgroup
+__device__ __forceinline__ void publish_pack(const u32 *__restrict__ info, u32 *pub, u32 seq) {
+  if (threadIdx.x < 10) pub[threadIdx.x] = info[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&pub[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(64) k_publish_pack(const u32 *__restrict__ info, u32 *pub, u32 seq) { publish_pack(info, pub, seq); }
+void publish_pack_now(Ctx *c) {
+  if (!c->pack_publish_pending) return;
+  c->pack_publish_pending = false;
+  hipLaunchKernelGGL(k_publish_pack, dim3(1), dim3(64), 0, c->stream, c->d_packinfo, c->d_packinfo_pub, c->pack_seq);
+}
 __global__ void __launch_bounds__(BLK) k_sort_count(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
-                                                    u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt) {
+                                                    u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt, const u32 *pack_info, u32 *pack_pub,
+                                                    u32 pack_seq) {
+  if (pack_pub && blockIdx.x == 0) publish_pack(pack_info, pack_pub, pack_seq);  // (uniform per workgroup; under the others' work)
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   const UploadRec q = in[i];
@@ -1689,6 +1704,7 @@ void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
 // stream (a blocking read-back here used to keep the GPU idle for ~40 us between the upload and the grouping).
 int resolve_scan_segments(Ctx *c) {
   if (!c->seg_pending) return MALIO_OK;
+  publish_pack_now(c);  // (nobody has yet: the caller wants the counts before any grouping kernel is queued)
   volatile u32 *pub = c->h_packinfo;
   unsigned long long spins = 0;
   while (__atomic_load_n(const_cast<u32 *>(&pub[15]), __ATOMIC_ACQUIRE) != c->pack_seq) {
@@ -1725,6 +1741,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   const int N = c->N;
   const dim3 grid((N + BLK - 1) / BLK);
   if (c->scan_keep_order) {  // malio_scan_order: the upload order is kept (it is grouped by LiDAR slot)
+    publish_pack_now(c);
     hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, N, c->d_scan, c->d_perm, c->d_ny,
                        c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
     c->scan_sorted = true;
@@ -1742,7 +1759,10 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(sc.get(&rnk, (size_t)N));
   MALIO_HIP(sc.get(&tkv, (size_t)N));
   MALIO_HIP(sc.get(&tbkt, (size_t)N));
-  hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, keys, bkt, rnk, cnt);
+  const bool pub = c->pack_publish_pending;
+  c->pack_publish_pending = false;
+  hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, keys, bkt, rnk, cnt,
+                     (const u32 *)c->d_packinfo, pub ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
   hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs);
   hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkv, tbkt);
   hipLaunchKernelGGL(k_sort_place, grid, dim3(BLK), 0, c->stream, c->d_upload, N, tkv, tbkt, offs, c->d_scan, c->d_perm,
