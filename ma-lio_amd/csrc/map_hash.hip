@@ -391,14 +391,16 @@ int group_by_cell(Ctx *c, const float4 *d_in, int n, float inv_cell, CellGrid &g
 // ---- neighbour lists -----------------------------------------------------------------------------------------
 // pass A: every point bumps the counters of the 27 fine cells whose 3x3x3 block contains it
 __global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts, int n, float inv_cf, u64 *keys, u32 *cnt,
-                                                  u32 mask, u32 *ncells, u32 *overflow) {
+                                                  u32 mask, u32 *ncells, u32 *overflow, int pruned) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  int ix = (int)floorf(p.x * inv_cf), iy = (int)floorf(p.y * inv_cf), iz = (int)floorf(p.z * inv_cf);
+  const float gx = p.x * inv_cf, gy = p.y * inv_cf, gz = p.z * inv_cf;
+  int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
   for (int dz = -1; dz <= 1; dz++)
     for (int dy = -1; dy <= 1; dy++)
       for (int dx = -1; dx <= 1; dx++) {
+        if (!nl_member(pruned, gx, gy, gz, ix, iy, iz, dx, dy, dz)) continue;
         u64 key = cell_key(ix + dx, iy + dy, iz + dz);
         u32 s = hash_key(key) & mask;
         int probes = 0;
@@ -430,15 +432,17 @@ __global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts
 // pass B: place every point into the 27 lists (cursor = running fill count of the list)
 __global__ void __launch_bounds__(BLK) k_nl_fill(const float4 *__restrict__ pts, int n, float inv_cf,
                                                  const u64 *__restrict__ keys, const u32 *__restrict__ start, u32 *cursor,
-                                                 u32 mask, float4 *out) {
+                                                 u32 mask, float4 *out, int pruned) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
   float4 rec = make_float4(p.x, p.y, p.z, __uint_as_float((u32)i));
-  int ix = (int)floorf(p.x * inv_cf), iy = (int)floorf(p.y * inv_cf), iz = (int)floorf(p.z * inv_cf);
+  const float gx = p.x * inv_cf, gy = p.y * inv_cf, gz = p.z * inv_cf;
+  int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
   for (int dz = -1; dz <= 1; dz++)
     for (int dy = -1; dy <= 1; dy++)
       for (int dx = -1; dx <= 1; dx++) {
+        if (!nl_member(pruned, gx, gy, gz, ix, iy, iz, dx, dy, dz)) continue;
         u64 key = cell_key(ix + dx, iy + dy, iz + dz);
         u32 s = hash_key(key) & mask;
         while (keys[s] != key) s = (s + 1) & mask;
@@ -493,8 +497,9 @@ __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys
   cap[d] = capv[s];
 }
 
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned) {
   nl.cf = cf;
+  nl.pruned = pruned;
   nl.inv_cf = 1.0f / nl.cf;
   // scratch table: halo cells are a few times the occupied ones; 8 slots per point keeps the load low
   u32 tbig = next_pow2((u32)std::max(4096, 8 * n));
@@ -517,7 +522,7 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
   MALIO_HIP(hipMemsetAsync(counters, 0, sizeof(u32) * 2, c->stream));
   int nb = (n + BLK - 1) / BLK;
   hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, cnt, tbig - 1, counters,
-                     counters + 1);
+                     counters + 1, pruned ? 1 : 0);
   // every list gets slack for incremental inserts (map_update.hip); starts = exclusive scan of the capacities
   hipLaunchKernelGGL(k_nl_caps, dim3((tbig + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, cnt, capv, tbig);
   exclusive_scan_u32(c, capv, start, tiles, (int)tbig + 1);
@@ -544,7 +549,7 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl) {
   }
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));  // reuse as the fill cursor
   hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,
-                     nl.pts);
+                     nl.pts, pruned ? 1 : 0);
   // compact directory (the fill cursors now equal the list lengths); sized for growth to load 0.7
   u32 tsize = next_pow2(std::max(1024u, 3u * h_cnt[0]));
   if ((size_t)tsize > nl.cap_table || !nl.table) {
@@ -583,7 +588,9 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
   if (i >= m || cidx >= 27 || !keep[i]) return;
   float4 p = newp[i];
-  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  const float gx = p.x * nl.inv_cf, gy = p.y * nl.inv_cf, gz = p.z * nl.inv_cf;
+  int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+  if (!nl_member(nl.pruned, gx, gy, gz, ix, iy, iz, cidx % 3 - 1, (cidx / 3) % 3 - 1, cidx / 9 - 1)) return;
   u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
   int probes = 0;
@@ -619,11 +626,13 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
   u32 s = 0;
   if (live) {
     float4 p = newp[i];
-    int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+    const float gx = p.x * nl.inv_cf, gy = p.y * nl.inv_cf, gz = p.z * nl.inv_cf;
+    int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+    live = nl_member(nl.pruned, gx, gy, gz, ix, iy, iz, cidx % 3 - 1, (cidx / 3) % 3 - 1, cidx / 9 - 1);
     u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
     s = hash_key(key) & nl.tmask;
     int probes = 0;
-    while (true) {
+    while (live) {
       const u64 k = nl.table[s].key;
       if (k == key) break;
       if (k == EMPTY_KEY || ++probes > NL_MAX_PROBES) {  // (1) already reported the overflow
@@ -683,7 +692,9 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
   if (i >= m || cidx >= 27 || !keep[i]) return;
   float4 p = newp[i];
   float4 rec = make_float4(p.x, p.y, p.z, __uint_as_float(og_base + rank[i]));
-  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  const float gx = p.x * nl.inv_cf, gy = p.y * nl.inv_cf, gz = p.z * nl.inv_cf;
+  int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+  if (!nl_member(nl.pruned, gx, gy, gz, ix, iy, iz, cidx % 3 - 1, (cidx / 3) % 3 - 1, cidx / 9 - 1)) return;
   u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
   int probes = 0;
@@ -717,7 +728,10 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
   if (d >= ndel) return;
   const u32 i = dlist[d];
   float4 p = mapp[i];
-  int ix = (int)floorf(p.x * nl.inv_cf), iy = (int)floorf(p.y * nl.inv_cf), iz = (int)floorf(p.z * nl.inv_cf);
+  const float gx = p.x * nl.inv_cf, gy = p.y * nl.inv_cf, gz = p.z * nl.inv_cf;
+  int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
+  // (16 lanes share (d, cidx): the whole group leaves together, the ballot below stays among lanes that walk a list)
+  if (!nl_member(nl.pruned, gx, gy, gz, ix, iy, iz, cidx % 3 - 1, (cidx / 3) % 3 - 1, cidx / 9 - 1)) return;
   u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
   u32 s = hash_key(key) & nl.tmask;
   while (true) {
@@ -744,7 +758,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
 NlDev nl_dev(const NList &nl) {
   NlDev v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state;
-  v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf;
+  v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.pruned = nl.pruned ? 1 : 0;
   return v;
 }
 
