@@ -292,7 +292,7 @@ def test_nearest_search_vs_reference_tree(capi, orc, scenes):
     assert np.array_equal(np.sort(d2g, 1), d2g)
 
 
-@pytest.mark.parametrize("cfg", [2, 3, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 5])
 def test_full_size_configs(capi, orc, scenes, cfg):
     """BASELINE.json configs at full size: direct parity with the oracle (reference ikd-Tree inside) plus
     size-independent properties."""

@@ -163,3 +163,74 @@ def test_tile_shards_map_mutations(capi, scenes):
         assert np.array_equal(ga[k], gb[k]), k
     assert np.array_equal(ga["nearest"][:, :, :3], gb["nearest"][:, :, :3])
     nd.close()
+
+
+@pytest.mark.gpu
+def test_config4_tile_sharded_8_shards_equals_single_engine(capi, scenes):
+    """BASELINE.json configs[3] at FULL size the way the driver's scaling run executes it: the 8 M-point map cut into 16 m
+    hashed tiles over 8 shards (here all on GPU 0, one after the other through the node handle), the 200 k-point scan
+    served by the shard that owns each point's tile - against ONE engine that holds the whole map. Flags, planes,
+    neighbours and Nearest_Points point for point; the sums to their summation order (per-shard partial sums)."""
+    sc = scenes.make_scene(cfg=4)
+    one = _single(capi, sc)
+    nd = capi.Node(sc["params"], [0] * 8, partition=capi.PART_TILES, tile_m=16.0)
+    nd.map_build(sc["map"])
+    sizes = nd.map_sizes()
+    assert max(sizes) < 0.5 * sc["Nmap"] and sum(sizes) >= sc["Nmap"]  # every shard holds its tiles + halo only
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    s2 = sc["state0"].copy()
+    s2[0:3] += [0.012, -0.02, 0.006]
+    for state, conv in ((sc["state0"], True), (s2, False), (s2, True)):
+        a, b = one.measure(state, conv), nd.measure(state, conv)
+        assert (a["valid"], a["M"]) == (b["valid"], b["M"]) and a["M"] > 0.8 * sc["N"]
+        assert a["unit_cov_minmax"] == b["unit_cov_minmax"] and a["R_minmax"] == b["R_minmax"]
+        assert np.abs(a["HtRinvH"] - b["HtRinvH"]).max() <= 1e-12 * np.abs(a["HtRinvH"]).max()
+        assert np.abs(a["HtRinvh"] - b["HtRinvh"]).max() <= 1e-12 * np.abs(a["HtRinvh"]).max()
+    ga, gb = one.scan_get(), nd.scan_get()
+    for k in ("selected", "world", "normvec", "res_last", "nearest_cnt", "nearest", "normal_y"):
+        assert np.array_equal(ga[k], gb[k]), k
+    one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    u, v = one.update_iterated(sc["state0"], sc["P0"]), nd.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    assert np.abs(u["state"] - v["state"]).max() < 1e-7
+    nd.close()
+
+
+def _gpu_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["tiles", "scan"])
+def test_node_handle_two_gpus_over_rccl(capi, scenes, partition):
+    """The first box with two GPUs runs RCCL with world > 1 under pytest: malio_node_create(n_gpus = 2, XCHG_RCCL) -
+    one worker thread and one communicator rank per GPU, ncclAllGather of the [sums | extrema] rows on each handle's
+    stream - against one engine on GPU 0. (Skipped on the one-GPU development boxes.)"""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    sc = scenes.make_scene(seed=316, N=20000, Nmap=300000, L=3)
+    one = _single(capi, sc)
+    nd = capi.Node(sc["params"], [0, 1], partition=capi.PART_TILES if partition == "tiles" else capi.PART_SCAN,
+                   exchange=capi.XCHG_RCCL, tile_m=16.0)
+    nd.map_build(sc["map"])
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    for conv in (True, False, True):
+        a, b = one.measure(sc["state0"], conv), nd.measure(sc["state0"], conv)
+        assert (a["valid"], a["M"]) == (b["valid"], b["M"])
+        assert np.abs(a["HtRinvH"] - b["HtRinvH"]).max() <= 1e-12 * np.abs(a["HtRinvH"]).max()
+    ga, gb = one.scan_get(), nd.scan_get()
+    for k in ("selected", "normvec", "nearest_cnt", "nearest"):
+        assert np.array_equal(ga[k], gb[k]), k
+    one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    u, v = one.update_iterated(sc["state0"], sc["P0"]), nd.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    assert np.abs(u["state"] - v["state"]).max() < 1e-8
+    nd.close()

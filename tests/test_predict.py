@@ -289,11 +289,13 @@ def test_golden_chain(capi, orc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("L", [1, 3, 4])
-def test_device_chain_equals_host_chain(capi, scenes, L):
+def test_device_chain_equals_host_chain(capi, orc, scenes, L):
     """malio_predict_chain (row f-3 on the device): three tracks of different lengths side by side - what
-    ImuProcess::UndistortPcl runs one after the other as kf.predict / predict_cont / back_predict - against the same
-    steps taken one by one with the host's malio_predict: the state after EVERY step and the final covariance. Same
-    operation order; the device's sin / cos may differ from glibc's in the last place."""
+    ImuProcess::UndistortPcl runs one after the other as kf.predict / predict_cont / back_predict - against the ORACLE's
+    dense restatement of esekf::predict (esekfom.hpp:388-492 with MA-LIO's process model, use-ikfom.hpp:67-112) stepped
+    alongside: the state after EVERY step (1e-12) and the covariance at the end of every track (1e-10 relative) - and,
+    second, against the same steps taken one by one with the host's malio_predict (same operation order; the device's
+    sin / cos may differ from glibc's in the last place)."""
     rng = np.random.default_rng(40 + L)
     n = 17 + 6 * L
     sc = scenes.make_scene(seed=12, N=200, Nmap=3000, L=L)
@@ -311,9 +313,14 @@ def test_device_chain_equals_host_chain(capi, scenes, L):
     ends, Pe, steps = eng.predict_chain(xs, Ps, dts, accs, gyros, Q)
     for t, K in enumerate(Ks):
         x, P = xs[t], Ps[t]
+        xo, Po = xs[t], Ps[t]
         for k in range(K):
+            xo, Po = orc.predict(L, xo, Po, dts[t][k], Q, accs[t][k], gyros[t][k])  # the oracle: parity proper
+            assert np.allclose(steps[t][k], xo, rtol=0, atol=1e-12 * max(1.0, np.abs(xo).max())), ("oracle", t, k)
             x, P = capi.predict(L, x, P, dts[t][k], Q, accs[t][k], gyros[t][k])
             assert np.allclose(steps[t][k], x, rtol=0, atol=1e-12 * max(1.0, np.abs(x).max())), (t, k)
+        assert np.allclose(ends[t], xo, rtol=0, atol=1e-12 * max(1.0, np.abs(xo).max()))
+        assert np.allclose(Pe[t], Po, rtol=1e-10, atol=1e-18 + 1e-13 * np.abs(Po).max()), ("oracle P", t)
         assert np.allclose(ends[t], x, rtol=0, atol=1e-12 * max(1.0, np.abs(x).max()))
         assert np.allclose(Pe[t], P, rtol=1e-10, atol=1e-18 + 1e-13 * np.abs(P).max())
     # states only (P == NULL), one track
