@@ -217,10 +217,20 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
 /* ---- per scan ------------------------------------------------------------------------------- */
 /* replaces the per-scan globals h_share_model reads: feats_down_body (laserMapping.cpp:86,982),
  * pose_unc[lid][k] (:1028-1048), kf.temporal_comp[lid-1] (IMU_Processing.hpp:510-522). Uploads the
- * scan to HBM once; resets Nearest_Points / point_selected_surf (:1024-1025). */
+ * scan to HBM once; resets Nearest_Points / point_selected_surf (:1024-1025).
+ * LIFETIME OF feats_down_body. From ordinary (pageable) memory the cloud has been read completely when the call returns.
+ * From page-locked memory (malio_host_alloc, hipHostMalloc, hipHostRegister - detected with hipPointerGetAttributes on the
+ * first and the last byte) the call returns with ONE DMA copy of the n * 48 bytes still in flight (~90 us for 100 k
+ * points): the caller must neither modify nor free the buffer until malio_scan_upload_wait(h) has returned, or any
+ * later call on the handle that waits for its results has (malio_measure, malio_update_iterated, malio_scan_get, ...).
+ * malio_host_free of the buffer is safe at any time (hipHostFree waits for the device). A caller that cannot promise
+ * that sets MALIO_SCAN_SET_SYNC=1 in the environment (the call then waits for the copy) or keeps its cloud pageable. */
 int malio_scan_set(malio_handle_t h, const malio_point_t *feats_down_body, int n,
                    const malio_pose_t *const *pose_unc, const int *pose_unc_len,
                    const malio_pose_t *temporal_comp);
+/* Blocks until the upload queued by the last malio_scan_set has left the caller's buffer (an event recorded right
+ * behind the copy: it does not wait for kernels queued after it). Returns at once when nothing is in flight. */
+int malio_scan_upload_wait(malio_handle_t h);
 
 /* ONE h_share_model pass (laserMapping.cpp:552-760) fused with the H^T R^-1 H / H^T R^-1 h
  * accumulation of esekfom.hpp:621-635. converge = ekfom_data.converge (search vs neighbour reuse,

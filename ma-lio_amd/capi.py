@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_spline_feed", "malio_spline_get_pose",
@@ -343,6 +343,10 @@ class Engine:
         tcp = _p(tc, Pose) if self.L > 1 else None
         self._keep = (tabs, tc)
         self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
+
+    def scan_upload_wait(self):
+        """malio_scan_upload_wait: the page-locked cloud handed to the last scan_set may be modified / freed after this."""
+        self._chk(lib().malio_scan_upload_wait(self.h), "malio_scan_upload_wait")
 
     def predict_chain(self, xs_flat, Ps, dts, accs, gyros, Q, want_states=True):
         """malio_predict_chain: tracks = len(xs_flat); dts/accs/gyros: per track arrays (K_t, K_t x 3, K_t x 3).

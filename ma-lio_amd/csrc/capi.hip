@@ -169,6 +169,7 @@ int malio_destroy(malio_handle_t h) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
+  if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
   return MALIO_OK;
@@ -514,7 +515,11 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     // back with the first pass (resolve_scan_segments). A pageable cloud would be staged by the runtime page by page
     // (~0.7 ms per 10 MB): it is packed here instead, in one pass over it.
     hipPointerAttribute_t attr;
-    const bool pinned = hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost;
+    bool pinned = hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (pinned) {  // ... and the last byte as well: a cloud that merely starts inside a registered range is staged like any other
+      const char *last = reinterpret_cast<const char *>(body) + sizeof(malio_point_t) * (size_t)n - 1;
+      pinned = hipPointerGetAttributes(&attr, last) == hipSuccess && attr.type == hipMemoryTypeHost;
+    }
     (void)hipGetLastError();
     if (pinned) {
       // (the pack kernel reading the page-locked cloud in place instead - no copy call, which costs this thread ~16 us -
@@ -525,6 +530,18 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
         MALIO_HIP(hipMalloc(&c->d_raw, sizeof(float) * 12 * c->cap_raw));
       }
       MALIO_HIP(hipMemcpyAsync(c->d_raw, body, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+      // the caller's buffer is in use until this event (include/malio.h: lifetime of feats_down_body)
+      if (!c->ev_upload) MALIO_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+      MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));
+      c->upload_in_flight = true;
+      if (c->scan_set_sync < 0) {
+        const char *e = getenv("MALIO_SCAN_SET_SYNC");
+        c->scan_set_sync = (e && e[0] == '1') ? 1 : 0;
+      }
+      if (c->scan_set_sync) {
+        MALIO_HIP(hipEventSynchronize(c->ev_upload));
+        c->upload_in_flight = false;
+      }
       const float *src = c->d_raw;
       if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
       MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
@@ -608,6 +625,16 @@ __global__ void __launch_bounds__(BLK) k_pack_resident(const float *__restrict__
   }
 }
 }  // namespace malio
+
+int malio_scan_upload_wait(malio_handle_t h) {
+  if (check(h)) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  if (!c->upload_in_flight || !c->ev_upload) return MALIO_OK;
+  MALIO_HIP(hipSetDevice(c->device));
+  MALIO_HIP(hipEventSynchronize(c->ev_upload));
+  c->upload_in_flight = false;
+  return MALIO_OK;
+}
 
 int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const malio_pose_t *const *pose_unc,
                             const int *pose_unc_len, const malio_pose_t *temporal_comp, malio_point_t *out_body, int cap,
@@ -973,7 +1000,7 @@ int malio_debug_counters(malio_handle_t h, int *out8) {
   if (check(h) || !out8) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
   if (int rc = map_apply_finish(c)) return rc;
-  out8[0] = (int)c->nl1.ncells, out8[1] = (int)(c->nl1.entries / 27), out8[2] = (int)c->nl2.ncells;
+  out8[0] = (int)c->nl1.ncells, out8[1] = c->map_n - c->map_dead, out8[2] = (int)c->nl2.ncells;
   out8[3] = c->n_rebuilds, out8[4] = c->n_inplace, out8[5] = c->map_dead, out8[6] = c->nl_tomb, out8[7] = c->map_n;
   return MALIO_OK;
 }

@@ -12,6 +12,7 @@
 // glibc: <= 1-2 ulp each), so states agree to ~1e-15 relative rather than bit for bit.
 // esekfom.hpp line numbers as in host/ieskf.cpp.
 #include <chrono>
+#include <unistd.h>
 #include "malio_internal.hpp"
 #include <immintrin.h>
 #include "../host/manifold.hpp"
@@ -600,6 +601,8 @@ int ensure_gate_buffers(Ctx *c) {
       }
     }
     c->gate_stage.assign(hdr, 0.0);
+    if (const char *e = getenv("MALIO_GATE_TIMEOUT_MS")) c->gate_timeout_ticks = (long long)(atof(e) * 1e5);  // 100 MHz
+    if (const char *e = getenv("MALIO_DEBUG_GATE_STALL_MS")) c->gate_debug_stall_ms = atoi(e);
   }
   return MALIO_OK;
 }
@@ -637,6 +640,8 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   malio_state_t x_ = *xio;
   const malio_state_t x_prop = x_;
   std::vector<double> P_prop;  // (copied once pass 0 is on its way)
+  std::vector<double> P_work;  // what the iterations leave; reaches the caller's P on the success path only (an early
+  bool P_written = false;      // MALIO_SMALL_M_FALLBACK or an error returns x and P as they came in)
   int converge = 1, t = 0, passes = 0, searches = 0, lastM = 0;
   bool done = false;
   double solve = 0;
@@ -675,6 +680,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   g.msg_seq = reinterpret_cast<int *>(c->d_gate + sizeof(double) * hdr + 128);
   g.ndoubles = (int)hdr;
   g.ticket = c->d_gate_ticket;
+  g.timeout_ticks = c->gate_timeout_ticks;
   auto set_gate = [&](int p) { g.publish = base + p, g.wait_for = base + p + 1; };
   auto enqueue_unit = [&](int p) -> int {  // pass p >= 1; gate p + 1 is the last workgroup of its last kernel
     set_gate(p + 1);
@@ -712,8 +718,13 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     while (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) != base + p + 1) {
       if ((++spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
         if (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) == base + p + 1) break;
-        c->err = "malio_update_iterated: the gated chain ended without publishing a pass";
-        return MALIO_ERR_HIP;
+        // The queue drained without this pass' word: a gate gave up waiting for this thread (descheduled, stopped in a
+        // debugger: gate_body's timeout) and the rest of the chain returned at once - or the stream failed. The first
+        // is no reason to fail the filter update: x and P are still the caller's, the host-driven loop redoes it.
+        MALIO_HIP(hipStreamSynchronize(c->stream));  // (a failed stream surfaces here)
+        if (int rcr = reset_pass_state(c)) return rcr;
+        c->gate_timeouts++;
+        return MALIO_SMALL_M_FALLBACK;
       }
       __builtin_ia32_pause();
     }
@@ -736,14 +747,17 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       }
       t0 = std::chrono::steady_clock::now();
       int dn = 0;
-      rc = ieskf_step_post(L, maximum_iter, limit, i, &x_, &x_prop, pre, mo.HtRinvH, mo.HtRinvh, &t, &converge, &dn, Pio);
+      if (!P_written) P_work.resize((size_t)n * n);
+      rc = ieskf_step_post(L, maximum_iter, limit, i, &x_, &x_prop, pre, mo.HtRinvH, mo.HtRinvh, &t, &converge, &dn, P_work.data());
       solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (rc != MALIO_OK) {
         rc_out = rc;
         break;
       }
+      P_written = true;
       done = dn != 0;
     }
+    if (c->gate_debug_stall_ms > 0 && p == 1) usleep(1000 * (useconds_t)c->gate_debug_stall_ms);
     if (!done && i + 1 < maximum_iter) publish(p + 1, false);
     if (ntr + 1 <= 60) tr[ntr++] = now_us() - t_begin;
   }
@@ -755,6 +769,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   }
   if (rc_out != MALIO_OK) return rc_out;
   *xio = x_;
+  if (P_written) memcpy(Pio, P_work.data(), sizeof(double) * (size_t)n * n);
   if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
   if (solve_time) *solve_time += solve;
   return MALIO_OK;

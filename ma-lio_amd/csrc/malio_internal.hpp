@@ -48,7 +48,7 @@ struct NList {
   u32 *inc = nullptr;     // [table size] entries the batch being applied brings to each list (zero between batches)
   u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells
   size_t total = 0;       // entries reserved by the lists built last (capacities)
-  size_t entries = 0;     // live entries at build time (27 per point)
+  size_t entries = 0;     // live entries at build time (27 per point for whole blocks; ~20.6 when pruned)
   size_t cap_pts = 0, cap_table = 0;
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
   bool pruned = false;    // lists hold the points within one cell edge of the cell instead of the whole 3x3x3 block
@@ -233,11 +233,13 @@ struct GateArgs {
   int *msg_seq;        // pinned: sequence word the GPU publishes
   u32 *ticket;         // device counter of the kernel the gate rides on (k_final_reduce: its last workgroup is the gate)
   int publish, wait_for, ndoubles;
+  long long timeout_ticks;  // 100 MHz ticks the gate waits for the host (0: GATE_TIMEOUT_US)
 };
+constexpr long long GATE_TIMEOUT_US = 200000;  // default; MALIO_GATE_TIMEOUT_MS overrides it per handle
 #if defined(__HIP__)
-constexpr long long GATE_TIMEOUT_US = 200000;
-// called by every thread of ONE workgroup (256 threads); a gate gives up after GATE_TIMEOUT_US (the host died or
-// returned): the rest of the chain then drains as on `done`
+// called by every thread of ONE workgroup (256 threads); a gate gives up after its timeout (the host died, returned, or
+// was descheduled for that long): the rest of the chain then drains as on `done`, and a host that is still there redoes
+// the update with the host-driven loop (ieskf_update_gated)
 __device__ inline void gate_body(const GateArgs &g) {
   __shared__ int s_gate_ok;
   if (threadIdx.x == 0) {
@@ -248,7 +250,7 @@ __device__ inline void gate_body(const GateArgs &g) {
     const long long t0 = wall_clock64();
     int ok = 1;
     while (__hip_atomic_load(g.cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != g.wait_for) {
-      if (wall_clock64() - t0 > GATE_TIMEOUT_US * 100) {  // 100 MHz
+      if (wall_clock64() - t0 > (g.timeout_ticks > 0 ? g.timeout_ticks : GATE_TIMEOUT_US * 100)) {  // 100 MHz
         ok = 0;
         break;
       }
@@ -356,6 +358,9 @@ struct Ctx {
   u32 *h_mbox = nullptr, *d_mbox = nullptr;  // pinned + device alias: small results for the host (counts), written
                                              // by kernels or copies; one stream sync serves all
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
+  hipEvent_t ev_upload = nullptr;  // recorded behind the DMA copy of a page-locked cloud (malio_scan_set): until then the
+  bool upload_in_flight = false;   // caller's buffer is in use (malio_scan_upload_wait)
+  int scan_set_sync = -1;          // MALIO_SCAN_SET_SYNC=1: malio_scan_set waits for that copy itself (-1: not read yet)
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool apply_pending = false;  // an in-place list update is queued, its verdict (fitted / overflowed) not read yet
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
@@ -432,6 +437,9 @@ struct Ctx {
   char *d_cmd = nullptr;
   std::vector<double> gate_stage;  // the block as the host composes it, before it goes out in one piece
   int gate_epoch = 1;
+  long long gate_timeout_ticks = 0;  // MALIO_GATE_TIMEOUT_MS (0: the default)
+  int gate_debug_stall_ms = 0;       // MALIO_DEBUG_GATE_STALL_MS: the host sleeps before publishing pass 2 (tests the timeout path)
+  int gate_timeouts = 0;             // updates that fell back to the host-driven loop because a gate gave up
   double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
   int gate_trace_n = 0;
   int update_mode = MALIO_UPDATE_GATED;  // malio_set_update_mode
@@ -519,6 +527,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
 // to d_mm_out)
 int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows,
                 const GateArgs *gate = nullptr);  // gate: the last kernel announces its completion (see k_final_reduce)
+int reset_pass_state(Ctx *c);  // measure.hip: extrema slots, deferral counters and parities as a fresh handle has them
 int ensure_gate_buffers(Ctx *c);  // ieskf_dev.hip: pinned sequence words + control block, ticket counter
 int gate_words(Ctx *c, volatile int **host_msg, int **dev_msg);
 int sums_len(const Ctx *c);

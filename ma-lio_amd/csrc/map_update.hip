@@ -499,9 +499,18 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   exclusive_scan_u32(c, addf, apos, tiles, m + 1, mbd + 8, counters, 2);
   e = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = hipGetLastError();
-  MALIO_HIP(e);
+  // From here until map_apply's kill kernel has consumed them, k_vox_add's marks are set in the persistent array: every
+  // way out that does not reach that kernel clears them, or the next batch would skip those still-live map points
+  // (`if (del[mi]) continue` in k_vox_add) and replay the keeper rule on a voxel with holes.
+  auto clear_marks = [&] { (void)hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream); };
+  if (e != hipSuccess) {
+    clear_marks();
+    MALIO_HIP(e);
+  }
   if (out_added) *out_added = (int)h_tot[1];
-  return map_apply(c, dlist, h_tot[2], d_new, addf, apos, m, h_tot[0]);
+  rc = map_apply(c, dlist, h_tot[2], d_new, addf, apos, m, h_tot[0]);
+  if (rc != MALIO_OK) clear_marks();  // (after the kill kernel ran this clears zeros)
+  return rc;
 }
 
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted) {

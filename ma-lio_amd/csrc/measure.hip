@@ -1560,6 +1560,18 @@ int measure_alloc(Ctx *c) {
   return MALIO_OK;
 }
 
+// After a chain of enqueued passes ended out of step with the host's bookkeeping (a gate that gave up): both extrema
+// slot sets and the deferral counters cleared, parities back to zero, no pending normal_y fold.
+int reset_pass_state(Ctx *c) {
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_mmslots) hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
+  if (c->d_dq_ctl) MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
+  if (c->d_gate_ticket) MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  c->mm_parity = 0, c->dq_parity = 0, c->last_M = -1;
+  return MALIO_OK;
+}
+
 // ---- once-per-scan grouping of the scan -------------------------------------------------------------------------------
 // What the search pass wants from the order of the scan: the points of one LiDAR slot contiguous, slots ascending
 // (k_rows_reduce works on per-slot blocks), queries of the same level-1 map cell adjacent (their list reads coalesce and

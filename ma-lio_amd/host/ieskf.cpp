@@ -375,6 +375,11 @@ int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn 
   malio_state_t x_ = *xio;
   const malio_state_t x_propagated = x_;
   const Mat P_prop(Pio, Pio + (size_t)n * n);
+  // The covariance of the iterations goes to a local buffer and reaches the caller's P on the success path only: an early
+  // return (MALIO_SMALL_M_FALLBACK when a LATER pass accepts fewer points than states, an error) leaves x and P as they
+  // came in - the caller redoes the update from them.
+  Mat P_work;
+  bool P_written = false;
   int converge = 1, t = 0, passes = 0, searches = 0, lastM = 0;
   double solve = 0;
   malio_measure_out_t mo;
@@ -440,14 +445,17 @@ int ieskf_update_fn(const malio_params_t &prm, const PassFn &pass, const PassFn 
       gain = normal_eq_gain(L, mo.HtRinvH, mo.HtRinvh);
     }
     int done = 0;
-    rc = step_core(L, maximum_iter, limit, i, &x_, &x_propagated, P_prop.data(), gain, &t, &converge, &done, Pio);
+    if (!P_written) P_work.resize((size_t)n * n);
+    rc = step_core(L, maximum_iter, limit, i, &x_, &x_propagated, P_prop.data(), gain, &t, &converge, &done, P_work.data());
     solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != MALIO_OK) return rc;
+    P_written = true;
     if (done) break;
   }
-  // When the loop ran out without `done` (its last pass was invalid), Pio holds what the last VALID iteration left in
+  // When the loop ran out without `done` (its last pass was invalid), P holds what the last VALID iteration left in
   // the reference's member P_: the projected P_propagated (step_core); with no valid pass at all it is untouched.
   *xio = x_;
+  if (P_written) memcpy(Pio, P_work.data(), sizeof(double) * (size_t)n * n);
   if (stats) stats[0] = passes, stats[1] = searches, stats[2] = lastM, stats[3] = t;
   if (solve_time) *solve_time += solve;
   return MALIO_OK;

@@ -234,3 +234,33 @@ def test_node_handle_two_gpus_over_rccl(capi, scenes, partition):
     assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
     assert np.abs(u["state"] - v["state"]).max() < 1e-8
     nd.close()
+
+
+@pytest.mark.gpu
+def test_node_update_small_M_on_a_later_pass_leaves_inputs_untouched(capi, scenes):
+    """malio_node_update_iterated has no rows path: a pass that accepts fewer points than there are states returns
+    MALIO_SMALL_M_FALLBACK - also when it is a LATER pass of the loop, after valid iterations have produced projected
+    covariances. The caller redoes the update from (x, P): both must come back exactly as they went in. A pass hook
+    empties the map around the scan before the second search pass, so that pass keeps a handful of points."""
+    sc = scenes.make_scene(seed=318, N=3000, Nmap=60000, L=3)
+    nd = capi.Node(sc["params"], [0, 0], partition=capi.PART_SCAN)
+    nd.map_build(sc["map"])
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    c = sc["state_gt"][0:3]
+    # everything but a thin slab of ground far from the sensor
+    boxes = np.array([[c[0] - 500, c[1] - 500, c[2] - 50, c[0] + 500, c[1] + 60, c[2] + 50],
+                      [c[0] - 500, c[1] + 61.5, c[2] - 50, c[0] + 500, c[1] + 500, c[2] + 50]], np.float32)
+    seen = []
+
+    def hook(k):
+        seen.append(k)
+        if k == 2:
+            nd.map_delete_boxes(boxes)
+    nd.set_pass_hook(hook)
+    P0 = sc["P0"].copy()
+    v = nd.update_iterated(sc["state0"], P0)
+    nd.set_pass_hook(None)
+    assert seen[:3] == [0, 1, 2]
+    assert v["rc"] == capi.SMALL_M_FALLBACK, v
+    assert np.array_equal(v["P"], sc["P0"]) and np.array_equal(v["state"], sc["state0"])
+    nd.close()
