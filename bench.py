@@ -35,7 +35,9 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 ALG_BYTES_SEARCH_PASS = 120.0  # algorithmic bytes per scan point of a search pass
-DOMINANT_KERNEL = "k_search"
+# One launch per pass from the second pass of a scan on (k_pass: a1-a10 with the extrema speculated); the
+# first pass of a scan - and every pass under MALIO_FUSE=0 - is k_search -> k_rows_reduce -> k_final_reduce.
+DOMINANT_KERNELS = ("k_pass", "k_search")
 PROFILE_ROUND, PROFILE_TAG = "round2", "r02"  # the committed rocprofv3 / PMC summaries the roofline block cites
 
 
@@ -416,6 +418,7 @@ def roofline_block(eng, state, args, n_points):
             per.setdefault(name, []).append(ms)
     eng.set_profiling(False)
     kt = {k: float(np.mean(v)) for k, v in per.items()}
+    DOMINANT_KERNEL = next((k for k in DOMINANT_KERNELS if k in kt and len(per[k]) >= len(per.get("k_search", []))), "k_search")
     dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
     achieved = ALG_BYTES_SEARCH_PASS * n_points / (dom_ms * 1e-3) / 1e9
     # PMC counters and rocprofv3's own kernel durations cannot be collected from inside this process: they come from

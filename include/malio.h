@@ -128,6 +128,10 @@ typedef struct malio_measure_out {
 int malio_create(const malio_params_t *params, int device, malio_handle_t *out);
 int malio_destroy(malio_handle_t h);
 const char *malio_version(void);
+/* HIP devices this process can use (0: none - malio_create would return MALIO_ERR_NO_DEVICE). Asked of the library's own
+ * HIP runtime: a caller that probes through a second copy of libamdhip64 (another search path, another version)
+ * initialises a second runtime in the process, and the one that comes second finds no device. */
+int malio_device_count(void);
 const char *malio_last_error(malio_handle_t h);
 /* external != 0: run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream; the value 0 /
  * NULL then means the legacy default stream, which is what PyTorch uses unless told otherwise).
@@ -514,6 +518,10 @@ int malio_set_profiling(malio_handle_t h, int on);
  * full list rebuilds so far, map changes applied to the lists in place so far, deleted slots awaiting compaction,
  * tombstoned points in the lists, map slots in use}. */
 int malio_debug_counters(malio_handle_t h, int *out8);
+/* {passes that ran as ONE kernel (the extrema of laserMapping.cpp:625-628,646-647 guessed from the previous pass of the
+ * scan), guesses that held, guesses that missed (the rows of that pass were redone with the true extrema), gated updates
+ * redone by the host-driven loop after a gate timed out}. MALIO_FUSE=0 in the environment disables the one-kernel pass. */
+int malio_debug_fuse_stats(malio_handle_t h, int *out4);
 
 #ifdef __cplusplus
 }

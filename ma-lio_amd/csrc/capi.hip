@@ -117,6 +117,15 @@ extern "C" {
 
 const char *malio_version(void) { return "malio-hip 0.1 (gfx950, ABI 1)"; }
 
+int malio_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 const char *malio_last_error(malio_handle_t h) { return h ? h->err.c_str() : "null handle"; }
 
 int malio_create(const malio_params_t *params, int device, malio_handle_t *out) {
@@ -427,6 +436,7 @@ static int scan_reset(Ctx *c) {
   c->nbr_epoch = c->map_epoch;
   c->scan_sorted = false;
   c->last_M = -1;
+  c->mm_guess_valid = false;  // the first pass of a scan runs as three kernels and leaves the first guess
   return MALIO_OK;
 }
 
@@ -810,8 +820,6 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   const bool want_rows = out->h_x || out->h || out->R;
   prof_begin(c);
   const int ns = sums_len(c);
-  int rc = pass_stage1(c, s, converge, nullptr);
-  if (rc != MALIO_OK) return rc;
   // The two result kernels store straight into pinned, device-mapped host memory (2.4 KB over PCIe): no copy kernel
   // between the last kernel and the host (worth ~1 us per pass).
   // How the call learns that the pass is over: the last workgroup of the last kernel stores a sequence word into pinned
@@ -820,15 +828,19 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   volatile int *h_msg = nullptr;
   GateArgs gate{};
   const bool poll = !c->profiling && !want_rows;
-  if (poll) {
+  auto arm = [&]() -> int {  // a fresh sequence number for the kernel that ends the pass
+    if (!poll) return MALIO_OK;
     int *d_msg = nullptr;
-    if ((rc = gate_words(c, &h_msg, &d_msg)) != MALIO_OK) return rc;
+    if (int rcg = gate_words(c, &h_msg, &d_msg)) return rcg;
     c->gate_epoch = c->gate_epoch >= (1 << 30) ? 1 : c->gate_epoch + 1;
     gate.msg_seq = d_msg, gate.ticket = c->d_gate_ticket, gate.publish = c->gate_epoch;
-  }
-  rc = pass_stage2(c, nullptr, c->d_res + ns, c->d_res, want_rows, poll ? &gate : nullptr);
-  if (rc != MALIO_OK) return rc;
-  if (poll) {
+    return MALIO_OK;
+  };
+  auto wait = [&]() -> int {
+    if (!poll) {
+      MALIO_HIP(hipStreamSynchronize(c->stream));
+      return MALIO_OK;
+    }
     long long spins = 0;
     while (__atomic_load_n(const_cast<int *>(h_msg), __ATOMIC_ACQUIRE) != gate.publish) {
       if ((++spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
@@ -839,13 +851,39 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
       }
       __builtin_ia32_pause();
     }
+    return MALIO_OK;
+  };
+  int rc;
+  const double *res = c->h_res;
+  std::vector<double> &fsums = c->fuse_sums;
+  bool need_stage2 = true;
+  if (!want_rows && fuse_eligible(c, converge)) {
+    // ONE kernel (k_pass): the rows are weighted with the extrema of the previous pass of this scan; the host adds the
+    // group nodes and checks the guess. A miss (rare: an extreme point changed sides) costs the two kernels below.
+    if ((rc = arm()) != MALIO_OK) return rc;
+    if (!poll) gate.msg_seq = nullptr;
+    if ((rc = pass_fused(c, s, converge, poll ? &gate : nullptr)) != MALIO_OK) return rc;
+    if ((rc = wait()) != MALIO_OK) return rc;
+    fsums.resize((size_t)ns + 8);
+    bool hit = false;
+    fused_collect(c, fsums.data(), &hit);
+    if (hit) res = fsums.data(), need_stage2 = false;
   } else {
-    MALIO_HIP(hipStreamSynchronize(c->stream));
+    rc = pass_stage1(c, s, converge, nullptr);
+    if (rc != MALIO_OK) return rc;
+  }
+  if (need_stage2) {
+    if ((rc = arm()) != MALIO_OK) return rc;
+    rc = pass_stage2(c, nullptr, c->d_res + ns, c->d_res, want_rows, poll ? &gate : nullptr);
+    if (rc != MALIO_OK) return rc;
+    if ((rc = wait()) != MALIO_OK) return rc;
+    res = c->h_res;
   }
   prof_end(c);
-  const double *res = c->h_res;
   rc = finish_host(c, res, res + ns, out);
   c->last_M = out->M;
+  memcpy(c->mm_guess, res + ns, sizeof(double) * 4);  // the next pass of this scan speculates on these
+  c->mm_guess_valid = true;
   // k_search_tail is launched with the next search pass only while search passes keep meeting workgroups full of
   // uncertified queries (word 5 after the sums); without it such workgroups serve their queries themselves
   if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;
@@ -1002,6 +1040,14 @@ int malio_debug_counters(malio_handle_t h, int *out8) {
   if (int rc = map_apply_finish(c)) return rc;
   out8[0] = (int)c->nl1.ncells, out8[1] = c->map_n - c->map_dead, out8[2] = (int)c->nl2.ncells;
   out8[3] = c->n_rebuilds, out8[4] = c->n_inplace, out8[5] = c->map_dead, out8[6] = c->nl_tomb, out8[7] = c->map_n;
+  return MALIO_OK;
+}
+
+// Diagnostics: {passes run as one kernel (k_pass), extrema guesses that held, guesses that missed (rows redone), gated
+// updates that fell back to the host-driven loop because a gate timed out}.
+int malio_debug_fuse_stats(malio_handle_t h, int *out4) {
+  if (check(h) || !out4) return MALIO_ERR_BAD_ARG;
+  out4[0] = h->fuse_passes, out4[1] = h->fuse_hits, out4[2] = h->fuse_misses, out4[3] = h->gate_timeouts;
   return MALIO_OK;
 }
 

@@ -632,8 +632,15 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   char *cmd_home = c->d_cmd ? c->d_cmd : c->h_gate;  // where the gate reads the block and its sequence word
   volatile int *cmd_seq = reinterpret_cast<volatile int *>(cmd_home + sizeof(double) * hdr);
   volatile int *msg_seq = reinterpret_cast<volatile int *>(c->h_gate + sizeof(double) * hdr + 128);
+  // The chain is made of UNITS: unit 0 is pass 0 with its arguments by value, every later unit is one pass reading the
+  // control block (one kernel - k_pass, speculating on the extrema - where that is possible, else the four kernels of
+  // enqueue_pass_dev), with a gate riding on its last workgroup. Unit u announces base + u + 1 and then waits for
+  // base + u + 2, the block of unit u + 1. A unit is normally the next pass of the loop; after a one-kernel pass whose
+  // guess of the extrema turned out wrong it is the SAME pass again (same state, neighbours and planes kept, rows
+  // weighted with the now known extrema), which the loop does not count.
+  const int max_units = 2 * (maximum_iter + 1) + 2;
   const int base = c->gate_epoch;
-  c->gate_epoch += maximum_iter + 4;
+  c->gate_epoch += max_units + 4;
   if (c->gate_epoch > (1 << 30)) c->gate_epoch = 1;
   const int ns_ = sums_len(c);
 
@@ -645,17 +652,23 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   int converge = 1, t = 0, passes = 0, searches = 0, lastM = 0;
   bool done = false;
   double solve = 0;
-  auto publish = [&](int p, bool stop) {  // the control block gate p waits for
+  auto publish = [&](int u, bool stop, bool redo) {  // the control block unit u runs on (the gate of unit u - 1 waits for it)
     memset(blk, 0, sizeof(DevLoop));
     blk->done = stop ? 1 : 0;
     if (!stop) {
-      blk->converge = converge, blk->L = L, blk->maximum_iter = maximum_iter, blk->extrinsic_est_en = c->prm.extrinsic_est_en;
+      blk->converge = redo ? 0 : converge;
+      blk->L = L, blk->maximum_iter = maximum_iter, blk->extrinsic_est_en = c->prm.extrinsic_est_en;
       c->mm_parity ^= 1;
-      if (converge) c->dq_parity ^= 1, c->nbr_epoch = c->map_epoch;
+      if (blk->converge) c->dq_parity ^= 1, c->nbr_epoch = c->map_epoch;
       blk->mm_parity = c->mm_parity, blk->dq_parity = c->dq_parity;
-      blk->commit_prev = c->last_M > 0 ? 1 : 0;
+      // (a repeated pass folds nothing: the pass it repeats has consumed the pending fold, and its own results are the
+      // repeat's results)
+      blk->commit_prev = (!redo && c->last_M > 0) ? 1 : 0;
       c->last_M = -1;
-      c->last_pass_search = converge != 0;
+      c->last_pass_search = blk->converge != 0;
+      memcpy(blk->mm_guess, c->mm_guess, sizeof(blk->mm_guess));
+      if (c->fuse_debug_bad_guess && !redo) blk->mm_guess[0] += 1.0;
+      memcpy(c->fuse_guess_used, blk->mm_guess, sizeof(blk->mm_guess));
       fill_quat_const(c, &x_, blk->qc);
       fill_pass_const(c, &x_, blk->pc);
     }
@@ -666,13 +679,9 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     memcpy(cmd_home + offsetof(DevLoop, qc), reinterpret_cast<const char *>(blk) + offsetof(DevLoop, qc),
            offsetof(DevLoop, loc_thresh_min) - offsetof(DevLoop, qc));
     _mm_sfence();
-    __atomic_store_n(const_cast<int *>(cmd_seq), base + p + 1, __ATOMIC_RELEASE);
+    __atomic_store_n(const_cast<int *>(cmd_seq), base + u + 1, __ATOMIC_RELEASE);
     _mm_sfence();
   };
-  // ---- the chain: pass 0 with its arguments by value, then units of [pass p | gate p + 1] (the gate is the last workgroup
-  // of the pass' last kernel) enqueued one pass ahead of the GPU: the launches of unit p + 1 and the first half of
-  // iteration p's algebra run on this thread while the GPU is busy with pass p; a loop that ends early leaves at most
-  // one unit of kernels behind, which exit at once ----
   GateArgs g;
   const char *cmd_dev = c->d_cmd ? c->d_cmd : c->d_gate;
   g.dl = c->d_loop, g.cmd = reinterpret_cast<const double *>(cmd_dev);
@@ -681,12 +690,19 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   g.ndoubles = (int)hdr;
   g.ticket = c->d_gate_ticket;
   g.timeout_ticks = c->gate_timeout_ticks;
-  auto set_gate = [&](int p) { g.publish = base + p, g.wait_for = base + p + 1; };
-  auto enqueue_unit = [&](int p) -> int {  // pass p >= 1; gate p + 1 is the last workgroup of its last kernel
-    set_gate(p + 1);
-    return enqueue_pass_dev(c, c->d_res, c->d_res + ns_, &g);
+  std::vector<char> unit_fused((size_t)max_units + 1, 0);
+  int u_enq = 1;  // units enqueued so far (unit 0 below)
+  auto enqueue_unit = [&]() -> int {
+    const int u = u_enq;
+    if (u >= max_units) return MALIO_ERR_BAD_ARG;
+    g.publish = base + u + 1, g.wait_for = base + u + 2;
+    // decided when the unit is enqueued, one pass ahead (the guess itself travels in the block)
+    const bool fused = fuse_eligible(c, /*converge: a search pass may come*/ 1, /*need_guess*/ false);
+    unit_fused[u] = fused ? 1 : 0;
+    u_enq++;
+    return fused ? enqueue_pass_fused_dev(c, &g) : enqueue_pass_dev(c, c->d_res, c->d_res + ns_, &g);
   };
-  set_gate(1);
+  g.publish = base + 1, g.wait_for = base + 2;
   if (int rc = pass_stage1(c, &x_, 1, nullptr)) return rc;
   if (int rc = pass_stage2(c, nullptr, c->d_res + ns_, c->d_res, false, &g)) return rc;
   P_prop.assign(Pio, Pio + (size_t)n * n);
@@ -698,26 +714,14 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   double *tr = c->gate_trace;
   int ntr = 0;
   const double t_begin = now_us();
-  for (int i = -1; i < maximum_iter && !done; i++) {
-    const int p = i + 1;
-    searches += converge ? 1 : 0;
-    if (ntr + 5 <= 60) tr[ntr++] = now_us() - t_begin;
-    if (p + 1 <= maximum_iter)
-      if (int rc = enqueue_unit(p + 1)) {
-        rc_out = rc;
-        passes = p + 1;
-        break;
-      }
-    auto t0 = std::chrono::steady_clock::now();
-    if (ntr + 4 <= 60) tr[ntr++] = now_us() - t_begin;
-    ieskf_step_pre(L, &x_, &x_prop, P_prop.data(), pre, true);  // :526-572 + the first inversion, under the GPU's pass
-    solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (ntr + 3 <= 60) tr[ntr++] = now_us() - t_begin;
-    // wait for gate p + 1 to announce the sums of pass p
+  std::vector<double> fsums((size_t)ns_ + 8);
+  int u = 0;  // the unit whose announcement the loop waits for next
+  // wait for unit `uu` to announce its sums; MALIO_SMALL_M_FALLBACK when the chain drained without it (gate timeout)
+  auto wait_unit = [&](int uu) -> int {
     long long spins = 0;
-    while (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) != base + p + 1) {
+    while (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) != base + uu + 1) {
       if ((++spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
-        if (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) == base + p + 1) break;
+        if (__atomic_load_n(const_cast<int *>(msg_seq), __ATOMIC_ACQUIRE) == base + uu + 1) break;
         // The queue drained without this pass' word: a gate gave up waiting for this thread (descheduled, stopped in a
         // debugger: gate_body's timeout) and the rest of the chain returned at once - or the stream failed. The first
         // is no reason to fail the filter update: x and P are still the caller's, the host-driven loop redoes it.
@@ -728,12 +732,62 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       }
       __builtin_ia32_pause();
     }
+    return MALIO_OK;
+  };
+  for (int i = -1; i < maximum_iter && !done; i++) {
+    const int p = i + 1;
+    searches += converge ? 1 : 0;
+    if (ntr + 5 <= 60) tr[ntr++] = now_us() - t_begin;
+    if (p + 1 <= maximum_iter && u_enq <= u + 1)  // the unit of pass p + 1, one ahead of the GPU
+      if (int rc = enqueue_unit()) {
+        rc_out = rc;
+        passes = p + 1;
+        break;
+      }
+    auto t0 = std::chrono::steady_clock::now();
+    if (ntr + 4 <= 60) tr[ntr++] = now_us() - t_begin;
+    ieskf_step_pre(L, &x_, &x_prop, P_prop.data(), pre, true);  // :526-572 + the first inversion, under the GPU's pass
+    solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ntr + 3 <= 60) tr[ntr++] = now_us() - t_begin;
+    const double *res = nullptr;
+    for (int attempt = 0;; attempt++) {  // the pass, and - rarely - its repeat with the right extrema
+      if (int rcw = wait_unit(u)) return rcw;
+      if (!unit_fused[u]) {
+        res = c->h_res;
+        break;
+      }
+      bool hit = false;
+      fused_collect(c, fsums.data(), &hit);
+      res = fsums.data();
+      if (hit) break;
+      if (attempt >= 2) {
+        c->err = "malio_update_iterated: the one-kernel pass keeps missing its own extrema";
+        rc_out = MALIO_ERR_HIP;
+        break;
+      }
+      // the guess missed: the next unit repeats this pass (reuse form, same state) with the extrema this one found
+      memcpy(c->mm_guess, res + ns_, sizeof(double) * 4);
+      c->mm_guess_valid = true;
+      if (u_enq <= u + 1)
+        if (int rc = enqueue_unit()) {
+          rc_out = rc;
+          break;
+        }
+      publish(u + 1, false, true);
+      u++;
+    }
+    if (rc_out != MALIO_OK) {
+      passes = p + 1;
+      break;
+    }
+    u++;
     passes++;
     if (ntr + 2 <= 60) tr[ntr++] = now_us() - t_begin;
     memset(&mo, 0, sizeof(mo));
-    const double *res = c->h_res;
     int rc = finish_host(c, res, res + ns_, &mo);
     c->last_M = mo.M;
+    memcpy(c->mm_guess, res + ns_, sizeof(double) * 4);
+    c->mm_guess_valid = true;
     if (converge) c->defer_enabled = res[ns_ + 5] >= DEFER_SCORE_MIN;
     if (rc < 0) {
       rc_out = rc;
@@ -758,11 +812,11 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       done = dn != 0;
     }
     if (c->gate_debug_stall_ms > 0 && p == 1) usleep(1000 * (useconds_t)c->gate_debug_stall_ms);
-    if (!done && i + 1 < maximum_iter) publish(p + 1, false);
+    if (!done && i + 1 < maximum_iter) publish(u, false, false);
     if (ntr + 1 <= 60) tr[ntr++] = now_us() - t_begin;
   }
   c->gate_trace_n = ntr;
-  publish(passes, true);  // the gate after the last pass that ran: everything behind it drains
+  publish(u, true, false);  // the gate of the last unit that ran: everything behind it drains
   if (rc_out == MALIO_SMALL_M_FALLBACK) {
     c->last_M = -1;
     return rc_out;

@@ -616,8 +616,10 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
 // a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
 __device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev, int i, const float4 w, double nb,
-                                            const u32 og[5], int nf, bool &selected, double &ucov, double &tr) {
+                                            const u32 og[5], int nf, bool &selected, double &ucov, double &tr, float4 &pl_out,
+                                            float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
+  pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
 #pragma unroll
   for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
   a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
@@ -654,19 +656,22 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev,
       const float4 m = a.map_in[og[k]];  // instead of two keeps the kernel at 6 waves per SIMD)
       if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
     }
-    a.plane[i] = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+    pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+    a.plane[i] = pl_out;
     a.ucov[i] = ucov;
     if (plane_ok) {
       float pd2;
       if (residual_gate(pabcd, w.x, w.y, w.z, nb, pd2)) {
         selected = true;
         a.pd2[i] = pd2;
+        pd2_out = pd2;
       }
     }
   }
   a.sel[i] = selected ? 1 : 0;
   PH(0, 7);
   const float4 q = a.scan[i];
+  q_out = q;
   const int packed = __float_as_int(q.w);
   tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
   a.trace[i] = tr;
@@ -675,10 +680,12 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev,
 // REUSE pass of one point (ekfom_data.converge == false, laserMapping.cpp:583-595): neighbours, plane and flag are kept; the
 // residual and the range gate are re-evaluated at the new state.
 __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst &qc, int commit_prev, int i, bool &selected,
-                                            double &ucov, double &tr) {
+                                            double &ucov, double &tr, float4 &pl_out, float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
+  pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f, q_out = pl_out;
   if (i >= a.N || a.nfound[i] == NF_NOTMINE) return;  // (a partitioned handle keeps serving the points of its last search pass)
   const float4 q = a.scan[i];
+  q_out = q;
   const int packed = __float_as_int(q.w);
   const int lid = packed & 0xFF, tidx = packed >> 8;
   float wx, wy, wz;
@@ -688,12 +695,14 @@ __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst 
   commit_normal_y(a, commit_prev, i);
   if (a.sel[i]) {
     const float4 pl = a.plane[i];
+    pl_out = pl;
     const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
     ucov = a.ucov[i];
     float pd2;
     if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
       selected = true;
       a.pd2[i] = pd2;
+      pd2_out = pd2;
     }
   }
   a.sel[i] = selected ? 1 : 0;
@@ -727,48 +736,32 @@ constexpr int KS_WAVES = KS_BLK / 64;
 #ifndef KS_WPE
 #define KS_WPE 7
 #endif
-// DEV = true: one pass of the device-resident update loop (DevLoop): exits when the loop is over, runs the REUSE pass on
-// its first wave when the control block asks for one (a reuse pass then costs one launch of this grid, no second
-// kernel that would have to be enqueued and skipped), and takes state, parities and commit_prev from the block.
+// what the control wave (wave 0) of a workgroup knows about its lane's query after the point phase
+struct PointOut {
+  bool selected;
+  double ucov, tr;
+  float4 pl, q;  // plane (n, d) and the scan point (body frame, packed slot word): what the row of a5 is built from
+  float pd2;
+};
+struct SearchLds {
+  float4 w[SQ];
+  u32 og[5][SQ];
+  unsigned char nf[SQ];
+  double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
+};
+// Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns true in the control wave (with its
+// lane's PointOut filled), false in the three search waves once they have nothing left to do.
 template <bool DEV>
-__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
-  __shared__ float4 s_w[SQ];
-  __shared__ u32 s_og[5][SQ];
-  __shared__ unsigned char s_nf[SQ];
-  __shared__ double s_nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
-  if (DEV && a.dl->done) return;
-  const QuatConst &qc = DEV ? a.dl->qc : a.qc;
-  const PassDyn dy = pass_dyn<DEV>(a);
-  // query of local slot l (one per lane of the control wave)
-#ifdef KS_CHUNKS
-  // balance: the four 16-query chunks of a workgroup come from four distant places of the sorted scan (one per search
-  // wave, so a wave's list reads stay coherent), instead of 64 consecutive queries that share a dense or a sparse region
-  const int nchunk_wg = (int)gridDim.x;
-  auto qidx = [&](int l) { return (((int)blockIdx.x + (l >> 4) * nchunk_wg) << 4) + (l & 15); };
-#else
-  const int q0 = blockIdx.x * SQ;
+__device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
+                                          const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
   auto qidx = [&](int l) { return q0 + l; };
-#endif
-#ifdef KS_CW
-  const int cw = (int)(blockIdx.x & (KS_WAVES - 1));  // the wave that runs the per-query phases A and C
-#else
-  const int cw = 0;
-#endif
   const int lane_ = (int)(threadIdx.x & 63);
-  const bool cwave = (int)(threadIdx.x >> 6) == cw;
+  const bool cwave = (int)(threadIdx.x >> 6) == 0;
+  po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
+  po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
   // ---- phase A ----
   const int i = qidx(lane_);  // meaningful for the control wave only
-  if (DEV && !a.dl->converge) {  // REUSE pass: thread = point, so the first quarter of the grid does all of it
-    const int base = (int)(blockIdx.x * KS_BLK);
-    if (base >= a.N) return;
-    bool selected;
-    double ucov, tr;
-    reuse_point(a, qc, dy.commit_prev, base + (int)threadIdx.x, selected, ucov, tr);
-    wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);
-    if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
-    return;
-  }
-  bool mine = cwave && i < a.N;
+  bool mine = cwave && i < qend;
   PH(0, 0);
   PH_ENTER();
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
@@ -782,28 +775,28 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
-      s_nb[lane_] = nb;
+      S.nb[lane_] = nb;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
         mine = false;
         a.nfound[i] = NF_NOTMINE, a.sel[i] = 0;
         w = make_float4(3e9f, 3e9f, 3e9f, 0.f);  // far from every list: its search lanes find an empty cell
       }
     }
-    s_w[lane_] = w;
+    S.w[lane_] = w;
   }
-  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) return;  // a workgroup of somebody else's tiles
+  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) return false;  // a workgroup of somebody else's tiles
   __syncthreads();
   PH(0, 1);
   // ---- phase B ----
   {
     const int ql = threadIdx.x / NL1_G, sub = threadIdx.x % NL1_G;
-    const float4 ww = s_w[ql];
+    const float4 ww = S.w[ql];
     Top5 t;
     const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t);
     if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) s_og[k][ql] = t.og(k);
-      s_nf[ql] = certified ? 5 : NF_PENDING;
+      for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
+      S.nf[ql] = certified ? 5 : NF_PENDING;
     }
   }
   __syncthreads();
@@ -816,7 +809,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lane <-> query, the same in every wave (a point of another shard sits at 3e9 and is never searched further)
-    const bool pend = (qidx(lane) < a.N) && s_nf[lane] == NF_PENDING && s_w[lane].x < 1e9f;
+    const bool pend = (qidx(lane) < qend) && S.nf[lane] == NF_PENDING && S.w[lane].x < 1e9f;
     unsigned long long todo = __ballot(pend);
     // every wave must have taken its snapshot of the flags before any wave rewrites one (the serving wave stores the
     // final count, wave 0 stores NF_DEFERRED): a wave that read s_nf late would see a different `todo`, the round-robin
@@ -837,7 +830,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
           base = __shfl(base, 0);
           if (pend) {
             a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)qidx(lane);
-            s_nf[lane] = NF_DEFERRED;
+            S.nf[lane] = NF_DEFERRED;
           }
         }
       } else {
@@ -846,35 +839,60 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
           const int l = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
           if ((ord++ % KS_WAVES) != wave) continue;
-          const float4 ww = s_w[l];
+          const float4 ww = S.w[l];
           Top5 t;
           nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
           if (lane < 5) {
-            s_og[lane][l] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
+            S.og[lane][l] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
           } else if (lane == 5) {
             int nf = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
-            s_nf[l] = (unsigned char)nf;
+            S.nf[l] = (unsigned char)nf;
           }
         }
       }
       __syncthreads();
     }
   }
-  if (!cwave) return;
+  if (!cwave) return false;
   // ---- phase C (control wave) ----
   const int lane = lane_;
   u32 og[5];
 #pragma unroll
-  for (int k = 0; k < 5; k++) og[k] = s_og[k][lane];
-  const int nf = s_nf[lane];
+  for (int k = 0; k < 5; k++) og[k] = S.og[k][lane];
+  const int nf = S.nf[lane];
   PH(0, 3);
-  bool selected = false;
-  double ucov = 0.0, tr = 0.0;
-  if (mine && nf != NF_DEFERRED) point_phase(a, dy.commit_prev, i, s_w[lane], s_nb[lane], og, nf, selected, ucov, tr);
+  if (mine && nf != NF_DEFERRED)
+    point_phase(a, dy.commit_prev, i, S.w[lane], S.nb[lane], og, nf, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   PH(0, 8);
-  wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);  // a4 over this wave's 64 queries
+  return true;
+}
+
+// DEV = true: one pass of the device-resident update loop (DevLoop): exits when the loop is over, runs the REUSE pass on
+// its first wave when the control block asks for one (a reuse pass then costs one launch of this grid, no second
+// kernel that would have to be enqueued and skipped), and takes state, parities and commit_prev from the block.
+template <bool DEV>
+__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
+  __shared__ SearchLds S;
+  if (DEV && a.dl->done) return;
+  const QuatConst &qc = DEV ? a.dl->qc : a.qc;
+  const PassDyn dy = pass_dyn<DEV>(a);
+  if (DEV && !a.dl->converge) {  // REUSE pass: thread = point, so the first quarter of the grid does all of it
+    const int base = (int)(blockIdx.x * KS_BLK);
+    if (base >= a.N) return;
+    bool selected;
+    double ucov, tr;
+    float4 pl, q;
+    float pd2;
+    reuse_point(a, qc, dy.commit_prev, base + (int)threadIdx.x, selected, ucov, tr, pl, pd2, q);
+    wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);
+    if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
+    return;
+  }
+  PointOut po;
+  if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po)) return;
+  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4 over this wave's 64 queries
   PH(0, 9);
   PH_EXIT();
 }
@@ -915,7 +933,9 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
         float wx, wy, wz;
         world_point(qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
       }
-      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, selected, ucov, tr);
+      float4 pl_, q_;
+      float pd2_;
+      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, selected, ucov, tr, pl_, pd2_, q_);
       if (selected) {
         nsel++;
         mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -936,7 +956,9 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
   const PassDyn dy = pass_dyn<false>(a);
   bool selected;
   double ucov, tr;
-  reuse_point(a, a.qc, dy.commit_prev, i, selected, ucov, tr);
+  float4 pl, q;
+  float pd2;
+  reuse_point(a, a.qc, dy.commit_prev, i, selected, ucov, tr, pl, pd2, q);
   block_minmax(a, dy, selected, ucov, tr);
 }
 
@@ -987,8 +1009,8 @@ struct RowIn {
   double ucov, trace;
   float pd2;
 };
-__device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &pc, const double mm[4], const RowIn &in, int lid,
-                                          double u[12], double &hs, double &r) {
+__device__ __forceinline__ void point_row(const WeightConst &wc, int extrinsic_est_en, const PassConst &pc, const double mm[4],
+                                          const RowIn &in, int lid, double u[12], double &hs, double &r) {
   const float4 q = in.q;
   const float4 pl = in.pl;
   const double max_u = mm[0], min_u = -mm[1], max_c = mm[2], min_c = -mm[3];
@@ -997,9 +1019,9 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &p
   if (cp == 0)
     cp = 1;
   else if (max_u == min_u)
-    cp = (a.wc.plane_cov_max + a.wc.plane_cov_min) / 2;
+    cp = (wc.plane_cov_max + wc.plane_cov_min) / 2;
   else
-    cp = 1 / ((a.wc.plane_cov_max - a.wc.plane_cov_min) * (cp - min_u) / (max_u - min_u) + a.wc.plane_cov_min);
+    cp = 1 / ((wc.plane_cov_max - wc.plane_cov_min) * (cp - min_u) / (max_u - min_u) + wc.plane_cov_min);
   // geometry (:658-693)
   D3 p{(double)q.x, (double)q.y, (double)q.z};
   const LidarConst &lc = pc.lid[lid];
@@ -1017,7 +1039,7 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &p
   D3 Cv = mulRt(pc.Rw, n);  // s.rot.conjugate() * norm_vec (:676)
   D3 A = cross(X, Cv);        // point_crossmat * C (:677)
   D3 B{0, 0, 0}, Cb{0, 0, 0};
-  if (a.extrinsic_est_en) {
+  if (extrinsic_est_en) {
     if (lid == 0) {
       B = cross(p_be, mulRt(pc.R0, Cv));  // :684
       Cb = Cv;
@@ -1032,15 +1054,15 @@ __device__ __forceinline__ void point_row(const Pass2Args &a, const PassConst &p
   u[9] = Cb.x * cp, u[10] = Cb.y * cp, u[11] = Cb.z * cp;
   hs = (-1.0) * (double)in.pd2 * cp;  // :707,715
   // point noise R_i by FIC (:716-721)
-  double R = a.extrinsic_est_en ? in.trace : 0.0;
-  const double lo = min_c + (max_c - min_c) * a.wc.range_min, hi = min_c + (max_c - min_c) * a.wc.range_max;
+  double R = extrinsic_est_en ? in.trace : 0.0;
+  const double lo = min_c + (max_c - min_c) * wc.range_min, hi = min_c + (max_c - min_c) * wc.range_max;
   if (R < lo)
-    R = a.wc.point_cov_min;
+    R = wc.point_cov_min;
   else if (R > hi)
-    R = a.wc.point_cov_max;
+    R = wc.point_cov_max;
   else
-    R = (a.wc.point_cov_max - a.wc.point_cov_min) * (R - lo) / ((a.wc.range_max - a.wc.range_min) * (max_c - min_c)) +
-        a.wc.point_cov_min;
+    R = (wc.point_cov_max - wc.point_cov_min) * (R - lo) / ((wc.range_max - wc.range_min) * (max_c - min_c)) +
+        wc.point_cov_min;
   r = R;
 }
 
@@ -1102,7 +1124,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   double u[12], hs = 0, r = 1;
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
-  if (selected) point_row(a, pc, mm, rin, lid, u, hs, r);
+  if (selected) point_row(a.wc, a.extrinsic_est_en, pc, mm, rin, lid, u, hs, r);
   PH(1, 2);
   if (a.rows && in) {
     double *row = a.rows + (size_t)i * 14;
@@ -1195,13 +1217,22 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_s
 }
 #endif
 
-// Fixed-order final sum, one wave per (LiDAR, entry): lane l adds that entry's partials l, l + 64, l + 128, ... of the
-// LiDAR's workgroups (contiguous in the entry-major layout: coalesced, all loads independent), then the 64 lane sums
-// are added by a fixed xor-butterfly. 291 waves at three LiDARs instead of three workgroups walking 130 rows each:
-// the kernel is one memory round trip deep. out: [L][NSUM].
+// Fixed-order final sum, one wave per (LiDAR, entry). THE ORDER (shared with the one-kernel pass, k_pass, and with the
+// host's last levels of it, tree_sum_nodes): a complete binary tree over the LiDAR's 64-point tiles in scan order - tile
+// pairs, pairs of pairs, ... - with missing leaves read as +0 (an exact identity: no partial sum is ever -0). A workgroup
+// partial of k_rows_reduce is the tree node over 4 tiles ((T0+T1)+(T2+T3)); here lane j adds four of them the same way
+// ((p0+p1)+(p2+p3): two more levels) and six xor-butterfly steps with growing stride finish the node over 256 partials =
+// 65 536 points (addition commutes, so both lanes of a pair hold the same bits); a LiDAR with more points than that takes
+// further rounds, whose results meet in a second butterfly. All loads independent: one memory round trip deep.
+// out: [L][NSUM].
 struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
+__device__ __forceinline__ double butterfly_up(double a) {
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) a += __shfl_xor(a, sft);
+  return a;
+}
 // With a gate (gate.msg_seq set): the workgroup that finishes last - a ticket counter - announces the sums to the host
 // through a sequence word in pinned memory and, in the gated update loop (gate.dl set), waits for the next pass' control
 // block and installs it (gate_body): the gate costs no launch of its own.
@@ -1214,17 +1245,18 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
     const int lid = w / NSUM, e = w - lid * NSUM;
     const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
     const double *row = partials + (size_t)e * pstride;
-    double acc = 0;
-    for (int b = b0 + lane; b < b1; b += 64 * 4) {
-      double v[4];
+    const int rounds = (b1 - b0 + 255) / 256;
+    double vr = 0.0, a = 0.0;
+    for (int r = 0; r < rounds; r++) {
+      const int base = b0 + 256 * r + 4 * lane;
+      double p[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = (b + 64 * u < b1) ? row[b + 64 * u] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) acc += v[u];
+      for (int u = 0; u < 4; u++) p[u] = (base + u < b1) ? row[base + u] : 0.0;
+      a = butterfly_up((p[0] + p[1]) + (p[2] + p[3]));
+      if (lane == r) vr = a;
     }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
-    if (lane == 0) out[lid * NSUM + e] = acc;
+    if (rounds > 1) a = butterfly_up(vr);  // (<= 64 rounds: 4 M points per LiDAR)
+    if (lane == 0) out[lid * NSUM + e] = a;
   }
   if (!gate.msg_seq) return;
   __shared__ int s_last;
@@ -1242,6 +1274,237 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
   } else if (threadIdx.x == 0) {  // announcement only (malio_measure polls this word instead of waiting for the queue's signal)
     __threadfence_system();
     __hip_atomic_store(gate.msg_seq, gate.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- ONE kernel per pass (k_pass) -------------------------------------------------------------------------------------
+// A pass is three kernels (k_search | k_reuse -> k_rows_reduce -> k_final_reduce) because the FIC weights of a5/a7 need the
+// extrema of unit_cov and R over ALL accepted points (laserMapping.cpp:625-628,646-656,716-721): a grid-wide dependency
+// between the point phase and the rows. From the second pass of a scan on those extrema are almost always the ones of
+// the pass before (they belong to two or three extreme points that stay accepted), so this kernel SPECULATES on them:
+//   - point phase as in k_search (search pass) or reuse_point (reuse pass), on workgroups of 64 points that never
+//     straddle two LiDAR segments; the true extrema still go to the atomic slots;
+//   - the control wave continues, with plane, residual, trace still in registers, into the Jacobian row (point_row,
+//     weighted with the GUESSED extrema) and 16 f64 MFMAs: the 97 sums of its 64 points = one TILE, stored write-through
+//     (sc1 stores: no release fence, whose L2 write-back would cost microseconds behind the megabytes of per-point
+//     state this kernel has just dirtied);
+//   - tickets instead of kernel boundaries: the last workgroup of each group of 64 tiles adds them in the tree order of
+//     k_final_reduce (256 threads, 32 sc1 loads each) and stores the NODE (4 096 points) into pinned host memory; the
+//     last group folds the extrema slots, stores them next to the nodes and announces the pass (or runs the gate of the
+//     gated update loop). The host adds the few dozen nodes (tree_sum_nodes: the upper levels of the same tree) and
+//     compares the true extrema with the guess: equal - the sums are the pass' sums, bit for bit those of the
+//     three-kernel path; different (or no guess: first pass of a scan) - the rows are redone by k_rows_reduce +
+//     k_final_reduce from the per-point state this kernel left, exactly as after k_search.
+// Not used when queries may be deferred to k_search_tail (their planes do not exist yet when the rows are formed), on
+// map shards (NF_NOTMINE workgroups), or for the dense rows of the rows path.
+constexpr int TILE_STRIDE = 104;  // doubles per tile / node record: NSUM padded to a multiple of 8
+constexpr int GRP_TILES = 64;     // tiles per group: one node = 4 096 points
+constexpr int FUSE_MAX_GROUPS_PER_LIDAR = 64;  // the host tree takes any count; kept small so that rounds stay one
+struct FuseArgs {
+  int seg_start[MALIO_MAX_LIDAR + 1];
+  int seg_blk0[MALIO_MAX_LIDAR + 1];  // first workgroup (64-point tile) of each LiDAR segment
+  int seg_grp0[MALIO_MAX_LIDAR + 1];  // first group of each segment
+  int L, ngroups, converge;
+  PassConst pc;     // DEV: read from the control block instead
+  WeightConst wc;
+  double guess[4];  // [max_u, -min_u, max_R, -min_R] the rows are weighted with (DEV: control block)
+  double *tiles;    // [workgroups][TILE_STRIDE] device memory
+  u32 *tickets;     // [0] global, [1 + g] group g; zero between kernels (the last arriver resets its word)
+  double *nodes;    // device alias of pinned host memory: [ngroups][TILE_STRIDE], then the tail
+  double *tail;     // ... [0..4] true extrema + M as mm_fold_wave leaves them, [5] heavy-workgroup score
+  GateArgs gate;
+};
+
+__device__ __forceinline__ int tile_entry(int ra, int cb) {  // (row, col) of the 16 x 16 MFMA block -> entry of the 97, or -1
+  if (ra < 12) {
+    if (cb >= ra && cb < 12) return ra * 12 - (ra * (ra - 1)) / 2 + (cb - ra);
+    return cb == 12 ? 78 + ra : -1;
+  }
+  const int a = ra - 12;
+  if (a > 2 || cb > 2 || cb < a) return -1;
+  if (a == cb) return 90 + a;
+  return a == 0 ? (cb == 1 ? 93 : 94) : 95;
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// extrema slots written by other workgroups' atomics of THIS launch: read past the (non-coherent) caches
+__device__ __forceinline__ void mm_fold_wave_sc1(const u64 *slots, int extrinsic_est_en, double out5[5]) {
+  const int lane = threadIdx.x & 63;
+  const u64 *o = slots + (size_t)lane * 5;
+  u64 k0 = __hip_atomic_load(&o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 k1 = __hip_atomic_load(&o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 k2 = __hip_atomic_load(&o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 k3 = __hip_atomic_load(&o[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 cnt = __hip_atomic_load(&o[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double r0 = wave_max(mm_dec(k0)), r1 = wave_min(mm_dec(k1)), r2 = wave_max(mm_dec(k2)), r3 = wave_min(mm_dec(k3));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+  double m0 = fmax(0.0, r0), m1 = fmin(1000.0, r1), m2 = 0.0, m3 = 9999.0;
+  if (extrinsic_est_en) m2 = fmax(m2, r2), m3 = fmin(m3, r3);
+  out5[0] = m0, out5[1] = -m1, out5[2] = m2, out5[3] = -m3, out5[4] = (double)cnt;
+}
+
+template <bool DEV>
+__global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE)))
+k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restrict__ dl) {
+  __shared__ SearchLds S;
+  __shared__ double SA[SQ][17];  // a_p, b_p of the 64 rows (see k_rows_reduce)
+  __shared__ double SB[SQ][17];
+  __shared__ double s_half[2][TILE_STRIDE];
+  __shared__ int s_flag;
+  if (DEV && dl->done) return;
+  const QuatConst &qc = DEV ? dl->qc : a.qc;
+  const PassConst &pc = DEV ? dl->pc : f.pc;
+  PassDyn dy;
+  if (DEV) {
+    const int mp = dl->mm_parity;
+    dy.commit_prev = dl->commit_prev, dy.parity = dl->dq_parity;
+    dy.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, dy.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
+  } else {
+    dy.commit_prev = a.commit_prev, dy.parity = a.parity, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
+  }
+  const int converge = DEV ? dl->converge : f.converge;
+  // this workgroup's 64 points: inside ONE LiDAR segment
+  int lid = 0;
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (l < f.L && (int)blockIdx.x >= f.seg_blk0[l]) lid = l;
+  const int tile_in_seg = (int)blockIdx.x - f.seg_blk0[lid];
+  const int q0 = f.seg_start[lid] + tile_in_seg * SQ, qend = f.seg_start[lid + 1];
+  const int lane = (int)(threadIdx.x & 63);
+  const bool cwave = threadIdx.x < 64;
+  PointOut po;
+  bool alive;
+  if (converge) {
+    alive = search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po);
+  } else {  // REUSE pass: the control wave alone, lane = point
+    alive = cwave;
+    if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
+    if (cwave) {
+      const int i = q0 + lane;
+      po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
+      po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
+      if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+    }
+  }
+  if (alive) {  // (control wave)
+    wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
+    // ---- a5 / a7 with the guessed extrema ----
+    double mm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
+    double u[12], hs = 0, r = 1;
+#pragma unroll
+    for (int k = 0; k < 12; k++) u[k] = 0;
+    if (po.selected) {
+      RowIn rin;
+      rin.q = po.q, rin.pl = po.pl, rin.ucov = po.ucov, rin.trace = po.tr, rin.pd2 = po.pd2;
+      point_row(f.wc, a.extrinsic_est_en, pc, mm, rin, lid, u, hs, r);
+    }
+    double rc = r;
+    if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+#ifndef ROWS_DIVIDE
+    const double rinv = po.selected ? 1.0 / rc : 0.0;
+#endif
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+#ifndef ROWS_DIVIDE
+      SA[lane][k] = u[k] * rinv;
+#else
+      SA[lane][k] = po.selected ? u[k] / rc : 0.0;
+#endif
+      SB[lane][k] = u[k];
+    }
+    SA[lane][12] = u[0], SA[lane][13] = u[1], SA[lane][14] = u[2], SA[lane][15] = 0.0;
+    SB[lane][12] = hs, SB[lane][13] = 0.0, SB[lane][14] = 0.0, SB[lane][15] = 0.0;
+    const unsigned long long bal = __ballot(po.selected);
+    __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above are ordered before its loads below (waitcnt by the compiler)
+    const int prow = lane >> 4, col = lane & 15;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 16; g++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[prow + 4 * g][col], SB[prow + 4 * g][col], acc, 0, 0, 0);
+    // ---- the tile, write-through; then this workgroup's arrival ----
+    double *tile = f.tiles + (size_t)blockIdx.x * TILE_STRIDE;
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int e = tile_entry(prow + 4 * rg, col);
+      if (e >= 0) st_sc1(&tile[e], acc[rg]);
+    }
+    if (lane == 0) st_sc1(&tile[NSUM - 1], (double)__popcll(bal));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store and atomic of this wave has been acknowledged
+    const int grp_in_seg = tile_in_seg / GRP_TILES;
+    const int tiles_in_seg = (qend - f.seg_start[lid] + SQ - 1) / SQ;
+    const int ntiles = min(GRP_TILES, tiles_in_seg - grp_in_seg * GRP_TILES);
+    if (lane == 0) {
+      const u32 t = __hip_atomic_fetch_add(&f.tickets[1 + f.seg_grp0[lid] + grp_in_seg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = t == (u32)(ntiles - 1);
+    }
+  }
+  __syncthreads();  // (the three search waves have been waiting here since their last search)
+  if (!s_flag) return;
+  // ---- last workgroup of its group: the node over the group's (up to) 64 tiles, all 256 threads ----
+  {
+    const int grp_in_seg = tile_in_seg / GRP_TILES;
+    const int grp = f.seg_grp0[lid] + grp_in_seg;
+    const int tiles_in_seg = (qend - f.seg_start[lid] + SQ - 1) / SQ;
+    const int t0 = grp_in_seg * GRP_TILES;  // first tile of the group, inside the segment
+    const int half = threadIdx.x >> 7, e = threadIdx.x & 127;
+    if (e < NSUM) {
+      const double *base = f.tiles + (size_t)f.seg_blk0[lid] * TILE_STRIDE + e;
+      double h2[2];
+#pragma unroll
+      for (int part = 0; part < 2; part++) {  // 16 tiles at a time: a node of the tree per part
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int t = t0 + half * 32 + part * 16 + k;
+          v[k] = t < tiles_in_seg ? ld_sc1(base + (size_t)t * TILE_STRIDE) : 0.0;
+        }
+#pragma unroll
+        for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+          for (int k = 0; k < 16; k += 2 * w) v[k] = v[k] + v[k + w];
+        h2[part] = v[0];
+      }
+      s_half[half][e] = h2[0] + h2[1];
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUM)
+      __hip_atomic_store(&f.nodes[(size_t)grp * TILE_STRIDE + threadIdx.x], s_half[0][threadIdx.x] + s_half[1][threadIdx.x],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&f.tickets[1 + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+      const u32 t = __hip_atomic_fetch_add(&f.tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_flag = t == (u32)(f.ngroups - 1);
+      if (s_flag) __hip_atomic_store(&f.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_flag) return;
+  }
+  // ---- last group of the launch: true extrema + M, the heavy-workgroup score; announce (or gate) ----
+  if (threadIdx.x < 64) {
+    double o5[5];
+    mm_fold_wave_sc1(dy.mm_cur, a.extrinsic_est_en, o5);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) __hip_atomic_store(&f.tail[k], o5[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const u32 hv = __hip_atomic_load(&a.dq_ctl[2 + dy.parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&f.tail[5], (double)hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (f.gate.dl) {
+    gate_body(f.gate);
+  } else if (threadIdx.x == 0 && f.gate.msg_seq) {
+    __hip_atomic_store(f.gate.msg_seq, f.gate.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1540,6 +1803,23 @@ int measure_alloc(Ctx *c) {
     c->cap_partials = nb + nb / 8 + 16;
     MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));  // [NSUM][cap_partials]
   }
+  {  // one-kernel pass: tiles (one per 64 points + one per LiDAR for the segment padding), tickets, pinned nodes
+    const size_t nt = (N + SQ - 1) / SQ + MALIO_MAX_LIDAR, ng = (nt + GRP_TILES - 1) / GRP_TILES + MALIO_MAX_LIDAR;
+    if (nt > c->cap_tiles) {
+      if (c->d_tiles) (void)hipFree(c->d_tiles);
+      c->cap_tiles = nt + nt / 8 + 16;
+      MALIO_HIP(hipMalloc(&c->d_tiles, sizeof(double) * TILE_STRIDE * c->cap_tiles));
+    }
+    if (ng > c->cap_groups) {
+      if (c->d_tickets) (void)hipFree(c->d_tickets);
+      if (c->h_nodes) (void)hipHostFree(c->h_nodes);
+      c->cap_groups = ng + ng / 8 + 8;
+      MALIO_HIP(hipMalloc(&c->d_tickets, sizeof(u32) * (1 + c->cap_groups)));
+      MALIO_HIP(hipMemsetAsync(c->d_tickets, 0, sizeof(u32) * (1 + c->cap_groups), c->stream));
+      MALIO_HIP(hipHostMalloc(&c->h_nodes, sizeof(double) * (TILE_STRIDE * c->cap_groups + 16), hipHostMallocMapped | hipHostMallocCoherent));
+      MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_nodes, c->h_nodes, 0));
+    }
+  }
   if (!c->d_dq_ctl) {
     MALIO_HIP(hipMalloc(&c->d_dq_ctl, sizeof(u32) * 4));
     MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
@@ -1567,8 +1847,10 @@ int reset_pass_state(Ctx *c) {
   if (c->d_mmslots) hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
   if (c->d_dq_ctl) MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
   if (c->d_gate_ticket) MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
+  if (c->d_tickets) MALIO_HIP(hipMemsetAsync(c->d_tickets, 0, sizeof(u32) * (1 + c->cap_groups), c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   c->mm_parity = 0, c->dq_parity = 0, c->last_M = -1;
+  c->mm_guess_valid = false;
   return MALIO_OK;
 }
 
@@ -1959,6 +2241,138 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
                      c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)c->d_loop,
                      gate ? *gate : GateArgs{});
   MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
+// ---- host side of the one-kernel pass ---------------------------------------------------------------------------------
+bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
+  if (c->fuse_enabled < 0) {
+    const char *e = getenv("MALIO_FUSE");
+    c->fuse_enabled = (e && e[0] == '0') ? 0 : 1;
+    const char *b = getenv("MALIO_DEBUG_FUSE_BAD_GUESS");  // tests: every guess is wrong, every one-kernel pass is redone
+    c->fuse_debug_bad_guess = b && b[0] == '1';
+  }
+  if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending || c->part.world > 1) return false;
+  if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
+  for (int l = 0; l < c->prm.lid_num; l++)
+    if ((size_t)(c->seg_start[l + 1] - c->seg_start[l]) > (size_t)FUSE_MAX_GROUPS_PER_LIDAR * GRP_TILES * SQ) return false;
+  return c->d_tiles != nullptr;
+}
+
+// everything of FuseArgs that does not depend on the pass; returns the number of workgroups
+static int fill_fuse_static(Ctx *c, FuseArgs &f) {
+  const int L = c->prm.lid_num;
+  int b = 0, g = 0;
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) {
+    const int ll = l < L ? l : L;
+    f.seg_start[l] = c->seg_start[ll];
+    f.seg_blk0[l] = b, f.seg_grp0[l] = g;
+    c->fuse_seg_grp0[l] = g;
+    if (l < L) {
+      const int nt = (c->seg_start[l + 1] - c->seg_start[l] + SQ - 1) / SQ;
+      b += nt, g += (nt + GRP_TILES - 1) / GRP_TILES;
+    }
+  }
+  f.L = L, f.ngroups = g, f.converge = 0;
+  c->fuse_groups = g;
+  f.wc.plane_cov_max = c->prm.plane_cov_max, f.wc.plane_cov_min = c->prm.plane_cov_min;
+  f.wc.point_cov_max = c->prm.point_cov_max, f.wc.point_cov_min = c->prm.point_cov_min;
+  f.wc.range_min = c->prm.range_min, f.wc.range_max = c->prm.range_max;
+  f.tiles = c->d_tiles, f.tickets = c->d_tickets;
+  f.nodes = c->d_nodes, f.tail = c->d_nodes + (size_t)TILE_STRIDE * c->cap_groups;
+  f.gate = GateArgs{};
+  memset(&f.pc, 0, sizeof(f.pc));
+  memset(f.guess, 0, sizeof(f.guess));
+  return b;
+}
+
+// one pass as ONE kernel, state in the kernel arguments (malio_measure, the host-driven loop): the bookkeeping of
+// pass_stage1 + the launch. The caller has checked fuse_eligible.
+int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate) {
+  if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
+  if (c->N <= 0) return MALIO_ERR_NO_SCAN;
+  if (int rc = map_sync_search(c)) return rc;
+  Pass1Args a;
+  fill_quat_const(c, s, a.qc);
+  fill_pass1_static(c, a);
+  a.defer = 0;
+  c->mm_parity ^= 1;
+  a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
+  a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
+  a.commit_prev = c->last_M > 0 ? 1 : 0;
+  c->last_M = -1;
+  c->last_pass_search = converge != 0;
+  if (converge) {
+    c->dq_parity ^= 1;
+    c->nbr_epoch = c->map_epoch;
+  }
+  a.parity = c->dq_parity;
+  FuseArgs f;
+  const int nwg = fill_fuse_static(c, f);
+  f.converge = converge;
+  fill_pass_const(c, s, c->pc);
+  f.pc = c->pc;
+  memcpy(f.guess, c->mm_guess, sizeof(f.guess));
+  if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
+  memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
+  if (gate) f.gate = *gate;
+  hipLaunchKernelGGL(k_pass<false>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
+                     (const DevLoop *)nullptr);
+  prof_mark(c, "k_pass");
+  MALIO_HIP(hipGetLastError());
+  c->fuse_passes++;
+  return MALIO_OK;
+}
+
+// the same kernel reading state, pass kind, parities and the guess from the device loop's control block
+int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
+  Pass1Args a;
+  fill_pass1_static(c, a);
+  a.defer = 0;
+  memset(&a.qc, 0, sizeof(a.qc));
+  FuseArgs f;
+  const int nwg = fill_fuse_static(c, f);
+  if (gate) f.gate = *gate;
+  hipLaunchKernelGGL(k_pass<true>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
+                     (const DevLoop *)c->d_loop);
+  MALIO_HIP(hipGetLastError());
+  c->fuse_passes++;
+  return MALIO_OK;
+}
+
+// The upper levels of the summation tree (see k_final_reduce): the nodes of one LiDAR, pairwise, until one is left; an
+// odd node moves up unchanged (+0 is an exact identity here). Works on whole records: 97 independent sums side by side.
+static void tree_sum_nodes(const double *nodes, int n, double *out /*[NSUM]*/, std::vector<double> &tmp) {
+  if (n <= 0) {
+    for (int e = 0; e < NSUM; e++) out[e] = 0.0;
+    return;
+  }
+  tmp.resize((size_t)n * NSUM);
+  for (int k = 0; k < n; k++) memcpy(&tmp[(size_t)k * NSUM], nodes + (size_t)k * TILE_STRIDE, sizeof(double) * NSUM);
+  while (n > 1) {
+    const int h = n / 2;
+    for (int k = 0; k < h; k++) {
+      const double *x = &tmp[(size_t)(2 * k) * NSUM], *y = x + NSUM;
+      double *o = &tmp[(size_t)k * NSUM];
+      for (int e = 0; e < NSUM; e++) o[e] = x[e] + y[e];
+    }
+    if (n & 1) memmove(&tmp[(size_t)h * NSUM], &tmp[(size_t)(n - 1) * NSUM], sizeof(double) * NSUM);
+    n = h + (n & 1);
+  }
+  memcpy(out, tmp.data(), sizeof(double) * NSUM);
+}
+
+int fused_collect(Ctx *c, double *sums_out, bool *hit) {
+  const int L = c->prm.lid_num, ns = L * NSUM;
+  static thread_local std::vector<double> tmp;
+  for (int l = 0; l < L; l++) {
+    const int g0 = c->fuse_seg_grp0[l], g1 = c->fuse_seg_grp0[l + 1];
+    tree_sum_nodes(c->h_nodes + (size_t)g0 * TILE_STRIDE, g1 - g0, sums_out + (size_t)l * NSUM, tmp);
+  }
+  const double *tail = c->h_nodes + (size_t)TILE_STRIDE * c->cap_groups;
+  for (int k = 0; k < 6; k++) sums_out[ns + k] = tail[k];
+  *hit = memcmp(tail, c->fuse_guess_used, sizeof(double) * 4) == 0;
+  if (*hit) c->fuse_hits++; else c->fuse_misses++;
   return MALIO_OK;
 }
 

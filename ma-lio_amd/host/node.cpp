@@ -118,6 +118,15 @@ int malio_node_create(const malio_params_t *params, int n_gpus, const int *devic
   if (partition != MALIO_PART_SCAN && partition != MALIO_PART_TILES) return MALIO_ERR_BAD_ARG;
   if (exchange != MALIO_NODE_XCHG_HOST && exchange != MALIO_NODE_XCHG_RCCL) return MALIO_ERR_BAD_ARG;
   *out = nullptr;
+  // The HIP runtime is initialised HERE, on the calling thread, before any worker exists: when this call is the first
+  // HIP use of the process, n workers entering hipGetDeviceCount at once race inside the runtime's one-time
+  // initialisation and some of them are told there is no device.
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MALIO_ERR_NO_DEVICE;
+  for (int r = 0; r < n_gpus; r++) {
+    const int d = devices ? devices[r] : r;
+    if (d < 0 || d >= ndev) return MALIO_ERR_NO_DEVICE;
+  }
   malio_node *nd = new malio_node();
   nd->prm = *params, nd->n = n_gpus, nd->partition = partition, nd->exchange = exchange, nd->tile_m = tile_m;
   nd->w.resize(n_gpus);

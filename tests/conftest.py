@@ -17,12 +17,12 @@ def pytest_configure(config):
 
 
 def _gpu_count():
-    import ctypes
+    """malio_device_count: the library's own HIP runtime is asked (a second copy of libamdhip64 loaded through ctypes
+    would initialise a second runtime in the process, and the one that comes second finds no device)."""
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        n = ctypes.c_int(0)
-        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
-    except OSError:
+        from malio_amd import capi as _c
+        return int(_c.lib().malio_device_count())
+    except Exception:
         return 0
 
 

@@ -682,3 +682,71 @@ def test_gate_timeout_degrades_to_host_loop(capi, scenes, monkeypatch):
     assert np.array_equal(u2["state"], v2["state"]) and np.array_equal(u2["P"], v2["P"])
     g, r = eng.measure(sc["state0"], True), ref.measure(sc["state0"], True)
     assert g["M"] == r["M"] and np.array_equal(g["HtRinvH"], r["HtRinvH"])
+
+
+def _fresh(capi, sc, mode=None):
+    e = capi.Engine(sc["params"], device=0)
+    if mode:
+        e.set_update_mode(mode)
+    e.map_build(sc["map"])
+    e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    return e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(seed=501, N=30000, Nmap=300000, L=3), dict(seed=502, N=9000, Nmap=120000, L=2, map_unc=True),
+                                dict(seed=503, N=5000, Nmap=60000, L=1), dict(cfg=2)], ids=lambda k: "s%s" % k.get("seed", "cfg2"))
+def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monkeypatch, kw):
+    """From the second pass of a scan on a pass runs as ONE kernel (k_pass) that weights its rows with the extrema of the
+    pass before and leaves the last levels of the summation tree to the host; a handle with MALIO_FUSE=0 runs every pass
+    as three kernels. Same summation tree, same per-point arithmetic: sums, extrema, per-point results and the whole
+    iterated update (gated and host-driven) must agree BIT FOR BIT - when the guess holds and when it does not
+    (MALIO_DEBUG_FUSE_BAD_GUESS=1: every guess is wrong, every pass redone)."""
+    sc = scenes.make_scene(**kw)
+    s2 = sc["state0"].copy()
+    s2[0:3] += [0.012, -0.02, 0.006]
+    s3 = sc["state0"].copy()
+    s3[0:3] += [0.4, 0.3, -0.1]  # far enough to change which points are accepted
+    seq = ((sc["state0"], True), (s2, False), (s2, True), (s3, False), (s3, True), (sc["state0"], False), (sc["state0"], True))
+    runs = {}
+    for name, env in (("plain", {"MALIO_FUSE": "0"}), ("fused", {}), ("bad", {"MALIO_DEBUG_FUSE_BAD_GUESS": "1"})):
+        for k in ("MALIO_FUSE", "MALIO_DEBUG_FUSE_BAD_GUESS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = _fresh(capi, sc)
+        out = [eng.measure(st, cv) for st, cv in seq]
+        side = eng.scan_get()
+        st = eng.fuse_stats()
+        upd = {}
+        for mode in ("gated", "host"):
+            e2 = _fresh(capi, sc, mode)
+            upd[mode] = e2.update_iterated(sc["state0"], sc["P0"])
+            upd[mode + "_stats"] = e2.fuse_stats()
+        runs[name] = (out, side, st, upd)
+    p_out, p_side, p_st, p_upd = runs["plain"]
+    assert p_st["passes"] == 0
+    for name in ("fused", "bad"):
+        out, side, st, upd = runs[name]
+        # every pass but the first of the scan - and the search passes that follow one with workgroups full of unmatched
+        # queries (s3 is 0.5 m off: such a pass hands them to k_search_tail, which the one-kernel form cannot)
+        assert len(seq) - 3 <= st["passes"] <= len(seq) - 1
+        if name == "bad":
+            assert st["misses"] == st["passes"] and st["hits"] == 0
+        else:
+            assert st["hits"] >= 3 and st["hits"] + st["misses"] == st["passes"]
+        for a, b in zip(p_out, out):
+            assert (a["valid"], a["M"]) == (b["valid"], b["M"]) and a["w_loc"] == b["w_loc"]
+            assert a["unit_cov_minmax"] == b["unit_cov_minmax"] and a["R_minmax"] == b["R_minmax"]
+            assert np.array_equal(a["HtRinvH"], b["HtRinvH"]) and np.array_equal(a["HtRinvh"], b["HtRinvh"])
+        for k in p_side:
+            assert np.array_equal(p_side[k], side[k]), k
+        for mode in ("gated", "host"):
+            u, v = p_upd[mode], upd[mode]
+            assert (u["passes"], u["searches"], u["M"], u["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
+            assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]), mode
+            # (a fresh handle does not know yet whether its search passes defer queries: the unit enqueued before the
+            # first pass' verdict is the four-kernel one in the gated loop)
+            assert upd[mode + "_stats"]["passes"] >= v["passes"] - 2
+            if name == "bad":
+                assert upd[mode + "_stats"]["misses"] >= v["passes"] - 2

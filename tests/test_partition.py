@@ -198,12 +198,12 @@ def test_config4_tile_sharded_8_shards_equals_single_engine(capi, scenes):
 
 
 def _gpu_count():
-    import ctypes
+    """malio_device_count: the library's own HIP runtime is asked (a second copy of libamdhip64 loaded through ctypes
+    would initialise a second runtime in the process, and the one that comes second finds no device)."""
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        n = ctypes.c_int(0)
-        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
-    except OSError:
+        from malio_amd import capi as _c
+        return int(_c.lib().malio_device_count())
+    except Exception:
         return 0
 
 
@@ -247,9 +247,31 @@ def test_node_update_small_M_on_a_later_pass_leaves_inputs_untouched(capi, scene
     nd.map_build(sc["map"])
     nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     c = sc["state_gt"][0:3]
-    # everything but a thin slab of ground far from the sensor
-    boxes = np.array([[c[0] - 500, c[1] - 500, c[2] - 50, c[0] + 500, c[1] + 60, c[2] + 50],
-                      [c[0] - 500, c[1] + 61.5, c[2] - 50, c[0] + 500, c[1] + 500, c[2] + 50]], np.float32)
+    # everything but a small cube around the sensor (six boxes = its complement), sized so that between 3 and 34 scan
+    # points can keep five neighbours inside sqrt(5) m: fewer accepted points than the 35 states, but not none
+    probe = _single(capi, sc)
+    probe.measure(sc["state0"], True)
+    pg = probe.scan_get()
+    sel = pg["selected"] > 0
+    far = np.argsort(-np.abs(pg["world"] - c.astype(np.float32)).max(1))  # sparse regions first
+    pick = None
+    for j in far[sel[far]][:1500]:
+        d = np.abs(pg["world"] - pg["world"][j]).max(1)
+        for hh in (3.0, 4.0, 5.0, 6.5, 8.0):
+            if (sel & (d < hh - 2.3)).sum() >= 3 and (sel & (d < hh + 2.3)).sum() < 35:
+                pick = (pg["world"][j].astype(np.float64), hh)
+                break
+        if pick:
+            break
+    assert pick is not None
+    c, h = pick
+    B = 2000.0
+    lo, hi = c - B, c + B
+    boxes = np.array([[lo[0], lo[1], lo[2], c[0] - h, hi[1], hi[2]], [c[0] + h, lo[1], lo[2], hi[0], hi[1], hi[2]],
+                      [c[0] - h, lo[1], lo[2], c[0] + h, c[1] - h, hi[2]], [c[0] - h, c[1] + h, lo[2], c[0] + h, hi[1], hi[2]],
+                      [c[0] - h, c[1] - h, lo[2], c[0] + h, c[1] + h, c[2] - h], [c[0] - h, c[1] - h, c[2] + h, c[0] + h, c[1] + h, hi[2]]],
+                     np.float32)
+    assert (np.abs(sc["map"][:, :3] - c) < h).all(1).sum() >= 5
     seen = []
 
     def hook(k):
