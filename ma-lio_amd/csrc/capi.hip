@@ -169,7 +169,7 @@ int malio_destroy(malio_handle_t h) {
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
   fr(c->d_world), fr(c->d_ucov), fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_partials);
-  fr(c->d_sums), fr(c->d_rows);
+  fr(c->d_sums), fr(c->d_rows), fr(c->d_tiles);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_node_mm) (void)hipHostFree(c->h_node_mm);
@@ -855,19 +855,18 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   };
   int rc;
   const double *res = c->h_res;
-  std::vector<double> &fsums = c->fuse_sums;
   bool need_stage2 = true;
-  if (!want_rows && fuse_eligible(c, converge)) {
-    // ONE kernel (k_pass): the rows are weighted with the extrema of the previous pass of this scan; the host adds the
-    // group nodes and checks the guess. A miss (rare: an extreme point changed sides) costs the two kernels below.
+  if (!want_rows && converge && fuse_eligible(c, converge)) {  // (search passes: a speculating reuse pass gains nothing here)
+    // k_pass -> k_final_reduce: the rows are formed inside the point-phase kernel, weighted with the extrema of the
+    // previous pass of this scan; the host checks the guess. A miss (rare: an extreme point changed sides) costs the two
+    // kernels below.
     if ((rc = arm()) != MALIO_OK) return rc;
     if (!poll) gate.msg_seq = nullptr;
     if ((rc = pass_fused(c, s, converge, poll ? &gate : nullptr)) != MALIO_OK) return rc;
     if ((rc = wait()) != MALIO_OK) return rc;
-    fsums.resize((size_t)ns + 8);
     bool hit = false;
-    fused_collect(c, fsums.data(), &hit);
-    if (hit) res = fsums.data(), need_stage2 = false;
+    fused_collect(c, nullptr, &hit);
+    if (hit) need_stage2 = false;
   } else {
     rc = pass_stage1(c, s, converge, nullptr);
     if (rc != MALIO_OK) return rc;

@@ -714,7 +714,6 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   double *tr = c->gate_trace;
   int ntr = 0;
   const double t_begin = now_us();
-  std::vector<double> fsums((size_t)ns_ + 8);
   int u = 0;  // the unit whose announcement the loop waits for next
   // wait for unit `uu` to announce its sums; MALIO_SMALL_M_FALLBACK when the chain drained without it (gate timeout)
   auto wait_unit = [&](int uu) -> int {
@@ -752,13 +751,10 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     const double *res = nullptr;
     for (int attempt = 0;; attempt++) {  // the pass, and - rarely - its repeat with the right extrema
       if (int rcw = wait_unit(u)) return rcw;
-      if (!unit_fused[u]) {
-        res = c->h_res;
-        break;
-      }
+      res = c->h_res;
+      if (!unit_fused[u]) break;
       bool hit = false;
-      fused_collect(c, fsums.data(), &hit);
-      res = fsums.data();
+      fused_collect(c, nullptr, &hit);
       if (hit) break;
       if (attempt >= 2) {
         c->err = "malio_update_iterated: the one-kernel pass keeps missing its own extrema";

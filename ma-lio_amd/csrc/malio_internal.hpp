@@ -420,21 +420,15 @@ struct Ctx {
   bool last_pass_search = false;
   u64 *d_mmslots = nullptr;  // [2 parities][64 slots][5]: max_u, min_u, max_R, min_R (order-encoded doubles), count
   int mm_parity = 0;
-  // one-kernel pass (measure.hip, k_pass): per-workgroup tiles, arrival tickets, the group nodes in pinned memory
-  double *d_tiles = nullptr;     // [cap_tiles][TILE_STRIDE]
+  // speculating pass (measure.hip, k_pass): the per-workgroup tiles, [NSUM][cap_tiles]
+  double *d_tiles = nullptr;
   size_t cap_tiles = 0;
-  u32 *d_tickets = nullptr;      // [1 + cap_groups], zero between launches
-  double *h_nodes = nullptr, *d_nodes = nullptr;  // pinned + device alias: [cap_groups][TILE_STRIDE] | tail [16]
-  size_t cap_groups = 0;
   double mm_guess[4] = {0, 0, 0, 0};  // true extrema of the last completed pass of this scan: the next pass' guess
   bool mm_guess_valid = false;
   double fuse_guess_used[4] = {0, 0, 0, 0};  // what the last k_pass launch was given
-  int fuse_seg_grp0[MALIO_MAX_LIDAR + 1] = {0};
-  int fuse_groups = 0;
   int fuse_enabled = -1;  // MALIO_FUSE=0 switches the one-kernel pass off (-1: environment not read yet)
   bool fuse_debug_bad_guess = false;  // MALIO_DEBUG_FUSE_BAD_GUESS=1
   int fuse_hits = 0, fuse_misses = 0, fuse_passes = 0;
-  std::vector<double> fuse_sums;  // host part of a one-kernel pass: [L][NSUM] sums | extrema
   double *d_partials = nullptr;  // [NSUM][cap_partials]
   double *d_sums = nullptr;      // [NSUM_OUT]
   double *h_sums = nullptr;      // pinned
@@ -544,9 +538,9 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
 int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows,
                 const GateArgs *gate = nullptr);  // gate: the last kernel announces its completion (see k_final_reduce)
 int reset_pass_state(Ctx *c);  // measure.hip: extrema slots, deferral counters and parities as a fresh handle has them
-// measure.hip, the one-kernel pass (k_pass): may this pass run as one kernel? launch it (arguments by value, or reading
-// the device loop's control block); collect the host's part of it: sums [L][NSUM] + [extrema 5 | heavy] behind them as the
-// three-kernel path leaves them in h_res, *hit = the guessed extrema were the true ones (else the caller redoes the rows)
+// measure.hip, the speculating pass (k_pass -> k_final_reduce<16>): may this pass run that way? launch it (arguments by
+// value, or reading the device loop's control block; results land in h_res like the three-kernel pass'); afterwards:
+// *hit = the guessed extrema were the true ones (else the caller redoes the rows)
 bool fuse_eligible(Ctx *c, int converge, bool need_guess = true);
 int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate);
 int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate);

@@ -1217,8 +1217,8 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_s
 }
 #endif
 
-// Fixed-order final sum, one wave per (LiDAR, entry). THE ORDER (shared with the one-kernel pass, k_pass, and with the
-// host's last levels of it, tree_sum_nodes): a complete binary tree over the LiDAR's 64-point tiles in scan order - tile
+// Fixed-order final sum, one wave per (LiDAR, entry). THE ORDER (shared by the three-kernel pass and the speculating pass,
+// k_pass): a complete binary tree over the LiDAR's 64-point tiles in scan order - tile
 // pairs, pairs of pairs, ... - with missing leaves read as +0 (an exact identity: no partial sum is ever -0). A workgroup
 // partial of k_rows_reduce is the tree node over 4 tiles ((T0+T1)+(T2+T3)); here lane j adds four of them the same way
 // ((p0+p1)+(p2+p3): two more levels) and six xor-butterfly steps with growing stride finish the node over 256 partials =
@@ -1233,26 +1233,51 @@ __device__ __forceinline__ double butterfly_up(double a) {
   for (int sft = 1; sft < 64; sft <<= 1) a += __shfl_xor(a, sft);
   return a;
 }
+// LPL = leaves per lane: 4 when the leaves are k_rows_reduce's workgroup partials (each the node over 4 tiles), 16 when they
+// are the tiles of k_pass themselves - the same tree either way.
+// fold (k_pass' pass: nobody has folded the extrema slots yet): the first wave of workgroup 0 folds them and publishes
+// [max_u, -min_u, max_R, -min_R, M, heavy score] next to the sums, as k_rows_reduce does on the three-kernel path.
 // With a gate (gate.msg_seq set): the workgroup that finishes last - a ticket counter - announces the sums to the host
 // through a sequence word in pinned memory and, in the gated update loop (gate.dl set), waits for the next pass' control
 // block and installs it (gate_body): the gate costs no launch of its own.
+struct FoldArgs {
+  const u64 *mmslots;  // this pass' slot set (device loop: the base of both sets, parity from the control block); null: no fold
+  const u32 *dq_ctl;   // deferral counters ([2 + parity]: heavy-workgroup score of the search kernel)
+  double *mm_out;
+  int extrinsic_est_en, dq_parity;
+};
+template <int LPL>
 __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
                                                       int L, double *out, const DevLoop *dl /* device loop, or null */,
-                                                      GateArgs gate /* gate.dl == null: none */) {
+                                                      GateArgs gate /* gate.dl == null: none */, FoldArgs fold) {
   if (dl && dl->done) return;
   const int w = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (fold.mmslots && blockIdx.x == 0 && threadIdx.x < 64) {
+    const u64 *slots = dl ? fold.mmslots + (size_t)dl->mm_parity * MM_SLOTS * 5 : fold.mmslots;
+    double o5[5];
+    mm_fold_wave(slots, fold.extrinsic_est_en, o5);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) fold.mm_out[k] = o5[k];
+      fold.mm_out[5] = (double)fold.dq_ctl[2 + (dl ? dl->dq_parity : fold.dq_parity)];
+    }
+  }
   if (w < L * NSUM) {  // wave-uniform
     const int lid = w / NSUM, e = w - lid * NSUM;
     const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
     const double *row = partials + (size_t)e * pstride;
-    const int rounds = (b1 - b0 + 255) / 256;
+    const int rounds = (b1 - b0 + 64 * LPL - 1) / (64 * LPL);
     double vr = 0.0, a = 0.0;
     for (int r = 0; r < rounds; r++) {
-      const int base = b0 + 256 * r + 4 * lane;
-      double p[4];
+      const int base = b0 + 64 * LPL * r + LPL * lane;
+      double p[LPL];
 #pragma unroll
-      for (int u = 0; u < 4; u++) p[u] = (base + u < b1) ? row[base + u] : 0.0;
-      a = butterfly_up((p[0] + p[1]) + (p[2] + p[3]));
+      for (int u = 0; u < LPL; u++) p[u] = (base + u < b1) ? row[base + u] : 0.0;
+#pragma unroll
+      for (int wd = 1; wd < LPL; wd <<= 1)
+#pragma unroll
+        for (int u = 0; u < LPL; u += 2 * wd) p[u] = p[u] + p[u + wd];
+      a = butterfly_up(p[0]);
       if (lane == r) vr = a;
     }
     if (rounds > 1) a = butterfly_up(vr);  // (<= 64 rounds: 4 M points per LiDAR)
@@ -1277,42 +1302,43 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
   }
 }
 
-// ---- ONE kernel per pass (k_pass) -------------------------------------------------------------------------------------
+// ---- the speculating pass: point phase + rows in ONE kernel (k_pass), then k_final_reduce ----------------------------------
 // A pass is three kernels (k_search | k_reuse -> k_rows_reduce -> k_final_reduce) because the FIC weights of a5/a7 need the
 // extrema of unit_cov and R over ALL accepted points (laserMapping.cpp:625-628,646-656,716-721): a grid-wide dependency
 // between the point phase and the rows. From the second pass of a scan on those extrema are almost always the ones of
-// the pass before (they belong to two or three extreme points that stay accepted), so this kernel SPECULATES on them:
+// the pass before (they belong to two or three extreme points that stay accepted), so k_pass SPECULATES on them:
 //   - point phase as in k_search (search pass) or reuse_point (reuse pass), on workgroups of 64 points that never
 //     straddle two LiDAR segments; the true extrema still go to the atomic slots;
-//   - the control wave continues, with plane, residual, trace still in registers, into the Jacobian row (point_row,
-//     weighted with the GUESSED extrema) and 16 f64 MFMAs: the 97 sums of its 64 points = one TILE, stored write-through
-//     (sc1 stores: no release fence, whose L2 write-back would cost microseconds behind the megabytes of per-point
-//     state this kernel has just dirtied);
-//   - tickets instead of kernel boundaries: the last workgroup of each group of 64 tiles adds them in the tree order of
-//     k_final_reduce (256 threads, 32 sc1 loads each) and stores the NODE (4 096 points) into pinned host memory; the
-//     last group folds the extrema slots, stores them next to the nodes and announces the pass (or runs the gate of the
-//     gated update loop). The host adds the few dozen nodes (tree_sum_nodes: the upper levels of the same tree) and
-//     compares the true extrema with the guess: equal - the sums are the pass' sums, bit for bit those of the
-//     three-kernel path; different (or no guess: first pass of a scan) - the rows are redone by k_rows_reduce +
-//     k_final_reduce from the per-point state this kernel left, exactly as after k_search.
+//   - the control wave continues, with plane, residual and trace still in registers, into the Jacobian row (point_row,
+//     weighted with the GUESSED extrema) and 16 f64 MFMAs: the 97 sums of its 64 points = one TILE, a leaf of the
+//     summation tree (k_rows_reduce's workgroup partial is the node over four of them);
+//   - k_final_reduce<16> adds the tiles in the tree's order behind ONE kernel boundary, folds the extrema slots and
+//     announces the pass. The host compares the true extrema with the guess: equal - the sums are the pass' sums, bit for
+//     bit those of the three-kernel path; different (or no guess: first pass of a scan) - the rows are redone by
+//     k_rows_reduce + k_final_reduce from the per-point state k_pass left, exactly as after k_search.
+// Measured and rejected (profiles/round3/r03a_one_launch_pass.txt): the whole pass as ONE launch - tiles stored
+// write-through, arrival tickets, the last workgroup of every 64 adding their tiles, nodes to pinned memory, a global
+// ticket for the extrema - took 50 / 38 us per search / reuse pass against 43 / 26.5 us for three kernels: three
+// in-launch hand-offs between workgroups cost 9 us on the critical path, more than the boundaries they replace.
+// What it buys (profiles/round3/r03b_*): the rows inside the issue-bound search kernel lengthen it by 4.9 us (23.5 ->
+// 28.4 us in rocprofv3) where their own kernel takes 7.4 us, and k_final_reduce over 4 x as many leaves takes 7.4 instead
+// of 5.7 us: a search pass 36.6 -> 35.8 us of kernels. A reuse pass (one active wave per workgroup here, against
+// k_reuse's and k_rows_reduce's thread-per-point grids) comes out even or worse - 21.0 against 20.4 us; forming a tile per
+// wave (thread = point, half-staged rows, 3 spilled VGPRs) was measured too: 16.2 against 15.6 us for the kernel - so
+// malio_measure speculates on search passes only. In the enqueued-ahead update every unit is a k_pass unit: there the
+// three-kernel unit pays for reading the matrix form of the state through vector loads (k_rows_reduce<true>: 82 VGPRs,
+// 8.1-8.6 us) and the update gains 4-9 us.
 // Not used when queries may be deferred to k_search_tail (their planes do not exist yet when the rows are formed), on
 // map shards (NF_NOTMINE workgroups), or for the dense rows of the rows path.
-constexpr int TILE_STRIDE = 104;  // doubles per tile / node record: NSUM padded to a multiple of 8
-constexpr int GRP_TILES = 64;     // tiles per group: one node = 4 096 points
-constexpr int FUSE_MAX_GROUPS_PER_LIDAR = 64;  // the host tree takes any count; kept small so that rounds stay one
 struct FuseArgs {
   int seg_start[MALIO_MAX_LIDAR + 1];
   int seg_blk0[MALIO_MAX_LIDAR + 1];  // first workgroup (64-point tile) of each LiDAR segment
-  int seg_grp0[MALIO_MAX_LIDAR + 1];  // first group of each segment
-  int L, ngroups, converge;
+  int L, converge;
   PassConst pc;     // DEV: read from the control block instead
   WeightConst wc;
   double guess[4];  // [max_u, -min_u, max_R, -min_R] the rows are weighted with (DEV: control block)
-  double *tiles;    // [workgroups][TILE_STRIDE] device memory
-  u32 *tickets;     // [0] global, [1 + g] group g; zero between kernels (the last arriver resets its word)
-  double *nodes;    // device alias of pinned host memory: [ngroups][TILE_STRIDE], then the tail
-  double *tail;     // ... [0..4] true extrema + M as mm_fold_wave leaves them, [5] heavy-workgroup score
-  GateArgs gate;
+  double *tiles;    // [NSUM][tstride]: entry-major like the workgroup partials of k_rows_reduce
+  int tstride;
 };
 
 __device__ __forceinline__ int tile_entry(int ra, int cb) {  // (row, col) of the 16 x 16 MFMA block -> entry of the 97, or -1
@@ -1325,37 +1351,14 @@ __device__ __forceinline__ int tile_entry(int ra, int cb) {  // (row, col) of th
   if (a == cb) return 90 + a;
   return a == 0 ? (cb == 1 ? 93 : 94) : 95;
 }
-__device__ __forceinline__ double ld_sc1(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// extrema slots written by other workgroups' atomics of THIS launch: read past the (non-coherent) caches
-__device__ __forceinline__ void mm_fold_wave_sc1(const u64 *slots, int extrinsic_est_en, double out5[5]) {
-  const int lane = threadIdx.x & 63;
-  const u64 *o = slots + (size_t)lane * 5;
-  u64 k0 = __hip_atomic_load(&o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u64 k1 = __hip_atomic_load(&o[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u64 k2 = __hip_atomic_load(&o[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u64 k3 = __hip_atomic_load(&o[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u64 cnt = __hip_atomic_load(&o[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  double r0 = wave_max(mm_dec(k0)), r1 = wave_min(mm_dec(k1)), r2 = wave_max(mm_dec(k2)), r3 = wave_min(mm_dec(k3));
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-  double m0 = fmax(0.0, r0), m1 = fmin(1000.0, r1), m2 = 0.0, m3 = 9999.0;
-  if (extrinsic_est_en) m2 = fmax(m2, r2), m3 = fmin(m3, r3);
-  out5[0] = m0, out5[1] = -m1, out5[2] = m2, out5[3] = -m3, out5[4] = (double)cnt;
-}
 
 template <bool DEV>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE)))
 k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restrict__ dl) {
   __shared__ SearchLds S;
-  __shared__ double SA[SQ][17];  // a_p, b_p of the 64 rows (see k_rows_reduce)
-  __shared__ double SB[SQ][17];
-  __shared__ double s_half[2][TILE_STRIDE];
-  __shared__ int s_flag;
+  // the 64 rows of the control wave for the MFMA operands: u[12], hs, 1/r (a_p = [u/r | u0..2 | 0], b_p = [u | hs | 0 0 0]
+  // are formed when they are read: 7.7 KB instead of the two 17-double records of k_rows_reduce)
+  __shared__ double U[SQ][15];
   if (DEV && dl->done) return;
   const QuatConst &qc = DEV ? dl->qc : a.qc;
   const PassConst &pc = DEV ? dl->pc : f.pc;
@@ -1373,139 +1376,66 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
 #pragma unroll
   for (int l = 1; l < MALIO_MAX_LIDAR; l++)
     if (l < f.L && (int)blockIdx.x >= f.seg_blk0[l]) lid = l;
-  const int tile_in_seg = (int)blockIdx.x - f.seg_blk0[lid];
-  const int q0 = f.seg_start[lid] + tile_in_seg * SQ, qend = f.seg_start[lid + 1];
+  const int q0 = f.seg_start[lid] + ((int)blockIdx.x - f.seg_blk0[lid]) * SQ, qend = f.seg_start[lid + 1];
   const int lane = (int)(threadIdx.x & 63);
-  const bool cwave = threadIdx.x < 64;
   PointOut po;
-  bool alive;
   if (converge) {
-    alive = search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po);
+    if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
   } else {  // REUSE pass: the control wave alone, lane = point
-    alive = cwave;
     if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
-    if (cwave) {
-      const int i = q0 + lane;
-      po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
-      po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
-      if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
-    }
+    if (threadIdx.x >= 64) return;
+    const int i = q0 + lane;
+    po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
+    po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
+    if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   }
-  if (alive) {  // (control wave)
-    wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
-    // ---- a5 / a7 with the guessed extrema ----
-    double mm[4];
+  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
+  // ---- a5 / a7 with the guessed extrema ----
+  double mm[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
-    double u[12], hs = 0, r = 1;
+  for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
+  double u[12], hs = 0, r = 1;
 #pragma unroll
-    for (int k = 0; k < 12; k++) u[k] = 0;
-    if (po.selected) {
-      RowIn rin;
-      rin.q = po.q, rin.pl = po.pl, rin.ucov = po.ucov, rin.trace = po.tr, rin.pd2 = po.pd2;
-      point_row(f.wc, a.extrinsic_est_en, pc, mm, rin, lid, u, hs, r);
-    }
-    double rc = r;
-    if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+  for (int k = 0; k < 12; k++) u[k] = 0;
+  if (po.selected) {
+    RowIn rin;
+    rin.q = po.q, rin.pl = po.pl, rin.ucov = po.ucov, rin.trace = po.tr, rin.pd2 = po.pd2;
+    point_row(f.wc, a.extrinsic_est_en, pc, mm, rin, lid, u, hs, r);
+  }
+  double rc = r;
+  if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+#pragma unroll
+  for (int k = 0; k < 12; k++) U[lane][k] = u[k];
+  U[lane][12] = hs;
 #ifndef ROWS_DIVIDE
-    const double rinv = po.selected ? 1.0 / rc : 0.0;
-#endif
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-#ifndef ROWS_DIVIDE
-      SA[lane][k] = u[k] * rinv;
+  U[lane][13] = po.selected ? 1.0 / rc : 0.0;
 #else
-      SA[lane][k] = po.selected ? u[k] / rc : 0.0;
+  U[lane][13] = po.selected ? rc : 0.0;
 #endif
-      SB[lane][k] = u[k];
-    }
-    SA[lane][12] = u[0], SA[lane][13] = u[1], SA[lane][14] = u[2], SA[lane][15] = 0.0;
-    SB[lane][12] = hs, SB[lane][13] = 0.0, SB[lane][14] = 0.0, SB[lane][15] = 0.0;
-    const unsigned long long bal = __ballot(po.selected);
-    __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above are ordered before its loads below (waitcnt by the compiler)
-    const int prow = lane >> 4, col = lane & 15;
-    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  const unsigned long long bal = __ballot(po.selected);
+  __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above precede its loads below (waitcnt by the compiler)
+  const int prow = lane >> 4, col = lane & 15;
+  const int ca = col < 12 ? col : (col < 15 ? col - 12 : 0), cb = col < 12 ? col : 12;
+  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int g = 0; g < 16; g++)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SA[prow + 4 * g][col], SB[prow + 4 * g][col], acc, 0, 0, 0);
-    // ---- the tile, write-through; then this workgroup's arrival ----
-    double *tile = f.tiles + (size_t)blockIdx.x * TILE_STRIDE;
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int e = tile_entry(prow + 4 * rg, col);
-      if (e >= 0) st_sc1(&tile[e], acc[rg]);
-    }
-    if (lane == 0) st_sc1(&tile[NSUM - 1], (double)__popcll(bal));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store and atomic of this wave has been acknowledged
-    const int grp_in_seg = tile_in_seg / GRP_TILES;
-    const int tiles_in_seg = (qend - f.seg_start[lid] + SQ - 1) / SQ;
-    const int ntiles = min(GRP_TILES, tiles_in_seg - grp_in_seg * GRP_TILES);
-    if (lane == 0) {
-      const u32 t = __hip_atomic_fetch_add(&f.tickets[1 + f.seg_grp0[lid] + grp_in_seg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_flag = t == (u32)(ntiles - 1);
-    }
+  for (int g = 0; g < 16; g++) {
+    const double *up = U[prow + 4 * g];
+    const double x = up[ca], w = up[13], y = up[cb];
+#ifndef ROWS_DIVIDE
+    const double av = col < 12 ? x * w : (col < 15 ? x : 0.0);
+#else
+    const double av = col < 12 ? (w != 0.0 ? x / w : 0.0) : (col < 15 ? x : 0.0);
+#endif
+    const double bv = col <= 12 ? y : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
   }
-  __syncthreads();  // (the three search waves have been waiting here since their last search)
-  if (!s_flag) return;
-  // ---- last workgroup of its group: the node over the group's (up to) 64 tiles, all 256 threads ----
-  {
-    const int grp_in_seg = tile_in_seg / GRP_TILES;
-    const int grp = f.seg_grp0[lid] + grp_in_seg;
-    const int tiles_in_seg = (qend - f.seg_start[lid] + SQ - 1) / SQ;
-    const int t0 = grp_in_seg * GRP_TILES;  // first tile of the group, inside the segment
-    const int half = threadIdx.x >> 7, e = threadIdx.x & 127;
-    if (e < NSUM) {
-      const double *base = f.tiles + (size_t)f.seg_blk0[lid] * TILE_STRIDE + e;
-      double h2[2];
+  // ---- the tile: a leaf of the summation tree, entry-major like k_rows_reduce's partials ----
 #pragma unroll
-      for (int part = 0; part < 2; part++) {  // 16 tiles at a time: a node of the tree per part
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const int t = t0 + half * 32 + part * 16 + k;
-          v[k] = t < tiles_in_seg ? ld_sc1(base + (size_t)t * TILE_STRIDE) : 0.0;
-        }
-#pragma unroll
-        for (int w = 1; w < 16; w <<= 1)
-#pragma unroll
-          for (int k = 0; k < 16; k += 2 * w) v[k] = v[k] + v[k + w];
-        h2[part] = v[0];
-      }
-      s_half[half][e] = h2[0] + h2[1];
-    }
-    __syncthreads();
-    if (threadIdx.x < NSUM)
-      __hip_atomic_store(&f.nodes[(size_t)grp * TILE_STRIDE + threadIdx.x], s_half[0][threadIdx.x] + s_half[1][threadIdx.x],
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(&f.tickets[1 + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-      const u32 t = __hip_atomic_fetch_add(&f.tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_flag = t == (u32)(f.ngroups - 1);
-      if (s_flag) __hip_atomic_store(&f.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_flag) return;
+  for (int rg = 0; rg < 4; rg++) {
+    const int e = tile_entry(prow + 4 * rg, col);
+    if (e >= 0) f.tiles[(size_t)e * f.tstride + blockIdx.x] = acc[rg];
   }
-  // ---- last group of the launch: true extrema + M, the heavy-workgroup score; announce (or gate) ----
-  if (threadIdx.x < 64) {
-    double o5[5];
-    mm_fold_wave_sc1(dy.mm_cur, a.extrinsic_est_en, o5);
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int k = 0; k < 5; k++) __hip_atomic_store(&f.tail[k], o5[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const u32 hv = __hip_atomic_load(&a.dq_ctl[2 + dy.parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&f.tail[5], (double)hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (f.gate.dl) {
-    gate_body(f.gate);
-  } else if (threadIdx.x == 0 && f.gate.msg_seq) {
-    __hip_atomic_store(f.gate.msg_seq, f.gate.publish, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (lane == 0) f.tiles[(size_t)(NSUM - 1) * f.tstride + blockIdx.x] = (double)__popcll(bal);
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
@@ -1803,21 +1733,12 @@ int measure_alloc(Ctx *c) {
     c->cap_partials = nb + nb / 8 + 16;
     MALIO_HIP(hipMalloc(&c->d_partials, sizeof(double) * NSUM * c->cap_partials));  // [NSUM][cap_partials]
   }
-  {  // one-kernel pass: tiles (one per 64 points + one per LiDAR for the segment padding), tickets, pinned nodes
-    const size_t nt = (N + SQ - 1) / SQ + MALIO_MAX_LIDAR, ng = (nt + GRP_TILES - 1) / GRP_TILES + MALIO_MAX_LIDAR;
+  {  // speculating pass (k_pass): one tile per 64 points (+ one per LiDAR for the segment padding), entry-major
+    const size_t nt = (N + SQ - 1) / SQ + MALIO_MAX_LIDAR;
     if (nt > c->cap_tiles) {
       if (c->d_tiles) (void)hipFree(c->d_tiles);
       c->cap_tiles = nt + nt / 8 + 16;
-      MALIO_HIP(hipMalloc(&c->d_tiles, sizeof(double) * TILE_STRIDE * c->cap_tiles));
-    }
-    if (ng > c->cap_groups) {
-      if (c->d_tickets) (void)hipFree(c->d_tickets);
-      if (c->h_nodes) (void)hipHostFree(c->h_nodes);
-      c->cap_groups = ng + ng / 8 + 8;
-      MALIO_HIP(hipMalloc(&c->d_tickets, sizeof(u32) * (1 + c->cap_groups)));
-      MALIO_HIP(hipMemsetAsync(c->d_tickets, 0, sizeof(u32) * (1 + c->cap_groups), c->stream));
-      MALIO_HIP(hipHostMalloc(&c->h_nodes, sizeof(double) * (TILE_STRIDE * c->cap_groups + 16), hipHostMallocMapped | hipHostMallocCoherent));
-      MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_nodes, c->h_nodes, 0));
+      MALIO_HIP(hipMalloc(&c->d_tiles, sizeof(double) * NSUM * c->cap_tiles));
     }
   }
   if (!c->d_dq_ctl) {
@@ -1847,7 +1768,6 @@ int reset_pass_state(Ctx *c) {
   if (c->d_mmslots) hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
   if (c->d_dq_ctl) MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
   if (c->d_gate_ticket) MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
-  if (c->d_tickets) MALIO_HIP(hipMemsetAsync(c->d_tickets, 0, sizeof(u32) * (1 + c->cap_groups), c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   c->mm_parity = 0, c->dq_parity = 0, c->last_M = -1;
   c->mm_guess_valid = false;
@@ -2199,9 +2119,9 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   prof_mark(c, "k_rows_reduce");
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = a.seg_block0[l];
-  hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+  hipLaunchKernelGGL(k_final_reduce<4>, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
                      c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)nullptr,
-                     gate ? *gate : GateArgs{});
+                     gate ? *gate : GateArgs{}, FoldArgs{});
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
@@ -2237,57 +2157,60 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
   hipLaunchKernelGGL(k_rows_reduce<true>, dim3(nb), dim3(BLK), 0, c->stream, b);
   SegBlocks sb;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = b.seg_block0[l];
-  hipLaunchKernelGGL(k_final_reduce, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+  hipLaunchKernelGGL(k_final_reduce<4>, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
                      c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, d_sums_out, (const DevLoop *)c->d_loop,
-                     gate ? *gate : GateArgs{});
+                     gate ? *gate : GateArgs{}, FoldArgs{});
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
 
-// ---- host side of the one-kernel pass ---------------------------------------------------------------------------------
+// ---- host side of the speculating pass ----------------------------------------------------------------------------------
 bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
   if (c->fuse_enabled < 0) {
     const char *e = getenv("MALIO_FUSE");
     c->fuse_enabled = (e && e[0] == '0') ? 0 : 1;
-    const char *b = getenv("MALIO_DEBUG_FUSE_BAD_GUESS");  // tests: every guess is wrong, every one-kernel pass is redone
+    const char *b = getenv("MALIO_DEBUG_FUSE_BAD_GUESS");  // tests: every guess is wrong, every speculating pass is redone
     c->fuse_debug_bad_guess = b && b[0] == '1';
   }
   if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending || c->part.world > 1) return false;
   if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
-  for (int l = 0; l < c->prm.lid_num; l++)
-    if ((size_t)(c->seg_start[l + 1] - c->seg_start[l]) > (size_t)FUSE_MAX_GROUPS_PER_LIDAR * GRP_TILES * SQ) return false;
   return c->d_tiles != nullptr;
 }
 
-// everything of FuseArgs that does not depend on the pass; returns the number of workgroups
-static int fill_fuse_static(Ctx *c, FuseArgs &f) {
+// everything of FuseArgs that does not depend on the pass; returns the number of workgroups (= tiles); sb: the segments
+// in tiles, for k_final_reduce<16>
+static int fill_fuse_static(Ctx *c, FuseArgs &f, SegBlocks &sb) {
   const int L = c->prm.lid_num;
-  int b = 0, g = 0;
+  int b = 0;
   for (int l = 0; l <= MALIO_MAX_LIDAR; l++) {
     const int ll = l < L ? l : L;
     f.seg_start[l] = c->seg_start[ll];
-    f.seg_blk0[l] = b, f.seg_grp0[l] = g;
-    c->fuse_seg_grp0[l] = g;
-    if (l < L) {
-      const int nt = (c->seg_start[l + 1] - c->seg_start[l] + SQ - 1) / SQ;
-      b += nt, g += (nt + GRP_TILES - 1) / GRP_TILES;
-    }
+    f.seg_blk0[l] = b, sb.b[l] = b;
+    if (l < L) b += (c->seg_start[l + 1] - c->seg_start[l] + SQ - 1) / SQ;
   }
-  f.L = L, f.ngroups = g, f.converge = 0;
-  c->fuse_groups = g;
+  f.L = L, f.converge = 0;
   f.wc.plane_cov_max = c->prm.plane_cov_max, f.wc.plane_cov_min = c->prm.plane_cov_min;
   f.wc.point_cov_max = c->prm.point_cov_max, f.wc.point_cov_min = c->prm.point_cov_min;
   f.wc.range_min = c->prm.range_min, f.wc.range_max = c->prm.range_max;
-  f.tiles = c->d_tiles, f.tickets = c->d_tickets;
-  f.nodes = c->d_nodes, f.tail = c->d_nodes + (size_t)TILE_STRIDE * c->cap_groups;
-  f.gate = GateArgs{};
+  f.tiles = c->d_tiles, f.tstride = (int)c->cap_tiles;
   memset(&f.pc, 0, sizeof(f.pc));
   memset(f.guess, 0, sizeof(f.guess));
   return b;
 }
 
-// one pass as ONE kernel, state in the kernel arguments (malio_measure, the host-driven loop): the bookkeeping of
-// pass_stage1 + the launch. The caller has checked fuse_eligible.
+static void launch_final_tiles(Ctx *c, const SegBlocks &sb, const DevLoop *dl, const GateArgs *gate) {
+  const int ns = sums_len(c);
+  FoldArgs fold;
+  fold.mmslots = dl ? c->d_mmslots : c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
+  fold.dq_ctl = c->d_dq_ctl, fold.mm_out = c->d_res + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
+  fold.dq_parity = c->dq_parity;
+  hipLaunchKernelGGL(k_final_reduce<16>, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+                     (const double *)c->d_tiles, (int)c->cap_tiles, sb, c->prm.lid_num, c->d_res, dl, gate ? *gate : GateArgs{}, fold);
+}
+
+// one pass as k_pass -> k_final_reduce<16>, state in the kernel arguments (malio_measure, the host-driven loop): the
+// bookkeeping of pass_stage1 + the launches. Results land in h_res like the three-kernel pass'. The caller has checked
+// fuse_eligible.
 int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate) {
   if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
@@ -2308,70 +2231,46 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   }
   a.parity = c->dq_parity;
   FuseArgs f;
-  const int nwg = fill_fuse_static(c, f);
+  SegBlocks sb;
+  const int nwg = fill_fuse_static(c, f, sb);
   f.converge = converge;
   fill_pass_const(c, s, c->pc);
   f.pc = c->pc;
   memcpy(f.guess, c->mm_guess, sizeof(f.guess));
   if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
   memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
-  if (gate) f.gate = *gate;
   hipLaunchKernelGGL(k_pass<false>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
                      (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
+  launch_final_tiles(c, sb, nullptr, gate);
+  prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;
   return MALIO_OK;
 }
 
-// the same kernel reading state, pass kind, parities and the guess from the device loop's control block
+// the same two kernels reading state, pass kind, parities and the guess from the device loop's control block
 int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   Pass1Args a;
   fill_pass1_static(c, a);
   a.defer = 0;
   memset(&a.qc, 0, sizeof(a.qc));
   FuseArgs f;
-  const int nwg = fill_fuse_static(c, f);
-  if (gate) f.gate = *gate;
+  SegBlocks sb;
+  const int nwg = fill_fuse_static(c, f, sb);
   hipLaunchKernelGGL(k_pass<true>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
                      (const DevLoop *)c->d_loop);
+  launch_final_tiles(c, sb, c->d_loop, gate);
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;
   return MALIO_OK;
 }
 
-// The upper levels of the summation tree (see k_final_reduce): the nodes of one LiDAR, pairwise, until one is left; an
-// odd node moves up unchanged (+0 is an exact identity here). Works on whole records: 97 independent sums side by side.
-static void tree_sum_nodes(const double *nodes, int n, double *out /*[NSUM]*/, std::vector<double> &tmp) {
-  if (n <= 0) {
-    for (int e = 0; e < NSUM; e++) out[e] = 0.0;
-    return;
-  }
-  tmp.resize((size_t)n * NSUM);
-  for (int k = 0; k < n; k++) memcpy(&tmp[(size_t)k * NSUM], nodes + (size_t)k * TILE_STRIDE, sizeof(double) * NSUM);
-  while (n > 1) {
-    const int h = n / 2;
-    for (int k = 0; k < h; k++) {
-      const double *x = &tmp[(size_t)(2 * k) * NSUM], *y = x + NSUM;
-      double *o = &tmp[(size_t)k * NSUM];
-      for (int e = 0; e < NSUM; e++) o[e] = x[e] + y[e];
-    }
-    if (n & 1) memmove(&tmp[(size_t)h * NSUM], &tmp[(size_t)(n - 1) * NSUM], sizeof(double) * NSUM);
-    n = h + (n & 1);
-  }
-  memcpy(out, tmp.data(), sizeof(double) * NSUM);
-}
-
+// the pass' results are in h_res (sums | true extrema | heavy score): did the guess hold?
 int fused_collect(Ctx *c, double *sums_out, bool *hit) {
-  const int L = c->prm.lid_num, ns = L * NSUM;
-  static thread_local std::vector<double> tmp;
-  for (int l = 0; l < L; l++) {
-    const int g0 = c->fuse_seg_grp0[l], g1 = c->fuse_seg_grp0[l + 1];
-    tree_sum_nodes(c->h_nodes + (size_t)g0 * TILE_STRIDE, g1 - g0, sums_out + (size_t)l * NSUM, tmp);
-  }
-  const double *tail = c->h_nodes + (size_t)TILE_STRIDE * c->cap_groups;
-  for (int k = 0; k < 6; k++) sums_out[ns + k] = tail[k];
-  *hit = memcmp(tail, c->fuse_guess_used, sizeof(double) * 4) == 0;
+  const int ns = sums_len(c);
+  (void)sums_out;
+  *hit = memcmp(c->h_res + ns, c->fuse_guess_used, sizeof(double) * 4) == 0;
   if (*hit) c->fuse_hits++; else c->fuse_misses++;
   return MALIO_OK;
 }

@@ -697,11 +697,12 @@ def _fresh(capi, sc, mode=None):
 @pytest.mark.parametrize("kw", [dict(seed=501, N=30000, Nmap=300000, L=3), dict(seed=502, N=9000, Nmap=120000, L=2, map_unc=True),
                                 dict(seed=503, N=5000, Nmap=60000, L=1), dict(cfg=2)], ids=lambda k: "s%s" % k.get("seed", "cfg2"))
 def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monkeypatch, kw):
-    """From the second pass of a scan on a pass runs as ONE kernel (k_pass) that weights its rows with the extrema of the
-    pass before and leaves the last levels of the summation tree to the host; a handle with MALIO_FUSE=0 runs every pass
-    as three kernels. Same summation tree, same per-point arithmetic: sums, extrema, per-point results and the whole
-    iterated update (gated and host-driven) must agree BIT FOR BIT - when the guess holds and when it does not
-    (MALIO_DEBUG_FUSE_BAD_GUESS=1: every guess is wrong, every pass redone)."""
+    """From the second pass of a scan on a pass can run as k_pass -> k_final_reduce: the point-phase kernel forms the rows
+    itself, weighted with the extrema of the pass before (search passes of malio_measure, every unit of the gated
+    update); a handle with MALIO_FUSE=0 runs every pass as three kernels. Same summation tree, same per-point
+    arithmetic: sums, extrema, per-point results and the whole iterated update (gated and host-driven) must agree BIT FOR
+    BIT - when the guess holds and when it does not (MALIO_DEBUG_FUSE_BAD_GUESS=1: every guess is wrong, every such pass
+    redone)."""
     sc = scenes.make_scene(**kw)
     s2 = sc["state0"].copy()
     s2[0:3] += [0.012, -0.02, 0.006]
@@ -728,13 +729,13 @@ def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monk
     assert p_st["passes"] == 0
     for name in ("fused", "bad"):
         out, side, st, upd = runs[name]
-        # every pass but the first of the scan - and the search passes that follow one with workgroups full of unmatched
-        # queries (s3 is 0.5 m off: such a pass hands them to k_search_tail, which the one-kernel form cannot)
-        assert len(seq) - 3 <= st["passes"] <= len(seq) - 1
+        # the search passes but the first of the scan - and but those that follow a search pass with workgroups full of
+        # unmatched queries (s3 is 0.5 m off: such a pass hands them to k_search_tail, which k_pass cannot)
+        assert 1 <= st["passes"] <= 3
         if name == "bad":
             assert st["misses"] == st["passes"] and st["hits"] == 0
         else:
-            assert st["hits"] >= 3 and st["hits"] + st["misses"] == st["passes"]
+            assert st["hits"] >= 1 and st["hits"] + st["misses"] == st["passes"]
         for a, b in zip(p_out, out):
             assert (a["valid"], a["M"]) == (b["valid"], b["M"]) and a["w_loc"] == b["w_loc"]
             assert a["unit_cov_minmax"] == b["unit_cov_minmax"] and a["R_minmax"] == b["R_minmax"]
@@ -746,7 +747,9 @@ def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monk
             assert (u["passes"], u["searches"], u["M"], u["t"]) == (v["passes"], v["searches"], v["M"], v["t"])
             assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]), mode
             # (a fresh handle does not know yet whether its search passes defer queries: the unit enqueued before the
-            # first pass' verdict is the four-kernel one in the gated loop)
-            assert upd[mode + "_stats"]["passes"] >= v["passes"] - 2
+            # first pass' verdict is the four-kernel one in the gated loop; the host-driven loop speculates on its
+            # search passes only)
+            need = v["passes"] - 2 if mode == "gated" else 1
+            assert upd[mode + "_stats"]["passes"] >= need
             if name == "bad":
-                assert upd[mode + "_stats"]["misses"] >= v["passes"] - 2
+                assert upd[mode + "_stats"]["misses"] >= need
