@@ -23,7 +23,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
     "malio_xchg_create_local", "malio_rccl_unique_id", "malio_xchg_create_rccl", "malio_xchg_device_row", "malio_xchg_kind",
     "malio_xchg_reduce_stream", "malio_node_create", "malio_node_destroy", "malio_node_last_error", "malio_node_gpus",
@@ -230,6 +230,11 @@ class Engine:
         lib().malio_debug_counters(self.h, out)
         return dict(nl1_cells=out[0], map_points=out[1], nl2_cells=out[2], rebuilds=out[3], inplace=out[4],
                     dead_slots=out[5], tombstones=out[6], slots=out[7])
+
+    def nfound_hist(self):
+        out = (C.c_int * 8)()
+        self._chk(lib().malio_debug_nfound_hist(self.h, out), "malio_debug_nfound_hist")
+        return list(out)
 
     def fuse_stats(self):
         out = (C.c_int * 4)()

@@ -1050,6 +1050,22 @@ int malio_debug_fuse_stats(malio_handle_t h, int *out4) {
   return MALIO_OK;
 }
 
+// Diagnostics: how the last search pass left the scan points - out8[k] = points with k neighbours inside sqrt(5) m
+// (k = 0..5), [6] = rejected by the count certificate alone (neighbours not looked for), [7] = not served here (another
+// shard's).
+int malio_debug_nfound_hist(malio_handle_t h, int *out8) {
+  if (check(h) || !out8) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  if (c->N <= 0 || !c->scan_sorted) return MALIO_ERR_NO_SCAN;
+  MALIO_HIP(hipSetDevice(c->device));
+  std::vector<unsigned char> nf(c->N);
+  MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (unsigned char v : nf) out8[v <= 5 ? v : (v == 0xFC ? 6 : 7)]++;
+  return MALIO_OK;
+}
+
 int malio_set_pass_hook(malio_handle_t h, void (*fn)(int, void *), void *user) {
   if (check(h)) return MALIO_ERR_BAD_ARG;
   h->pass_hook = fn, h->pass_hook_user = user;

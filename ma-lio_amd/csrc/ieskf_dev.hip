@@ -737,12 +737,13 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     const int p = i + 1;
     searches += converge ? 1 : 0;
     if (ntr + 5 <= 60) tr[ntr++] = now_us() - t_begin;
-    if (p + 1 <= maximum_iter && u_enq <= u + 1)  // the unit of pass p + 1, one ahead of the GPU
-      if (int rc = enqueue_unit()) {
-        rc_out = rc;
-        passes = p + 1;
-        break;
-      }
+    // the unit of THIS pass (missing only after a repeated pass used up the one that was enqueued ahead), then the unit
+    // of pass p + 1, one ahead of the GPU
+    while (rc_out == MALIO_OK && (u_enq <= u || (p + 1 <= maximum_iter && u_enq <= u + 1))) rc_out = enqueue_unit();
+    if (rc_out != MALIO_OK) {
+      passes = p + 1;
+      break;
+    }
     auto t0 = std::chrono::steady_clock::now();
     if (ntr + 4 <= 60) tr[ntr++] = now_us() - t_begin;
     ieskf_step_pre(L, &x_, &x_prop, P_prop.data(), pre, true);  // :526-572 + the first inversion, under the GPU's pass

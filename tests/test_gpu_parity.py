@@ -750,6 +750,7 @@ def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monk
             # first pass' verdict is the four-kernel one in the gated loop; the host-driven loop speculates on its
             # search passes only)
             need = v["passes"] - 2 if mode == "gated" else 1
+            assert upd[mode + "_stats"]["gate_timeouts"] == 0  # (no silent fall-back to the host-driven loop)
             assert upd[mode + "_stats"]["passes"] >= need
             if name == "bad":
                 assert upd[mode + "_stats"]["misses"] >= need
