@@ -4,7 +4,7 @@ marshalled beforehand, world_normal_y = NULL. PAGEABLE=1 / WNY=1 select the slow
 rocprofv3 --kernel-trace --memory-copy-trace for tools/loop_timeline.py."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes
