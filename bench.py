@@ -247,6 +247,7 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
     dbg = eng.debug_counters()
     out["scan_loop"] = {k: float(np.median(v)) for k, v in loop.items()}
     out["scan_loop"]["total_ms"] = float(sum(out["scan_loop"].values()))
+    out["scan_loop"]["points_per_s"] = float(sc["N"] / (out["scan_loop"]["total_ms"] * 1e-3))  # whole turn, not one pass
     out["scan_loop"]["scan_set_pageable_ms"] = float(np.median(pageable))
     out["scan_loop"]["map_incremental_with_wny_ms"] = float(np.median(with_wny)) if with_wny else None
     out["scan_loop"].update(map_points=eng.map_size(), added_per_scan=added,
@@ -282,6 +283,9 @@ def main():
     ap.add_argument("--config", type=int, default=0, help="BASELINE.json config number (1-based); default 2 at one GPU, 4 beyond")
     ap.add_argument("--tile", type=float, default=16.0, help="tile edge [m] of the spatially sharded map (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--virtual-shards", type=int, default=0,
+                    help="N = 1 only: a proxy for the scaling run on ONE GPU - every shard of a G-way sharded BASELINE config "
+                         "(default 4) run alone, its pass timed; prints its own JSON line instead of the headline")
     args = ap.parse_args()
 
     import torch
@@ -310,6 +314,8 @@ def main():
     if distributed:
         return main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backend)
 
+    if args.virtual_shards > 1:
+        return main_virtual_shards(args, torch, capi, scenes, dev_index)
     args.config = args.config or 2
     cfg = scenes.CONFIGS[args.config]
     sc = scenes.make_scene(cfg=args.config)
@@ -395,7 +401,9 @@ def main():
         "value": value, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "timed_blocks": blocks,
         "ms_per_step_minmax": [min(dts) / args.steps * 1e3, max(dts) / args.steps * 1e3],
-        "cold": cold, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "cold": cold, "higher_is_better": True, "scaling": "weak",
+        "scaling_note": "one GPU: nothing scales on this line; --gpus N runs ONE config-4 job on N ranks (\"strong\")",
+        "vs_baseline": None,
         "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step" % (
             cfg["name"], N, L, sc["Nmap"]), "points_per_gpu": N, "map_points": sc["Nmap"], "lidars": L,
@@ -430,11 +438,104 @@ def roofline_block(eng, state, args, n_points):
         traffic, traffic_src = tjd["traffic_bytes_per_launch"], "committed PMC run " + os.path.relpath(tj, ROOT)
         rp_ms, rp_src = tjd.get("rocprof_kernel_ms"), tjd.get("rocprof_source")
     return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_committed_pmc": traffic,
+            "traffic_source": traffic_src,
             "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * n_points, "kernel_ms": dom_ms,
             "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes the marker gap)",
             "frac_rocprof": (ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rp_ms else None,
             "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src, "kernel_event_ms": kt}
+
+
+def main_virtual_shards(args, torch, capi, scenes, dev_index):
+    """A single-GPU PROXY for the 1/2/4/8-GPU curve (the boxes this repository is developed on have one GPU; only the
+    driver's scaling run measures the real thing). For G = 2, 4, ... --virtual-shards and both partitionings, every shard
+    of the G-way sharded job - BASELINE config 4 by default: ONE 200 k-point scan against ONE 8 M-point map - is built on
+    this GPU and its search pass is timed ALONE (wall time of malio_measure on the shard's handle + the k_search event
+    time): what one GPU of a G-GPU node would spend per pass, were it the only user of its GPU - which it is. Reported
+    per shard: scan points served, map points stored, pass time; per G: the slowest shard, the load balance and
+    predicted_ms = slowest shard + the exchange's latency measured between G threads of this process on host memory
+    (malio_xchg_create_local: what MALIO_NODE_XCHG_HOST uses; RCCL's own latency can only be measured on G GPUs).
+    Not measured by this proxy: G GPUs' contention for the host's PCIe root / memory, the RCCL collective."""
+    import ctypes as C
+    cfg_index = args.config or 4
+    cfg = scenes.CONFIGS[cfg_index]
+    sc = scenes.make_scene(cfg=cfg_index)
+    N, L, state = sc["N"], sc["L"], sc["state0"]
+    Gmax = args.virtual_shards
+
+    def time_pass(e, steps):
+        fn, out = e.measure_fn(state, True)
+        for _ in range(max(10, args.warmup)):
+            assert fn() >= 0
+        ts = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            rc = fn()
+            ts.append(time.perf_counter() - t)
+            assert rc >= 0
+        e.set_profiling(True)
+        ks = []
+        for _ in range(12):
+            e.measure(state, True)
+            ks.append(dict(e.last_kernel_times()))
+        e.set_profiling(False)
+        kname = "k_pass" if all("k_pass" in k for k in ks) else "k_search"
+        return float(np.median(ts) * 1e3), float(np.median([k.get(kname, float("nan")) for k in ks])), kname, int(out.M)
+
+    def exchange_us(G):
+        """G native threads of this process meet in malio_xchg_reduce (host memory, spinning) with rows of the pass' size."""
+        us = C.c_double(0)
+        rc = capi.lib().malio_debug_xchg_latency(G, 97 * L + 8, 20000, C.byref(us))
+        return float(us.value) if rc == 0 else None
+
+    steps = max(50, min(args.steps, 200))
+    one = capi.Engine(sc["params"], device=dev_index)
+    one.map_build(sc["map"])
+    one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    ms1, k1, kn1, M1 = time_pass(one, steps)
+    del one
+    curve = {"1": {"pass_ms": ms1, "kernel_ms": k1, "kernel": kn1, "M": M1}}
+    G = 2
+    while G <= Gmax:
+        entry = {}
+        xus = exchange_us(G)
+        for part in ("tiles", "scan"):
+            shards = []
+            for r in range(G):
+                e = capi.Engine(sc["params"], device=dev_index)
+                if part == "tiles":
+                    e.set_partition(r, G, args.tile)
+                    e.map_build(sc["map"])
+                    e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+                    e.measure(state, True)
+                    served = int(e.scan_owned().sum())
+                else:
+                    lo, hi = N * r // G, N * (r + 1) // G
+                    e.map_build(sc["map"])
+                    e.scan_set(sc["scan"][lo:hi], sc["tables"], sc["temporal_comp"])
+                    served = hi - lo
+                ms, km, kn, M = time_pass(e, steps)
+                shards.append({"rank": r, "scan_points_served": served, "map_points_stored": e.map_size(), "pass_ms": ms,
+                               "kernel_ms": km, "kernel": kn, "M": M})
+                del e
+            slow = max(s["pass_ms"] for s in shards)
+            served = [s["scan_points_served"] for s in shards]
+            entry[part] = {"shards": shards, "slowest_pass_ms": slow,
+                           "balance_max_over_mean": float(max(served) / (sum(served) / G)),
+                           "exchange_us_host_threads": xus,
+                           "predicted_ms": slow + (xus or 0.0) * 1e-3,
+                           "predicted_speedup_vs_one_gpu": ms1 / (slow + (xus or 0.0) * 1e-3),
+                           "M_total": int(sum(s["M"] for s in shards))}
+        curve[str(G)] = entry
+        G *= 2
+    line = {"metric": "PROXY (one GPU, shards run one at a time): per-shard search-pass time of the G-way sharded job",
+            "unit": "ms per pass", "n_gpus": 1, "virtual_shards": Gmax, "steps": steps, "warmup": args.warmup,
+            "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass per step, sharded G ways" % (
+                cfg["name"], N, L, sc["Nmap"]), "tile_m": args.tile},
+            "data": "synthetic", "curve": curve,
+            "note": "not the scaling run: G GPUs' contention for the host and the RCCL collective are not in it"}
+    print(json.dumps(line), flush=True)
 
 
 def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backend):
@@ -574,6 +675,10 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
             "variants": {"%s+%s" % k: v for k, v in results.items()},
             "balance": extras["balance"], "single_gpu_same_job": single, "roofline": extras["roofline"], "cpu_baseline": None,
         }
+        # what carried the headline's exchange, at the top level: a silent fall-back from RCCL to shared memory must be
+        # visible to whoever checks "did RCCL see N ranks"
+        line["exchange"] = head[1]
+        line["rccl_ranks"] = world if head[1] == "rccl" else 0
         if rccl_note[0]:
             line["rccl_note"] = rccl_note[0]
         print(json.dumps(line), flush=True)

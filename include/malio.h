@@ -416,6 +416,9 @@ int malio_xchg_row(malio_xchg_t x); /* row_doubles the exchange was created with
 /* The same exchange between the THREADS of one process (one per GPU: what the node handle below runs on): creates all
  * `world` endpoints at once over a private block; endpoint r is used by thread r only. */
 int malio_xchg_create_local(int world, int row_doubles, malio_xchg_t *out_world);
+/* Diagnostics: mean latency [us] of one malio_xchg_reduce between `world` native threads of this process over a local
+ * exchange (no GPU work): what MALIO_NODE_XCHG_HOST adds to a pass. The slowest thread's figure. */
+int malio_debug_xchg_latency(int world, int row_doubles, int iters, double *us_out);
 /* ... and over RCCL (xGMI between the GPUs of a node, the network beyond): the producing kernels leave the row in HBM
  * (malio_xchg_device_row), ncclAllGather runs on the handle's stream right behind them, one copy brings all rows to
  * pinned memory, ONE stream synchronisation per exchange; the rows are then added in rank order on the host like

@@ -25,7 +25,7 @@ EXPORTS = [
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
-    "malio_xchg_create_local", "malio_rccl_unique_id", "malio_xchg_create_rccl", "malio_xchg_device_row", "malio_xchg_kind",
+    "malio_xchg_create_local", "malio_debug_xchg_latency", "malio_rccl_unique_id", "malio_xchg_create_rccl", "malio_xchg_device_row", "malio_xchg_kind",
     "malio_xchg_reduce_stream", "malio_node_create", "malio_node_destroy", "malio_node_last_error", "malio_node_gpus",
     "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",

@@ -21,7 +21,6 @@
 #include <cmath>
 #include "malio_internal.hpp"
 #include "../host/manifold.hpp"
-#include <hipcub/hipcub.hpp>
 
 namespace malio {
 
@@ -332,22 +331,57 @@ void spline_interval_logs(const double *poses16, int n, double *logs6);
 // is A_i = min(D_i, A_{i+1} + 1) with A_n = 0. With B_i = A_i + i this is B_i = min(D_i + i, B_{i+1}), B_n = n: a
 // suffix minimum, i.e. an inclusive min-scan over the reversed sequence. intensity <- A_i - 1 (:504); point i opens
 // an uncertainty entry when A_i > A_{i+1}, and that entry's number is A_i - 1.
-__global__ void __launch_bounds__(BLK) k_und_rev(const int *__restrict__ D, int n, int *rev) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  rev[n - 1 - i] = i >= 1 ? D[i] + i : 0x7FFFFFFF;
+// Two small kernels instead of a library scan (hipcub::DeviceScan: reverse + two scan kernels + the consumer):
+// k_und_blockmin leaves the minimum of D_i + i of every block of 256 points; k_und_final first folds the minima of the
+// blocks to its right (a few hundred values) into its carry, then runs the suffix minimum inside its own 256 points in
+// LDS, and goes on to what it always did with A_i and A_{i+1}.
+__global__ void __launch_bounds__(BLK) k_und_blockmin(const int *__restrict__ D, int n, int *bm) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  int v = (i >= 1 && i < n) ? D[i] + i : 0x7FFFFFFF;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+  __shared__ int sm[BLK / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int m = sm[0];
+#pragma unroll
+    for (int k = 1; k < BLK / 64; k++) m = min(m, sm[k]);
+    bm[blockIdx.x] = m;
+  }
 }
 __global__ void __launch_bounds__(BLK) k_und_final(const float *__restrict__ in12, const float4 *__restrict__ und,
-                                                   const int *__restrict__ brev, int n, float *out12, int *entry, int entry_cap,
-                                                   int *n_entries, float *entry_pts) {
-  int i = blockIdx.x * BLK + threadIdx.x;
+                                                   const int *__restrict__ D, const int *__restrict__ bm, int nblk, int n,
+                                                   float *out12, int *entry, int entry_cap, int *n_entries, float *entry_pts) {
+  __shared__ int s_b[BLK];
+  __shared__ int s_carry[BLK / 64];
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  // carry: B of the first point behind this block = min(n, minima of the blocks to the right)
+  int cy = n;
+  for (int b = (int)blockIdx.x + 1 + (int)threadIdx.x; b < nblk; b += BLK) cy = min(cy, bm[b]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cy = min(cy, __shfl_xor(cy, d));
+  if ((threadIdx.x & 63) == 0) s_carry[threadIdx.x >> 6] = cy;
+  s_b[threadIdx.x] = (i >= 1 && i < n) ? D[i] + i : 0x7FFFFFFF;
+  __syncthreads();
+  int carry = s_carry[0];
+#pragma unroll
+  for (int k = 1; k < BLK / 64; k++) carry = min(carry, s_carry[k]);
+  // suffix minimum inside the block (Hillis-Steele on 256 values)
+#pragma unroll
+  for (int d = 1; d < BLK; d <<= 1) {
+    const int o = threadIdx.x + d < BLK ? s_b[threadIdx.x + d] : 0x7FFFFFFF;
+    __syncthreads();
+    s_b[threadIdx.x] = min(s_b[threadIdx.x], o);
+    __syncthreads();
+  }
   if (i >= n) return;
   float v[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) v[k] = in12[(size_t)i * 12 + k];
   if (i >= 1) {
-    const int A = min(n, brev[n - 1 - i]) - i;
-    const int An = (i + 1 < n) ? min(n, brev[n - 2 - i]) - (i + 1) : 0;
+    const int A = min(carry, s_b[threadIdx.x]) - i;
+    const int An = min(carry, threadIdx.x + 1 < BLK ? s_b[threadIdx.x + 1] : 0x7FFFFFFF) - (i + 1);  // (0 at i + 1 == n)
     if (i == 1) *n_entries = A;
     const float4 u = und[i];
     if (u.w != 0.f) v[0] = u.x, v[1] = u.y, v[2] = u.z, v[8] = (float)(A - 1);
@@ -377,9 +411,8 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   spline_interval_logs(knot_poses, n_knots, logs.data());
   ArenaScope sc(c->arena);
   float4 *d_und = nullptr;
-  int *d_D = nullptr, *d_rev = nullptr, *d_brev = nullptr, *d_entry = nullptr, *d_ne = nullptr;
+  int *d_D = nullptr, *d_rev = nullptr, *d_entry = nullptr, *d_ne = nullptr;
   double *d_tab = nullptr;
-  char *d_tmp = nullptr;
   // the same twists in axis-angle form (k_undistort): angle, unit axis k, K^2 = k k^T - I, translational part
   std::vector<double> ivl((size_t)(n_knots - 1) * UND_IVL, 0.0);
   for (int k = 0; k + 1 < n_knots; k++) {
@@ -397,8 +430,7 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   const int entry_cap = n_imu + 4;
   MALIO_HIP(sc.get(&d_und, (size_t)n));
   MALIO_HIP(sc.get(&d_D, (size_t)n));
-  MALIO_HIP(sc.get(&d_rev, (size_t)n));
-  MALIO_HIP(sc.get(&d_brev, (size_t)n));
+  MALIO_HIP(sc.get(&d_rev, (size_t)(n + BLK - 1) / BLK + 1));  // block minima of D_i + i
   MALIO_HIP(sc.get(&d_entry, (size_t)entry_cap));
   MALIO_HIP(sc.get(&d_ne, 1));
   float *d_entry_pts = nullptr;  // the undistorted points that open the entries, for a caller that keeps the cloud in HBM
@@ -433,13 +465,9 @@ int undistort_core(Ctx *c, const float *d_in12, int n, double lidar_beg_time, co
   else
     hipLaunchKernelGGL(k_undistort_big, dim3(nb), dim3(BLK), 0, c->stream, a);
   prof_mark(c, "k_undistort");
-  hipLaunchKernelGGL(k_und_rev, dim3(nb), dim3(BLK), 0, c->stream, d_D, n, d_rev);
-  size_t tmp_bytes = 0;
-  MALIO_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_bytes, d_rev, d_brev, hipcub::Min(), n, c->stream));
-  MALIO_HIP(sc.get(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-  MALIO_HIP(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_rev, d_brev, hipcub::Min(), n, c->stream));
-  hipLaunchKernelGGL(k_und_final, dim3(nb), dim3(BLK), 0, c->stream, d_in12, d_und, d_brev, n, d_out12, d_entry,
-                     entry_cap, d_ne, d_entry_pts);
+  hipLaunchKernelGGL(k_und_blockmin, dim3(nb), dim3(BLK), 0, c->stream, (const int *)d_D, n, d_rev);
+  hipLaunchKernelGGL(k_und_final, dim3(nb), dim3(BLK), 0, c->stream, d_in12, d_und, (const int *)d_D, (const int *)d_rev, nb, n,
+                     d_out12, d_entry, entry_cap, d_ne, d_entry_pts);
   // read-backs through the pinned buffer: [64] count, [65 ..) entry indices, then the entry points
   u32 *mb = nullptr;
   MALIO_HIP(mbox(c, &mb));

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -248,6 +250,38 @@ static int reduce_gathered(malio_xchg *x, int ns, const double *guess4, double *
 }
 
 int malio_xchg_row(malio_xchg_t x) { return x ? x->row : 0; }
+
+// Diagnostics: the latency of one malio_xchg_reduce between `world` native threads of this process on host memory (what
+// the node handle's MALIO_NODE_XCHG_HOST exchange costs a pass, without any GPU work around it): median-free mean over
+// `iters` lock-step rounds after a warm-up, the slowest thread's figure, in microseconds.
+int malio_debug_xchg_latency(int world, int row_doubles, int iters, double *us_out) {
+  if (world < 1 || world > 64 || row_doubles < 9 || iters < 1 || !us_out) return MALIO_ERR_BAD_ARG;
+  std::vector<malio_xchg_t> xs(world, nullptr);
+  if (malio_xchg_create_local(world, row_doubles, xs.data()) != MALIO_OK) return MALIO_ERR_ALLOC;
+  std::vector<double> us(world, 0.0);
+  std::vector<int> rcs(world, 0);
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; r++)
+    th.emplace_back([&, r] {
+      std::vector<double> row(row_doubles), E(4);
+      for (int k = 0; k < row_doubles; k++) row[k] = k + r;
+      const int ns = row_doubles - 8;
+      for (int k = 0; k < 200 && rcs[r] >= 0; k++) rcs[r] = malio_xchg_reduce(xs[r], row.data(), ns, nullptr, row.data(), E.data(), 20.0);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < iters && rcs[r] >= 0; k++) rcs[r] = malio_xchg_reduce(xs[r], row.data(), ns, nullptr, row.data(), E.data(), 20.0);
+      us[r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+    });
+  for (auto &t : th) t.join();
+  double worst = 0;
+  int rc = MALIO_OK;
+  for (int r = 0; r < world; r++) {
+    worst = std::max(worst, us[r]);
+    if (rcs[r] < 0) rc = rcs[r];
+    malio_xchg_destroy(xs[r]);
+  }
+  *us_out = worst;
+  return rc;
+}
 
 int malio_xchg_unlink(malio_xchg_t x) {  // once every rank has opened the segment its name is no longer needed
   if (!x) return MALIO_ERR_BAD_ARG;
