@@ -170,6 +170,13 @@ int malio_map_delete_boxes(malio_handle_t h, const malio_box_t *boxes, int nb, i
  * out_counts3 (may be NULL): |PointToAdd|, |PointNoNeedDownsample|, return value of the first Add_Points. */
 int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
                           const float *world_normal_y, int *out_counts3);
+/* The selection of map_incremental alone (laserMapping.cpp:398-442), the map untouched: out_pts[0, counts2[0]) =
+ * PointToAdd, out_pts[counts2[0], counts2[0] + counts2[1]) = PointNoNeedDownsample, both in scan order, as (x, y, z,
+ * normal_y); out_index (may be NULL): the scan index of each. On a map shard (malio_set_partition) the points this
+ * shard serves. What malio_node_map_incremental merges over its GPUs before every shard is handed both lists. */
+int malio_map_incremental_select(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
+                                 const float *world_normal_y, malio_point_t *out_pts, int *out_index, int cap,
+                                 int *out_counts2);
 /* ikdtree.flatten(Root_Node, PCL_Storage, NOT_RECORD) laserMapping.cpp:1018-1019 (map publishing / saving).
  * Copies min(cap, size) valid points in map order, *out_n = size. Order differs from the tree's traversal. */
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n);
@@ -503,6 +510,12 @@ int malio_node_measure(malio_node_t nd, const malio_state_t *s, int converge, ma
 int malio_node_update_iterated(malio_node_t nd, malio_state_t *x, double *P, double R, int *stats, double *solve_time);
 int malio_node_scan_get(malio_node_t nd, float *normal_y, malio_point_t *nearest, int *nearest_count, uint8_t *selected,
                         float *res_last, float *world_xyz, float *normvec4);
+/* map_incremental() on the node (see malio_map_incremental): every GPU classifies the scan points it serves, the two
+ * lists are merged in scan order and handed to every GPU (a replica takes all, a tile shard what it stores). No
+ * Nearest_Points cross PCIe. out_counts3: |PointToAdd|, |PointNoNeedDownsample|, GPU 0's return value of the first
+ * Add_Points (the reference's value when the map is replicated). */
+int malio_node_map_incremental(malio_node_t nd, const malio_state_t *state_point, int flg_EKF_inited,
+                               const float *world_normal_y, int *out_counts3);
 int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int pass, void *user), void *user);
 int malio_node_exchange_stats(malio_node_t nd, int *stats2); /* passes that needed one / two exchanges so far */
 /* shard geometry, host code (no GPU): which shard serves each of n world points (xyz [n][3]) / whether shard `rank`

@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
@@ -831,6 +831,25 @@ class Node:
                                             _p(out["res_last"], C.c_float), _p(out["world"], C.c_float),
                                             _p(out["normvec"], C.c_float)), "malio_node_scan_get")
         return out
+
+    def map_incremental(self, state_flat, flg_EKF_inited=True, world_normal_y=None):
+        """malio_node_map_incremental. Returns (|PointToAdd|, |PointNoNeedDownsample|, added on GPU 0)."""
+        s = state_from_flat(state_flat, self.L)
+        wny = None if world_normal_y is None else np.ascontiguousarray(world_normal_y, np.float32)
+        cnt = (C.c_int * 3)()
+        self._chk(lib().malio_node_map_incremental(self.h, C.byref(s), int(bool(flg_EKF_inited)),
+                                                   None if wny is None else _p(wny, C.c_float), cnt), "malio_node_map_incremental")
+        return int(cnt[0]), int(cnt[1]), int(cnt[2])
+
+    def map_get(self, rank):
+        """The map points GPU `rank` holds (malio_map_get on its handle)."""
+        hh = C.c_void_p()
+        self._chk(lib().malio_node_handle(self.h, int(rank), C.byref(hh)), "malio_node_handle")
+        n = C.c_int(0)
+        lib().malio_map_get(hh, None, 0, C.byref(n))
+        out = np.zeros((max(n.value, 1), 12), np.float32)
+        lib().malio_map_get(hh, _p(out, Point), n.value, C.byref(n))
+        return out[:n.value]
 
     def exchange_stats(self):
         st = (C.c_int * 2)()

@@ -349,6 +349,12 @@ int malio_map_incremental(malio_handle_t h, const malio_state_t *state_point, in
   return map_incremental(h, state_point, flg_EKF_inited, world_normal_y, out_counts3);
 }
 
+int malio_map_incremental_select(malio_handle_t h, const malio_state_t *state_point, int flg_EKF_inited,
+                                 const float *world_normal_y, malio_point_t *out_pts, int *out_index, int cap, int *out_counts2) {
+  if (check(h) || !state_point || !out_counts2 || cap < 0 || (cap > 0 && !out_pts)) return MALIO_ERR_BAD_ARG;
+  return map_incremental_select(h, state_point, flg_EKF_inited, world_normal_y, out_pts, out_index, cap, out_counts2);
+}
+
 int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   if (check(h) || !out_n || cap < 0 || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;

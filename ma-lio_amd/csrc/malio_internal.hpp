@@ -531,6 +531,8 @@ int map_add_dev(Ctx *c, const float4 *d_pts, int n, int downsample_on, int *out_
 int map_add_pair_dev(Ctx *c, const float4 *d_pts, int m_ds, int m_plain, int *out_added);  // [0,m_ds): down-sampled add, rest: plain add
 int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
                     int *out_counts);
+int map_incremental_select(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
+                           malio_point_t *out_pts, int *out_index, int cap, int *out_counts2);
 // measure.hip: PointToAdd / PointNoNeedDownsample membership + world points, all in ORIGINAL scan order
 int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
                     u32 *d_nonf, float4 *d_wp);

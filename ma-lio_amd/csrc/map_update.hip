@@ -244,6 +244,18 @@ __global__ void __launch_bounds__(BLK) k_compact2(const float4 *__restrict__ src
   }
 }
 
+// the same for the positions themselves: which scan point each listed point is (malio_map_incremental_select)
+__global__ void __launch_bounds__(BLK) k_compact2_idx(const u32 *__restrict__ flagA, const u32 *__restrict__ posA, u32 *dstA,
+                                                      const u32 *__restrict__ flagB, const u32 *__restrict__ posB, u32 *dstB, int n) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  if (blockIdx.y == 0) {
+    if (flagA[i]) dstA[posA[i]] = (u32)i;
+  } else {
+    if (flagB[i]) dstB[posB[i]] = (u32)i;
+  }
+}
+
 int ensure_alt(Ctx *c, size_t need) {
   if (need > c->cap_map_alt) {
     if (c->d_map_alt) (void)hipFree(c->d_map_alt);
@@ -545,12 +557,12 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
 // map_incremental(), laserMapping.cpp:398-446, entirely on the device: selection (measure.hip), stable compaction
 // of the two lists in scan order, then the two Add_Points calls of :443-444.
 namespace malio {
-int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
-                    int *out_counts) {
-  MALIO_HIP(hipSetDevice(c->device));
+// selection of map_incremental (laserMapping.cpp:398-442) on the device: d_add = PointToAdd | PointNoNeedDownsample back to
+// back in scan order (arena memory of the caller's scope), their counts; d_idx (optional): the scan index of each
+static int mapinc_select_dev(Ctx *c, ArenaScope &sc, const malio_state_t *state_point, int flg_EKF_inited,
+                             const float *h_world_normal_y, float4 **d_add_out, int *na_out, int *nn_out, u32 **d_idx_out) {
   const int N = c->N;
   if (N <= 0) return MALIO_ERR_NO_SCAN;
-  ArenaScope sc(c->arena);
   float *d_wny = nullptr;
   u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr, *tiles2 = nullptr;
   float4 *wp = nullptr, *d_add = nullptr, *d_non = nullptr;
@@ -583,6 +595,25 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   d_non = d_add + na;
   hipLaunchKernelGGL(k_compact2, dim3((N + BLK - 1) / BLK, 2), dim3(BLK), 0, c->stream, wp, addf, apos, d_add, nonf, npos,
                      d_non, N);
+  if (d_idx_out) {
+    u32 *d_idx = nullptr;
+    MALIO_HIP(sc.get(&d_idx, (size_t)na + (size_t)nn));
+    hipLaunchKernelGGL(k_compact2_idx, dim3((N + BLK - 1) / BLK, 2), dim3(BLK), 0, c->stream, addf, apos, d_idx, nonf, npos,
+                       d_idx + na, N);
+    *d_idx_out = d_idx;
+  }
+  *d_add_out = d_add, *na_out = na, *nn_out = nn;
+  return MALIO_OK;
+}
+
+int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
+                    int *out_counts) {
+  MALIO_HIP(hipSetDevice(c->device));
+  ArenaScope sc(c->arena);
+  float4 *d_add = nullptr;
+  int na = 0, nn = 0;
+  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, nullptr);
+  if (rc != MALIO_OK) return rc;
   int added = 0;
   // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)   (:443-444)
   if ((float)c->prm.filter_size_map > 0.f)
@@ -591,5 +622,38 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
     rc = map_add_pair_dev(c, d_add, 0, na + nn, nullptr);
   if (out_counts) out_counts[0] = na, out_counts[1] = nn, out_counts[2] = added;
   return rc;
+}
+
+// The selection alone, lists to the host (what a node spreads over its shards): out_pts = PointToAdd | PointNoNeedDownsample
+// (x, y, z, normal_y), out_index = the scan index of each, counts2 = the two lengths. The map is not touched.
+int map_incremental_select(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *h_world_normal_y,
+                           malio_point_t *out_pts, int *out_index, int cap, int *out_counts2) {
+  MALIO_HIP(hipSetDevice(c->device));
+  ArenaScope sc(c->arena);
+  float4 *d_add = nullptr;
+  u32 *d_idx = nullptr;
+  int na = 0, nn = 0;
+  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, &d_idx);
+  if (rc != MALIO_OK) return rc;
+  out_counts2[0] = na, out_counts2[1] = nn;
+  const int m = na + nn;
+  if (m > cap) {
+    c->err = "malio_map_incremental_select: output capacity too small";
+    return MALIO_ERR_BAD_ARG;
+  }
+  if (m == 0) return MALIO_OK;
+  std::vector<float4> hp((size_t)m);
+  std::vector<u32> hi((size_t)m);
+  MALIO_HIP(hipMemcpyAsync(hp.data(), d_add, sizeof(float4) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(hi.data(), d_idx, sizeof(u32) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < m; k++) {
+    malio_point_t p;
+    memset(&p, 0, sizeof(p));
+    p.x = hp[k].x, p.y = hp[k].y, p.z = hp[k].z, p._pad0 = 1.f, p.normal_y = hp[k].w;
+    out_pts[k] = p;
+    if (out_index) out_index[k] = (int)hi[k];
+  }
+  return MALIO_OK;
 }
 }  // namespace malio

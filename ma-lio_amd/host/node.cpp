@@ -311,6 +311,61 @@ int malio_node_scan_get(malio_node_t nd, float *normal_y, malio_point_t *nearest
   });
 }
 
+// map_incremental() (laserMapping.cpp:398-446) on the node: every GPU classifies the scan points it serves (its range of
+// the scan, or the points of its tiles) from the neighbours of ITS last search pass - no Nearest_Points cross PCIe - and
+// hands back its two lists; they are merged in scan order on the caller's thread (the order Add_Points' sequential
+// semantics inside a voxel depends on) and every GPU is handed both merged lists: a replica takes all of them, a tile
+// shard what it stores (own tiles + halo). counts3: |PointToAdd|, |PointNoNeedDownsample|, and the return value of the
+// first Add_Points on GPU 0 (the reference's value for MALIO_PART_SCAN; for MALIO_PART_TILES GPU 0's share of it).
+int malio_node_map_incremental(malio_node_t nd, const malio_state_t *state_point, int flg_EKF_inited,
+                               const float *world_normal_y, int *out_counts3) {
+  if (!nd || !state_point) return MALIO_ERR_BAD_ARG;
+  if (nd->N <= 0) return MALIO_ERR_NO_SCAN;
+  const int G = nd->n;
+  struct Sel {
+    std::vector<malio_point_t> pts;
+    std::vector<int> idx;
+    int cnt[2] = {0, 0};
+  };
+  std::vector<Sel> sel(G);
+  int rc = nd->run([&](Worker &k) -> int {
+    Sel &s = sel[k.rank];
+    const int n = k.hi - k.lo;
+    s.pts.resize((size_t)n), s.idx.resize((size_t)n);
+    const int r = malio_map_incremental_select(k.h, state_point, flg_EKF_inited, world_normal_y ? world_normal_y + k.lo : nullptr,
+                                               s.pts.data(), s.idx.data(), n, s.cnt);
+    if (r != MALIO_OK) return r;
+    for (int j = 0; j < s.cnt[0] + s.cnt[1]; j++) s.idx[j] += k.lo;  // positions in the caller's cloud
+    return MALIO_OK;
+  });
+  if (rc != MALIO_OK) return rc;
+  // merge by scan index: PointToAdd of all GPUs, then PointNoNeedDownsample (each GPU's lists are ascending already)
+  std::vector<malio_point_t> lists[2];
+  for (int part = 0; part < 2; part++) {
+    std::vector<int> at(G);
+    size_t total = 0;
+    for (int r = 0; r < G; r++) at[r] = part == 0 ? 0 : sel[r].cnt[0], total += (size_t)sel[r].cnt[part];
+    lists[part].reserve(total);
+    while (lists[part].size() < total) {
+      int best = -1, bidx = 0x7FFFFFFF;
+      for (int r = 0; r < G; r++) {
+        const int end = part == 0 ? sel[r].cnt[0] : sel[r].cnt[0] + sel[r].cnt[1];
+        if (at[r] < end && sel[r].idx[at[r]] < bidx) best = r, bidx = sel[r].idx[at[r]];
+      }
+      lists[part].push_back(sel[best].pts[at[best]++]);
+    }
+  }
+  std::vector<int> added(G, 0);
+  const bool ds = (float)nd->prm.filter_size_map > 0.f;
+  rc = nd->run([&](Worker &k) -> int {  // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)
+    int r = malio_map_add(k.h, lists[0].data(), (int)lists[0].size(), ds ? 1 : 0, &added[k.rank]);
+    if (r != MALIO_OK) return r;
+    return malio_map_add(k.h, lists[1].data(), (int)lists[1].size(), 0, nullptr);
+  });
+  if (out_counts3) out_counts3[0] = (int)lists[0].size(), out_counts3[1] = (int)lists[1].size(), out_counts3[2] = ds ? added[0] : 0;
+  return rc;
+}
+
 // ---- shard geometry (host code: tests, and callers that want to know where a point lives) -------------------------
 int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner) {
   if (!xyz || !out_owner || n < 0 || world < 1) return MALIO_ERR_BAD_ARG;

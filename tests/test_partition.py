@@ -286,3 +286,40 @@ def test_node_update_small_M_on_a_later_pass_leaves_inputs_untouched(capi, scene
     assert v["rc"] == capi.SMALL_M_FALLBACK, v
     assert np.array_equal(v["P"], sc["P0"]) and np.array_equal(v["state"], sc["state0"])
     nd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["scan", "tiles"])
+def test_node_map_incremental_equals_single_engine(capi, scenes, partition):
+    """map_incremental() on the node (laserMapping.cpp:398-446): every GPU classifies the points it serves from its own
+    neighbour cache, the lists are merged in scan order and handed to every GPU. Against ONE engine over three consecutive
+    scans of a moving sensor: same |PointToAdd| / |PointNoNeedDownsample|, every GPU's map = the single engine's map
+    (a replica: all of it; a tile shard: what malio_part_stores keeps), and the next scan's passes agree."""
+    G, tile = 3, 12.0
+    sc = scenes.make_scene(seed=321, N=6000, Nmap=120000, L=3)
+    one = _single(capi, sc)
+    nd = capi.Node(sc["params"], [0] * G, partition=capi.PART_TILES if partition == "tiles" else capi.PART_SCAN, tile_m=tile)
+    nd.map_build(sc["map"])
+    key = lambda p: p[np.lexsort(p[:, [5, 2, 1, 0]].T)][:, [0, 1, 2, 5]]
+    state = sc["state0"]
+    for turn in range(3):
+        s2 = scenes.make_scene(seed=321, N=6000, Nmap=120000, L=3, scan_seed=700 + turn)
+        wny = np.random.default_rng(turn).uniform(0, 0.002, s2["N"]).astype(np.float32)
+        one.scan_set(s2["scan"], sc["tables"], sc["temporal_comp"])
+        nd.scan_set(s2["scan"], sc["tables"], sc["temporal_comp"])
+        u, v = one.update_iterated(state, sc["P0"]), nd.update_iterated(state, sc["P0"])
+        assert (u["passes"], u["M"]) == (v["passes"], v["M"])
+        # the same posterior for both (the node's differs in the last bits: per-shard partial sums)
+        a = one.map_incremental(u["state"], True, wny)
+        b = nd.map_incremental(u["state"], True, wny)
+        assert (a[0], a[1]) == (b[0], b[1]) and a[0] > 20
+        if partition == "scan":
+            assert a[2] == b[2]
+        full = one.map_get()
+        for r in range(G):
+            mine = nd.map_get(r)
+            want = full if partition == "scan" else full[capi.part_stores(full[:, :3], r, G, tile, sc["params"]["filter_size_map"])]
+            assert np.array_equal(key(mine), key(want)), (turn, r, mine.shape, want.shape)
+        state = u["state"].copy()
+        state[0:3] += [0.05, 0.02, 0.0]  # (the next scan's prior)
+    nd.close()
