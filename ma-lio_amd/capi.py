@@ -21,7 +21,7 @@ ERR_TIMEOUT = -7
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
-    "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_undistort", "malio_sums_len",
+    "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
@@ -432,6 +432,19 @@ class Engine:
             return f(h, sp, cv, op)
         fn._keep = keep
         return fn, out
+
+    def update_iterated_async(self, state_flat, P):
+        """malio_update_iterated_begin: returns a function that ends the update (malio_update_iterated_end) and returns the
+        same dict as update_iterated; the calling thread is free in between."""
+        s = state_from_flat(state_flat, self.L)
+        Pw = np.ascontiguousarray(P, np.float64).copy()
+        self._chk(lib().malio_update_iterated_begin(self.h, C.byref(s), _p(Pw, C.c_double)), "malio_update_iterated_begin")
+
+        def end():
+            stats = (C.c_int * 4)()
+            rc = self._chk(lib().malio_update_iterated_end(self.h, C.byref(s), _p(Pw, C.c_double), stats), "malio_update_iterated_end")
+            return dict(rc=rc, state=state_to_flat(s, self.L), P=Pw, passes=stats[0], searches=stats[1], M=stats[2], t=stats[3])
+        return end
 
     def update_iterated_fn(self, state_flat, P, R=0.001):
         """Pre-bound malio_update_iterated for timing loops: returns (fn, result); fn() restores the prior (state, P) and

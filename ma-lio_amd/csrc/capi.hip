@@ -1032,6 +1032,25 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
   return ieskf_update(h, nullptr, x, P, R, stats, solve_time);
 }
 
+// The update without the host in the loop, in two calls (csrc/ieskf_dev.hip: device-resident loop): `begin` enqueues all
+// max_iteration + 1 passes with the n x n algebra of every iteration as kernels and returns; the caller's thread is free
+// until it calls `end`, which waits and returns what malio_update_iterated returns. MALIO_SMALL_M_FALLBACK from `end`
+// (a pass accepted fewer points than there are states): x and P are untouched, call malio_update_iterated.
+int malio_update_iterated_begin(malio_handle_t h, const malio_state_t *x, const double *P) {
+  if (check(h) || !x || !P) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP_H(hipSetDevice(h->device));
+  if (h->dev_update_pending) {
+    h->err = "malio_update_iterated_begin: the previous update has not been ended";
+    return MALIO_ERR_BAD_ARG;
+  }
+  return ieskf_update_device_begin(h, x, P);
+}
+int malio_update_iterated_end(malio_handle_t h, malio_state_t *x, double *P, int *stats) {
+  if (check(h) || !x || !P) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP_H(hipSetDevice(h->device));
+  return ieskf_update_device_end(h, x, P, stats);
+}
+
 int malio_set_update_mode(malio_handle_t h, int mode) {
   if (check(h) || (mode != MALIO_UPDATE_DEVICE && mode != MALIO_UPDATE_HOST && mode != MALIO_UPDATE_GATED)) return MALIO_ERR_BAD_ARG;
   h->update_mode = mode;

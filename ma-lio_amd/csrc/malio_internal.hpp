@@ -475,6 +475,7 @@ struct Ctx {
   double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
   int gate_trace_n = 0;
   int update_mode = MALIO_UPDATE_GATED;  // malio_set_update_mode
+  bool dev_update_pending = false;       // malio_update_iterated_begin was called, _end not yet
   double *d_rows = nullptr;      // optional dense rows [N][C+2]
   size_t cap_rows = 0;
   size_t cap_partials = 0;
@@ -605,6 +606,8 @@ int ieskf_update(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, double 
 // csrc/ieskf_dev.hip: the same update as ONE enqueued chain of kernels with the n x n algebra on the device; returns
 // MALIO_SMALL_M_FALLBACK untouched inputs when a pass accepted fewer points than there are states (rows path: host loop)
 int ieskf_update_device(Ctx *c, malio_state_t *x, double *P, int *stats);
+int ieskf_update_device_begin(Ctx *c, const malio_state_t *x, const double *P);  // enqueue everything, return
+int ieskf_update_device_end(Ctx *c, malio_state_t *x, double *P, int *stats);    // wait, hand out the results
 void free_dev_loop(Ctx *c);
 int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
 // measure.hip: the pass kernels of one iteration of the device loop (k_search/k_reuse by the control block's converge

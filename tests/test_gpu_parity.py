@@ -754,3 +754,30 @@ def test_one_kernel_pass_equals_three_kernel_pass_bit_for_bit(capi, scenes, monk
             assert upd[mode + "_stats"]["passes"] >= need
             if name == "bad":
                 assert upd[mode + "_stats"]["misses"] >= need
+
+
+@pytest.mark.gpu
+def test_update_begin_end_frees_the_host(capi, scenes):
+    """malio_update_iterated_begin / _end: the device-resident loop as an asynchronous call. `begin` returns with the whole
+    update enqueued (well before it could have finished), the thread does something else, `end` returns the result of
+    the device mode (same passes; state as the gated loop's to the device's libm)."""
+    import time
+    sc = scenes.make_scene(seed=88, N=20000, Nmap=200000, L=3)
+    ref = _fresh(capi, sc, "device")
+    v = ref.update_iterated(sc["state0"], sc["P0"])
+    g = _fresh(capi, sc, "gated").update_iterated(sc["state0"], sc["P0"])
+    eng = _fresh(capi, sc)
+    eng.measure(sc["state0"], True)  # (the once-per-scan grouping out of the way)
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    t0 = time.perf_counter()
+    end = eng.update_iterated_async(sc["state0"], sc["P0"])
+    t_begin = time.perf_counter() - t0
+    busy = sum(i * i for i in range(20000))  # the caller's own work
+    u = end()
+    assert busy > 0 and u["rc"] == 0
+    assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"])
+    assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"])
+    assert np.abs(u["state"] - g["state"]).max() < 1e-8
+    assert t_begin < 0.5e-3 * 4  # begin does not wait for the 0.3-0.8 ms the loop takes (generous: first-call allocations)
+    with pytest.raises(RuntimeError):
+        eng._chk(capi.lib().malio_update_iterated_end(eng.h, None, None, None), "end without begin")
