@@ -546,8 +546,7 @@ int malio_debug_counters(malio_handle_t h, int *out8);
  * redone by the host-driven loop after a gate timed out}. MALIO_FUSE=0 in the environment disables the one-kernel pass. */
 int malio_debug_fuse_stats(malio_handle_t h, int *out4);
 /* After a search pass: out8[k] = scan points with k map points inside the sqrt(5) m acceptance radius (k = 0..5),
- * [6] = points rejected by the count certificate alone (fewer than five map points can lie inside the radius; their
- * neighbours are looked for only when malio_scan_get / malio_map_incremental ask), [7] = points another shard serves. */
+ * [6] = 0, [7] = points another shard serves. */
 int malio_debug_nfound_hist(malio_handle_t h, int *out8);
 
 #ifdef __cplusplus

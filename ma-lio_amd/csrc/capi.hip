@@ -1076,8 +1076,7 @@ int malio_debug_fuse_stats(malio_handle_t h, int *out4) {
 }
 
 // Diagnostics: how the last search pass left the scan points - out8[k] = points with k neighbours inside sqrt(5) m
-// (k = 0..5), [6] = rejected by the count certificate alone (neighbours not looked for), [7] = not served here (another
-// shard's).
+// (k = 0..5), [6] = unused, [7] = not served here (another shard's).
 int malio_debug_nfound_hist(malio_handle_t h, int *out8) {
   if (check(h) || !out8) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
@@ -1087,7 +1086,7 @@ int malio_debug_nfound_hist(malio_handle_t h, int *out8) {
   std::vector<unsigned char> nf(c->N);
   MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  for (unsigned char v : nf) out8[v <= 5 ? v : (v == 0xFC ? 6 : 7)]++;
+  for (unsigned char v : nf) out8[v <= 5 ? v : 7]++;
   return MALIO_OK;
 }
 

@@ -46,9 +46,6 @@ struct NList {
   float4 *pts = nullptr;  // [cap_pts] x, y, z, bits(map index); a deleted point's entries carry x = +inf
   u32 *cap = nullptr;     // [table size] capacity of every list (count + slack): room for incremental inserts
   u32 *inc = nullptr;     // [table size] entries the batch being applied brings to each list (zero between batches)
-  u32 *own = nullptr;     // level 2 only: [table size][NL_OWN_W] what the count certificate of the search needs of every cell
-                          // (ball_count_ub): [0..7] map points per half-edge subcell, [8..13] bounding box of the cell's
-                          // points (nl_own_add); never decremented / shrunk by deletions: upper bounds
   u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells
   size_t total = 0;       // entries reserved by the lists built last (capacities)
   size_t entries = 0;     // live entries at build time (27 per point for whole blocks; ~20.6 when pruned)
@@ -69,7 +66,7 @@ struct NlDev {
   Cell *table;
   u32 tmask;
   float4 *pts;
-  u32 *cap, *inc, *state, *own;
+  u32 *cap, *inc, *state;
   u32 bump_end;
   float inv_cf;
   int pruned;  // level 1: a list holds only the block's points within one cell edge of its cell (nl_member)
@@ -98,24 +95,6 @@ __device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
   const u64 B = 1ull << 20;
   return ((u64)(ix + (long long)B) & 0x1FFFFF) | (((u64)(iy + (long long)B) & 0x1FFFFF) << 21) |
          (((u64)(iz + (long long)B) & 0x1FFFFF) << 42);
-}
-// One record of NList::own per directory slot, one 64-byte line: [0..7] counts per subcell, [8..10] the bitwise complement
-// of the order-preserving code of min x, y, z and [11..13] the code of max x, y, z of the cell's points - both grow under
-// atomicMax from the all-zero record a build (and a new cell) starts with.
-constexpr int NL_OWN_W = 16;
-__device__ __forceinline__ u32 f32_ord(float f) {
-  const u32 b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float f32_unord(u32 e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
-__device__ __forceinline__ void nl_own_add(u32 *rec, int sub, float x, float y, float z) {
-  atomicAdd(&rec[sub], 1u);
-  atomicMax(&rec[8], ~f32_ord(x)), atomicMax(&rec[9], ~f32_ord(y)), atomicMax(&rec[10], ~f32_ord(z));
-  atomicMax(&rec[11], f32_ord(x)), atomicMax(&rec[12], f32_ord(y)), atomicMax(&rec[13], f32_ord(z));
-}
-// the half-edge subcell (0..7) of its cell a coordinate triple in cell units falls into
-__device__ __forceinline__ int nl_subcell(float gx, float gy, float gz, int ix, int iy, int iz) {
-  return (gx - (float)ix >= 0.5f ? 1 : 0) | (gy - (float)iy >= 0.5f ? 2 : 0) | (gz - (float)iz >= 0.5f ? 4 : 0);
 }
 __device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (7 VALU ops); == hash_key_d()
   u32 lo = (u32)k, hi = (u32)(k >> 32);
@@ -516,7 +495,7 @@ int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n,
 int exclusive_scan_u32_pair(Ctx *c, const u32 *inA, u32 *outA, u32 *tilesA, u32 *totalA, const u32 *inB, u32 *outB,
                             u32 *tilesB, u32 *totalB, int n);  // two scans of one length in one pair of launches
 void free_grid(CellGrid &g);
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false, bool with_own = false);
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false);
 void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
 void nl_ensure(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m);  // both levels at once
@@ -537,7 +516,6 @@ int map_incremental_select(Ctx *c, const malio_state_t *state_point, int flg_EKF
 // measure.hip: PointToAdd / PointNoNeedDownsample membership + world points, all in ORIGINAL scan order
 int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited, const float *d_wny, u32 *d_addf,
                     u32 *d_nonf, float4 *d_wp);
-int resolve_few(Ctx *c);  // measure.hip: neighbours of the points the last search pass rejected by the count certificate
 int far_knn5(Ctx *c, u32 *d_far);  // measure.hip: unrestricted 5-NN of the queries with nfound < 5, [5][N] sorted order
 int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted);
 int map_rebuild_search(Ctx *c);  // neighbour lists of both levels from d_map_in[map_n], now

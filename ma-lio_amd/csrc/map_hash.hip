@@ -461,7 +461,6 @@ void free_nl_scratch(NlScratch &s) {
 }
 
 void free_nlist(NList &nl) {
-  if (nl.own) (void)hipFree(nl.own);
   if (nl.table) (void)hipFree(nl.table);
   if (nl.pts) (void)hipFree(nl.pts);
   if (nl.cap) (void)hipFree(nl.cap);
@@ -498,25 +497,7 @@ __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys
   cap[d] = capv[s];
 }
 
-// own[slot]: how many points of the build fall into each half-edge subcell of every cell, and their bounding box (NList::own)
-__global__ void __launch_bounds__(BLK) k_nl_own(const float4 *__restrict__ pts, int n, float inv_cf, const Cell *__restrict__ table,
-                                                u32 tmask, u32 *own) {
-  int i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  if (!(p.x < INFINITY)) return;  // (a dead slot)
-  const float gx = p.x * inv_cf, gy = p.y * inv_cf, gz = p.z * inv_cf;
-  const int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
-  const u64 key = cell_key(ix, iy, iz);
-  u32 s = hash_key(key) & tmask;
-  while (table[s].key != key) {
-    if (table[s].key == EMPTY_KEY) return;  // cannot happen: the point's own cell holds it
-    s = (s + 1) & tmask;
-  }
-  nl_own_add(own + (size_t)s * NL_OWN_W, nl_subcell(gx, gy, gz, ix, iy, iz), p.x, p.y, p.z);
-}
-
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned, bool with_own) {
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned) {
   nl.cf = cf;
   nl.pruned = pruned;
   nl.inv_cf = 1.0f / nl.cf;
@@ -580,21 +561,13 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
     MALIO_HIP(hipMalloc(&nl.cap, sizeof(u32) * nl.cap_table));
     if (nl.inc) (void)hipFree(nl.inc);
     MALIO_HIP(hipMalloc(&nl.inc, sizeof(u32) * nl.cap_table));
-    if (nl.own) (void)hipFree(nl.own);
-    nl.own = nullptr;
-    if (with_own) MALIO_HIP(hipMalloc(&nl.own, sizeof(u32) * NL_OWN_W * nl.cap_table));
   }
-  if (with_own && !nl.own) MALIO_HIP(hipMalloc(&nl.own, sizeof(u32) * NL_OWN_W * nl.cap_table));
   if (!nl.state) MALIO_HIP(hipMalloc(&nl.state, sizeof(u32) * 4));
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
   MALIO_HIP(hipMemsetAsync(nl.cap, 0, sizeof(u32) * tsize, c->stream));
   MALIO_HIP(hipMemsetAsync(nl.inc, 0, sizeof(u32) * tsize, c->stream));
   hipLaunchKernelGGL(k_nl_compact, dim3((tbig + BLK - 1) / BLK), dim3(BLK), 0, c->stream, keys, cnt, start, capv, tbig,
                      nl.table, nl.cap, tsize - 1);
-  if (nl.own) {
-    MALIO_HIP(hipMemsetAsync(nl.own, 0, sizeof(u32) * NL_OWN_W * tsize, c->stream));
-    hipLaunchKernelGGL(k_nl_own, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, (const Cell *)nl.table, tsize - 1, nl.own);
-  }
   const u32 h_state[4] = {(u32)used, 0u, h_cnt[0], 0u};  // bump cursor, overflow flag, cells, -
   MALIO_HIP(hipMemcpyAsync(nl.state, h_state, sizeof(h_state), hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
@@ -734,7 +707,6 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
     }
     s = (s + 1) & nl.tmask;
   }
-  if (cidx == 13 && nl.own) nl_own_add(nl.own + (size_t)s * NL_OWN_W, nl_subcell(gx, gy, gz, ix, iy, iz), p.x, p.y, p.z);  // its own cell
   u32 pos = atomicAdd(&nl.table[s].count, 1u);
   if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
     atomicSub(&nl.table[s].count, 1u);
@@ -785,7 +757,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
 
 NlDev nl_dev(const NList &nl) {
   NlDev v;
-  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state, v.own = nl.own;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state;
   v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.pruned = nl.pruned ? 1 : 0;
   return v;
 }

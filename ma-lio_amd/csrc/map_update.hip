@@ -363,7 +363,7 @@ int map_rebuild_search(Ctx *c) {
   // coarse that k_vox_add needs the whole block (a voxel's half diagonal must stay inside the kept reach)
   const bool prune1 = getenv("MALIO_NL_FULL_BLOCKS") == nullptr && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * c->cell;
   int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1);
-  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2, false, /*with_own*/ true);
+  if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;
 }
 

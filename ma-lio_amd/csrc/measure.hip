@@ -568,11 +568,8 @@ constexpr int NL1_G = KS_G;  // lanes per query on the level-1 lists (~45 candid
 constexpr unsigned char NF_PENDING = 0xFF;
 constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
-constexpr unsigned char NF_FEW = 0xFC;       // fewer than five map points within sqrt(5) m, certified by counts alone: the
-                                             // pass rejects the point (laserMapping.cpp:587) without having looked for its
-                                             // neighbours; whoever needs them (map_incremental, malio_scan_get) asks
-                                             // resolve_few() first
-constexpr int TAIL_BLOCKS = 1024;  // k_search_tail: 4096 waves x 4 queries per sweep
+constexpr int TAIL_BLOCKS = 2048;  // k_search_tail: 8192 waves x 4 queries = one sweep up to 32 k deferred queries (a second sweep
+                                   // costs its waves the whole search + point-phase chain again: 45 us instead of 25)
 constexpr int TAIL_G = 16;         // lanes per deferred query (level-2 lists hold ~180..900 points)
 constexpr int DEFER_MIN = 8;                 // a workgroup serves up to this many uncertified queries itself
 struct NlView {
@@ -580,85 +577,7 @@ struct NlView {
   u32 tmask;
   const float4 *pts;
   float cf, inv_cf;
-  const u32 *own;  // level 2: points per half-edge subcell of every cell (upper bounds), or null
 };
-// Count certificate of the gate `size < 5 || d2[4] > 5` (laserMapping.cpp:587): an UPPER bound on the number of map points
-// within sqrt(5) m of w, from the per-cell records of the level-2 directory alone (NList::own, one 64-byte line per cell).
-// The 27 cells around the query's cell cover the ball (cf2 >= 2.25 m > sqrt 5). A cell counts only if the bounding box
-// of its points reaches into the ball (map points lie on surfaces: the box of a wall's cell is a thin slab, and a query
-// 2.3 m off the wall is certified), and then only with the subcells - half the edge, eight per cell - whose box, grown by
-// the allowance for the float rounding of cell coordinates, does. Fewer than five => the reference rejects the point, and
-// no map point has been read: what a query at the map frontier (or displaced by the prior's rotation error at long
-// range) used to learn from a whole level-2 list of several hundred entries.
-// G lanes share the 27 probes (lane `sub` takes cells sub, sub + G, ...); the sum is returned in every lane of the group.
-template <int G>
-__device__ __forceinline__ u32 ball_count_ub(const NlView &nl, float wx, float wy, float wz, int sub) {
-  const float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
-  const float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
-  const int ix = (int)kxf, iy = (int)kyf, iz = (int)kzf;
-  const float margin = 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f);
-  const float lim = 2.2360680f * nl.inv_cf * 1.00001f + margin;  // radius in cell units, generous
-  const float lim2 = lim * lim;
-  constexpr int NP = (27 + G - 1) / G;  // probes per lane, in batches of NB whose loads are issued together (one dependent
-  constexpr int NB = NP < 4 ? NP : 4;   // pair at a time was 20 us per query group; all seven at once spills 25 VGPRs)
-  u32 ub = 0;
-  for (int k0 = 0; k0 < NP; k0 += NB) {
-    u32 slot[NB];
-    Cell c[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const int cidx = min(sub + (k0 + k) * G, 26);
-      const u64 key = cell_key_d(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
-      slot[k] = hash_key_d(key) & nl.tmask;
-      c[k] = nl.table[slot[k]];
-    }
-    bool found[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const int cidx = min(sub + (k0 + k) * G, 26);
-      const u64 key = cell_key_d(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
-      while (c[k].key != key && c[k].key != EMPTY_KEY) {  // (a displaced entry: rare)
-        slot[k] = (slot[k] + 1) & nl.tmask;
-        c[k] = nl.table[slot[k]];
-      }
-      found[k] = c[k].key == key && k0 + k < NP && sub + (k0 + k) * G < 27;
-    }
-    uint4 bb0[NB];
-    uint2 bb1[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const u32 *rec = nl.own + (size_t)(found[k] ? slot[k] : 0u) * NL_OWN_W;
-      bb0[k] = *reinterpret_cast<const uint4 *>(rec + 8), bb1[k] = *reinterpret_cast<const uint2 *>(rec + 12);
-    }
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if (!found[k]) continue;
-      {  // the bounding box of the cell's points, in metres (their stored coordinates): squared distance as the search forms it
-        const float lox = f32_unord(~bb0[k].x), loy = f32_unord(~bb0[k].y), loz = f32_unord(~bb0[k].z);
-        const float hix = f32_unord(bb0[k].w), hiy = f32_unord(bb1[k].x), hiz = f32_unord(bb1[k].y);
-        const float ex = fmaxf(fmaxf(lox - wx, wx - hix), 0.f), ey = fmaxf(fmaxf(loy - wy, wy - hiy), 0.f),
-                    ez = fmaxf(fmaxf(loz - wz, wz - hiz), 0.f);
-        if (!(ex * ex + ey * ey + ez * ez <= 5.0f * 1.0001f)) continue;  // (an empty record has NaN bounds and zero counts)
-      }
-      // (the counts only for the few cells whose box reaches the ball)
-      const uint4 *rec = reinterpret_cast<const uint4 *>(nl.own + (size_t)slot[k] * NL_OWN_W);
-      const uint4 o0 = rec[0], o1 = rec[1];
-      const u32 cnt[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-      const int cidx = sub + (k0 + k) * G;
-      const float bx = kxf + (float)(cidx % 3 - 1), by = kyf + (float)((cidx / 3) % 3 - 1), bz = kzf + (float)(cidx / 9 - 1);
-#pragma unroll
-      for (int sc = 0; sc < 8; sc++) {
-        const float lx = bx + ((sc & 1) ? 0.5f : 0.f), ly = by + ((sc & 2) ? 0.5f : 0.f), lz = bz + ((sc & 4) ? 0.5f : 0.f);
-        const float ex = fmaxf(fmaxf(lx - gx, gx - (lx + 0.5f)), 0.f), ey = fmaxf(fmaxf(ly - gy, gy - (ly + 0.5f)), 0.f),
-                    ez = fmaxf(fmaxf(lz - gz, gz - (lz + 0.5f)), 0.f);
-        if (ex * ex + ey * ey + ez * ez <= lim2) ub += cnt[sc];
-      }
-    }
-  }
-#pragma unroll
-  for (int sft = G / 2; sft > 0; sft >>= 1) ub += __shfl_xor(ub, sft);
-  return ub;
-}
 template <int G>
 __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
                                           Top5 &t) {
@@ -882,21 +801,6 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
     }
   }
   __syncthreads();
-  // ---- count certificate: an uncertified query with fewer than five map points anywhere inside its sqrt(5) m ball is
-  // rejected here, from 27 probes of the level-2 directory (4 lanes per query, as in phase B), instead of walking a
-  // level-2 list of several hundred entries to find that out ----
-  if (nl2.own) {
-    const int ql = threadIdx.x / NL1_G, sub = threadIdx.x % NL1_G;
-    const bool pendq = (qidx(ql) < qend) && S.nf[ql] == NF_PENDING && S.w[ql].x < 1e9f;
-    if (__syncthreads_or(pendq ? 1 : 0)) {
-      if (pendq) {  // (uniform over the 4 lanes of a query)
-        const float4 ww = S.w[ql];
-        const u32 ub = ball_count_ub<NL1_G>(nl2, ww.x, ww.y, ww.z, sub);
-        if (sub == 0 && ub < 5u) S.nf[ql] = NF_FEW;
-      }
-      __syncthreads();
-    }
-  }
   PH(0, 2);
   PH_NOTE(2, wall_clock64());
   PH_NOTE(3, 0);
@@ -1008,11 +912,11 @@ __global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
   const u32 cnt = a.dq_ctl[dy.parity];
   double mxu = -INFINITY, mnu = INFINITY, mxr = -INFINITY, mnr = INFINITY;
   u64 nsel = 0;
-  // Few deferred queries (the count certificate of k_search has taken the empty neighbourhoods out): a whole wave per
-  // query - 14 entries of a level-2 list per lane instead of 54, two batches of loads instead of seven on the chain that
-  // IS this kernel's duration (31 us for 3.7 k queries with 16 lanes each, whatever their number).
+  // Few deferred queries: a whole wave per query - 14 entries of a level-2 list per lane instead of 54, two batches of
+  // loads instead of seven on the chain that IS this kernel's duration (its waves all run at once: the kernel takes as
+  // long as one 16-lane walk + one point phase, whatever the number of queries).
   const u32 nwaves = (gridDim.x * BLK) >> 6;
-  if (cnt <= 2 * nwaves) {
+  if (cnt <= nwaves) {
     const u32 wv = (blockIdx.x * BLK + threadIdx.x) >> 6;
     for (u32 j = wv; j < cnt; j += nwaves) {  // wave-uniform
       const int i = (int)a.dq[j];
@@ -1600,7 +1504,7 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
 
 static NlView view_of(const NList &nl) {
   NlView v;
-  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf, v.own = nl.own;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
   return v;
 }
 
@@ -1775,53 +1679,8 @@ __global__ void __launch_bounds__(BLK) k_mapinc_classify(MapIncArgs a) {
   a.wp[o] = make_float4(wx, wy, wz, a.wny ? a.wny[o] : 0.f);
 }
 
-// The neighbours of the points a search pass rejected by the count certificate alone (NF_FEW): the restricted level-2
-// search that pass skipped, now, for whoever reads Nearest_Points - once per scan instead of once per search pass, and
-// not at all when nobody asks. A wave per 64 points; the flagged ones are served four at a time, 16 lanes each.
-__global__ void __launch_bounds__(BLK) k_resolve_few(int N, const float4 *__restrict__ world4, unsigned char *nfound, NlView nl2,
-                                                     u32 *nbr) {
-  const int lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & 15;
-  const int wave0 = (int)((blockIdx.x * BLK + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * BLK) >> 6);
-  for (int base = wave0 * 64; base < N; base += nwaves * 64) {
-    const int i = base + lane;
-    unsigned long long todo = __ballot(i < N && nfound[i] == NF_FEW);
-    while (todo) {
-      int idx[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        idx[k] = todo ? __ffsll((long long)todo) - 1 : -1;
-        if (todo) todo &= todo - 1;
-      }
-      const int my = grp == 0 ? idx[0] : grp == 1 ? idx[1] : grp == 2 ? idx[2] : idx[3];
-      const bool live = my >= 0;
-      const int qi = base + (live ? my : idx[0]);
-      const float4 w = world4[qi];
-      Top5 t;
-      nl_search<16>(nl2, w.x, w.y, w.z, sub, 5.0f, t);
-      if (live && sub == 0) {
-        int nf = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-          nbr[(size_t)k * N + qi] = t.og(k);
-          nf += t.og(k) != INVALID;
-        }
-        nfound[qi] = (unsigned char)(nf < 5 ? nf : 4);  // (the certificate says < 5; never let a marker value through)
-      }
-    }
-  }
-}
-int resolve_few(Ctx *c) {
-  if (!c->nl2.own || c->N <= 0 || !c->scan_sorted) return MALIO_OK;
-  const int waves = (c->N + 63) / 64;
-  hipLaunchKernelGGL(k_resolve_few, dim3((unsigned)std::min((waves + 3) / 4, 1024)), dim3(BLK), 0, c->stream, c->N, c->d_world4,
-                     c->d_nfound, view_of(c->nl2), c->d_nbr);
-  MALIO_HIP(hipGetLastError());
-  return MALIO_OK;
-}
-
 // Nearest_Points beyond the search radius (malio_scan_get): d_far [5][N], INVALID where the search pass found all five
 int far_knn5(Ctx *c, u32 *d_far) {
-  if (int rcf = resolve_few(c)) return rcf;
   const long long th = ((long long)c->N + FAR_GROUP - 1) / FAR_GROUP * 64;
   hipLaunchKernelGGL(k_far_nearest<5>, dim3((unsigned)std::min<long long>((th + BLK - 1) / BLK, 2048)), dim3(BLK), 0, c->stream, c->N, c->d_world4,
                      c->d_nfound, view_of(c->nl2), c->d_map_in, c->map_n, d_far);
@@ -1848,7 +1707,6 @@ int mapinc_classify(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   ArenaScope sc(c->arena);
   u32 *d_far = nullptr;
   MALIO_HIP(sc.get(&d_far, (size_t)N));
-  if (int rcf = resolve_few(c)) return rcf;  // points rejected by counts alone: their neighbours inside sqrt(5) m, now
   if (c->map_n - c->map_dead > 0 && flg_EKF_inited) {
     long long th = ((long long)N + FAR_GROUP - 1) / FAR_GROUP * 64;
     hipLaunchKernelGGL(k_far_nearest<1>, dim3((unsigned)std::min<long long>((th + BLK - 1) / BLK, 2048)), dim3(BLK), 0, c->stream, N, c->d_world4,
