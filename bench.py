@@ -244,10 +244,30 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
             loop["scan_set_ms"].append((t1 - t) * 1e3), loop["update_ms"].append((t2 - t1) * 1e3)
             loop["map_incremental_ms"].append((t4 - t3) * 1e3)
         added = int(minc_counts[0] + minc_counts[1])
+    # the same turn with the scan handed over as 20-byte records (malio_scan_set_packed, page-locked): what a caller pays
+    # that fills the records in the per-point loop it already has (laserMapping.cpp:972-976)
+    packed = []
+    pin_rec = capi.PinnedArray((sc["N"], 5), np.float32)
+    for k in range(5):
+        s2 = scenes.make_scene(cfg=cfg_index, scan_seed=600 + k)
+        pin_rec.array[:] = capi.Engine.pack_scan(s2["scan"])
+        call = eng.scan_set_packed_fn(pin_rec.array, sc["tables"], sc["temporal_comp"])
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        call()
+        assert upd() == 0
+        t2 = time.perf_counter()
+        st = capi.state_from_flat(upd_result()["state"], sc["L"])
+        t3 = time.perf_counter()
+        minc(st)
+        t4 = time.perf_counter()
+        if k:
+            packed.append(((t2 - t) + (t4 - t3)) * 1e3)
     dbg = eng.debug_counters()
     out["scan_loop"] = {k: float(np.median(v)) for k, v in loop.items()}
     out["scan_loop"]["total_ms"] = float(sum(out["scan_loop"].values()))
     out["scan_loop"]["points_per_s"] = float(sc["N"] / (out["scan_loop"]["total_ms"] * 1e-3))  # whole turn, not one pass
+    out["scan_loop"]["total_packed_upload_ms"] = float(np.median(packed))  # malio_scan_set_packed instead of malio_scan_set
     out["scan_loop"]["scan_set_pageable_ms"] = float(np.median(pageable))
     out["scan_loop"]["map_incremental_with_wny_ms"] = float(np.median(with_wny)) if with_wny else None
     out["scan_loop"].update(map_points=eng.map_size(), added_per_scan=added,

@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_upload_wait",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
@@ -353,6 +353,39 @@ class Engine:
         tcp = _p(tc, Pose) if self.L > 1 else None
         self._keep = (tabs, tc)
         self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
+
+    @staticmethod
+    def pack_scan(pts12):
+        """The 20-byte records of malio_scan_set_packed from 48-byte points: [n] structured as 5 x 4 bytes (x, y, z, w, ny)."""
+        pts12 = np.ascontiguousarray(pts12, np.float32)
+        rec = np.zeros((pts12.shape[0], 5), np.float32)
+        rec[:, 0:3] = pts12[:, 0:3]
+        idx = np.clip(pts12[:, 4].astype(np.int64), -0x3FFFFF, 0x3FFFFF)
+        w = ((idx << 8) & 0xFFFFFFFF) | pts12[:, 8].astype(np.int64)
+        rec.view(np.uint32)[:, 3] = w.astype(np.uint32)
+        rec[:, 4] = pts12[:, 5]
+        return rec
+
+    def scan_set_packed_fn(self, rec5, pose_tables, temporal_comp):
+        """malio_scan_set_packed with its arguments built beforehand (see scan_set_fn)."""
+        rec5 = np.ascontiguousarray(rec5, np.float32) if not isinstance(rec5, np.ndarray) or rec5.dtype != np.float32 else rec5
+        n = rec5.shape[0]
+        tabs = [np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1, 59)) for t in pose_tables]
+        ptrs = (C.POINTER(Pose) * self.L)(*[_p(t, Pose) for t in tabs])
+        lens = (C.c_int * self.L)(*[t.shape[0] for t in tabs])
+        tc = np.ascontiguousarray(np.asarray(temporal_comp, np.float64).reshape(-1, 59))
+        tcp = _p(tc, Pose) if self.L > 1 else None
+        p = rec5.ctypes.data_as(C.c_void_p)
+        fn = lib().malio_scan_set_packed
+
+        def call():
+            self.N = n
+            self._keep = (tabs, tc, rec5)
+            self._chk(fn(self.h, p, n, ptrs, lens, tcp), "malio_scan_set_packed")
+        return call
+
+    def scan_set_packed(self, rec5, pose_tables, temporal_comp):
+        self.scan_set_packed_fn(rec5, pose_tables, temporal_comp)()
 
     def scan_upload_wait(self):
         """malio_scan_upload_wait: the page-locked cloud handed to the last scan_set may be modified / freed after this."""

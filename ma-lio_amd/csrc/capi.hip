@@ -642,6 +642,97 @@ __global__ void __launch_bounds__(BLK) k_pack_resident(const float *__restrict__
 }
 }  // namespace malio
 
+namespace malio {
+// what k_pack_raw leaves in info[] for records that arrive packed: points per LiDAR slot, slots outside [0, L), descents of
+// the slot sequence
+__global__ void __launch_bounds__(BLK) k_count_packed(UploadRec *rec, int n, int L, u32 *info) {
+  __shared__ u32 s_cnt[10];
+  if (threadIdx.x < 10) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  int lid = -1;
+  bool descent = false;
+  if (i < n) {
+    const u32 w = rec[i].w;
+    lid = (int)(w & 0xFFu);
+    descent = i > 0 && (int)(rec[i - 1].w & 0xFFu) > lid;  // (a neighbour's bad slot may already read 0: the scan is refused anyway)
+    if (lid >= L) {  // counted, reported by the first pass; slot 0 meanwhile, so that the grouping stays inside its buckets
+      lid = MALIO_MAX_LIDAR;
+      rec[i].w = w & 0xFFFFFF00u;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int l = 0; l <= MALIO_MAX_LIDAR; l++) {
+    const unsigned long long m = __ballot(lid == l);
+    if (m && lane == 0) atomicAdd(&s_cnt[l == MALIO_MAX_LIDAR ? 8 : l], (u32)__popcll(m));
+  }
+  {
+    const unsigned long long m = __ballot(descent);
+    if (m && lane == 0) atomicAdd(&s_cnt[9], (u32)__popcll(m));
+  }
+  __syncthreads();
+  if (threadIdx.x < 10 && s_cnt[threadIdx.x]) atomicAdd(&info[threadIdx.x], s_cnt[threadIdx.x]);
+}
+}  // namespace malio
+
+int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n, const malio_pose_t *const *pose_unc,
+                          const int *pose_unc_len, const malio_pose_t *temporal_comp) {
+  if (check(h) || !recs || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
+  static_assert(sizeof(malio_scan_rec_t) == sizeof(UploadRec), "malio_scan_rec_t is the upload record");
+  Ctx *c = h;
+  const int L = c->prm.lid_num;
+  if (L > 1 && !temporal_comp) return MALIO_ERR_BAD_ARG;
+  MALIO_HIP(hipSetDevice(c->device));
+  for (int l = 0; l < L; l++)
+    if (pose_unc_len[l] < 2 || !pose_unc[l]) return MALIO_ERR_BAD_ARG;
+  c->N = n;
+  int rc = measure_alloc(c);
+  if (rc != MALIO_OK) return rc;
+  c->seg_pending = false;
+  hipPointerAttribute_t attr;
+  bool pinned = hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (pinned) {
+    const char *last = reinterpret_cast<const char *>(recs) + sizeof(malio_scan_rec_t) * (size_t)n - 1;
+    pinned = hipPointerGetAttributes(&attr, last) == hipSuccess && attr.type == hipMemoryTypeHost;
+  }
+  (void)hipGetLastError();
+  const void *src = recs;
+  if (!pinned) {  // through the handle's staging buffer: one pass over the records, one copy nothing here waits for
+    void *stage = nullptr;
+    if (int rcs = host_stage(c, sizeof(UploadRec) * (size_t)n, &stage)) return rcs;
+    memcpy(stage, recs, sizeof(UploadRec) * (size_t)n);
+    src = stage;
+    c->stage_pending = true;
+  }
+  MALIO_HIP(hipMemcpyAsync(c->d_upload, src, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (pinned) {
+    if (!c->ev_upload) MALIO_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));
+    c->upload_in_flight = true;
+  }
+  // the per-slot counts (and the validation of the slots) come back with the first pass, as for a page-locked cloud
+  if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
+  MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
+  if (!c->h_packinfo) {
+    MALIO_HIP(hipHostMalloc((void **)&c->h_packinfo, sizeof(u32) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+    MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_packinfo_pub, c->h_packinfo, 0));
+    memset(c->h_packinfo, 0, sizeof(u32) * 16);
+  }
+  if (++c->pack_seq == 0) c->pack_seq = 1;
+  hipLaunchKernelGGL(k_count_packed, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_upload, n, L, c->d_packinfo);
+  c->pack_publish_pending = true;
+  if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP) publish_pack_now(c);
+  MALIO_HIP(hipGetLastError());
+  c->seg_pending = true;
+  c->scan_keep_order = false;
+  if (int rct = scan_tables(c, pose_unc, pose_unc_len, temporal_comp)) {
+    c->N = 0, c->seg_pending = false;
+    return rct;
+  }
+  return scan_reset(c);
+}
+
 int malio_scan_upload_wait(malio_handle_t h) {
   if (check(h)) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;

@@ -781,3 +781,36 @@ def test_update_begin_end_frees_the_host(capi, scenes):
     assert t_begin < 0.5e-3 * 4  # begin does not wait for the 0.3-0.8 ms the loop takes (generous: first-call allocations)
     with pytest.raises(RuntimeError):
         eng._chk(capi.lib().malio_update_iterated_end(eng.h, None, None, None), "end without begin")
+
+
+@pytest.mark.gpu
+def test_scan_set_packed_equals_scan_set(capi, scenes):
+    """malio_scan_set_packed: the scan as 20-byte records (what the engine keeps of a 48-byte point) - from pageable and
+    from page-locked memory the same bits as malio_scan_set on the points themselves: pass, rows, update, side effects;
+    a slot outside [0, lid_num) is reported by the first pass."""
+    sc = scenes.make_scene(seed=242, N=5000, Nmap=40000, L=3)
+    rec = capi.Engine.pack_scan(sc["scan"])
+    pin = capi.PinnedArray(rec.shape, np.float32)
+    pin.array[:] = rec
+    ref = _fresh(capi, sc)
+    g0 = ref.measure(sc["state0"], True, want_rows=True)
+    u0 = ref.update_iterated(sc["state0"], sc["P0"])
+    s0 = ref.scan_get()
+    for cloud in (rec, pin.array):
+        eng = capi.Engine(sc["params"], device=0)
+        eng.map_build(sc["map"])
+        eng.scan_set_packed(cloud, sc["tables"], sc["temporal_comp"])
+        g = eng.measure(sc["state0"], True, want_rows=True)
+        u = eng.update_iterated(sc["state0"], sc["P0"])
+        s = eng.scan_get()
+        assert g["M"] == g0["M"] and np.array_equal(g["HtRinvH"], g0["HtRinvH"]) and np.array_equal(g["h_x"], g0["h_x"])
+        assert np.array_equal(u["state"], u0["state"]) and np.array_equal(u["P"], u0["P"])
+        for k in s0:
+            assert np.array_equal(s0[k], s[k]), k
+    bad = rec.copy()
+    bad.view(np.uint32)[7, 3] = (bad.view(np.uint32)[7, 3] & 0xFFFFFF00) | 5  # slot 5 of 3
+    eng = capi.Engine(sc["params"], device=0)
+    eng.map_build(sc["map"])
+    eng.scan_set_packed(bad, sc["tables"], sc["temporal_comp"])
+    with pytest.raises(RuntimeError):
+        eng.measure(sc["state0"], True)
