@@ -38,7 +38,7 @@ ALG_BYTES_SEARCH_PASS = 120.0  # algorithmic bytes per scan po
 # One launch per pass from the second pass of a scan on (k_pass: a1-a10 with the extrema speculated); the
 # first pass of a scan - and every pass under MALIO_FUSE=0 - is k_search -> k_rows_reduce -> k_final_reduce.
 DOMINANT_KERNELS = ("k_pass", "k_search")
-PROFILE_ROUND, PROFILE_TAG = "round2", "r02"  # the committed rocprofv3 / PMC summaries the roofline block cites
+PROFILE_ROUND, PROFILE_TAG = "round3", "r03"  # the committed rocprofv3 / PMC summaries the roofline block cites
 
 
 class _quiet_stdout:
@@ -414,6 +414,29 @@ def main():
             "host_algebra_ms": float(np.median(solve) * 1e3)}  # a11: the n x n filter algebra of all passes
 
     roofline = roofline_block(eng, state, args, N)
+    # the same pass as three kernels (MALIO_FUSE=0 handle), same process, same scan: what k_pass replaces
+    try:
+        os.environ["MALIO_FUSE"] = "0"
+        e3 = capi.Engine(sc["params"], device=dev_index)
+        e3.set_stream(torch.cuda.current_stream().cuda_stream)
+        e3.map_build(sc["map"])
+        e3.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        f3, _ = e3.measure_fn(state, True)
+        for _ in range(30):
+            f3()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(300):
+            f3()
+        w3 = (time.perf_counter() - t) / 300 * 1e3
+        r3 = roofline_block(e3, state, args, N)
+        roofline["three_kernel_pass"] = {"ms_per_step": w3, "kernel_event_ms": r3["kernel_event_ms"],
+                                         "k_search_frac": ALG_BYTES_SEARCH_PASS * N / (r3["kernel_event_ms"].get("k_search", float("nan")) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "MALIO_FUSE=0: k_search -> k_rows_reduce -> k_final_reduce; k_pass = k_search + the rows of "
+                                                 "k_rows_reduce, so its 120 B/point cover a5/a7/a10 as well"}
+        del e3
+    finally:
+        os.environ.pop("MALIO_FUSE", None)
     secondary = secondary_figures(eng, sc, scenes, capi, args.config)
     cpu = None if args.no_cpu_baseline else cpu_baseline(sc)
     line = {

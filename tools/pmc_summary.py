@@ -8,5 +8,5 @@ for f in sorted(glob.glob(d + "/*counter_collection.csv")):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", f.split("/")[-1])
     for k, cs in acc.items():
-        if not any(x in k for x in ("search", "rows", "reuse", "final")): continue
+        if not any(x in k for x in ("search", "rows", "reuse", "final", "k_pass")): continue
         print("  %-52s" % k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()})
