@@ -1285,8 +1285,9 @@ struct FoldArgs {
   double *mm_out;
   int extrinsic_est_en, dq_parity;
 };
+constexpr int FR16_BLK = 1024;  // workgroup of k_final_reduce<16>: four (LiDAR, entry) pairs, four waves each
 template <int LPL>
-__global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
+__global__ void __launch_bounds__(LPL == 16 ? FR16_BLK : BLK) k_final_reduce(const double *__restrict__ partials, int pstride, SegBlocks sb,
                                                       int L, double *out, const DevLoop *dl /* device loop, or null */,
                                                       GateArgs gate /* gate.dl == null: none */, FoldArgs fold) {
   if (dl && dl->done) return;
@@ -1301,7 +1302,41 @@ __global__ void __launch_bounds__(BLK) k_final_reduce(const double *__restrict__
       fold.mm_out[5] = (double)fold.dq_ctl[2 + (dl ? dl->dq_parity : fold.dq_parity)];
     }
   }
-  if (w < L * NSUM) {  // wave-uniform
+  if (LPL == 16) {
+    // tiles of k_pass: 4 x as many leaves as workgroup partials. FOUR waves per (LiDAR, entry) - every wave takes a
+    // contiguous 256 leaves of each round, lane j four of them: four loads per lane on the chain instead of sixteen -
+    // whose nodes meet in LDS as (n0 + n1) + (n2 + n3): the same tree. Workgroups of 1 024 threads (four entries each), so
+    // that the gate's ticket still sees ~73 arrivals (291 same-address atomics behind system-scope fences cost the pass
+    // 3 us of its 0.5 us gain).
+    __shared__ double s_node[FR16_BLK / 64], s_round[FR16_BLK / 256][64];
+    const int grp = (int)(threadIdx.x >> 8), wv = (int)((threadIdx.x >> 6) & 3);
+    const int we = (int)blockIdx.x * (FR16_BLK / 256) + grp;
+    const bool live = we < L * NSUM;
+    const int lid = live ? we / NSUM : 0, e = live ? we - lid * NSUM : 0;
+    const int b0 = sb.b[lid], b1 = live ? sb.b[lid + 1] : sb.b[lid];
+    const double *row = partials + (size_t)e * pstride;
+    int rounds_max = 0;  // workgroup-uniform loop bound: the longest segment
+#pragma unroll
+    for (int l = 0; l < MALIO_MAX_LIDAR; l++) rounds_max = max(rounds_max, (sb.b[l + 1] - sb.b[l] + 1023) / 1024);
+    const int rounds = (b1 - b0 + 1023) / 1024;
+    for (int r = 0; r < rounds_max; r++) {
+      const int base = b0 + 1024 * r + 256 * wv + 4 * lane;
+      double p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) p[u] = (r < rounds && base + u < b1) ? row[base + u] : 0.0;
+      const double nd = butterfly_up((p[0] + p[1]) + (p[2] + p[3]));
+      if (lane == 0) s_node[grp * 4 + wv] = nd;
+      __syncthreads();
+      if ((threadIdx.x & 255) == 0 && r < rounds)
+        s_round[grp][r] = (s_node[grp * 4] + s_node[grp * 4 + 1]) + (s_node[grp * 4 + 2] + s_node[grp * 4 + 3]);
+      __syncthreads();
+    }
+    if (live && wv == 0) {
+      double a = lane < rounds ? s_round[grp][lane] : 0.0;
+      if (rounds > 1) a = butterfly_up(a);  // (<= 64 rounds: 4 M points per LiDAR)
+      if (lane == 0) out[lid * NSUM + e] = a;
+    }
+  } else if (w < L * NSUM) {  // wave-uniform
     const int lid = w / NSUM, e = w - lid * NSUM;
     const int b0 = sb.b[lid], b1 = sb.b[lid + 1];
     const double *row = partials + (size_t)e * pstride;
@@ -2252,7 +2287,7 @@ static void launch_final_tiles(Ctx *c, const SegBlocks &sb, const DevLoop *dl, c
   fold.mmslots = dl ? c->d_mmslots : c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
   fold.dq_ctl = c->d_dq_ctl, fold.mm_out = c->d_res + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
   fold.dq_parity = c->dq_parity;
-  hipLaunchKernelGGL(k_final_reduce<16>, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+  hipLaunchKernelGGL(k_final_reduce<16>, dim3((c->prm.lid_num * NSUM + FR16_BLK / 256 - 1) / (FR16_BLK / 256)), dim3(FR16_BLK), 0, c->stream,
                      (const double *)c->d_tiles, (int)c->cap_tiles, sb, c->prm.lid_num, c->d_res, dl, gate ? *gate : GateArgs{}, fold);
 }
 
