@@ -536,6 +536,21 @@ int malio_node_scan_get(malio_node_t nd, float *normal_y, malio_point_t *nearest
  * Add_Points (the reference's value when the map is replicated). */
 int malio_node_map_incremental(malio_node_t nd, const malio_state_t *state_point, int flg_EKF_inited,
                                const float *world_normal_y, int *out_counts3);
+/* The resident front end on the node: LiDAR `lid` is undistorted and voxel-filtered on GPU lid % n_gpus (the L clouds of a
+ * scan side by side instead of one after the other), the filtered clouds are concatenated in LiDAR order on the host and
+ * installed on every GPU like malio_node_scan_set. Arguments as malio_undistort_resident / malio_scan_set_resident. */
+int malio_node_undistort_resident(malio_node_t nd, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
+                                  const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
+                                  const double ext_t[3], const double end_q[4], const double end_t[3],
+                                  const double *imu_stamps, int n_imu, int cov_pointer0, int *out_entry_point,
+                                  int *out_n_entries, malio_point_t *out_entry_pts);
+int malio_node_scan_set_resident(malio_node_t nd, float leaf, int normal_mode, const malio_pose_t *const *pose_unc,
+                                 const int *pose_unc_len, const malio_pose_t *temporal_comp, malio_point_t *out_body, int cap,
+                                 int *out_n);
+/* malio_nearest_search on the node: replicas share the queries; a tile shard answers the queries of its tiles (it stores
+ * every map point within 2.3 m of them; refused when 2 * cell_size is larger). */
+int malio_node_nearest_search(malio_node_t nd, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,
+                              float *out_d2, int *out_count);
 int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int pass, void *user), void *user);
 int malio_node_exchange_stats(malio_node_t nd, int *stats2); /* passes that needed one / two exchanges so far */
 /* shard geometry, host code (no GPU): which shard serves each of n world points (xyz [n][3]) / whether shard `rank`

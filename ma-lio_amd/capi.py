@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
@@ -886,6 +886,47 @@ class Node:
         self._chk(lib().malio_node_map_incremental(self.h, C.byref(s), int(bool(flg_EKF_inited)),
                                                    None if wny is None else _p(wny, C.c_float), cnt), "malio_node_map_incremental")
         return int(cnt[0]), int(cnt[1]), int(cnt[2])
+
+    def undistort_resident(self, lid, pts12, lidar_beg_time, knot_times, knot_poses, ext_q, ext_t, end_q, end_t, imu_stamps,
+                           cov_pointer0):
+        """malio_node_undistort_resident: LiDAR `lid`'s cloud stays on GPU lid % n; returns the entry point indices."""
+        pts = np.ascontiguousarray(pts12, np.float32)
+        kt = np.ascontiguousarray(knot_times, np.float64)
+        kp = np.ascontiguousarray(knot_poses, np.float64).reshape(-1, 16)
+        imu = np.ascontiguousarray(imu_stamps, np.float64)
+        v = lambda a: _p(np.ascontiguousarray(a, np.float64), C.c_double)
+        ent = np.zeros(max(len(imu), 1) + 4, np.int32)
+        ne = C.c_int(0)
+        self._res_n = getattr(self, "_res_n", {})
+        self._res_n[int(lid)] = pts.shape[0]
+        self._chk(lib().malio_node_undistort_resident(self.h, int(lid), _p(pts, Point), pts.shape[0], C.c_double(lidar_beg_time),
+                                                      _p(kt, C.c_double), _p(kp, C.c_double), len(kt), v(ext_q), v(ext_t),
+                                                      v(end_q), v(end_t), _p(imu, C.c_double), len(imu), int(cov_pointer0),
+                                                      _p(ent, C.c_int), C.byref(ne), None), "malio_node_undistort_resident")
+        return ent[:ne.value].copy()
+
+    def scan_set_resident(self, leaf, pose_tables, temporal_comp, normal_mode=1):
+        """malio_node_scan_set_resident: returns feats_down_body."""
+        self._scan_keep = _scan_tables(self.L, pose_tables, temporal_comp)
+        ptrs, lens, tcp = self._scan_keep[:3]
+        cap = int(sum(getattr(self, "_res_n", {}).values()))
+        out = np.zeros((max(cap, 1), 12), np.float32)
+        n = C.c_int(0)
+        self._chk(lib().malio_node_scan_set_resident(self.h, C.c_float(leaf), int(normal_mode), ptrs, lens, tcp, _p(out, Point), cap,
+                                                     C.byref(n)), "malio_node_scan_set_resident")
+        self.N = n.value
+        self._res_n = {}
+        return out[:n.value].copy()
+
+    def nearest_search(self, q12, k=5):
+        q12 = np.ascontiguousarray(q12, np.float32)
+        n = q12.shape[0]
+        out = np.zeros((n, k, 12), np.float32)
+        d2 = np.zeros((n, k), np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(lib().malio_node_nearest_search(self.h, _p(q12, Point), n, k, _p(out, Point), _p(d2, C.c_float),
+                                                  _p(cnt, C.c_int)), "malio_node_nearest_search")
+        return out, d2, cnt
 
     def map_get(self, rank):
         """The map points GPU `rank` holds (malio_map_get on its handle)."""

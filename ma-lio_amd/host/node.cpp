@@ -10,6 +10,7 @@
 //   MALIO_PART_SCAN   map replicated, scan cut into contiguous shards (every BASELINE map fits one GPU many times over)
 //   MALIO_PART_TILES  map sharded by spatial tiles with a halo, every worker sees the whole scan and serves the points
 //                     of its own tiles (BASELINE config 4; malio_set_partition)
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -53,6 +54,10 @@ struct malio_node {
   std::atomic<int> sleepers{0};
   void (*pass_hook)(int, void *) = nullptr;
   void *pass_hook_user = nullptr;
+  // resident front end: LiDAR l's raw cloud lives on GPU l % n until malio_node_scan_set_resident consumes it
+  bool res_has[MALIO_MAX_LIDAR] = {false, false, false, false};
+  int res_n[MALIO_MAX_LIDAR] = {0, 0, 0, 0};
+  std::vector<malio_point_t> body;  // feats_down_body of the current resident scan (page-locked would not pay: one copy per scan)
 
   int run(const std::function<int(Worker &)> &j) {  // all workers, in parallel; first non-zero status wins (errors first)
     job = j;
@@ -240,6 +245,113 @@ int malio_node_scan_set(malio_node_t nd, const malio_point_t *body, int n, const
       k.lo = 0, k.hi = n;
   }
   return nd->run([=](Worker &k) { return malio_scan_set(k.h, body + k.lo, k.hi - k.lo, pose_unc, pose_unc_len, temporal_comp); });
+}
+
+// ---- resident front end on the node (malio_undistort_resident / malio_scan_set_resident, include/malio.h) ------------------
+// The L raw clouds of a scan do not depend on each other until they are concatenated (IMU_Processing.hpp:475-507 per
+// LiDAR, laserMapping.cpp:966-983): LiDAR l is undistorted and voxel-filtered on GPU l % n - L GPUs work side by side
+// on what one GPU does one LiDAR after the other - and only the FILTERED clouds (a sixth of the raw points) cross PCIe:
+// to the host once, concatenated in LiDAR order (:982), and from there to every GPU as malio_node_scan_set does.
+int malio_node_undistort_resident(malio_node_t nd, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
+                                  const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
+                                  const double ext_t[3], const double end_q[4], const double end_t[3],
+                                  const double *imu_stamps, int n_imu, int cov_pointer0, int *out_entry_point,
+                                  int *out_n_entries, malio_point_t *out_entry_pts) {
+  if (!nd || lid < 0 || lid >= nd->prm.lid_num) return MALIO_ERR_BAD_ARG;
+  const int owner = lid % nd->n;
+  const int rc = nd->run([=](Worker &k) -> int {
+    if (k.rank != owner) return MALIO_OK;
+    return malio_undistort_resident(k.h, lid, pts, n, lidar_beg_time, knot_times, knot_poses, n_knots, ext_q, ext_t, end_q, end_t,
+                                    imu_stamps, n_imu, cov_pointer0, out_entry_point, out_n_entries, out_entry_pts);
+  });
+  if (rc == MALIO_OK) nd->res_has[lid] = true, nd->res_n[lid] = n;
+  return rc;
+}
+
+int malio_node_scan_set_resident(malio_node_t nd, float leaf, int normal_mode, const malio_pose_t *const *pose_unc,
+                                 const int *pose_unc_len, const malio_pose_t *temporal_comp, malio_point_t *out_body, int cap,
+                                 int *out_n) {
+  if (!nd || !pose_unc || !pose_unc_len || !out_n || cap < 0 || (cap > 0 && !out_body)) return MALIO_ERR_BAD_ARG;
+  const int L = nd->prm.lid_num, G = nd->n;
+  // every GPU that holds raw clouds filters them (its handle's own resident call; the scan it installs on the way is
+  // replaced below) and hands its part of feats_down_body to the host
+  std::vector<std::vector<malio_point_t>> part(G);
+  std::vector<int> pn(G, 0);
+  int rc = nd->run([&](Worker &k) -> int {
+    int mine = 0;
+    for (int l = k.rank; l < L; l += G)
+      if (nd->res_has[l]) mine += nd->res_n[l];
+    if (mine == 0) return MALIO_OK;
+    part[k.rank].resize((size_t)mine);
+    return malio_scan_set_resident(k.h, leaf, normal_mode, pose_unc, pose_unc_len, temporal_comp, part[k.rank].data(), mine,
+                                   &pn[k.rank]);
+  });
+  for (int l = 0; l < MALIO_MAX_LIDAR; l++) nd->res_has[l] = false, nd->res_n[l] = 0;  // consumed (or lost with the error)
+  if (rc != MALIO_OK) return rc;
+  // concatenate in LiDAR order (:982): a GPU's part holds its LiDARs ascending, each point carries its LiDAR in `intensity`
+  size_t total = 0;
+  for (int r = 0; r < G; r++) total += (size_t)pn[r];
+  *out_n = (int)total;
+  if (total == 0) return MALIO_ERR_NO_SCAN;
+  nd->body.resize(total);
+  std::vector<size_t> at(G, 0);
+  size_t w = 0;
+  for (int l = 0; l < L; l++) {
+    const int r = l % G;
+    size_t &a = at[r];
+    const size_t a0 = a;
+    while (a < (size_t)pn[r] && (int)part[r][a].intensity == l) a++;
+    memcpy(nd->body.data() + w, part[r].data() + a0, sizeof(malio_point_t) * (a - a0));
+    w += a - a0;
+  }
+  if (w != total) {
+    nd->err = "malio_node_scan_set_resident: a filtered cloud does not carry its LiDAR number";
+    return MALIO_ERR_BAD_ARG;
+  }
+  if (out_body && cap > 0) memcpy(out_body, nd->body.data(), sizeof(malio_point_t) * std::min(total, (size_t)cap));
+  return malio_node_scan_set(nd, nd->body.data(), (int)total, pose_unc, pose_unc_len, temporal_comp);
+}
+
+// ikdtree.Nearest_Search, batched (malio_nearest_search): a replica answers a contiguous share of the queries; a tile
+// shard the queries of its own tiles - it stores every map point within PART_HALO = 2.3 m of them, and the search radius
+// is 2 * cell_size (2.25 m at the default edge; a larger edge is refused here).
+int malio_node_nearest_search(malio_node_t nd, const malio_point_t *queries, int n, int k, malio_point_t *out_pts, float *out_d2,
+                              int *out_count) {
+  if (!nd || !queries || n <= 0 || k < 1 || k > 5 || !out_pts || !out_d2 || !out_count) return MALIO_ERR_BAD_ARG;
+  const int G = nd->n;
+  if (nd->partition == MALIO_PART_SCAN)
+    return nd->run([=](Worker &w) -> int {
+      const int lo = (int)((long long)n * w.rank / G), hi = (int)((long long)n * (w.rank + 1) / G);
+      if (hi <= lo) return MALIO_OK;
+      return malio_nearest_search(w.h, queries + lo, hi - lo, k, out_pts + (size_t)lo * k, out_d2 + (size_t)lo * k, out_count + lo);
+    });
+  const float cell = nd->prm.cell_size > 0.f ? nd->prm.cell_size : 1.125f;
+  if (2.f * cell > malio::PART_HALO) {
+    nd->err = "malio_node_nearest_search: search radius 2 * cell_size exceeds the halo of a tile shard";
+    return MALIO_ERR_BAD_ARG;
+  }
+  const float inv = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : 16.f);
+  std::vector<std::vector<int>> idx(G);
+  for (int i = 0; i < n; i++)
+    idx[malio::tile_owner(malio::tile_coord(queries[i].x, inv), malio::tile_coord(queries[i].y, inv),
+                          malio::tile_coord(queries[i].z, inv), (unsigned)G)].push_back(i);
+  return nd->run([&](Worker &w) -> int {
+    const std::vector<int> &mine = idx[w.rank];
+    const int m = (int)mine.size();
+    if (m == 0) return MALIO_OK;
+    std::vector<malio_point_t> q((size_t)m), o((size_t)m * k);
+    std::vector<float> d2((size_t)m * k);
+    std::vector<int> cnt((size_t)m);
+    for (int j = 0; j < m; j++) q[j] = queries[mine[j]];
+    const int rc = malio_nearest_search(w.h, q.data(), m, k, o.data(), d2.data(), cnt.data());
+    if (rc != MALIO_OK) return rc;
+    for (int j = 0; j < m; j++) {
+      memcpy(out_pts + (size_t)mine[j] * k, o.data() + (size_t)j * k, sizeof(malio_point_t) * k);
+      memcpy(out_d2 + (size_t)mine[j] * k, d2.data() + (size_t)j * k, sizeof(float) * k);
+      out_count[mine[j]] = cnt[j];
+    }
+    return MALIO_OK;
+  });
 }
 
 int malio_node_measure(malio_node_t nd, const malio_state_t *s, int converge, malio_measure_out_t *out) {

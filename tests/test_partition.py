@@ -323,3 +323,63 @@ def test_node_map_incremental_equals_single_engine(capi, scenes, partition):
         state = u["state"].copy()
         state[0:3] += [0.05, 0.02, 0.0]  # (the next scan's prior)
     nd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partition", ["scan", "tiles"])
+def test_node_resident_front_end_and_nearest_search(capi, scenes, partition):
+    """The resident front end on the node (malio_node_undistort_resident / malio_node_scan_set_resident: LiDAR l on GPU
+    l % n, filtered clouds concatenated in LiDAR order) against ONE engine's resident front end: the same
+    feats_down_body byte for byte, the same entry points, the same update (sums to summation order); and
+    malio_node_nearest_search against malio_nearest_search: identical points, distances and counts."""
+    from test_frontend_resident import _traj
+    G, L, tile = 2, 3, 12.0
+    sc = scenes.make_scene(seed=77, N=9000, Nmap=100000, L=L)
+    rng = np.random.default_rng(9)
+    t0 = 1671631987.6
+    traj = _traj(scenes, t0)
+    kt, kT = capi.spline_feed(traj)
+    beg, end = t0 + 0.05, t0 + 0.15
+    _, q_end, p_end = capi.spline_get_pose(kt, kT, end)
+    imu_t = traj[::2, 0].copy()
+    cp = int(np.searchsorted(imu_t, end, side="right"))
+    st = scenes.unpack_state(sc["state_gt"], L)
+    leaf = 0.4
+    raws = []
+    for l in range(L):
+        base = sc["scan"][sc["scan"][:, 8] == l]
+        raw = np.repeat(base, 3, axis=0).copy()
+        raw[:, :3] += rng.normal(0, 0.05, size=(raw.shape[0], 3)).astype(np.float32)
+        raw[:, 9] = np.sort(rng.uniform(0, (end - beg) * 1000.0, raw.shape[0])).astype(np.float32)
+        raw[:, 5] = rng.uniform(0, 0.01, raw.shape[0]).astype(np.float32)
+        raw[:, 8] = rng.uniform(0, 200, raw.shape[0]).astype(np.float32)
+        raws.append(raw)
+    one = _single(capi, sc)
+    nd = capi.Node(sc["params"], [0] * G, partition=capi.PART_TILES if partition == "tiles" else capi.PART_SCAN, tile_m=tile)
+    nd.map_build(sc["map"])
+    # nearest search: queries all over the map, some far outside it
+    q = sc["scan"][:3000].copy()
+    q[:, :3] = sc["map"][rng.integers(0, sc["map"].shape[0], 3000), :3] + rng.normal(0, 0.4, (3000, 3)).astype(np.float32)
+    q[:50, :3] += 500.0
+    p1, d1, c1 = one.nearest_search(q, 5)
+    p2, d2, c2 = nd.nearest_search(q, 5)
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(d1, d2)
+    np.testing.assert_array_equal(p1[:, :, [0, 1, 2, 5]], p2[:, :, [0, 1, 2, 5]])
+    assert (c1 == 5).sum() > 2000 and (c1[:50] == 0).all()
+    # front end
+    for l in range(L):
+        e1, _ = one.undistort_resident(l, raws[l], beg, kt, kT, st["offR"][l], st["offT"][l], q_end, p_end, imu_t, cp)
+        e2 = nd.undistort_resident(l, raws[l], beg, kt, kT, st["offR"][l], st["offT"][l], q_end, p_end, imu_t, cp)
+        np.testing.assert_array_equal(e1, e2)
+    b1 = one.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    b2 = nd.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    np.testing.assert_array_equal(b1, b2)
+    assert b1.shape[0] > 4000 and set(np.unique(b1[:, 8]).astype(int)) == {0, 1, 2}
+    u, v = one.update_iterated(sc["state0"], sc["P0"]), nd.update_iterated(sc["state0"], sc["P0"])
+    assert (u["passes"], u["M"]) == (v["passes"], v["M"]) and u["M"] > 0.3 * b1.shape[0]
+    assert np.abs(u["state"] - v["state"]).max() < 1e-9
+    np.testing.assert_array_equal(one.scan_get()["selected"], nd.scan_get()["selected"])
+    with pytest.raises(RuntimeError):  # the resident clouds were consumed
+        nd.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
+    nd.close()
