@@ -263,11 +263,43 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
         t4 = time.perf_counter()
         if k:
             packed.append(((t2 - t) + (t4 - t3)) * 1e3)
+    # the loop as a pipeline: scan k+1 staged (malio_scan_stage) right before map_incremental of scan k, T turns back to back
+    # with no synchronisation between them - so the part of map_incremental that runs after its call has returned is
+    # inside the figure too. One figure per upload format.
+    pipelined = {}
+    try:
+        T = 8
+        for fmt, conv, mk in (("points", lambda a: a, eng.scan_set_fn), ("packed", capi.Engine.pack_scan, eng.scan_set_packed_fn)):
+            bufs = [capi.PinnedArray(conv(sc["scan"]).shape, np.float32) for _ in range(T + 1)]
+            for k in range(T + 1):
+                bufs[k].array[:] = conv(scenes.make_scene(cfg=cfg_index, scan_seed=700 + k)["scan"])
+            calls = [mk(b.array, sc["tables"], sc["temporal_comp"]) for b in bufs]
+            stage = capi.lib().malio_scan_stage
+            ptrs = [C.c_void_p(b.array.ctypes.data) for b in bufs]
+            pk = 1 if fmt == "packed" else 0
+            for staged in (False, True):
+                calls[0]()
+                assert upd() == 0  # (turn 0 outside the clock: allocations)
+                st = capi.state_from_flat(upd_result()["state"], sc["L"])
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for k in range(1, T + 1):
+                    if staged:
+                        stage(eng.h, ptrs[k], sc["N"], pk)
+                    minc(st)
+                    calls[k]()
+                    assert upd() == 0
+                torch.cuda.synchronize()
+                pipelined[fmt + ("_staged_ms" if staged else "_ms")] = (time.perf_counter() - t) * 1e3 / T
+                minc(st)
+    except Exception as e:
+        pipelined = {"error": str(e)}
     dbg = eng.debug_counters()
     out["scan_loop"] = {k: float(np.median(v)) for k, v in loop.items()}
     out["scan_loop"]["total_ms"] = float(sum(out["scan_loop"].values()))
     out["scan_loop"]["points_per_s"] = float(sc["N"] / (out["scan_loop"]["total_ms"] * 1e-3))  # whole turn, not one pass
     out["scan_loop"]["total_packed_upload_ms"] = float(np.median(packed))  # malio_scan_set_packed instead of malio_scan_set
+    out["scan_loop"]["pipelined_turn"] = pipelined  # ms per turn over 8 back-to-back turns; *_staged: next scan copied ahead
     out["scan_loop"]["scan_set_pageable_ms"] = float(np.median(pageable))
     out["scan_loop"]["map_incremental_with_wny_ms"] = float(np.median(with_wny)) if with_wny else None
     out["scan_loop"].update(map_points=eng.map_size(), added_per_scan=added,

@@ -255,6 +255,16 @@ int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n,
 /* Blocks until the upload queued by the last malio_scan_set has left the caller's buffer (an event recorded right
  * behind the copy: it does not wait for kernels queued after it). Returns at once when nothing is in flight. */
 int malio_scan_upload_wait(malio_handle_t h);
+/* The NEXT scan's cloud on its way to HBM while the current scan is still being worked on: `buf` = the page-locked array
+ * a following malio_scan_set (packed == 0: n malio_point_t) or malio_scan_set_packed (packed != 0: n malio_scan_rec_t)
+ * will be handed. The copy runs on a stream of its own into a spare device buffer - call it right before
+ * malio_map_incremental and its 90 us (38 us packed, 100 k points) are hidden behind that call. The scan_set of the SAME
+ * pointer and count then copies nothing; any other scan_set simply ignores what was staged. No counterpart in the
+ * reference (its clouds never leave the host); feats_down_body of scan k+1 is ready at this point when the caller
+ * undistorts scan k+1 (IMU_Processing.hpp:475-507 needs the posterior of scan k, not its map_incremental) before it
+ * calls map_incremental for scan k. Lifetime of the buffer: untouched until malio_scan_upload_wait after that scan_set.
+ * MALIO_ERR_BAD_ARG for a buffer that is not page-locked. */
+int malio_scan_stage(malio_handle_t h, const void *buf, int n, int packed);
 
 /* ONE h_share_model pass (laserMapping.cpp:552-760) fused with the H^T R^-1 H / H^T R^-1 h
  * accumulation of esekfom.hpp:621-635. converge = ekfom_data.converge (search vs neighbour reuse,

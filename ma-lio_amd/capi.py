@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
@@ -353,6 +353,11 @@ class Engine:
         tcp = _p(tc, Pose) if self.L > 1 else None
         self._keep = (tabs, tc)
         self._chk(lib().malio_scan_set(self.h, _p(pts12, Point), self.N, ptrs, lens, tcp), "malio_scan_set")
+
+    def scan_stage(self, arr, packed=False):
+        """malio_scan_stage: copy the NEXT scan's page-locked array ([n,12] points or [n,5] packed records) ahead."""
+        assert arr.dtype == np.float32 and arr.flags.c_contiguous
+        self._chk(lib().malio_scan_stage(self.h, C.c_void_p(arr.ctypes.data), arr.shape[0], int(bool(packed))), "malio_scan_stage")
 
     @staticmethod
     def pack_scan(pts12):

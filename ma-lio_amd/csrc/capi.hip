@@ -179,6 +179,12 @@ int malio_destroy(malio_handle_t h) {
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+  if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipEventDestroy(c->ev_ahead), (void)hipEventDestroy(c->ev_ahead_free);
+    (void)hipStreamDestroy(c->copy_stream);
+  }
+  if (c->d_ahead) (void)hipFree(c->d_ahead);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
   return MALIO_OK;
@@ -510,6 +516,55 @@ __global__ void __launch_bounds__(BLK) k_pack_raw(const float *__restrict__ raw1
 }
 }  // namespace malio
 
+// Was this very buffer copied ahead by malio_scan_stage? Consumes the record either way: a scan_set of anything else
+// means the caller changed its mind, and a buffer staged twice must be copied twice.
+static bool stage_take(Ctx *c, const void *buf, int n, int packed) {
+  const bool hit = c->ahead_ptr && c->ahead_ptr == buf && c->ahead_n == n && c->ahead_packed == packed;
+  c->ahead_ptr = nullptr;
+  return hit;
+}
+
+// The NEXT scan's cloud on its way to HBM while the current scan is still being worked on - typically called right
+// before malio_map_incremental, whose 0.15 ms hide the copy (90 us for 100 k 48-byte points, 38 us as 20-byte records):
+// a copy stream of its own, a spare device buffer. The following malio_scan_set / malio_scan_set_packed of the SAME
+// buffer and count uses the staged bytes and copies nothing. The buffer must be page-locked and stay untouched until
+// malio_scan_upload_wait after that scan_set (the lifetime rule of malio_scan_set).
+int malio_scan_stage(malio_handle_t h, const void *buf, int n, int packed) {
+  if (check(h) || !buf || n <= 0) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  MALIO_HIP(hipSetDevice(c->device));
+  const size_t bytes = (packed ? sizeof(UploadRec) : sizeof(malio_point_t)) * (size_t)n;
+  hipPointerAttribute_t attr;
+  bool pinned = hipPointerGetAttributes(&attr, buf) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (pinned) pinned = hipPointerGetAttributes(&attr, static_cast<const char *>(buf) + bytes - 1) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();
+  if (!pinned) {
+    c->err = "malio_scan_stage: the buffer is not page-locked (malio_host_alloc / hipHostMalloc / hipHostRegister)";
+    return MALIO_ERR_BAD_ARG;
+  }
+  if (!c->copy_stream) {
+    MALIO_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    MALIO_HIP(hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
+    MALIO_HIP(hipEventCreateWithFlags(&c->ev_ahead_free, hipEventDisableTiming));
+  }
+  if (c->ahead_busy) {  // the consumer of the previous staged cloud (pack kernel / device copy on `stream`) first
+    MALIO_HIP(hipEventRecord(c->ev_ahead_free, c->stream));
+    MALIO_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_ahead_free, 0));
+    c->ahead_busy = false;
+  }
+  if (bytes > c->cap_ahead) {
+    MALIO_HIP(hipStreamSynchronize(c->copy_stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_ahead) (void)hipFree(c->d_ahead);
+    c->d_ahead = nullptr, c->cap_ahead = bytes + bytes / 8 + 4096;
+    MALIO_HIP(hipMalloc(&c->d_ahead, c->cap_ahead));
+  }
+  MALIO_HIP(hipMemcpyAsync(c->d_ahead, buf, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  MALIO_HIP(hipEventRecord(c->ev_ahead, c->copy_stream));
+  c->ahead_ptr = buf, c->ahead_n = n, c->ahead_packed = packed ? 1 : 0;
+  return MALIO_OK;
+}
+
 int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
                    const int *pose_unc_len, const malio_pose_t *temporal_comp) {
   if (check(h) || !body || n <= 0 || !pose_unc || !pose_unc_len) return MALIO_ERR_BAD_ARG;
@@ -530,9 +585,10 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     // by this thread at all: one DMA copy of the 48-byte points and a kernel that packs them; the per-slot counts come
     // back with the first pass (resolve_scan_segments). A pageable cloud would be staged by the runtime page by page
     // (~0.7 ms per 10 MB): it is packed here instead, in one pass over it.
+    const bool staged = stage_take(c, body, n, 0);  // copied ahead by malio_scan_stage: no copy at all here
     hipPointerAttribute_t attr;
-    bool pinned = hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (pinned) {  // ... and the last byte as well: a cloud that merely starts inside a registered range is staged like any other
+    bool pinned = staged || (hipPointerGetAttributes(&attr, body) == hipSuccess && attr.type == hipMemoryTypeHost);
+    if (pinned && !staged) {  // ... and the last byte as well: a cloud that merely starts inside a registered range is staged like any other
       const char *last = reinterpret_cast<const char *>(body) + sizeof(malio_point_t) * (size_t)n - 1;
       pinned = hipPointerGetAttributes(&attr, last) == hipSuccess && attr.type == hipMemoryTypeHost;
     }
@@ -540,12 +596,16 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
     if (pinned) {
       // (the pack kernel reading the page-locked cloud in place instead - no copy call, which costs this thread ~16 us -
       // was measured: 109 us of kernel against 90 us of DMA + 15 us of pack, the turn 10 us slower)
-      if ((size_t)n > c->cap_raw) {
-        if (c->d_raw) (void)hipFree(c->d_raw);
-        c->d_raw = nullptr, c->cap_raw = (size_t)n + (size_t)n / 8 + 1024;
-        MALIO_HIP(hipMalloc(&c->d_raw, sizeof(float) * 12 * c->cap_raw));
+      if (staged) {
+        MALIO_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+      } else {
+        if ((size_t)n > c->cap_raw) {
+          if (c->d_raw) (void)hipFree(c->d_raw);
+          c->d_raw = nullptr, c->cap_raw = (size_t)n + (size_t)n / 8 + 1024;
+          MALIO_HIP(hipMalloc(&c->d_raw, sizeof(float) * 12 * c->cap_raw));
+        }
+        MALIO_HIP(hipMemcpyAsync(c->d_raw, body, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
       }
-      MALIO_HIP(hipMemcpyAsync(c->d_raw, body, sizeof(float) * 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
       // the caller's buffer is in use until this event (include/malio.h: lifetime of feats_down_body)
       if (!c->ev_upload) MALIO_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
       MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));
@@ -558,7 +618,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
         MALIO_HIP(hipEventSynchronize(c->ev_upload));
         c->upload_in_flight = false;
       }
-      const float *src = c->d_raw;
+      const float *src = staged ? static_cast<const float *>(c->d_ahead) : c->d_raw;
       if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
       MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
       if (!c->h_packinfo) {
@@ -568,6 +628,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
       }
       if (++c->pack_seq == 0) c->pack_seq = 1;
       hipLaunchKernelGGL(k_pack_raw, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, src, n, L, c->d_upload, c->d_packinfo);
+      if (staged) c->ahead_busy = true;  // (the next malio_scan_stage waits for this kernel before it overwrites d_ahead)
       c->pack_publish_pending = true;
       if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP) publish_pack_now(c);
       MALIO_HIP(hipGetLastError());
@@ -690,9 +751,10 @@ int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n,
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
   c->seg_pending = false;
+  const bool staged = stage_take(c, recs, n, 1);  // copied ahead by malio_scan_stage: a device-to-device copy is left
   hipPointerAttribute_t attr;
-  bool pinned = hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeHost;
-  if (pinned) {
+  bool pinned = staged || (hipPointerGetAttributes(&attr, recs) == hipSuccess && attr.type == hipMemoryTypeHost);
+  if (pinned && !staged) {
     const char *last = reinterpret_cast<const char *>(recs) + sizeof(malio_scan_rec_t) * (size_t)n - 1;
     pinned = hipPointerGetAttributes(&attr, last) == hipSuccess && attr.type == hipMemoryTypeHost;
   }
@@ -705,7 +767,13 @@ int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n,
     src = stage;
     c->stage_pending = true;
   }
-  MALIO_HIP(hipMemcpyAsync(c->d_upload, src, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (staged) {
+    MALIO_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+    MALIO_HIP(hipMemcpyAsync(c->d_upload, c->d_ahead, sizeof(UploadRec) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    c->ahead_busy = true;
+  } else {
+    MALIO_HIP(hipMemcpyAsync(c->d_upload, src, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  }
   if (pinned) {
     if (!c->ev_upload) MALIO_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
     MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));

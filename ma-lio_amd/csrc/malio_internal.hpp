@@ -385,6 +385,14 @@ struct Ctx {
   UploadRec *d_upload = nullptr;  // [N] scan as uploaded, caller's order (see UploadRec)
   float *d_raw = nullptr;         // [N][12] the caller's page-locked cloud as copied (malio_scan_set, pinned path)
   size_t cap_raw = 0;
+  // malio_scan_stage: the NEXT scan's cloud copied ahead on a stream of its own (under map_incremental of the current scan)
+  void *d_ahead = nullptr;
+  size_t cap_ahead = 0;            // bytes
+  const void *ahead_ptr = nullptr;  // the caller's buffer the staged bytes came from (nullptr: nothing staged)
+  int ahead_n = 0, ahead_packed = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_ahead = nullptr, ev_ahead_free = nullptr;
+  bool ahead_busy = false;          // a consumer of d_ahead was enqueued on `stream` after ev_ahead_free was last recorded
   u32 *d_packinfo = nullptr;      // k_pack_raw: per-slot counts, bad slots, descents
   u32 *h_packinfo = nullptr, *d_packinfo_pub = nullptr;  // pinned copy (+ sequence word [15]) of k_pack_raw's counts
   u32 pack_seq = 0, apply_seq = 0;

@@ -814,3 +814,48 @@ def test_scan_set_packed_equals_scan_set(capi, scenes):
     eng.scan_set_packed(bad, sc["tables"], sc["temporal_comp"])
     with pytest.raises(RuntimeError):
         eng.measure(sc["state0"], True)
+
+
+@pytest.mark.gpu
+def test_scan_stage_then_scan_set_equals_scan_set(capi, scenes):
+    """malio_scan_stage: the next scan copied ahead on a stream of its own while the current scan's map_incremental runs.
+    Three turns of the loop, points and packed records alike, against a handle that never stages: same update, same
+    side effects, same map, bit for bit; a scan_set of another buffer ignores what was staged; a pageable buffer is
+    refused."""
+    sc = scenes.make_scene(seed=77, N=6000, Nmap=60000, L=3)
+    scans = [scenes.make_scene(seed=77, N=6000, Nmap=60000, L=3, scan_seed=900 + k)["scan"] for k in range(4)]
+    for packed in (False, True):
+        ref, eng = _fresh(capi, sc), _fresh(capi, sc)
+        conv = (lambda a: capi.Engine.pack_scan(a)) if packed else (lambda a: a)
+        pins = [capi.PinnedArray(conv(scans[0]).shape, np.float32) for _ in range(2)]
+        set_fn = (lambda e, a: e.scan_set_packed(a, sc["tables"], sc["temporal_comp"])) if packed else \
+                 (lambda e, a: e.scan_set(a, sc["tables"], sc["temporal_comp"]))
+        pins[0].array[:] = conv(scans[0])
+        set_fn(eng, pins[0].array)
+        set_fn(ref, conv(scans[0]))
+        state = sc["state0"]
+        for k in range(3):
+            u, v = ref.update_iterated(state, sc["P0"]), eng.update_iterated(state, sc["P0"])
+            assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]) and u["passes"] == v["passes"]
+            nxt = pins[(k + 1) % 2]
+            eng.scan_upload_wait()
+            nxt.array[:] = conv(scans[k + 1])
+            eng.scan_stage(nxt.array, packed)                      # ... on its way under map_incremental
+            assert ref.map_incremental(u["state"], True, None) == eng.map_incremental(v["state"], True, None)
+            if k == 1:  # a change of mind: another buffer is set, the staged bytes are ignored
+                other = capi.PinnedArray(nxt.array.shape, np.float32)
+                other.array[:] = conv(scans[0])
+                set_fn(eng, other.array)
+                eng.scan_upload_wait()
+                eng.scan_stage(nxt.array, packed)
+            set_fn(eng, nxt.array)
+            set_fn(ref, conv(scans[k + 1]))
+            a, b = ref.measure(u["state"], True), eng.measure(u["state"], True)
+            assert a["M"] == b["M"] and np.array_equal(a["HtRinvH"], b["HtRinvH"]) and np.array_equal(a["HtRinvh"], b["HtRinvh"])
+            s0, s1 = ref.scan_get(), eng.scan_get()
+            for key in s0:
+                assert np.array_equal(s0[key], s1[key]), key
+            state = u["state"]
+        assert np.array_equal(ref.map_get(), eng.map_get())
+        with pytest.raises(RuntimeError):
+            eng.scan_stage(np.zeros((100, 5 if packed else 12), np.float32), packed)
