@@ -179,6 +179,7 @@ int malio_destroy(malio_handle_t h) {
   if (c->h_minmax) (void)hipHostFree(c->h_minmax);
   for (auto &e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+  maint_destroy(c);
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipEventDestroy(c->ev_ahead), (void)hipEventDestroy(c->ev_ahead_free);
@@ -245,6 +246,8 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   if (check(h) || !pts || n <= 0) return MALIO_ERR_BAD_ARG;
   Ctx *c = h;
   MALIO_HIP(hipSetDevice(c->device));
+  if (int rcj = maint_join(c)) return rcj;  // (queued maintenance of the map this call replaces)
+  (void)map_apply_finish(c);
   float4 *stage = nullptr;
   if (int rcs = host_stage(c, sizeof(float4) * (size_t)n + 16, (void **)&stage)) return rcs;
   if (c->part.world > 1) {
@@ -367,6 +370,7 @@ int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   *out_n = c->map_n - c->map_dead;
   if (cap <= 0 || c->map_n <= 0) return MALIO_OK;
   MALIO_HIP(hipSetDevice(c->device));
+  if (int rcj = maint_join(c)) return rcj;
   std::vector<float4> mp((size_t)c->map_n);
   MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));

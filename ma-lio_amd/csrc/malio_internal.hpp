@@ -364,6 +364,17 @@ struct Ctx {
   int scan_set_sync = -1;          // MALIO_SCAN_SET_SYNC=1: malio_scan_set waits for that copy itself (-1: not read yet)
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool apply_pending = false;  // an in-place list update is queued, its verdict (fitted / overflowed) not read yet
+  // map_apply's kernels (tombstones, kill, append, list maintenance) run on a stream of their own: the next scan's upload,
+  // pack and grouping do not read the map and overlap with them; whoever reads or writes the map or the lists on `stream`
+  // joins first (maint_join: map_sync_search and every map entry point). Their inputs live in arena_maint until the
+  // next mutator has seen ev_maint_done complete.
+  hipStream_t maint_stream = nullptr;
+  hipEvent_t ev_maint_in = nullptr, ev_maint_done = nullptr;
+  bool maint_pending = false;   // `stream` has not waited for ev_maint_done yet
+  bool maint_inflight = false;  // the host has not seen ev_maint_done complete yet (arena_maint in use)
+  int maint_enabled = -1;       // MALIO_MAINT_STREAM=0: everything on `stream` (A/B)
+  Arena arena_maint;
+  ArenaScope *maint_scope = nullptr;
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
@@ -506,9 +517,12 @@ void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false);
 void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
-void nl_ensure(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m);  // both levels at once
-void nl_append(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
-void nl_tombstone(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
+void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m);  // both levels at once
+void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
+void nl_tombstone(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
+int maint_join(Ctx *c);         // `stream` waits for the queued map maintenance (no host wait)
+int maint_scope_begin(Ctx *c);  // a mutator's entry: recycle arena_maint once the previous batch is known to be done
+void maint_destroy(Ctx *c);
 void free_nl_scratch(NlScratch &s);
 
 // capi.hip: the handle's pinned upload staging buffer (waits for an upload still in flight out of it)

@@ -762,23 +762,23 @@ NlDev nl_dev(const NList &nl) {
   return v;
 }
 
-void nl_ensure(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m) {
+void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m) {
   const long long th = (long long)m * 32;
   const dim3 grid((unsigned)((th + BLK - 1) / BLK), 2);
   const NlDev a = nl_dev(nl_a), b = nl_dev(nl_b);
-  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b);
-  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b, 0);
-  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, c->stream, d_new, keep, m, a, b, 1);
+  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, st, d_new, keep, m, a, b);
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 0);
+  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 1);
 }
-void nl_append(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base,
+void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base,
                int m) {
   const long long th = (long long)m * 32;
-  hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, c->stream, d_new, keep, rank,
+  hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, st, d_new, keep, rank,
                      og_base, m, nl_dev(nl_a), nl_dev(nl_b));
 }
-void nl_tombstone(Ctx *c, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel) {
+void nl_tombstone(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel) {
   const long long th = (long long)ndel * 27 * 16;
-  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, c->stream, d_map, dlist,
+  hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, st, d_map, dlist,
                      ndel, nl_dev(nl_a), nl_dev(nl_b));
 }
 

@@ -301,7 +301,7 @@ int map_apply_finish(Ctx *c) {
     unsigned long long spins = 0;
     while (__atomic_load_n(const_cast<const u32 *>(word), __ATOMIC_ACQUIRE) != c->apply_seq) {
       if ((++spins & 0x3FFF) == 0) {
-        hipError_t q = hipStreamQuery(c->stream);
+        hipError_t q = hipStreamQuery(c->maint_stream && c->maint_enabled ? c->maint_stream : c->stream);
         if (q != hipErrorNotReady && __atomic_load_n(const_cast<const u32 *>(word), __ATOMIC_ACQUIRE) != c->apply_seq) {
           MALIO_HIP(q);
           c->err = "map update: the list maintenance ended without publishing its verdict";
@@ -324,7 +324,64 @@ int map_apply_finish(Ctx *c) {
   return MALIO_OK;
 }
 
+int maint_join(Ctx *c) {
+  if (!c->maint_pending) return MALIO_OK;
+  c->maint_pending = false;
+  MALIO_HIP(hipStreamWaitEvent(c->stream, c->ev_maint_done, 0));
+  return MALIO_OK;
+}
+int maint_scope_begin(Ctx *c) {
+  if (c->maint_inflight) {
+    MALIO_HIP(hipEventSynchronize(c->ev_maint_done));  // (long done: it was recorded a whole scan ago)
+    c->maint_inflight = false;
+  }
+  delete c->maint_scope;
+  c->maint_scope = new ArenaScope(c->arena_maint);
+  return MALIO_OK;
+}
+void maint_destroy(Ctx *c) {
+  if (c->maint_stream) (void)hipStreamSynchronize(c->maint_stream);
+  delete c->maint_scope;
+  c->maint_scope = nullptr;
+  c->arena_maint.release_all();
+  if (c->maint_stream) {
+    (void)hipEventDestroy(c->ev_maint_in), (void)hipEventDestroy(c->ev_maint_done);
+    (void)hipStreamDestroy(c->maint_stream);
+    c->maint_stream = nullptr;
+  }
+}
+// the stream map_apply launches on: its own, entered behind everything queued on `stream` so far
+static int maint_enter(Ctx *c, hipStream_t *out, bool inputs_ready) {
+  if (c->maint_enabled < 0) {
+    const char *e = getenv("MALIO_MAINT_STREAM");
+    c->maint_enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!c->maint_enabled) {
+    *out = c->stream;
+    return MALIO_OK;
+  }
+  if (!c->maint_stream) {
+    MALIO_HIP(hipStreamCreateWithFlags(&c->maint_stream, hipStreamNonBlocking));
+    MALIO_HIP(hipEventCreateWithFlags(&c->ev_maint_in, hipEventDisableTiming));
+    MALIO_HIP(hipEventCreateWithFlags(&c->ev_maint_done, hipEventDisableTiming));
+  }
+  if (!inputs_ready) {  // (an event record + a stream wait cost this thread ~10 us: skipped when the caller has just
+                        // synchronised `stream` - the read-back of the counts - and queued nothing since)
+    MALIO_HIP(hipEventRecord(c->ev_maint_in, c->stream));
+    MALIO_HIP(hipStreamWaitEvent(c->maint_stream, c->ev_maint_in, 0));
+  }
+  *out = c->maint_stream;
+  return MALIO_OK;
+}
+static int maint_leave(Ctx *c, hipStream_t st) {
+  if (st == c->stream) return MALIO_OK;
+  MALIO_HIP(hipEventRecord(c->ev_maint_done, st));
+  c->maint_pending = true, c->maint_inflight = true;
+  return MALIO_OK;
+}
+
 int map_sync_search(Ctx *c) {
+  if (int rcj = maint_join(c)) return rcj;
   if (int rc = map_apply_finish(c)) return rc;
   if (!c->search_dirty) return MALIO_OK;
   return map_rebuild_search(c);
@@ -332,6 +389,7 @@ int map_sync_search(Ctx *c) {
 
 // Full rebuild: sweep the deleted slots out of the map array (indices change), then both list levels from scratch.
 int map_rebuild_search(Ctx *c) {
+  if (int rcj = maint_join(c)) return rcj;
   if (int rc = map_apply_finish(c)) return rc;
   c->search_dirty = false;
   if (c->map_dead > 0 && c->map_n > 0) {
@@ -393,9 +451,16 @@ __global__ void k_publish_states(const u32 *__restrict__ s1, const u32 *__restri
 // Falls back to "lists are stale" (rebuilt by the next search) when a list or the directory runs out of room or
 // too many tombstones have piled up.
 static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, const u32 *keep, const u32 *rank,
-                     int m, u32 nadd) {
+                     int m, u32 nadd, bool inputs_ready) {
+  if (int rcj = maint_join(c)) return rcj;         // (map_reserve below copies the map array on `stream`)
   if (int rcf = map_apply_finish(c)) return rcf;  // (the previous batch's verdict decides whether this one goes in place)
   const int hw = c->map_n;
+  if (nadd) {
+    int rc = map_reserve(c, nadd);
+    if (rc != MALIO_OK) return rc;
+  }
+  hipStream_t ms = nullptr;
+  if (int rcm = maint_enter(c, &ms, inputs_ready)) return rcm;
   bool in_place = !c->search_dirty && hw > 0;
   // in place only while the directory is comfortably loaded and tombstones stay below a fifth of the live points
   // (a batch that fills the directory or a list is detected by the kernels themselves and reported as overflow)
@@ -406,30 +471,29 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
   }
   if (ndel) {
     if (in_place) {
-      nl_tombstone(c, c->nl1, c->nl2, c->d_map_in, dlist, (int)ndel);
+      nl_tombstone(c, ms, c->nl1, c->nl2, c->d_map_in, dlist, (int)ndel);
     }
-    hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, dlist,
+    hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, ms, c->d_map_in, dlist,
                        (int)ndel, c->d_del, (u32)(c->d_del ? c->cap_del : 0));
     c->map_dead += (int)ndel, c->nl_tomb += (int)ndel;
   }
   if (nadd) {
-    int rc = map_reserve(c, nadd);
-    if (rc != MALIO_OK) return rc;
-    hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_new, keep, rank, m,
+    hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, ms, d_new, keep, rank, m,
                        (const u32 *)nullptr, c->d_map_in + hw);
     if (in_place) {
-      nl_ensure(c, c->nl1, c->nl2, d_new, keep, m);
-      nl_append(c, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
+      nl_ensure(c, ms, c->nl1, c->nl2, d_new, keep, m);
+      nl_append(c, ms, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
       u32 *mb = nullptr, *mbd = nullptr;
       MALIO_HIP(mbox(c, &mb, &mbd));
       if (++c->apply_seq == 0) c->apply_seq = 1;
-      hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, c->stream, c->nl1.state, c->nl2.state, mbd + 16,
+      hipLaunchKernelGGL(k_publish_states, dim3(1), dim3(8), 0, ms, c->nl1.state, c->nl2.state, mbd + 16,
                          mbd + MBOX_APPLY_SEQ, c->apply_seq);
       c->apply_pending = true;  // verdict read by map_apply_finish
     }
     c->map_n = hw + (int)nadd;
   }
   MALIO_HIP(hipGetLastError());
+  if (int rcl = maint_leave(c, ms)) return rcl;
   if ((ndel || nadd)) {
     c->map_epoch++;  // neighbour ids handed out before this call may now name a dead slot
     if (!in_place) c->search_dirty = true;
@@ -442,9 +506,9 @@ int map_add(Ctx *c, const float4 *h_pts, int m, int downsample_on, int *out_adde
   MALIO_HIP(hipSetDevice(c->device));
   if (out_added) *out_added = 0;
   if (m <= 0) return MALIO_OK;
-  ArenaScope up(c->arena);
-  float4 *d_new = nullptr;
-  MALIO_HIP(up.get(&d_new, (size_t)m));
+  if (int rcm = maint_scope_begin(c)) return rcm;
+  float4 *d_new = nullptr;  // read by map_apply's kernels on the maintenance stream after this call has returned
+  MALIO_HIP(c->maint_scope->get(&d_new, (size_t)m));
   MALIO_HIP(hipMemcpyAsync(d_new, h_pts, sizeof(float4) * (size_t)m, hipMemcpyHostToDevice, c->stream));
   return map_add_dev(c, d_new, m, downsample_on, out_added);
 }
@@ -467,14 +531,17 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   if (m <= 0) return MALIO_OK;
   const float ds = (float)c->prm.filter_size_map;
   ArenaScope sc(c->arena);
+  if (!c->maint_scope)
+    if (int rcm = maint_scope_begin(c)) return rcm;
+  ArenaScope &ms = *c->maint_scope;  // what map_apply's kernels read (maintenance stream): alive until the next mutator
   u32 *addf = nullptr, *apos = nullptr, *tiles = nullptr, *counters = nullptr;
-  MALIO_HIP(sc.get(&addf, (size_t)m + 1 + 2));  // keep flags, then the two counters of k_vox_add: one clear for both
+  MALIO_HIP(ms.get(&addf, (size_t)m + 1 + 2));  // keep flags, then the two counters of k_vox_add: one clear for both
   counters = addf + m + 1;
-  MALIO_HIP(sc.get(&apos, (size_t)m + 1));
+  MALIO_HIP(ms.get(&apos, (size_t)m + 1));
   if (m_ds <= 0) {
     hipLaunchKernelGGL(k_fill_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, addf, 1u, m);
     hipLaunchKernelGGL(k_iota_u32, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, c->stream, apos, m);
-    return map_apply(c, nullptr, 0, d_new, addf, apos, m, (u32)m);
+    return map_apply(c, nullptr, 0, d_new, addf, apos, m, (u32)m, false);
   }
   if (ds > 2.0f * c->cell) {
     c->err = "malio_map_add: filter_size_map larger than twice the level-1 cell edge is not supported";
@@ -496,7 +563,7 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   }
   unsigned char *del = c->d_del;
   u32 *dlist = nullptr, *mb = nullptr, *mbd = nullptr;
-  hipError_t e = sc.get(&dlist, (size_t)hw + 1);
+  hipError_t e = ms.get(&dlist, (size_t)hw + 1);
   if (e == hipSuccess) e = sc.get(&tiles, (size_t)(m + 1 + 1023) / 1024 + 2);
   if (e == hipSuccess) e = mbox(c, &mb, &mbd);
   MALIO_HIP(e);
@@ -520,7 +587,7 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
     MALIO_HIP(e);
   }
   if (out_added) *out_added = (int)h_tot[1];
-  rc = map_apply(c, dlist, h_tot[2], d_new, addf, apos, m, h_tot[0]);
+  rc = map_apply(c, dlist, h_tot[2], d_new, addf, apos, m, h_tot[0], true);  // (synchronised above, nothing queued since)
   if (rc != MALIO_OK) clear_marks();  // (after the kill kernel ran this clears zeros)
   return rc;
 }
@@ -530,11 +597,13 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   if (out_deleted) *out_deleted = 0;
   const int hw = c->map_n;
   if (nb <= 0 || hw <= 0) return MALIO_OK;
+  if (int rcj = maint_join(c)) return rcj;
+  if (int rcm = maint_scope_begin(c)) return rcm;
   ArenaScope sc(c->arena);
   malio_box_t *d_boxes = nullptr;
   u32 *dlist = nullptr, *counter = nullptr;
   MALIO_HIP(sc.get(&d_boxes, (size_t)nb));
-  MALIO_HIP(sc.get(&dlist, (size_t)hw + 1));
+  MALIO_HIP(c->maint_scope->get(&dlist, (size_t)hw + 1));
   MALIO_HIP(sc.get(&counter, 1));
   MALIO_HIP(hipMemcpyAsync(d_boxes, boxes, sizeof(malio_box_t) * (size_t)nb, hipMemcpyHostToDevice, c->stream));
   MALIO_HIP(hipMemsetAsync(counter, 0, sizeof(u32), c->stream));
@@ -549,7 +618,7 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
   MALIO_HIP(hipGetLastError());
   if (out_deleted) *out_deleted = (int)ndel;
   if (ndel == 0) return MALIO_OK;
-  return map_apply(c, dlist, ndel, nullptr, nullptr, nullptr, 0, 0);
+  return map_apply(c, dlist, ndel, nullptr, nullptr, nullptr, 0, 0, true);
 }
 
 }  // namespace malio
@@ -560,9 +629,11 @@ namespace malio {
 // selection of map_incremental (laserMapping.cpp:398-442) on the device: d_add = PointToAdd | PointNoNeedDownsample back to
 // back in scan order (arena memory of the caller's scope), their counts; d_idx (optional): the scan index of each
 static int mapinc_select_dev(Ctx *c, ArenaScope &sc, const malio_state_t *state_point, int flg_EKF_inited,
-                             const float *h_world_normal_y, float4 **d_add_out, int *na_out, int *nn_out, u32 **d_idx_out) {
+                             const float *h_world_normal_y, float4 **d_add_out, int *na_out, int *nn_out, u32 **d_idx_out,
+                             bool for_apply) {
   const int N = c->N;
   if (N <= 0) return MALIO_ERR_NO_SCAN;
+  if (int rcj = maint_join(c)) return rcj;  // (the classification reads the map array)
   float *d_wny = nullptr;
   u32 *addf = nullptr, *nonf = nullptr, *apos = nullptr, *npos = nullptr, *tiles = nullptr, *tiles2 = nullptr;
   float4 *wp = nullptr, *d_add = nullptr, *d_non = nullptr;
@@ -591,7 +662,8 @@ static int mapinc_select_dev(Ctx *c, ArenaScope &sc, const malio_state_t *state_
   exclusive_scan_u32_pair(c, addf, apos, tiles, mbd + 0, nonf, npos, tiles2, mbd + 2, N + 1);
   MALIO_HIP(hipStreamSynchronize(c->stream));
   const int na = (int)mb[0], nn = (int)mb[2];
-  MALIO_HIP(sc.get(&d_add, (size_t)na + (size_t)nn));  // PointToAdd | PointNoNeedDownsample, back to back
+  // PointToAdd | PointNoNeedDownsample, back to back (for map_apply: read on the maintenance stream after the return)
+  MALIO_HIP((for_apply ? *c->maint_scope : sc).get(&d_add, (size_t)na + (size_t)nn));
   d_non = d_add + na;
   hipLaunchKernelGGL(k_compact2, dim3((N + BLK - 1) / BLK, 2), dim3(BLK), 0, c->stream, wp, addf, apos, d_add, nonf, npos,
                      d_non, N);
@@ -612,7 +684,8 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   ArenaScope sc(c->arena);
   float4 *d_add = nullptr;
   int na = 0, nn = 0;
-  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, nullptr);
+  if (int rcm = maint_scope_begin(c)) return rcm;
+  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, nullptr, true);
   if (rc != MALIO_OK) return rc;
   int added = 0;
   // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)   (:443-444)
@@ -633,7 +706,7 @@ int map_incremental_select(Ctx *c, const malio_state_t *state_point, int flg_EKF
   float4 *d_add = nullptr;
   u32 *d_idx = nullptr;
   int na = 0, nn = 0;
-  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, &d_idx);
+  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, &d_idx, false);
   if (rc != MALIO_OK) return rc;
   out_counts2[0] = na, out_counts2[1] = nn;
   const int m = na + nn;

@@ -2060,7 +2060,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(sc.get(&tbkt, (size_t)N));
   const bool pub = c->pack_publish_pending;
   c->pack_publish_pending = false;
-  hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->nl1.inv_cf, keys, bkt, rnk, cnt,
+  hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->inv_cell /* == nl1.inv_cf, which exists only once the lists are built */, keys, bkt, rnk, cnt,
                      (const u32 *)c->d_packinfo, pub ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
   hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs);
   hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkv, tbkt);
@@ -2115,16 +2115,18 @@ void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
   if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
-  if (int rc = map_sync_search(c)) return rc;
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
   if (!c->scan_sorted) {
-    // (the grouping needs the counts only to decide whether the caller's order can be kept)
+    // (the grouping needs the counts only to decide whether the caller's order can be kept). BEFORE map_sync_search: it
+    // reads neither the map nor the lists, so it is queued - and runs - while the previous scan's list maintenance is
+    // still busy on its own stream; the search kernels join behind that (maint_join in map_sync_search).
     if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
       if (int rc = resolve_scan_segments(c)) return rc;
     int rc = sort_scan(c, a.qc);
     if (rc != MALIO_OK) return rc;
   }
+  if (int rc = map_sync_search(c)) return rc;
   fill_pass1_static(c, a);
   c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
   a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
@@ -2205,14 +2207,14 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
 int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
   if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
-  if (int rc = map_sync_search(c)) return rc;
-  if (!c->scan_sorted) {
+  if (!c->scan_sorted) {  // (before map_sync_search: see pass_stage1)
     if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
       if (int rc = resolve_scan_segments(c)) return rc;
     QuatConst qc;
     fill_quat_const(c, s, qc);
     if (int rc = sort_scan(c, qc)) return rc;
   }
+  if (int rc = map_sync_search(c)) return rc;
   return MALIO_OK;  // (the segments are resolved by whoever launches a stage 2: pass_stage1, or the device loop)
 }
 

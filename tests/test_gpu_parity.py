@@ -859,3 +859,43 @@ def test_scan_stage_then_scan_set_equals_scan_set(capi, scenes):
         assert np.array_equal(ref.map_get(), eng.map_get())
         with pytest.raises(RuntimeError):
             eng.scan_stage(np.zeros((100, 5 if packed else 12), np.float32), packed)
+
+
+@pytest.mark.gpu
+def test_maintenance_stream_equals_single_stream(capi, scenes, monkeypatch):
+    """map_apply's kernels (tombstones, kill, append, list maintenance) run on a stream of their own so that the next
+    scan's upload and grouping overlap with them; searches and every map entry point join behind them. Against a handle
+    with MALIO_MAINT_STREAM=0 (everything on one stream) over four turns of the loop, with box deletions and a plain
+    map_add in between: same updates, same side effects, same map, bit for bit."""
+    sc = scenes.make_scene(seed=55, N=6000, Nmap=60000, L=3)
+    monkeypatch.setenv("MALIO_MAINT_STREAM", "0")
+    one = _fresh(capi, sc)
+    one.map_add(sc["map"][:10], True)                   # (the switch is read by the first map mutation)
+    monkeypatch.setenv("MALIO_MAINT_STREAM", "1")
+    two = _fresh(capi, sc)
+    two.map_add(sc["map"][:10], True)
+    state = sc["state0"]
+    rng = np.random.default_rng(3)
+    for k in range(4):
+        scan = scenes.make_scene(seed=55, N=6000, Nmap=60000, L=3, scan_seed=300 + k)["scan"]
+        for e in (one, two):
+            e.scan_set(scan, sc["tables"], sc["temporal_comp"])
+        u, v = one.update_iterated(state, sc["P0"]), two.update_iterated(state, sc["P0"])
+        assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]) and u["passes"] == v["passes"]
+        s0, s1 = one.scan_get(), two.scan_get()
+        for key in s0:
+            assert np.array_equal(s0[key], s1[key]), key
+        assert one.map_incremental(u["state"], True, None) == two.map_incremental(v["state"], True, None)
+        if k == 1:    # queued maintenance followed at once by another mutator, a read-back and a search
+            box = np.array([[-3, -3, -3, 3, 3, 3]], np.float32) + np.r_[u["state"][:3], u["state"][:3]].astype(np.float32)
+            assert one.map_delete_boxes(box) == two.map_delete_boxes(box)
+            extra = scan[:500].copy()
+            extra[:, :3] += rng.normal(0, 2.0, (500, 3)).astype(np.float32)
+            assert one.map_add(extra, False) == two.map_add(extra, False)
+            assert np.array_equal(one.map_get(), two.map_get())
+            q = scan[:200]
+            for a, b in zip(one.nearest_search(q, 5), two.nearest_search(q, 5)):
+                assert np.array_equal(a, b)
+        state = u["state"]
+    assert np.array_equal(one.map_get(), two.map_get())
+    assert one.debug_counters()["inplace"] > 0 and one.debug_counters() == two.debug_counters()
