@@ -180,6 +180,8 @@ int malio_destroy(malio_handle_t h) {
   for (auto &e : c->ev) (void)hipEventDestroy(e);
   if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
   maint_destroy(c);
+  if (c->d_small_table) (void)hipFree(c->d_small_table);
+  if (c->d_small_orig) (void)hipFree(c->d_small_orig);
   if (c->copy_stream) {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipEventDestroy(c->ev_ahead), (void)hipEventDestroy(c->ev_ahead_free);

@@ -375,6 +375,9 @@ struct Ctx {
   int maint_enabled = -1;       // MALIO_MAINT_STREAM=0: everything on `stream` (A/B)
   Arena arena_maint;
   ArenaScope *maint_scope = nullptr;
+  Cell *d_small_table = nullptr;  // map_incremental's usual batch: voxel table + member lists of k_group_small
+  u32 *d_small_orig = nullptr;
+  int mapinc_small = -1;
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)

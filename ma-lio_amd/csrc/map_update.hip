@@ -256,6 +256,133 @@ __global__ void __launch_bounds__(BLK) k_compact2_idx(const u32 *__restrict__ fl
   }
 }
 
+// ---- the usual batch of map_incremental (a few thousand new points) without its first read-back ------------------------
+// The lengths of PointToAdd / PointNoNeedDownsample stay on the device (posA[n], posB[n]: exclusive scans over n + 1
+// flags) until the ONE read-back that also brings the keeper rule's counts: the compaction, the voxel grouping and the
+// scan of the keep flags read them there. The grouping - five launches of group_by_cell for ~1.7 k points - is one
+// workgroup with its hash table in LDS. A batch above SMALL_CAP leaves everything untouched (empty voxel table: k_vox_add
+// does nothing) and the host takes the general path.
+constexpr int SMALL_CAP = 4096;  // new points (both lists)
+constexpr int SMALL_TS = 8192;   // voxel table slots (load <= 0.5)
+__global__ void __launch_bounds__(BLK) k_compact2_dev(const float4 *__restrict__ src, const u32 *__restrict__ flagA,
+                                                      const u32 *__restrict__ posA, const u32 *__restrict__ flagB,
+                                                      const u32 *__restrict__ posB, float4 *dst, int n, u32 cap) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const u32 na = posA[n], nb = posB[n];
+  if (na + nb > cap) return;
+  if (blockIdx.y == 0) {
+    if (flagA[i]) dst[posA[i]] = src[i];
+  } else {
+    if (flagB[i]) dst[na + posB[i]] = src[i];
+  }
+}
+// one workgroup: voxel table (key -> start, count) + member lists of the first *cntA points of newp (the down-sampled
+// list), as group_by_cell leaves them; keep flags as k_init_addf leaves them (the two counters at addf + SMALL_CAP + 1);
+// info = {m_ds, m, overflow}
+__global__ void __launch_bounds__(1024) k_group_small(const float4 *__restrict__ newp, const u32 *__restrict__ cntA,
+                                                      const u32 *__restrict__ cntB, float ds, Cell *table, u32 *orig,
+                                                      u32 *addf, u32 *info, u32 cap /* <= SMALL_CAP */) {
+  __shared__ u64 s_key[SMALL_TS];
+  __shared__ u32 s_cnt[SMALL_TS], s_start[SMALL_TS], s_wsum[16];
+  const int t = threadIdx.x;
+  const u32 na = *cntA, nb = *cntB;
+  const bool over = na + nb > cap;
+  const u32 m_ds = over ? 0u : na, m = over ? 0u : na + nb;
+  for (int s = t; s < SMALL_TS; s += 1024) s_key[s] = EMPTY_KEY, s_cnt[s] = 0u;
+  for (u32 i = t; i < (u32)SMALL_CAP + 3u; i += 1024) addf[i] = (i >= m_ds && i < m) ? 1u : 0u;
+  __syncthreads();
+  u32 slot[SMALL_CAP / 1024], rank[SMALL_CAP / 1024];
+#pragma unroll
+  for (int k = 0; k < SMALL_CAP / 1024; k++) {
+    const u32 i = (u32)t + 1024u * k;
+    slot[k] = 0u, rank[k] = 0u;
+    if (i < m_ds) {
+      const float4 p = newp[i];  // voxel index exactly as ikd_Tree.cpp:494-499 forms it: floor(x / downsample_size)
+      const u64 key = cell_key((int)floorf(p.x / ds), (int)floorf(p.y / ds), (int)floorf(p.z / ds));
+      u32 s = hash_key(key) & (SMALL_TS - 1);
+      while (true) {
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_key[s]), (unsigned long long)EMPTY_KEY,
+                                  (unsigned long long)key);
+        if (old == EMPTY_KEY || old == key) break;
+        s = (s + 1) & (SMALL_TS - 1);
+      }
+      slot[k] = s, rank[k] = atomicAdd(&s_cnt[s], 1u);
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of the slot counts: 8 consecutive slots per thread, wave scans, 16 wave totals
+    constexpr int PER = SMALL_TS / 1024;
+    u32 v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) v[k] = s_cnt[t * PER + k], sum += v[k];
+    u32 incl = sum;
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    u32 run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < 16; w++) run += w < wave ? s_wsum[w] : 0u;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const int s = t * PER + k;
+      s_start[s] = run;
+      Cell c;
+      c.key = s_key[s], c.start = run, c.count = v[k];
+      table[s] = c;  // (an empty slot carries EMPTY_KEY and count 0)
+      run += v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SMALL_CAP / 1024; k++) {
+    const u32 i = (u32)t + 1024u * k;
+    if (i < m_ds) orig[s_start[slot[k]] + rank[k]] = i;
+  }
+  if (t == 0) info[0] = m_ds, info[1] = m, info[2] = over ? 1u : 0u;
+}
+// k_scan_small over *m_p + 1 elements (the keep flags and their terminating zero)
+__global__ void __launch_bounds__(1024) k_scan_small_dev(const u32 *__restrict__ in, u32 *out, const u32 *__restrict__ m_p,
+                                                         u32 *total_out, const u32 *__restrict__ fwd, int nfwd) {
+  __shared__ u32 wsum[16];
+  const int n = (int)*m_p + 1;
+  const int per = (n + 1023) / 1024;  // <= 5
+  const int base = threadIdx.x * per;
+  u32 v[8];
+  u32 tsum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    v[k] = (k < per && base + k < n) ? in[base + k] : 0u;
+    tsum += v[k];
+  }
+  u32 incl = tsum;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 excl = incl - tsum;
+#pragma unroll
+  for (int w = 0; w < 16; w++) excl += w < wave ? wsum[w] : 0u;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < per && base + k < n) {
+      out[base + k] = excl;
+      if (base + k == n - 1) total_out[0] = excl;
+    }
+    excl += v[k];
+  }
+  if ((int)threadIdx.x < nfwd) total_out[1 + threadIdx.x] = fwd[threadIdx.x];
+}
+
 int ensure_alt(Ctx *c, size_t need) {
   if (need > c->cap_map_alt) {
     if (c->d_map_alt) (void)hipFree(c->d_map_alt);
@@ -626,11 +753,79 @@ int map_delete_boxes(Ctx *c, const malio_box_t *boxes, int nb, int *out_deleted)
 // map_incremental(), laserMapping.cpp:398-446, entirely on the device: selection (measure.hip), stable compaction
 // of the two lists in scan order, then the two Add_Points calls of :443-444.
 namespace malio {
+// map_incremental's usual batch (<= SMALL_CAP new points, map down-sampling on): compaction, voxel grouping, keeper rule
+// and the scan of the keep flags queued behind the selection's scans with the list lengths still on the device, then
+// the one read-back and map_apply. *done = 0: not applicable or the batch was larger - the caller takes the general path
+// (the stream is synchronised and nothing was changed).
+static int mapinc_small_batch(Ctx *c, ArenaScope &sc, const float4 *wp, const u32 *addf_sel, const u32 *apos_sel,
+                              const u32 *nonf_sel, const u32 *npos_sel, int N, int *na_out, int *nn_out, int *added_out,
+                              int *done) {
+  *done = 0;
+  const float ds = (float)c->prm.filter_size_map;
+  u32 *mb = nullptr, *mbd = nullptr;
+  MALIO_HIP(mbox(c, &mb, &mbd));
+  if (c->mapinc_small < 0) {  // MALIO_MAPINC_SMALL=<cap>: 0 = always the general path, a small cap to exercise the fall-back (tests)
+    const char *e = getenv("MALIO_MAPINC_SMALL");
+    c->mapinc_small = e ? std::min(std::max(atoi(e), 0), SMALL_CAP) : SMALL_CAP;
+  }
+  const u32 cap = (u32)c->mapinc_small;
+  if (!c->mapinc_small || !(ds > 0.f) || ds > 2.0f * c->cell || c->map_n <= 0) {
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    return MALIO_OK;
+  }
+  int rc = map_sync_search(c);  // the voxel lookups read the level-1 lists
+  if (rc != MALIO_OK) return rc;
+  const int hw = c->map_n;
+  if (!c->d_small_table) {
+    MALIO_HIP(hipMalloc(&c->d_small_table, sizeof(Cell) * SMALL_TS));
+    MALIO_HIP(hipMalloc(&c->d_small_orig, sizeof(u32) * (SMALL_CAP + 8)));
+  }
+  if ((size_t)hw + 1 > c->cap_del) {
+    if (c->d_del) (void)hipFree(c->d_del);
+    c->d_del = nullptr, c->cap_del = c->cap_map_in + 1024;
+    MALIO_HIP(hipMalloc(&c->d_del, c->cap_del));
+    MALIO_HIP(hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream));
+  }
+  ArenaScope &ms = *c->maint_scope;
+  float4 *d_add = nullptr;
+  u32 *addf = nullptr, *apos = nullptr, *dlist = nullptr;
+  MALIO_HIP(ms.get(&d_add, (size_t)SMALL_CAP));
+  MALIO_HIP(ms.get(&addf, (size_t)SMALL_CAP + 3 + 4));  // keep flags, a zero, k_vox_add's two counters, info[3]
+  MALIO_HIP(ms.get(&apos, (size_t)SMALL_CAP + 1));
+  MALIO_HIP(ms.get(&dlist, (size_t)hw + 1));
+  u32 *counters = addf + SMALL_CAP + 1, *info = addf + SMALL_CAP + 3;
+  (void)sc;
+  hipLaunchKernelGGL(k_compact2_dev, dim3((N + BLK - 1) / BLK, 2), dim3(BLK), 0, c->stream, wp, addf_sel, apos_sel, nonf_sel,
+                     npos_sel, d_add, N, cap);
+  hipLaunchKernelGGL(k_group_small, dim3(1), dim3(1024), 0, c->stream, d_add, apos_sel + N, npos_sel + N, ds, c->d_small_table,
+                     c->d_small_orig, addf, info, cap);
+  hipLaunchKernelGGL(k_vox_add, dim3(SMALL_TS / BLK), dim3(BLK), 0, c->stream, c->d_small_table, (u32)SMALL_TS,
+                     c->d_small_orig, d_add, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, 1, ds, c->d_del,
+                     dlist, addf, counters);
+  hipLaunchKernelGGL(k_scan_small_dev, dim3(1), dim3(1024), 0, c->stream, addf, apos, info + 1, mbd + 8, counters, 2);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  auto clear_marks = [&] { (void)hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream); };
+  if (e != hipSuccess) {
+    clear_marks();
+    MALIO_HIP(e);
+  }
+  const int na = (int)mb[0], nn = (int)mb[2];
+  if (na + nn > (int)cap) return MALIO_OK;  // (nothing was touched: empty voxel table)
+  *na_out = na, *nn_out = nn;
+  if (added_out) *added_out = (int)mb[8 + 1];
+  *done = 1;
+  if (na + nn == 0) return MALIO_OK;
+  rc = map_apply(c, dlist, mb[8 + 2], d_add, addf, apos, na + nn, mb[8 + 0], true);
+  if (rc != MALIO_OK) clear_marks();
+  return rc;
+}
+
 // selection of map_incremental (laserMapping.cpp:398-442) on the device: d_add = PointToAdd | PointNoNeedDownsample back to
 // back in scan order (arena memory of the caller's scope), their counts; d_idx (optional): the scan index of each
 static int mapinc_select_dev(Ctx *c, ArenaScope &sc, const malio_state_t *state_point, int flg_EKF_inited,
                              const float *h_world_normal_y, float4 **d_add_out, int *na_out, int *nn_out, u32 **d_idx_out,
-                             bool for_apply) {
+                             bool for_apply, int *added_out = nullptr) {
   const int N = c->N;
   if (N <= 0) return MALIO_ERR_NO_SCAN;
   if (int rcj = maint_join(c)) return rcj;  // (the classification reads the map array)
@@ -660,7 +855,17 @@ static int mapinc_select_dev(Ctx *c, ArenaScope &sc, const malio_state_t *state_
   if (rc != MALIO_OK) return rc;
   // the two list lengths go straight from the scans' last kernels into the host's mapped buffer: no copy launches
   exclusive_scan_u32_pair(c, addf, apos, tiles, mbd + 0, nonf, npos, tiles2, mbd + 2, N + 1);
-  MALIO_HIP(hipStreamSynchronize(c->stream));
+  if (for_apply && !d_idx_out) {
+    // the usual batch: everything up to the keeper rule's counts queued behind the scans, ONE read-back
+    int done = 0;
+    rc = mapinc_small_batch(c, sc, wp, addf, apos, nonf, npos, N, na_out, nn_out, added_out, &done);
+    if (rc != MALIO_OK || done) {
+      *d_add_out = nullptr;
+      return rc;
+    }
+  } else {
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+  }
   const int na = (int)mb[0], nn = (int)mb[2];
   // PointToAdd | PointNoNeedDownsample, back to back (for map_apply: read on the maintenance stream after the return)
   MALIO_HIP((for_apply ? *c->maint_scope : sc).get(&d_add, (size_t)na + (size_t)nn));
@@ -685,11 +890,13 @@ int map_incremental(Ctx *c, const malio_state_t *state_point, int flg_EKF_inited
   float4 *d_add = nullptr;
   int na = 0, nn = 0;
   if (int rcm = maint_scope_begin(c)) return rcm;
-  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, nullptr, true);
-  if (rc != MALIO_OK) return rc;
   int added = 0;
+  int rc = mapinc_select_dev(c, sc, state_point, flg_EKF_inited, h_world_normal_y, &d_add, &na, &nn, nullptr, true, &added);
+  if (rc != MALIO_OK) return rc;
   // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false)   (:443-444)
-  if ((float)c->prm.filter_size_map > 0.f)
+  if (!d_add) {
+    // (the usual batch: applied by mapinc_small_batch)
+  } else if ((float)c->prm.filter_size_map > 0.f)
     rc = map_add_pair_dev(c, d_add, na, nn, &added);
   else
     rc = map_add_pair_dev(c, d_add, 0, na + nn, nullptr);

@@ -899,3 +899,35 @@ def test_maintenance_stream_equals_single_stream(capi, scenes, monkeypatch):
         state = u["state"]
     assert np.array_equal(one.map_get(), two.map_get())
     assert one.debug_counters()["inplace"] > 0 and one.debug_counters() == two.debug_counters()
+
+
+@pytest.mark.gpu
+def test_map_incremental_small_batch_equals_general_path(capi, scenes, monkeypatch):
+    """map_incremental's usual batch (<= 4 096 new points: list lengths kept on the device, voxel grouping in one
+    workgroup, one read-back) against the general path (MALIO_MAPINC_SMALL=0) and against a handle whose cap is 300
+    (batches of 300..4 096 points fall back behind the one-workgroup attempt) over four scans of a moving sensor: same
+    counts, same return value of the down-sampling Add_Points, same map, same next update, bit for bit."""
+    sc = scenes.make_scene(seed=91, N=8000, Nmap=80000, L=3)
+    engs = [_fresh(capi, sc) for _ in range(3)]
+    caps = ["0", "4096", "300"]
+    state = sc["state0"]
+    sizes = []
+    for k in range(4):
+        scan = scenes.make_scene(seed=91, N=8000, Nmap=80000, L=3, scan_seed=400 + k)["scan"]
+        wny = np.random.default_rng(k).uniform(0, 0.002, scan.shape[0]).astype(np.float32)
+        ups, res = [], []
+        for e, cap in zip(engs, caps):
+            e.scan_set(scan, sc["tables"], sc["temporal_comp"])
+            ups.append(e.update_iterated(state, sc["P0"]))
+            monkeypatch.setenv("MALIO_MAPINC_SMALL", cap)   # (a handle reads the switch in its first call)
+            res.append(e.map_incremental(ups[0]["state"], True, wny))
+        for u in ups[1:]:
+            assert np.array_equal(u["state"], ups[0]["state"]) and np.array_equal(u["P"], ups[0]["P"])
+        assert res[0] == res[1] == res[2] and res[0][0] + res[0][1] > 0
+        sizes.append(res[0][0] + res[0][1])
+        m0 = engs[0].map_get()
+        assert np.array_equal(m0, engs[1].map_get()) and np.array_equal(m0, engs[2].map_get())
+        state = ups[0]["state"].copy()
+        state[0:3] += [0.05, 0.02, 0.0]
+    assert max(sizes) > 300 and max(sizes) <= 4096, sizes
+    assert engs[0].debug_counters() == engs[1].debug_counters() == engs[2].debug_counters()
