@@ -602,15 +602,19 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
     u64 old = __builtin_nontemporal_load(&nl.table[s].key);
     if (old == EMPTY_KEY) {
       old = atomicCAS(&nl.table[s].key, EMPTY_KEY, key);
-      if (old == EMPTY_KEY) {  // this thread created the cell; its list is sized and placed by the next two kernels
+      if (old == EMPTY_KEY) {  // this thread created the cell; its list is sized and placed by the next kernel
         nl.table[s].start = 0;
         nl.table[s].count = 0;
         nl.cap[s] = 0;
         atomicAdd(&nl.state[2], 1u);
+        atomicAdd(&nl.inc[s], 1u);  // (1b) what this batch brings to the cell (was a launch of its own: k_nl_place, mode 0)
         return;
       }
     }
-    if (old == key) return;
+    if (old == key) {
+      atomicAdd(&nl.inc[s], 1u);
+      return;
+    }
     s = (s + 1) & nl.tmask;
   }
 }
@@ -720,10 +724,13 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
 __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__ mapp, const u32 *__restrict__ dlist,
                                                       int ndel, NlDev nl_a, NlDev nl_b) {
   const NlDev nl = blockIdx.y ? nl_b : nl_a;
-  // 16 lanes per (deleted point, one of its 27 lists): a level-2 list has 180..900 entries to look through
+  // 16 lanes per (deleted point, one of its 27 lists) on level 1 (~45 entries), a whole wave on level 2 (180..900
+  // entries: 4 round trips instead of 14; the kernel is as long as its longest walk)
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
-  const int sub = (int)(t & 15);
-  const long long pc = t >> 4;
+  const int lg = blockIdx.y ? 6 : 4;
+  const u32 lanes = 1u << lg;
+  const int sub = (int)(t & (lanes - 1));
+  const long long pc = t >> lg;
   const int d = (int)(pc / 27), cidx = (int)(pc % 27);
   if (d >= ndel) return;
   const u32 i = dlist[d];
@@ -741,17 +748,18 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
     s = (s + 1) & nl.tmask;
   }
   const u32 st = nl.table[s].start, cn = nl.table[s].count;
-  const int gsh = (threadIdx.x & 63) & ~15;  // first lane of this 16-lane group inside the wave
-  for (u32 j = (u32)sub; j < cn; j += 16 * 4) {  // 4 independent loads in flight per lane
+  const int gsh = (threadIdx.x & 63) & ~(int)(lanes - 1);  // first lane of this group inside the wave
+  const unsigned long long gmask = lanes == 64 ? ~0ull : 0xFFFFull;
+  for (u32 j = (u32)sub; j < cn; j += lanes * 4) {  // 4 independent loads in flight per lane
     u32 og[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) og[u] = __float_as_uint(nl.pts[(size_t)st + min(j + 16u * u, cn - 1)].w);
+    for (int u = 0; u < 4; u++) og[u] = __float_as_uint(nl.pts[(size_t)st + min(j + lanes * u, cn - 1)].w);
     bool hit = false;
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (og[u] == i && j + 16u * u < cn) nl.pts[(size_t)st + j + 16u * u].x = INFINITY, hit = true;
+      if (og[u] == i && j + lanes * u < cn) nl.pts[(size_t)st + j + lanes * u].x = INFINITY, hit = true;
     // one entry per list matches: once a lane of the group has found it the rest of the list need not be read
-    if ((__ballot(hit) >> gsh) & 0xFFFFull) break;
+    if ((__ballot(hit) >> gsh) & gmask) break;
   }
 }
 
@@ -767,7 +775,6 @@ void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
   const dim3 grid((unsigned)((th + BLK - 1) / BLK), 2);
   const NlDev a = nl_dev(nl_a), b = nl_dev(nl_b);
   hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, st, d_new, keep, m, a, b);
-  hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 0);
   hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 1);
 }
 void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base,
@@ -777,7 +784,7 @@ void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
                      og_base, m, nl_dev(nl_a), nl_dev(nl_b));
 }
 void nl_tombstone(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel) {
-  const long long th = (long long)ndel * 27 * 16;
+  const long long th = (long long)ndel * 27 * 64;  // (level 2's need; the level-1 half of the grid leaves early)
   hipLaunchKernelGGL(k_nl_tombstone, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, st, d_map, dlist,
                      ndel, nl_dev(nl_a), nl_dev(nl_b));
 }
