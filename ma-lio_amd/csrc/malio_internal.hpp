@@ -451,6 +451,7 @@ struct Ctx {
   int fuse_enabled = -1;  // MALIO_FUSE=0 switches the one-kernel pass off (-1: environment not read yet)
   bool fuse_debug_bad_guess = false;  // MALIO_DEBUG_FUSE_BAD_GUESS=1
   int fuse_cooldown = 0;  // eligible passes left that do NOT speculate (set by a miss, see fuse_eligible)
+  int fuse_cooldown_len = 3, fuse_hits_in_row = 0;  // (FUSE_COOLDOWN_MIN; adapted by fused_collect)
   int fuse_hits = 0, fuse_misses = 0, fuse_passes = 0;
   double *d_partials = nullptr;  // [NSUM][cap_partials]
   double *d_sums = nullptr;      // [NSUM_OUT]
@@ -600,7 +601,7 @@ constexpr int MBOX_APPLY_SEQ = 14;  // sequence word of k_publish_states (map_ap
 // when at least this many workgroups were loaded with uncertified queries (each counts 1, or 64 when more than half of
 // its queries are), i.e. when serving them in place would stretch the search kernel by more than that.
 constexpr double DEFER_SCORE_MIN = 64.0;
-constexpr int FUSE_COOLDOWN = 24;  // passes without speculation after a wrong guess of the extrema (fuse_eligible)
+constexpr int FUSE_COOLDOWN_MIN = 3, FUSE_COOLDOWN_MAX = 48;  // passes without speculation after a wrong guess (fused_collect)
 
 // host/predict.cpp
 int predict_step(int L, malio_state_t *x, double *P, double dt, const double *Q, const double *acc, const double *gyro);

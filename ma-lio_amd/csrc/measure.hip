@@ -2252,9 +2252,9 @@ bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
   if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
   if (!c->d_tiles) return false;
   // A wrong guess costs a pass its rows a second time (and the enqueued-ahead update a whole repeated unit, ~30 us), a
-  // right one saves 1-4 us: after a miss the handle stops speculating for FUSE_COOLDOWN eligible passes. Scenes whose
-  // extrema move with every iterate (planes of very uneven covariance: BASELINE config 3 misses 8 % of its guesses) then
-  // speculate rarely; the usual scene never misses.
+  // right one saves 1-4 us: after a miss the handle stops speculating for a number of eligible passes that grows with the
+  // miss rate (fused_collect). Scenes whose extrema move with every iterate (planes of very uneven covariance: BASELINE
+  // config 3 misses 8 % of its guesses) then speculate rarely; the usual scene misses one guess in 25 or fewer.
   if (c->fuse_cooldown > 0 && !c->fuse_debug_bad_guess) {
     c->fuse_cooldown--;
     return false;
@@ -2356,7 +2356,17 @@ int fused_collect(Ctx *c, double *sums_out, bool *hit) {
   const int ns = sums_len(c);
   (void)sums_out;
   *hit = memcmp(c->h_res + ns, c->fuse_guess_used, sizeof(double) * 4) == 0;
-  if (*hit) c->fuse_hits++; else c->fuse_misses++, c->fuse_cooldown = FUSE_COOLDOWN;
+  // A miss stops the speculation for the rest of the update at first (3 passes); every further miss before 16 hits in a
+  // row doubles that, up to FUSE_COOLDOWN_MAX: a scene that misses one guess in 25 keeps speculating (a hit is worth
+  // ~2.5 us, a miss ~25 us: break-even at one in 11), one that misses one in 12 (BASELINE config 3) soon stops.
+  if (*hit) {
+    c->fuse_hits++;
+    if (++c->fuse_hits_in_row >= 16) c->fuse_cooldown_len = FUSE_COOLDOWN_MIN;
+  } else {
+    c->fuse_misses++, c->fuse_hits_in_row = 0;
+    c->fuse_cooldown = c->fuse_cooldown_len;
+    c->fuse_cooldown_len = std::min(2 * c->fuse_cooldown_len, FUSE_COOLDOWN_MAX);
+  }
   return MALIO_OK;
 }
 

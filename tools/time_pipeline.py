@@ -31,3 +31,4 @@ for rep in range(3):
     tot = (time.perf_counter() - t0) / T * 1e6
     minc(st)
     print("turn %.1f us | " % tot + "  ".join("%s %.1f" % (k, v / T * 1e6) for k, v in ts.items()))
+print("fuse stats", e.fuse_stats(), {k: v for k, v in e.debug_counters().items() if k in ("rebuilds", "inplace")})
