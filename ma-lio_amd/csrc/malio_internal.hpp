@@ -521,7 +521,18 @@ void free_grid(CellGrid &g);
 int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false);
 void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
-void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m);  // both levels at once
+// the map array's share of a batch, done by a third slice of k_nl_ensure's grid: dlist[ndel] die, kept new points go to dst[rank]
+struct MapSide {
+  float4 *mapp;
+  const u32 *dlist;
+  int ndel;
+  unsigned char *del;
+  u32 del_n;
+  const u32 *rank;
+  float4 *dst;
+};
+void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m,
+               const MapSide &side);  // both levels at once
 void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base, int m);
 void nl_tombstone(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel);  // dlist: deleted map indices
 int maint_join(Ctx *c);         // `stream` waits for the queued map maintenance (no host wait)

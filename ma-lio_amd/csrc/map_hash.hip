@@ -581,7 +581,20 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
 // All four kernels serve both list levels in one launch: blockIdx.y picks the level (two launches of latency-bound
 // kernels back to back cost twice the latency, one launch of both overlaps them).
 __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ newp, const u32 *__restrict__ keep, int m,
-                                                   NlDev nl_a, NlDev nl_b) {
+                                                   NlDev nl_a, NlDev nl_b, MapSide ms) {
+  if (blockIdx.y == 2) {
+    // the map array's share of the batch, riding along (two launches less; the tombstone kernel, which reads the
+    // deleted points' coordinates, is through): deleted slots die, kept new points are appended
+    const int stride = (int)gridDim.x * BLK;
+    for (int d = blockIdx.x * BLK + threadIdx.x; d < ms.ndel; d += stride) {
+      const u32 mi = ms.dlist[d];
+      ms.mapp[mi].x = INFINITY;  // the slot stays (indices are stable between rebuilds)
+      if (mi < ms.del_n) ms.del[mi] = 0;  // the voxel update's mark: the array is all zero again when the batch is through
+    }
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < m; i += stride)
+      if (keep[i]) ms.dst[ms.rank[i]] = newp[i];
+    return;
+  }
   const NlDev nl = blockIdx.y ? nl_b : nl_a;
   // 32 lanes per point, one of its 27 cells each
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
@@ -770,11 +783,12 @@ NlDev nl_dev(const NList &nl) {
   return v;
 }
 
-void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m) {
+void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m,
+               const MapSide &side) {
   const long long th = (long long)m * 32;
   const dim3 grid((unsigned)((th + BLK - 1) / BLK), 2);
   const NlDev a = nl_dev(nl_a), b = nl_dev(nl_b);
-  hipLaunchKernelGGL(k_nl_ensure, grid, dim3(BLK), 0, st, d_new, keep, m, a, b);
+  hipLaunchKernelGGL(k_nl_ensure, dim3(grid.x, 3), dim3(BLK), 0, st, d_new, keep, m, a, b, side);
   hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 1);
 }
 void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, const u32 *rank, u32 og_base,

@@ -600,15 +600,20 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
     if (in_place) {
       nl_tombstone(c, ms, c->nl1, c->nl2, c->d_map_in, dlist, (int)ndel);
     }
-    hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, ms, c->d_map_in, dlist,
-                       (int)ndel, c->d_del, (u32)(c->d_del ? c->cap_del : 0));
+    if (!(in_place && nadd))  // (otherwise a slice of k_nl_ensure's grid does it)
+      hipLaunchKernelGGL(k_map_kill_list, dim3((ndel + BLK - 1) / BLK), dim3(BLK), 0, ms, c->d_map_in, dlist,
+                         (int)ndel, c->d_del, (u32)(c->d_del ? c->cap_del : 0));
     c->map_dead += (int)ndel, c->nl_tomb += (int)ndel;
   }
   if (nadd) {
-    hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, ms, d_new, keep, rank, m,
-                       (const u32 *)nullptr, c->d_map_in + hw);
+    if (!in_place)
+      hipLaunchKernelGGL(k_compact, dim3((m + BLK - 1) / BLK), dim3(BLK), 0, ms, d_new, keep, rank, m,
+                         (const u32 *)nullptr, c->d_map_in + hw);
     if (in_place) {
-      nl_ensure(c, ms, c->nl1, c->nl2, d_new, keep, m);
+      MapSide side;
+      side.mapp = c->d_map_in, side.dlist = dlist, side.ndel = (int)ndel, side.del = c->d_del;
+      side.del_n = (u32)(c->d_del ? c->cap_del : 0), side.rank = rank, side.dst = c->d_map_in + hw;
+      nl_ensure(c, ms, c->nl1, c->nl2, d_new, keep, m, side);
       nl_append(c, ms, c->nl1, c->nl2, d_new, keep, rank, (u32)hw, m);
       u32 *mb = nullptr, *mbd = nullptr;
       MALIO_HIP(mbox(c, &mb, &mbd));
