@@ -562,7 +562,8 @@ int malio_scan_stage(malio_handle_t h, const void *buf, int n, int packed) {
     MALIO_HIP(hipStreamSynchronize(c->copy_stream));
     MALIO_HIP(hipStreamSynchronize(c->stream));
     if (c->d_ahead) (void)hipFree(c->d_ahead);
-    c->d_ahead = nullptr, c->cap_ahead = bytes + bytes / 8 + 4096;
+    // (packed records: as large as the upload array, so that malio_scan_set_packed can swap the two instead of copying)
+    c->d_ahead = nullptr, c->cap_ahead = std::max(bytes + bytes / 8 + 4096, sizeof(UploadRec) * c->cap_scan);
     MALIO_HIP(hipMalloc(&c->d_ahead, c->cap_ahead));
   }
   MALIO_HIP(hipMemcpyAsync(c->d_ahead, buf, bytes, hipMemcpyHostToDevice, c->copy_stream));
@@ -775,7 +776,15 @@ int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n,
   }
   if (staged) {
     MALIO_HIP(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
-    MALIO_HIP(hipMemcpyAsync(c->d_upload, c->d_ahead, sizeof(UploadRec) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    if (c->cap_ahead >= sizeof(UploadRec) * c->cap_scan) {
+      // the staged buffer BECOMES the upload array (what was the upload array is the next scan's staging buffer):
+      // nothing is copied
+      void *old_up = c->d_upload;
+      c->d_upload = static_cast<UploadRec *>(c->d_ahead);
+      c->d_ahead = old_up, c->cap_ahead = sizeof(UploadRec) * c->cap_scan;
+    } else {
+      MALIO_HIP(hipMemcpyAsync(c->d_upload, c->d_ahead, sizeof(UploadRec) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    }
     c->ahead_busy = true;
   } else {
     MALIO_HIP(hipMemcpyAsync(c->d_upload, src, sizeof(UploadRec) * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -785,16 +794,21 @@ int malio_scan_set_packed(malio_handle_t h, const malio_scan_rec_t *recs, int n,
     MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));
     c->upload_in_flight = true;
   }
-  // the per-slot counts (and the validation of the slots) come back with the first pass, as for a page-locked cloud
+  // the per-slot counts (and the validation of the slots) come back with the first pass, as for a page-locked cloud.
+  // A scan that will be grouped is counted by the grouping's first kernel (count_in_sort): no kernel and no clear here.
+  const bool cis = c->scan_order_mode != MALIO_SCAN_ORDER_KEEP;
+  const bool first_info = !c->d_packinfo;
   if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
-  MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
+  if (!cis || first_info || !c->packinfo_clean) MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
+  c->packinfo_clean = cis;  // (k_sort_scan leaves it cleared; every other producer leaves its counts in it)
   if (!c->h_packinfo) {
     MALIO_HIP(hipHostMalloc((void **)&c->h_packinfo, sizeof(u32) * 16, hipHostMallocMapped | hipHostMallocCoherent));
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_packinfo_pub, c->h_packinfo, 0));
     memset(c->h_packinfo, 0, sizeof(u32) * 16);
   }
   if (++c->pack_seq == 0) c->pack_seq = 1;
-  hipLaunchKernelGGL(k_count_packed, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_upload, n, L, c->d_packinfo);
+  if (!cis) hipLaunchKernelGGL(k_count_packed, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_upload, n, L, c->d_packinfo);
+  c->count_in_sort = cis;
   c->pack_publish_pending = true;
   if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP) publish_pack_now(c);
   MALIO_HIP(hipGetLastError());

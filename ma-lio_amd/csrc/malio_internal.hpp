@@ -400,6 +400,8 @@ struct Ctx {
   float *d_raw = nullptr;         // [N][12] the caller's page-locked cloud as copied (malio_scan_set, pinned path)
   size_t cap_raw = 0;
   // malio_scan_stage: the NEXT scan's cloud copied ahead on a stream of its own (under map_incremental of the current scan)
+  bool packinfo_clean = false;  // d_packinfo is all zero (left so by k_sort_scan)
+  bool count_in_sort = false;  // malio_scan_set_packed (sorted scans): the per-slot counts are formed by k_sort_count
   void *d_ahead = nullptr;
   size_t cap_ahead = 0;            // bytes
   const void *ahead_ptr = nullptr;  // the caller's buffer the staged bytes came from (nullptr: nothing staged)

@@ -1877,11 +1877,34 @@ void publish_pack_now(Ctx *c) {
   c->pack_publish_pending = false;
   hipLaunchKernelGGL(k_publish_pack, dim3(1), dim3(64), 0, c->stream, c->d_packinfo, c->d_packinfo_pub, c->pack_seq);
 }
-__global__ void __launch_bounds__(BLK) k_sort_count(const UploadRec *__restrict__ in, int n, QuatConst qc, float inv_cf,
-                                                    u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt, const u32 *pack_info, u32 *pack_pub,
-                                                    u32 pack_seq) {
+// count_L != 0 (records that arrived packed, malio_scan_set_packed): the points per LiDAR slot and the slots outside
+// [0, count_L) are counted HERE instead of by a kernel of their own (a bad slot reads 0 from now on, so that the grouping
+// stays inside its buckets; the first pass reports it) and k_sort_scan publishes them.
+__global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatConst qc, float inv_cf,
+                                                    u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt, u32 *pack_info, u32 *pack_pub,
+                                                    u32 pack_seq, int count_L) {
   if (pack_pub && blockIdx.x == 0) publish_pack(pack_info, pack_pub, pack_seq);  // (uniform per workgroup; under the others' work)
   int i = blockIdx.x * BLK + threadIdx.x;
+  if (count_L) {  // (workgroup-uniform)
+    __shared__ u32 s_cnt[MALIO_MAX_LIDAR + 1];
+    if (threadIdx.x <= MALIO_MAX_LIDAR) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int lid = -1;
+    if (i < n) {
+      const u32 w = in[i].w;
+      lid = (int)(w & 0xFFu);
+      if (lid >= count_L) lid = MALIO_MAX_LIDAR, in[i].w = w & 0xFFFFFF00u;
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int l = 0; l <= MALIO_MAX_LIDAR; l++) {
+      const unsigned long long m = __ballot(lid == l);
+      if (m && lane == 0) atomicAdd(&s_cnt[l], (u32)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x <= MALIO_MAX_LIDAR && s_cnt[threadIdx.x])
+      atomicAdd(&pack_info[threadIdx.x == MALIO_MAX_LIDAR ? 8 : threadIdx.x], s_cnt[threadIdx.x]);
+  }
   if (i >= n) return;
   const UploadRec q = in[i];
   const int lid = (int)(q.w & 0xFF);
@@ -1902,8 +1925,13 @@ __global__ void __launch_bounds__(BLK) k_sort_count(const UploadRec *__restrict_
   rnk[i] = atomicAdd(&cnt[b], 1u);
 }
 // one workgroup: 1024 threads x 16 consecutive buckets; thread sums -> wave scan (shuffles) -> scan of the 16 wave totals
-__global__ void __launch_bounds__(1024) k_sort_scan(u32 *cnt, u32 *offs) {  // offs[SORT_NB + 1]
+__global__ void __launch_bounds__(1024) k_sort_scan(u32 *cnt, u32 *offs, u32 *pack_info, u32 *pack_pub, u32 pack_seq) {  // offs[SORT_NB + 1]
   __shared__ u32 s_wave[16];
+  if (pack_pub) {  // counts of k_sort_count<count_L>: to the host, then cleared for the next scan
+    publish_pack(pack_info, pack_pub, pack_seq);
+    __syncthreads();
+    if (threadIdx.x < 16) pack_info[threadIdx.x] = 0u;
+  }
   constexpr int PER = SORT_NB / 1024;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   uint4 *c4 = reinterpret_cast<uint4 *>(cnt + (size_t)t * PER);
@@ -2060,9 +2088,12 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   MALIO_HIP(sc.get(&tbkt, (size_t)N));
   const bool pub = c->pack_publish_pending;
   c->pack_publish_pending = false;
+  const bool cis = pub && c->count_in_sort;  // the counts do not exist yet: k_sort_count forms them, k_sort_scan publishes
+  c->count_in_sort = false;
   hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->inv_cell /* == nl1.inv_cf, which exists only once the lists are built */, keys, bkt, rnk, cnt,
-                     (const u32 *)c->d_packinfo, pub ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs);
+                     c->d_packinfo, pub && !cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq, cis ? c->prm.lid_num : 0);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs, c->d_packinfo,
+                     cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
   hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkv, tbkt);
   hipLaunchKernelGGL(k_sort_place, grid, dim3(BLK), 0, c->stream, c->d_upload, N, tkv, tbkt, offs, c->d_scan, c->d_perm,
                      c->d_ny, c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
