@@ -8,9 +8,12 @@ e = capi.Engine(sc["params"]); e.map_build(sc["map"])
 upd, upd_result = e.update_iterated_fn(sc["state0"], sc["P0"])
 minc, cnt = e.map_incremental_fn(None, True)
 T = 8
-bufs = [capi.PinnedArray((sc["N"], 5), np.float32) for _ in range(T + 1)]
-for k in range(T + 1): bufs[k].array[:] = capi.Engine.pack_scan(scenes.make_scene(cfg=2, scan_seed=700 + k)["scan"])
-calls = [e.scan_set_packed_fn(b.array, sc["tables"], sc["temporal_comp"]) for b in bufs]
+PACKED = os.environ.get("POINTS") != "1"
+bufs = [capi.PinnedArray((sc["N"], 5 if PACKED else 12), np.float32) for _ in range(T + 1)]
+for k in range(T + 1):
+    a = scenes.make_scene(cfg=2, scan_seed=700 + k)["scan"]
+    bufs[k].array[:] = capi.Engine.pack_scan(a) if PACKED else a
+calls = [(e.scan_set_packed_fn if PACKED else e.scan_set_fn)(b.array, sc["tables"], sc["temporal_comp"]) for b in bufs]
 stage = capi.lib().malio_scan_stage
 ptrs = [C.c_void_p(b.array.ctypes.data) for b in bufs]
 import torch
@@ -21,7 +24,7 @@ for rep in range(3):
     ts = {"stage": 0, "minc": 0, "set": 0, "upd": 0}
     t0 = time.perf_counter()
     for k in range(1, T + 1):
-        a = time.perf_counter(); stage(e.h, ptrs[k], sc["N"], 1)
+        a = time.perf_counter(); stage(e.h, ptrs[k], sc["N"], 1 if PACKED else 0)
         b = time.perf_counter(); minc(st)
         c_ = time.perf_counter(); calls[k]()
         d = time.perf_counter(); assert upd() == 0
