@@ -378,6 +378,7 @@ struct Ctx {
   Cell *d_small_table = nullptr;  // map_incremental's usual batch: voxel table + member lists of k_group_small
   u32 *d_small_orig = nullptr;
   int mapinc_small = -1;
+  u32 small_seq = 0;
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
@@ -608,6 +609,7 @@ inline hipError_t mbox(Ctx *c, u32 **out, u32 **dev = nullptr) {
   if (dev) *dev = c->d_mbox;
   return hipSuccess;
 }
+constexpr int MBOX_SMALL_SEQ = 13;  // sequence word of k_scan_small_dev (mapinc_small_batch polls it instead of synchronising the stream)
 constexpr int MBOX_APPLY_SEQ = 14;  // sequence word of k_publish_states (map_apply_finish waits for it, not for the stream)
 
 // k_search_tail costs ~17 us even for a handful of queries (launch + one dependent chain): it is only worth launching
