@@ -533,6 +533,13 @@ int malio_node_map_build(malio_node_t nd, const malio_point_t *pts, int n);
 int malio_node_map_size(malio_node_t nd, int *out_sizes);
 int malio_node_map_add(malio_node_t nd, const malio_point_t *pts, int n, int downsample_on, int *out_added);
 int malio_node_map_delete_boxes(malio_node_t nd, const malio_box_t *boxes, int nb, int *out_deleted);
+/* ikdtree.flatten / ikdtree.size for the whole node: a replica answers for all; tile shards contribute the points of their
+ * own tiles (halo copies are not counted twice), rank after rank. */
+int malio_node_map_get(malio_node_t nd, malio_point_t *out, int cap, int *out_n);
+int malio_node_map_total(malio_node_t nd, int *out_size);
+/* malio_voxel_downsample on the node (GPU 0) */
+int malio_node_voxel_downsample(malio_node_t nd, const malio_point_t *pts, int n, float leaf, int normal_mode,
+                                malio_point_t *out, int cap, int *out_n);
 /* == malio_scan_set / malio_measure (no rows path) / malio_update_iterated / malio_scan_get / malio_set_pass_hook */
 int malio_node_scan_set(malio_node_t nd, const malio_point_t *feats_down_body, int n, const malio_pose_t *const *pose_unc,
                         const int *pose_unc_len, const malio_pose_t *temporal_comp);

@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_node_map_get", "malio_node_map_total", "malio_node_voxel_downsample", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",

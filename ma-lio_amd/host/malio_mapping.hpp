@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -34,41 +35,70 @@ struct dyn_share_datastruct {
   double w_loc = 0;
 };
 
+// One GPU (malio_create) or all GPUs of the node behind one handle (malio_node_create, include/malio.h): the classes below
+// call malio_xxx or malio_node_xxx accordingly, so a loop written against them runs on either. The environment can
+// turn a plain Handle into a node without touching the caller: MALIO_NODE="<gpus>[,scan|tiles[,rccl]]" (every shard on
+// `device` when MALIO_NODE_SAME_DEVICE=1: the single-GPU test boxes).
 class Handle {
  public:
   Handle(const malio_params_t &prm, int device = 0) : prm_(prm) {
+    if (const char *e = std::getenv("MALIO_NODE")) {
+      const int g = std::atoi(e);
+      if (g >= 1) {
+        const bool tiles = std::strstr(e, "tiles") != nullptr, rccl = std::strstr(e, "rccl") != nullptr;
+        const char *same = std::getenv("MALIO_NODE_SAME_DEVICE");
+        std::vector<int> dev(g);
+        for (int r = 0; r < g; r++) dev[r] = (same && same[0] == '1') ? device : r;
+        init_node(g, dev.data(), tiles ? MALIO_PART_TILES : MALIO_PART_SCAN, rccl ? MALIO_NODE_XCHG_RCCL : MALIO_NODE_XCHG_HOST, 0.f);
+        return;
+      }
+    }
     int rc = malio_create(&prm, device, &h_);
     if (rc != MALIO_OK) throw std::runtime_error("malio_create failed (" + std::to_string(rc) + "): no gfx950 device?");
   }
+  Handle(const malio_params_t &prm, int n_gpus, const int *devices, int partition, int exchange, float tile_m) : prm_(prm) {
+    init_node(n_gpus, devices, partition, exchange, tile_m);
+  }
   ~Handle() {
     if (h_) malio_destroy(h_);
+    if (nd_) malio_node_destroy(nd_);
   }
   Handle(const Handle &) = delete;
   Handle &operator=(const Handle &) = delete;
   malio_handle_t get() const { return h_; }
+  malio_node_t node() const { return nd_; }
+  bool is_node() const { return nd_ != nullptr; }
   const malio_params_t &params() const { return prm_; }
   void check(int rc, const char *what) const {
-    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + malio_last_error(h_));
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + (nd_ ? malio_node_last_error(nd_) : malio_last_error(h_)));
   }
 
  private:
+  void init_node(int n_gpus, const int *devices, int partition, int exchange, float tile_m) {
+    int rc = malio_node_create(&prm_, n_gpus, devices, partition, exchange, tile_m, &nd_);
+    if (rc != MALIO_OK) throw std::runtime_error("malio_node_create failed (" + std::to_string(rc) + ")");
+  }
   malio_handle_t h_ = nullptr;
+  malio_node_t nd_ = nullptr;
   malio_params_t prm_;
 };
 
-// The ikd-Tree call sites of laserMapping.cpp, same member names (ikd_Tree.h:308-340).
 class KdTreeGpu {
  public:
   explicit KdTreeGpu(Handle &h) : h_(h) {}
   void set_downsample_param(float) {}                                  // laserMapping.cpp:999 (kept in params)
   void Build(const PointVector &pts) {                                 // :1007
-    h_.check(malio_map_build(h_.get(), pts.data(), (int)pts.size()), "Build");
+    h_.check(h_.is_node() ? malio_node_map_build(h_.node(), pts.data(), (int)pts.size())
+                          : malio_map_build(h_.get(), pts.data(), (int)pts.size()), "Build");
     built_ = true;
   }
   bool empty() const { return !built_; }                               // `Root_Node == nullptr` test, :995
   int size() const {                                                   // :824
     int n = 0;
-    malio_map_size(h_.get(), &n);
+    if (h_.is_node())
+      malio_node_map_total(h_.node(), &n);
+    else
+      malio_map_size(h_.get(), &n);
     return n;
   }
   // Batched form of Nearest_Search (:586): all queries of a scan in one call.
@@ -78,7 +108,8 @@ class KdTreeGpu {
     std::vector<PointType> out((size_t)n * k);
     std::vector<float> d2((size_t)n * k);
     std::vector<int> cnt(n);
-    h_.check(malio_nearest_search(h_.get(), queries.data(), n, k, out.data(), d2.data(), cnt.data()), "Nearest_Search");
+    h_.check(h_.is_node() ? malio_node_nearest_search(h_.node(), queries.data(), n, k, out.data(), d2.data(), cnt.data())
+                          : malio_nearest_search(h_.get(), queries.data(), n, k, out.data(), d2.data(), cnt.data()), "Nearest_Search");
     Nearest_Points.assign(n, PointVector());
     Point_Distance.assign(n, std::vector<float>());
     for (int i = 0; i < n; i++) {
@@ -88,11 +119,21 @@ class KdTreeGpu {
   }
   int Add_Points(PointVector &PointToAdd, bool downsample_on) {         // :443-444
     int added = 0;
+    if (h_.is_node()) {  // (every GPU reports its own count: a replica's is the reference's, a tile shard's its share)
+      std::vector<int> per((size_t)malio_node_gpus(h_.node()), 0);
+      h_.check(malio_node_map_add(h_.node(), PointToAdd.data(), (int)PointToAdd.size(), downsample_on ? 1 : 0, per.data()), "Add_Points");
+      return per[0];
+    }
     h_.check(malio_map_add(h_.get(), PointToAdd.data(), (int)PointToAdd.size(), downsample_on ? 1 : 0, &added), "Add_Points");
     return added;
   }
   int Delete_Point_Boxes(std::vector<BoxPointType> &BoxPoints) {        // :223
     int del = 0;
+    if (h_.is_node()) {
+      std::vector<int> per((size_t)malio_node_gpus(h_.node()), 0);
+      h_.check(malio_node_map_delete_boxes(h_.node(), BoxPoints.data(), (int)BoxPoints.size(), per.data()), "Delete_Point_Boxes");
+      return per[0];
+    }
     h_.check(malio_map_delete_boxes(h_.get(), BoxPoints.data(), (int)BoxPoints.size(), &del), "Delete_Point_Boxes");
     return del;
   }
@@ -100,7 +141,7 @@ class KdTreeGpu {
   void flatten(PointVector &Storage) const {
     int n = size();
     Storage.resize((size_t)n);
-    h_.check(malio_map_get(h_.get(), Storage.data(), n, &n), "flatten");
+    h_.check(h_.is_node() ? malio_node_map_get(h_.node(), Storage.data(), n, &n) : malio_map_get(h_.get(), Storage.data(), n, &n), "flatten");
   }
 
  private:
@@ -118,8 +159,10 @@ class VoxelGridGpu {
     const int n = in_ ? (int)in_->size() : 0;
     output.resize((size_t)n);
     int m = 0;
-    h_.check(malio_voxel_downsample(h_.get(), n ? in_->data() : nullptr, n, leaf_, MALIO_VOXEL_NORMAL_NORMALIZE,
-                                    output.data(), n, &m), "VoxelGrid::filter");
+    h_.check(h_.is_node() ? malio_node_voxel_downsample(h_.node(), n ? in_->data() : nullptr, n, leaf_, MALIO_VOXEL_NORMAL_NORMALIZE,
+                                                        output.data(), n, &m)
+                          : malio_voxel_downsample(h_.get(), n ? in_->data() : nullptr, n, leaf_, MALIO_VOXEL_NORMAL_NORMALIZE,
+                                                   output.data(), n, &m), "VoxelGrid::filter");
     output.resize((size_t)m);
   }
 
@@ -141,8 +184,10 @@ class Mapping {
     std::vector<int> len(L);
     for (int l = 0; l < L; l++) ptr[l] = pose_unc[l].data(), len[l] = (int)pose_unc[l].size();
     feats_down_size_ = (int)feats_down_body.size();
-    h_.check(malio_scan_set(h_.get(), feats_down_body.data(), feats_down_size_, ptr.data(), len.data(),
-                            L > 1 ? temporal_comp.data() : nullptr), "set_scan");
+    h_.check(h_.is_node() ? malio_node_scan_set(h_.node(), feats_down_body.data(), feats_down_size_, ptr.data(), len.data(),
+                                                L > 1 ? temporal_comp.data() : nullptr)
+                          : malio_scan_set(h_.get(), feats_down_body.data(), feats_down_size_, ptr.data(), len.data(),
+                                           L > 1 ? temporal_comp.data() : nullptr), "set_scan");
   }
   // Resident front end: the undistorted clouds stay in HBM (one malio_undistort_resident call per LiDAR, see
   // INTEGRATION.md §4b), then downSizeFilterSurf + the field shuffle + the concatenation of laserMapping.cpp:966-983 run
@@ -155,8 +200,10 @@ class Mapping {
     for (int l = 0; l < L; l++) ptr[l] = pose_unc[l].data(), len[l] = (int)pose_unc[l].size();
     feats_down_body.resize((size_t)max_points);
     int n = 0;
-    h_.check(malio_scan_set_resident(h_.get(), filter_size_surf, MALIO_VOXEL_NORMAL_NORMALIZE, ptr.data(), len.data(),
-                                     L > 1 ? temporal_comp.data() : nullptr, feats_down_body.data(), max_points, &n),
+    h_.check(h_.is_node() ? malio_node_scan_set_resident(h_.node(), filter_size_surf, MALIO_VOXEL_NORMAL_NORMALIZE, ptr.data(), len.data(),
+                                                         L > 1 ? temporal_comp.data() : nullptr, feats_down_body.data(), max_points, &n)
+                          : malio_scan_set_resident(h_.get(), filter_size_surf, MALIO_VOXEL_NORMAL_NORMALIZE, ptr.data(), len.data(),
+                                                    L > 1 ? temporal_comp.data() : nullptr, feats_down_body.data(), max_points, &n),
              "set_scan_resident");
     feats_down_body.resize((size_t)std::min(n, max_points));
     feats_down_size_ = n;
@@ -168,13 +215,17 @@ class Mapping {
     const int C = 6 * (1 + h_.params().lid_num);
     malio_measure_out_t out;
     std::memset(&out, 0, sizeof(out));
+    const bool rows_on_node = want_rows && h_.is_node();
+    if (h_.is_node()) want_rows = false;  // (the dense rows are a single-GPU path: the node hands out the normal equations;
+                                          //  h_x / h / R come back zero-filled at their sizes, so that indexing stays valid)
     if (want_rows) {
       ekfom_data.h_x.assign((size_t)feats_down_size_ * C, 0.0);
       ekfom_data.h.assign(feats_down_size_, 0.0);
       ekfom_data.R.assign(feats_down_size_, 0.0);
       out.h_x = ekfom_data.h_x.data(), out.h = ekfom_data.h.data(), out.R = ekfom_data.R.data();
     }
-    int rc = malio_measure(h_.get(), &s, ekfom_data.converge ? 1 : 0, &out);
+    int rc = h_.is_node() ? malio_node_measure(h_.node(), &s, ekfom_data.converge ? 1 : 0, &out)
+                          : malio_measure(h_.get(), &s, ekfom_data.converge ? 1 : 0, &out);
     h_.check(rc, "h_share_model");
     if (!out.valid) {  // laserMapping.cpp:635-639: ekfom_data.valid = false; ROS_WARN("No Effective Points!")
       ekfom_data.valid = false;
@@ -187,6 +238,11 @@ class Mapping {
       ekfom_data.h_x.resize((size_t)out.M * C);
       ekfom_data.h.resize(out.M);
       ekfom_data.R.resize(out.M);
+    }
+    if (rows_on_node) {
+      ekfom_data.h_x.assign((size_t)out.M * C, 0.0);
+      ekfom_data.h.assign(out.M, 0.0);
+      ekfom_data.R.assign(out.M, 0.0);
     }
   }
   // h_share_model of a scan sharded over the ranks of one node (malio_measure_node): same fused outputs, scan-global
@@ -210,10 +266,13 @@ class Mapping {
   // kf.update_iterated_dyn_share_modified(LASER_POINT_COV, solve_H_time), laserMapping.cpp:1052.
   // P: n x n row-major, n = 17 + 6 lid_num.
   void update_iterated_dyn_share_modified(malio_state_t &x, std::vector<double> &P, double R, double &solve_time) {
-    h_.check(malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
+    h_.check(h_.is_node() ? malio_node_update_iterated(h_.node(), &x, P.data(), R, nullptr, &solve_time)
+                          : malio_update_iterated(h_.get(), &x, P.data(), R, nullptr, &solve_time), "update_iterated");
   }
   // order of the scan inside the engine (malio_scan_order): MALIO_SCAN_ORDER_AUTO / _SORT / _KEEP
-  void set_scan_order(int mode) { h_.check(malio_scan_order(h_.get(), mode), "scan_order"); }
+  void set_scan_order(int mode) {
+    if (!h_.is_node()) h_.check(malio_scan_order(h_.get(), mode), "scan_order");
+  }
   // kf.predict(dt, Q, in) (esekfom.hpp:388-492; also predict_cont :171 / back_predict :281 when handed x_cont /
   // x_unc and P_unc_), IMU_Processing.hpp:332,345,364,386,399. Host code; Q is 12 x 12 row-major.
   static void predict(int lid_num, malio_state_t &x, std::vector<double> &P, double dt, const std::vector<double> &Q,
@@ -253,7 +312,8 @@ class Mapping {
     std::vector<float> wny(feats_down_size_, 0.f);
     for (int i = 0; i < feats_down_size_ && i < (int)feats_down_world.size(); i++) wny[i] = feats_down_world[i].normal_y;
     int counts[3] = {0, 0, 0};
-    h_.check(malio_map_incremental(h_.get(), &state_point, flg_EKF_inited ? 1 : 0, wny.data(), counts), "map_incremental");
+    h_.check(h_.is_node() ? malio_node_map_incremental(h_.node(), &state_point, flg_EKF_inited ? 1 : 0, wny.data(), counts)
+                          : malio_map_incremental(h_.get(), &state_point, flg_EKF_inited ? 1 : 0, wny.data(), counts), "map_incremental");
     return counts[0] + counts[1];
   }
   // the same side effects on the host, for a caller that keeps its own map_incremental (laserMapping.cpp:406,411-435).
@@ -264,8 +324,10 @@ class Mapping {
     Nearest_Points_flat.resize((size_t)feats_down_size_ * 5);
     nearest_count.resize(feats_down_size_);
     point_selected_surf.resize(feats_down_size_);
-    h_.check(malio_scan_get(h_.get(), normal_y.data(), Nearest_Points_flat.data(), nearest_count.data(),
-                            point_selected_surf.data(), nullptr, nullptr, nullptr), "scan_get");
+    h_.check(h_.is_node() ? malio_node_scan_get(h_.node(), normal_y.data(), Nearest_Points_flat.data(), nearest_count.data(),
+                                                point_selected_surf.data(), nullptr, nullptr, nullptr)
+                          : malio_scan_get(h_.get(), normal_y.data(), Nearest_Points_flat.data(), nearest_count.data(),
+                                           point_selected_surf.data(), nullptr, nullptr, nullptr), "scan_get");
   }
 
  private:

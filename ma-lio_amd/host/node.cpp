@@ -231,6 +231,59 @@ int malio_node_map_delete_boxes(malio_node_t nd, const malio_box_t *boxes, int n
   return nd->run([=](Worker &k) { return malio_map_delete_boxes(k.h, boxes, nb, out_deleted ? &out_deleted[k.rank] : nullptr); });
 }
 
+// ikdtree.flatten / ikdtree.size on the node: a replica answers for all; tile shards answer with the points of their OWN
+// tiles (a point in a halo is stored by several shards and owned by one), rank after rank.
+int malio_node_map_get(malio_node_t nd, malio_point_t *out, int cap, int *out_n) {
+  if (!nd || !out_n || cap < 0 || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;
+  if (nd->partition == MALIO_PART_SCAN) {
+    int rc = MALIO_OK;
+    nd->run([&](Worker &k) -> int {
+      if (k.rank == 0) rc = malio_map_get(k.h, out, cap, out_n);
+      return MALIO_OK;
+    });
+    return rc;
+  }
+  const int G = nd->n;
+  std::vector<std::vector<malio_point_t>> part(G);
+  int rc = nd->run([&](Worker &k) -> int {
+    int n = 0;
+    int r = malio_map_get(k.h, nullptr, 0, &n);
+    if (r != MALIO_OK) return r;
+    std::vector<malio_point_t> all((size_t)std::max(n, 1));
+    if ((r = malio_map_get(k.h, all.data(), n, &n)) != MALIO_OK) return r;
+    malio::PartView pv;
+    pv.rank = k.rank, pv.world = G, pv.inv_tile = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : 16.f);
+    for (int i = 0; i < n; i++)
+      if (all[i].x < 1e8f && malio::part_owns(pv, all[i].x, all[i].y, all[i].z)) part[k.rank].push_back(all[i]);  // (1e9: an empty shard's placeholder)
+    return MALIO_OK;
+  });
+  if (rc != MALIO_OK) return rc;
+  size_t total = 0;
+  for (auto &v : part) total += v.size();
+  *out_n = (int)total;
+  size_t w = 0;
+  for (auto &v : part)
+    for (auto &p : v)
+      if (w < (size_t)cap) out[w++] = p;
+  return MALIO_OK;
+}
+int malio_node_map_total(malio_node_t nd, int *out_size) {
+  if (!nd || !out_size) return MALIO_ERR_BAD_ARG;
+  if (nd->partition == MALIO_PART_SCAN) return malio_map_size(nd->w[0].h, out_size);
+  return malio_node_map_get(nd, nullptr, 0, out_size);
+}
+// pcl::VoxelGrid::filter on the node: a stateless service, GPU 0 renders it
+int malio_node_voxel_downsample(malio_node_t nd, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out,
+                                int cap, int *out_n) {
+  if (!nd) return MALIO_ERR_BAD_ARG;
+  int rc = MALIO_OK;
+  nd->run([&](Worker &k) -> int {
+    if (k.rank == 0) rc = malio_voxel_downsample(k.h, pts, n, leaf, normal_mode, out, cap, out_n);
+    return MALIO_OK;
+  });
+  return rc;
+}
+
 // ---- scan -----------------------------------------------------------------------------------------------------------
 int malio_node_scan_set(malio_node_t nd, const malio_point_t *body, int n, const malio_pose_t *const *pose_unc,
                         const int *pose_unc_len, const malio_pose_t *temporal_comp) {

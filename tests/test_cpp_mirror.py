@@ -104,3 +104,50 @@ def test_cpp_mirror_mapping_loop_equals_ctypes_path(tmp_path, orc, capi, scenes,
         assert [int(got["tables"][0]), int(got["tables"][1])] == [tabs[0].shape[0] - 1, tabs[-1].shape[0] - 1]
         assert hexf(got["tables"][3]) == ts
     assert [hexf(v) for v in got["predict"]] == [xp[0], xp[iv + 2], Pp[0, 0], Pp[4, 5]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("part", ["scan", "tiles"])
+def test_cpp_mirror_mapping_loop_unchanged_on_a_three_shard_node(tmp_path, orc, capi, scenes, part):
+    """The SAME program (tests/cpp/mapping_loop.cpp, not a line changed) with MALIO_NODE=3,<partition> in its environment:
+    malio::Handle then puts three shards behind the one handle (on this box all on GPU 0) and every class of the mirror
+    calls malio_node_*. Compared with ONE engine driven through ctypes: discrete results exactly (sizes, rows, counts,
+    deletions, k-NN), the posterior to the summation order of the shards, the flattened map as a set."""
+    sc = scenes.make_scene(cfg=1)
+    wny = np.where(np.arange(sc["N"]) < sc["N"] // 2, 0.001, 0.0).astype(np.float32)
+    scene = str(tmp_path / "scene.bin")
+    _dump(scene, sc, orc, wny)
+    exe = _compile(tmp_path)
+    env = dict(os.environ, MALIO_NODE="3," + part, MALIO_NODE_SAME_DEVICE="1")
+    out = subprocess.run([exe, scene], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    got = {ln.split()[0]: ln.split()[1:] for ln in out.stdout.strip().splitlines()}
+    hexf = float.fromhex
+
+    eng = capi.Engine(sc["params"])
+    eng.map_build(sc["map"])
+    assert int(got["size0"][0]) == eng.map_size()
+    eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    r = eng.measure(sc["state0"], True)
+    kv = dict(zip(got["pass"][0::2], got["pass"][1::2]))
+    assert int(kv["valid"]) == int(r["valid"]) and int(kv["rows"]) == r["M"] and int(kv["cols"]) == 6 * (1 + sc["L"])
+    assert abs(hexf(kv["HtH00"]) - r["HtRinvH"][0, 0]) <= 1e-12 * abs(r["HtRinvH"][0, 0])
+    u = eng.update_iterated(sc["state0"], sc["P0"])
+    vals = np.array([hexf(v) for v in re.findall(r"-?0x[0-9a-fp.+-]+", " ".join(got["pos"]))])
+    # (the posterior covariance is the ill-conditioned end of the update: per-shard partial sums move it in the 6th digit)
+    assert np.abs(vals[:7] - u["state"][:7]).max() < 1e-10 and abs(vals[7] - u["P"][0, 0]) <= 1e-4 * abs(u["P"][0, 0])
+    na, nn, _ = eng.map_incremental(u["state"], True, wny)
+    assert int(got["add_point_size"][0]) == na + nn and int(got["add_point_size"][2]) == eng.map_size()
+    pos = np.asarray(vals[:3], np.float32)
+    deleted = eng.map_delete_boxes(np.concatenate([pos - np.float32(4), pos + np.float32(4)])[None])
+    if part == "scan":
+        assert int(got["deleted"][0]) == deleted
+    assert int(got["deleted"][2]) == eng.map_size()
+    m = eng.map_get().astype(np.float64)
+    assert int(got["flatten"][0]) == m.shape[0]
+    cs = (m[:, 0] + 2.0 * m[:, 1] + 3.0 * m[:, 2] + 1000.0 * m[:, 5]).sum()
+    assert abs(hexf(got["flatten"][2]) - cs) <= 1e-9 * abs(cs)       # (the shards hand their points over in another order)
+    q = np.zeros((4, 12), np.float32)
+    q[:, 0], q[:, 1], q[:, 2] = vals[0] + 6.0, vals[1], vals[2]
+    _, d2, cnt = eng.nearest_search(q, 5)
+    assert int(got["knn"][0]) == cnt[0] and (cnt[0] == 0 or hexf(got["knn"][2]) == float(d2[0, 0]))
