@@ -310,9 +310,10 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
 
 
 def timed_blocks(step, steps, fence, distributed, dist, torch):
-    """EXACTLY `steps` steps between two fences (barrier + device sync), max over ranks - repeated until >= 400 steps
-    have been timed; returns (median seconds per region, all regions)."""
-    blocks = max(1, -(-400 // max(steps, 1)))
+    """EXACTLY `steps` steps between two fences (barrier + device sync), max over ranks - repeated at least five times and
+    until >= 1000 steps have been timed; returns (median seconds per region, all regions). (Two regions were too few: one
+    scheduling hiccup in one of them - 93 instead of 42 us per step, profiles/round3/r03h - moved their 'median' by 60 %.)"""
+    blocks = max(5, -(-1000 // max(steps, 1)))
     dts = []
     for _ in range(blocks):
         fence()
@@ -398,7 +399,7 @@ def main():
 
     # The timed region is EXACTLY --steps steps between two fences. A step is ~50 us, so a region of a few dozen steps is
     # ~1 ms and one scheduling hiccup moves it by percents: the region is therefore repeated (every repetition is the
-    # contract's measurement) until >= 400 steps have been timed, and the MEDIAN repetition is reported.
+    # contract's measurement) at least five times and until >= 1000 steps have been timed, and the MEDIAN repetition is reported.
     dt, dts = timed_blocks(step, args.steps, fence, False, dist, torch)
     blocks = len(dts)
     ms_per_step = dt / args.steps * 1e3
