@@ -628,6 +628,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
       const float *src = staged ? static_cast<const float *>(c->d_ahead) : c->d_raw;
       if (!c->d_packinfo) MALIO_HIP(hipMalloc(&c->d_packinfo, sizeof(u32) * 16));
       MALIO_HIP(hipMemsetAsync(c->d_packinfo, 0, sizeof(u32) * 16, c->stream));
+      c->packinfo_clean = false;  // (k_pack_raw leaves its counts in it: a later malio_scan_set_packed must clear them)
       if (!c->h_packinfo) {
         MALIO_HIP(hipHostMalloc((void **)&c->h_packinfo, sizeof(u32) * 16, hipHostMallocMapped | hipHostMallocCoherent));
         MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_packinfo_pub, c->h_packinfo, 0));

@@ -2152,7 +2152,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
     // (the grouping needs the counts only to decide whether the caller's order can be kept). BEFORE map_sync_search: it
     // reads neither the map nor the lists, so it is queued - and runs - while the previous scan's list maintenance is
     // still busy on its own stream; the search kernels join behind that (maint_join in map_sync_search).
-    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
+    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP && !c->count_in_sort)  // (a packed scan set under SORT is sorted: its counts come from the grouping)
       if (int rc = resolve_scan_segments(c)) return rc;
     int rc = sort_scan(c, a.qc);
     if (rc != MALIO_OK) return rc;
@@ -2239,7 +2239,7 @@ int prepare_scan_dev(Ctx *c, const malio_state_t *s) {
   if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   if (!c->scan_sorted) {  // (before map_sync_search: see pass_stage1)
-    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP)
+    if (c->scan_order_mode == MALIO_SCAN_ORDER_KEEP && !c->count_in_sort)  // (a packed scan set under SORT is sorted: its counts come from the grouping)
       if (int rc = resolve_scan_segments(c)) return rc;
     QuatConst qc;
     fill_quat_const(c, s, qc);

@@ -931,3 +931,39 @@ def test_map_incremental_small_batch_equals_general_path(capi, scenes, monkeypat
         state[0:3] += [0.05, 0.02, 0.0]
     assert max(sizes) > 300 and max(sizes) <= 4096, sizes
     assert engs[0].debug_counters() == engs[1].debug_counters() == engs[2].debug_counters()
+
+
+@pytest.mark.gpu
+def test_scan_formats_alternate_on_one_handle(capi, scenes):
+    """One handle fed packed records, then 48-byte points from page-locked memory, then packed records again, then pageable
+    points (round 3 moved the per-slot counts of packed records into the grouping kernels; the counts a page-locked cloud
+    leaves behind must not survive into the next packed scan): every scan's update, side effects and map_incremental
+    equal those of a handle that only ever sees pageable points."""
+    sc = scenes.make_scene(seed=17, N=7000, Nmap=60000, L=3)
+    ref, eng = _fresh(capi, sc), _fresh(capi, sc)
+    state = sc["state0"]
+    pin12 = capi.PinnedArray((7000, 12), np.float32)
+    pin5 = capi.PinnedArray((7000, 5), np.float32)
+    for k, fmt in enumerate(["packed", "pinned", "packed", "pageable", "pinned_packed", "pinned", "pinned_packed", "packed"]):
+        scan = scenes.make_scene(seed=17, N=7000, Nmap=60000, L=3, scan_seed=50 + k)["scan"]
+        ref.scan_set(scan, sc["tables"], sc["temporal_comp"])
+        if fmt == "packed":
+            eng.scan_set_packed(capi.Engine.pack_scan(scan), sc["tables"], sc["temporal_comp"])
+        elif fmt == "pinned_packed":
+            eng.scan_upload_wait()
+            pin5.array[:] = capi.Engine.pack_scan(scan)
+            eng.scan_set_packed(pin5.array, sc["tables"], sc["temporal_comp"])
+        elif fmt == "pinned":
+            eng.scan_upload_wait()
+            pin12.array[:] = scan
+            eng.scan_set(pin12.array, sc["tables"], sc["temporal_comp"])
+        else:
+            eng.scan_set(scan, sc["tables"], sc["temporal_comp"])
+        u, v = ref.update_iterated(state, sc["P0"]), eng.update_iterated(state, sc["P0"])
+        assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]) and u["M"] == v["M"], (k, fmt)
+        s0, s1 = ref.scan_get(), eng.scan_get()
+        for key in s0:
+            assert np.array_equal(s0[key], s1[key]), (k, fmt, key)
+        assert ref.map_incremental(u["state"], True, None) == eng.map_incremental(v["state"], True, None)
+        state = u["state"]
+    assert np.array_equal(ref.map_get(), eng.map_get())

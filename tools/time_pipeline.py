@@ -3,7 +3,8 @@ import numpy as np, ctypes as C
 sys.path.insert(0, "/root/repo")
 import __graft_entry__ as ge; ge.load_package()
 from malio_amd import capi, scenes
-sc = scenes.make_scene(cfg=2)
+CFG = int(os.environ.get("CFG", "2"))
+sc = scenes.make_scene(cfg=CFG)
 e = capi.Engine(sc["params"]); e.map_build(sc["map"])
 upd, upd_result = e.update_iterated_fn(sc["state0"], sc["P0"])
 minc, cnt = e.map_incremental_fn(None, True)
@@ -11,13 +12,13 @@ T = 8
 PACKED = os.environ.get("POINTS") != "1"
 bufs = [capi.PinnedArray((sc["N"], 5 if PACKED else 12), np.float32) for _ in range(T + 1)]
 for k in range(T + 1):
-    a = scenes.make_scene(cfg=2, scan_seed=700 + k)["scan"]
+    a = scenes.make_scene(cfg=CFG, scan_seed=700 + k)["scan"]
     bufs[k].array[:] = capi.Engine.pack_scan(a) if PACKED else a
 calls = [(e.scan_set_packed_fn if PACKED else e.scan_set_fn)(b.array, sc["tables"], sc["temporal_comp"]) for b in bufs]
 stage = capi.lib().malio_scan_stage
 ptrs = [C.c_void_p(b.array.ctypes.data) for b in bufs]
 import torch
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", "3"))):
     calls[0](); assert upd() == 0
     st = capi.state_from_flat(upd_result()["state"], sc["L"])
     torch.cuda.synchronize()
