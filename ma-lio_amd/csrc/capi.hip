@@ -154,6 +154,8 @@ int malio_destroy(malio_handle_t h) {
   Ctx *c = h;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->maint_stream) (void)hipStreamSynchronize(c->maint_stream);  // (queued list maintenance, a staged copy: done before
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);    //  anything they touch is freed)
   auto fr = [](void *p) {
     if (p) (void)hipFree(p);
   };
