@@ -521,7 +521,10 @@ def roofline_block(eng, state, args, n_points):
             "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * n_points, "kernel_ms": dom_ms,
             "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes the marker gap)",
             "frac_rocprof": (ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rp_ms else None,
-            "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src, "kernel_event_ms": kt}
+            "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src, "kernel_event_ms": kt,
+            # the same kernel priced on the bytes it really moved (committed PMC run) instead of the contract's: what it
+            # is bound by - not the contract's `frac`
+            "frac_on_measured_traffic": (traffic / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and rp_ms) else None}
 
 
 def main_virtual_shards(args, torch, capi, scenes, dev_index):
