@@ -10,6 +10,17 @@ using namespace malio;
 namespace malio {
 
 __global__ void k_noop() {}
+// malio_map_build on a tile shard: which points of the whole map does this shard store (keep[n] = 0 closes the scan)?
+__global__ void __launch_bounds__(BLK) k_part_flags(const float4 *__restrict__ pts, int n, PartView part, float fs, u32 *keep) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i > n) return;
+  keep[i] = (i < n && part_stores(part, pts[i].x, pts[i].y, pts[i].z, fs)) ? 1u : 0u;
+}
+__global__ void __launch_bounds__(BLK) k_part_compact(const float4 *__restrict__ src, const u32 *__restrict__ keep,
+                                                      const u32 *__restrict__ pos, int n, float4 *dst) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n && keep[i]) dst[pos[i]] = src[i];
+}
 
 void prof_begin(Ctx *c) {
   c->ev_used = 0;
@@ -254,18 +265,49 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   (void)map_apply_finish(c);
   float4 *stage = nullptr;
   if (int rcs = host_stage(c, sizeof(float4) * (size_t)n + 16, (void **)&stage)) return rcs;
+  for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
   if (c->part.world > 1) {
     // this shard's part of the map: own tiles + halo, in the caller's order (ties between equal distances are broken by
-    // map index, so the relative order must be the unsharded one)
-    const float fs = (float)c->prm.filter_size_map;
-    int m = 0;
-    for (int i = 0; i < n; i++)
-      if (part_stores(c->part, pts[i].x, pts[i].y, pts[i].z, fs)) stage[m++] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+    // map index, so the relative order must be the unsharded one). Every shard of a node is handed the whole map
+    // (8 M points at BASELINE config 4): the ownership test runs on the GPU - flags, scan, stable compaction - instead
+    // of 8 M part_stores() calls on this thread (same float arithmetic on host and device: malio_part_stores is the
+    // host's view of it).
+    ArenaScope sc(c->arena);
+    float4 *d_all = nullptr;
+    u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr;
+    MALIO_HIP(sc.get(&d_all, (size_t)n));
+    MALIO_HIP(sc.get(&keep, (size_t)n + 1));
+    MALIO_HIP(sc.get(&kpos, (size_t)n + 1));
+    MALIO_HIP(sc.get(&tiles, (size_t)(n + 1 + 1023) / 1024 + 2));
+    MALIO_HIP(hipMemcpyAsync(d_all, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_part_flags, dim3((n + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_all, n, c->part,
+                       (float)c->prm.filter_size_map, keep);
+    exclusive_scan_u32(c, keep, kpos, tiles, n + 1);
+    u32 m = 0;
+    MALIO_HIP(hipMemcpyAsync(&m, kpos + n, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
     c->part_sentinel = m == 0;
-    if (m == 0) stage[m++] = make_float4(1e9f, 1e9f, 1e9f, 0.f);  // an empty shard still answers "no neighbours" for its tiles
-    n = m;
-  } else {
-    for (int i = 0; i < n; i++) stage[i] = make_float4(pts[i].x, pts[i].y, pts[i].z, pts[i].normal_y);
+    const size_t need = m ? m : 1;
+    if (need > c->cap_map_in) {
+      if (c->d_map_in) (void)hipFree(c->d_map_in);
+      c->d_map_in = nullptr;
+      c->cap_map_in = need + need / 8 + 1024;
+      MALIO_HIP(hipMalloc(&c->d_map_in, sizeof(float4) * c->cap_map_in));
+    }
+    if (m == 0) {  // an empty shard still answers "no neighbours" for its tiles
+      stage[0] = make_float4(1e9f, 1e9f, 1e9f, 0.f);
+      MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    } else {
+      hipLaunchKernelGGL(k_part_compact, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, d_all, keep, kpos, n, c->d_map_in);
+    }
+    MALIO_HIP(hipStreamSynchronize(c->stream));  // (the arena's temporaries are handed back with this scope)
+    c->map_n = (int)need;
+    c->map_dead = 0;
+    c->map_epoch++;
+    int rc = map_rebuild_search(c);
+    (void)hipStreamSynchronize(c->stream);
+    if (rc != MALIO_OK) c->map_n = 0;
+    return rc;
   }
   if ((size_t)n > c->cap_map_in) {
     if (c->d_map_in) (void)hipFree(c->d_map_in);

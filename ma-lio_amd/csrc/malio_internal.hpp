@@ -130,7 +130,7 @@ __host__ __device__ inline bool part_owns(const PartView &p, float x, float y, f
          tile_owner(tile_coord(x, p.inv_tile), tile_coord(y, p.inv_tile), tile_coord(z, p.inv_tile), (u32)p.world) == (u32)p.rank;
 }
 // does the box [c - r, c + r] touch a tile of this shard? (at most 8 tiles while 2 r < tile edge)
-inline bool part_touches(const PartView &p, float cx, float cy, float cz, float r) {
+__host__ __device__ inline bool part_touches(const PartView &p, float cx, float cy, float cz, float r) {
   if (p.world <= 1) return true;
   const int x0 = tile_coord(cx - r, p.inv_tile), x1 = tile_coord(cx + r, p.inv_tile);
   const int y0 = tile_coord(cy - r, p.inv_tile), y1 = tile_coord(cy + r, p.inv_tile);
@@ -143,7 +143,7 @@ inline bool part_touches(const PartView &p, float cx, float cy, float cz, float 
 }
 // a map point is stored by every shard its down-sampling voxel (edge fs; the point itself when fs <= 0) reaches: all
 // points of one voxel live on the same shards, so the per-voxel keeper rule of Add_Points sees complete voxels everywhere
-inline bool part_stores(const PartView &p, float x, float y, float z, float fs) {
+__host__ __device__ inline bool part_stores(const PartView &p, float x, float y, float z, float fs) {
   if (p.world <= 1) return true;
   if (!(fs > 0.f)) return part_touches(p, x, y, z, PART_HALO);
   const float hx = (floorf(x / fs) + 0.5f) * fs, hy = (floorf(y / fs) + 0.5f) * fs, hz = (floorf(z / fs) + 0.5f) * fs;
