@@ -967,3 +967,40 @@ def test_scan_formats_alternate_on_one_handle(capi, scenes):
         assert ref.map_incremental(u["state"], True, None) == eng.map_incremental(v["state"], True, None)
         state = u["state"]
     assert np.array_equal(ref.map_get(), eng.map_get())
+
+
+@pytest.mark.gpu
+def test_round3_entry_points_refuse_bad_arguments(capi, scenes):
+    """The entry points added in round 3 return MALIO_ERR_BAD_ARG / MALIO_ERR_NO_SCAN instead of touching the GPU with bad
+    arguments, and a handle can be destroyed with a staged copy and queued list maintenance still in flight."""
+    import ctypes as C
+    lib = capi.lib()
+    sc = scenes.make_scene(seed=5, N=3000, Nmap=30000, L=3)
+    eng = capi.Engine(sc["params"])
+    pin = capi.PinnedArray((3000, 12), np.float32)
+    pin.array[:] = sc["scan"]
+    p = C.c_void_p(pin.array.ctypes.data)
+    assert lib.malio_scan_stage(None, p, 3000, 0) == capi.ERR_BAD_ARG
+    assert lib.malio_scan_stage(eng.h, None, 3000, 0) == capi.ERR_BAD_ARG
+    assert lib.malio_scan_stage(eng.h, p, 0, 0) == capi.ERR_BAD_ARG
+    assert lib.malio_scan_stage(eng.h, p, 3000, 0) == 0           # before any map or scan exists: only a copy
+    cnt = (C.c_int * 3)()
+    st = capi.state_from_flat(sc["state0"], sc["L"])
+    assert lib.malio_map_incremental(eng.h, C.byref(st), 1, None, cnt) < 0    # no scan
+    eng.map_build(sc["map"])
+    eng.scan_set(pin.array, sc["tables"], sc["temporal_comp"])     # takes the staged copy
+    u = eng.update_iterated(sc["state0"], sc["P0"])
+    eng.scan_upload_wait()
+    eng.scan_stage(pin.array, False)                               # a copy on its way ...
+    assert eng.map_incremental(u["state"], True, None)[0] >= 0     # ... and list maintenance queued: destroyed like that
+    eng.close() if hasattr(eng, "close") else None
+    del eng
+    nd = capi.Node(sc["params"], [0, 0], partition=capi.PART_TILES, tile_m=12.0)
+    n = C.c_int(0)
+    assert lib.malio_node_map_get(None, None, 0, C.byref(n)) == capi.ERR_BAD_ARG
+    assert lib.malio_node_map_total(nd.h, None) == capi.ERR_BAD_ARG
+    assert lib.malio_node_nearest_search(nd.h, None, 4, 5, None, None, None) == capi.ERR_BAD_ARG
+    assert lib.malio_node_scan_set_resident(nd.h, C.c_float(0.4), 1, None, None, None, None, 0, C.byref(n)) == capi.ERR_BAD_ARG
+    nd.map_build(sc["map"])
+    assert lib.malio_node_map_total(nd.h, C.byref(n)) == 0 and n.value == sc["map"].shape[0]
+    nd.close()
