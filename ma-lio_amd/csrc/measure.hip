@@ -901,8 +901,10 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
 // Deferred level-2 work of k_search: 16 lanes per query on the level-2 list, then the first lane of each group runs
 // the point phase. Workgroups whose queries are mostly unmatched - the map frontier, a thinned map - would otherwise serialise
 // 16 such searches per wave while the rest of the GPU idles.
+// (4 waves per SIMD: 109 VGPRs without a spill, and the 4 250 waves that 17 k deferred queries need - config 5 - are one
+// generation instead of one and a half: 38.8 -> 36.4 us; 5 spills 31 VGPRs, 6 spills 79)
 template <bool DEV>
-__global__ void __launch_bounds__(BLK) k_search_tail(Pass1Args a, NlView nl2) {
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_search_tail(Pass1Args a, NlView nl2) {
   if (DEV && (a.dl->done || !a.dl->converge)) return;  // the loop is over, or this pass is a reuse pass
   const PassDyn dy = pass_dyn<DEV>(a);
   const QuatConst &qc = DEV ? a.dl->qc : a.qc;
