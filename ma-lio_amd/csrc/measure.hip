@@ -571,7 +571,9 @@ constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's 
 constexpr int TAIL_BLOCKS = 2048;  // k_search_tail: 8192 waves x 4 queries = one sweep up to 32 k deferred queries (a second sweep
                                    // costs its waves the whole search + point-phase chain again: 45 us instead of 25)
 constexpr int TAIL_G = 16;         // lanes per deferred query (level-2 lists hold ~180..900 points)
-constexpr int DEFER_MIN = 8;                 // a workgroup serves up to this many uncertified queries itself
+constexpr int DEFER_MIN = 24;                // a workgroup serves up to this many uncertified queries itself (six level-2 walks
+                                             // per wave cost it less than the tail kernel costs the pass; swept at config 5:
+                                             // 8 / 12 / 16 / 24 / 32 / 48 -> 92.6 / 87.4 / 82.4 / 80.2 / 82.2 / 82.0 us per pass)
 struct NlView {
   const Cell *table;
   u32 tmask;
