@@ -570,7 +570,9 @@ constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
 constexpr int TAIL_BLOCKS = 2048;  // k_search_tail: 8192 waves x 4 queries = one sweep up to 32 k deferred queries (a second sweep
                                    // costs its waves the whole search + point-phase chain again: 45 us instead of 25)
-constexpr int TAIL_G = 16;         // lanes per deferred query (level-2 lists hold ~180..900 points)
+constexpr int TAIL_G = 8;          // lanes per deferred query (level-2 lists hold ~180..900 points). Swept at config 5 with
+                                   // the tail at 4 waves per SIMD: 32 / 16 / 8 / 4 lanes -> 38.0 / 27.5 / 21.5 / 22.4 us - above
+                                   // 8 k deferred queries the kernel is bound by the number of waves, not by a walk's length
 constexpr int DEFER_MIN = 24;                // a workgroup serves up to this many uncertified queries itself (six level-2 walks
                                              // per wave cost it less than the tail kernel costs the pass; swept at config 5:
                                              // 8 / 12 / 16 / 24 / 32 / 48 -> 92.6 / 87.4 / 82.4 / 80.2 / 82.2 / 82.0 us per pass)
@@ -910,7 +912,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
   if (DEV && (a.dl->done || !a.dl->converge)) return;  // the loop is over, or this pass is a reuse pass
   const PassDyn dy = pass_dyn<DEV>(a);
   const QuatConst &qc = DEV ? a.dl->qc : a.qc;
-  // 16 lanes per query: 4 queries per wave search concurrently, then their first lanes run the point phase together
+  // TAIL_G lanes per query: 64 / TAIL_G queries per wave search concurrently, then their first lanes run the point phase together
   const int lane = threadIdx.x & 63, sub = threadIdx.x & (TAIL_G - 1);
   const u32 grp = (blockIdx.x * BLK + threadIdx.x) / TAIL_G, ngrp = (gridDim.x * BLK) / TAIL_G;
   const u32 cnt = a.dq_ctl[dy.parity];
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
   const u32 sweeps = (cnt + ngrp - 1) / ngrp;
   for (u32 sw = 0; sw < sweeps; sw++) {  // wave-uniform trip count: the shuffles inside need every lane
     const u32 j = sw * ngrp + grp;
-    if (j - (u32)(lane / TAIL_G) >= cnt) break;  // none of this wave's 4 queries exists (wave-uniform)
+    if (j - (u32)(lane / TAIL_G) >= cnt) break;  // none of this wave's queries exists (wave-uniform)
     const bool live = j < cnt;
     const int i = (int)a.dq[live ? j : 0];
     const float4 w = a.world4[i];
