@@ -972,20 +972,62 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
   const bool dev_xchg = malio_xchg_kind(x) == 2;
   if (dev_xchg && (rc_dev_row(x, &row) != MALIO_OK)) return MALIO_ERR_BAD_ARG;
   double own[MALIO_MINMAX_LEN] = {0};
+  // host exchange: the kernel that ends a stage announces it through a sequence word in pinned memory (as malio_measure's
+  // passes do) and this thread polls it - the row is in hand ~5 us before a stream synchronisation would have returned
+  volatile int *h_msg = nullptr;
+  GateArgs gate{};
+  const bool poll = !dev_xchg && !c->profiling;
+  auto arm = [&]() -> const GateArgs * {
+    if (!poll) return nullptr;
+    int *d_msg = nullptr;
+    if (gate_words(c, &h_msg, &d_msg)) return nullptr;
+    c->gate_epoch = c->gate_epoch >= (1 << 30) ? 1 : c->gate_epoch + 1;
+    gate = GateArgs{};
+    gate.msg_seq = d_msg, gate.ticket = c->d_gate_ticket, gate.publish = c->gate_epoch;
+    return &gate;
+  };
   auto reduce = [&](const double *guess, double *Eout) -> int {  // one exchange: gather, true extrema, rank-ordered sum
     if (dev_xchg) return malio_xchg_reduce_stream(x, c->stream, ns, guess, res, Eout, own + 4);
-    MALIO_HIP(hipStreamSynchronize(c->stream));
+    if (poll && gate.msg_seq) {
+      long long spins = 0;
+      while (__atomic_load_n(const_cast<int *>(h_msg), __ATOMIC_ACQUIRE) != gate.publish) {
+        if ((++spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+          if (__atomic_load_n(const_cast<int *>(h_msg), __ATOMIC_ACQUIRE) == gate.publish) break;
+          MALIO_HIP(hipStreamSynchronize(c->stream));  // surfaces the error that ended the queue early
+          c->err = "malio_measure_node: the pass ended without announcing its result";
+          return MALIO_ERR_HIP;
+        }
+        __builtin_ia32_pause();
+      }
+      gate.msg_seq = nullptr;
+    } else {
+      MALIO_HIP(hipStreamSynchronize(c->stream));
+    }
     memcpy(own + 4, res + ns + 4, sizeof(double) * 4);
     return malio_xchg_reduce(x, res, ns, guess, res, Eout, timeout_s);
   };
   const bool spec = c->node_guess_valid;
-  int rc = pass_stage1(c, s, converge, spec ? nullptr : row + ns);
-  if (rc != MALIO_OK) return rc;
+  // A speculating pass is ONE kernel + the final sum where the single-GPU pass is (k_pass: the rows are weighted with the
+  // previous pass' GLOBAL extrema; workgroups of other shards' tiles contribute zero tiles); hit or miss is decided
+  // across the shards by the exchange below, a miss redoes the rows from the per-point state as after k_search.
+  const bool fused = spec && fuse_eligible(c, converge, false);
+  int rc = MALIO_OK;
   double E[4];
   bool have_sums = false;
-  if (spec) {
+  if (fused) {
+    memcpy(c->mm_guess, c->node_guess, sizeof(double) * 4);
+    c->mm_guess_valid = true;
+    if ((rc = pass_fused(c, s, converge, arm(), row)) != MALIO_OK) return rc;
+    rc = reduce(c->node_guess, E);
+    if (rc < 0) return rc;
+    have_sums = rc == MALIO_OK;
+    fuse_note(c, have_sums);
+    if (have_sums) c->node_hits++;
+  } else if ((rc = pass_stage1(c, s, converge, spec ? nullptr : row + ns)) != MALIO_OK) {
+    return rc;
+  } else if (spec) {
     if ((rc = upload(c->node_guess)) != MALIO_OK) return rc;
-    if ((rc = pass_stage2(c, c->d_node_mm, row + ns, row, false)) != MALIO_OK) return rc;
+    if ((rc = pass_stage2(c, c->d_node_mm, row + ns, row, false, arm())) != MALIO_OK) return rc;
     rc = reduce(c->node_guess, E);
     if (rc < 0) return rc;
     have_sums = rc == MALIO_OK;
@@ -1000,7 +1042,7 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
     double keep[4];
     memcpy(keep, own + 4, sizeof(keep));  // (this rank's own words come with the extrema: the second round has none)
     if ((rc = upload(E)) != MALIO_OK) return rc;
-    if ((rc = pass_stage2(c, c->d_node_mm, nullptr, row, false)) != MALIO_OK) return rc;
+    if ((rc = pass_stage2(c, c->d_node_mm, nullptr, row, false, arm())) != MALIO_OK) return rc;
     double E2[4];
     rc = reduce(nullptr, E2);
     if (rc != MALIO_OK) return rc < 0 ? rc : MALIO_ERR_HIP;

@@ -586,7 +586,8 @@ int reset_pass_state(Ctx *c);  // measure.hip: extrema slots, deferral counters 
 // value, or reading the device loop's control block; results land in h_res like the three-kernel pass'); afterwards:
 // *hit = the guessed extrema were the true ones (else the caller redoes the rows)
 bool fuse_eligible(Ctx *c, int converge, bool need_guess = true);
-int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate);
+int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate, double *row = nullptr);  // row: [sums | extrema words] (default: the pinned result buffer)
+void fuse_note(Ctx *c, bool hit);
 int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate);
 int fused_collect(Ctx *c, double *sums_out, bool *hit);
 int ensure_gate_buffers(Ctx *c);  // ieskf_dev.hip: pinned sequence words + control block, ticket counter

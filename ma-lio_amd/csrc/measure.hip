@@ -743,10 +743,11 @@ constexpr int KS_WAVES = KS_BLK / 64;
 #endif
 // what the control wave (wave 0) of a workgroup knows about its lane's query after the point phase
 struct PointOut {
-  bool selected;
-  double ucov, tr;
-  float4 pl, q;  // plane (n, d) and the scan point (body frame, packed slot word): what the row of a5 is built from
-  float pd2;
+  bool selected = false;
+  bool skipped = false;  // the whole workgroup belongs to other shards: nothing was searched
+  double ucov = 0.0, tr = 0.0;
+  float4 pl = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};  // plane (n, d) and the scan point (body frame, packed slot word): what the row of a5 is built from
+  float pd2 = 0.f;
 };
 struct SearchLds {
   float4 w[SQ];
@@ -789,7 +790,10 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
     }
     S.w[lane_] = w;
   }
-  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) return false;  // a workgroup of somebody else's tiles
+  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) {  // a workgroup of somebody else's tiles
+    po.selected = false, po.skipped = true;                   // (k_pass still owes the summation tree a zero tile)
+    return cwave;
+  }
   __syncthreads();
   PH(0, 1);
   // ---- phase B ----
@@ -896,7 +900,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     return;
   }
   PointOut po;
-  if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po)) return;
+  if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po) || po.skipped) return;
   wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4 over this wave's 64 queries
   PH(0, 9);
   PH_EXIT();
@@ -1461,6 +1465,7 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   PointOut po;
   if (converge) {
     if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
+    // (a workgroup of another shard's tiles comes back `skipped` with nothing selected: it goes on to store a zero tile)
   } else {  // REUSE pass: the control wave alone, lane = point
     if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
     if (threadIdx.x >= 64) return;
@@ -2285,7 +2290,7 @@ bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
     const char *b = getenv("MALIO_DEBUG_FUSE_BAD_GUESS");  // tests: every guess is wrong, every speculating pass is redone
     c->fuse_debug_bad_guess = b && b[0] == '1';
   }
-  if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending || c->part.world > 1) return false;
+  if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending) return false;
   if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
   if (!c->d_tiles) return false;
   // A wrong guess costs a pass its rows a second time (and the enqueued-ahead update a whole repeated unit, ~30 us), a
@@ -2320,20 +2325,22 @@ static int fill_fuse_static(Ctx *c, FuseArgs &f, SegBlocks &sb) {
   return b;
 }
 
-static void launch_final_tiles(Ctx *c, const SegBlocks &sb, const DevLoop *dl, const GateArgs *gate) {
+// row (optional): where [sums | extrema words] go - the handle's pinned result buffer, or the device row of an exchange
+static void launch_final_tiles(Ctx *c, const SegBlocks &sb, const DevLoop *dl, const GateArgs *gate, double *row = nullptr) {
   const int ns = sums_len(c);
+  if (!row) row = c->d_res;
   FoldArgs fold;
   fold.mmslots = dl ? c->d_mmslots : c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
-  fold.dq_ctl = c->d_dq_ctl, fold.mm_out = c->d_res + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
+  fold.dq_ctl = c->d_dq_ctl, fold.mm_out = row + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
   fold.dq_parity = c->dq_parity;
   hipLaunchKernelGGL(k_final_reduce<16>, dim3((c->prm.lid_num * NSUM + FR16_BLK / 256 - 1) / (FR16_BLK / 256)), dim3(FR16_BLK), 0, c->stream,
-                     (const double *)c->d_tiles, (int)c->cap_tiles, sb, c->prm.lid_num, c->d_res, dl, gate ? *gate : GateArgs{}, fold);
+                     (const double *)c->d_tiles, (int)c->cap_tiles, sb, c->prm.lid_num, row, dl, gate ? *gate : GateArgs{}, fold);
 }
 
 // one pass as k_pass -> k_final_reduce<16>, state in the kernel arguments (malio_measure, the host-driven loop): the
 // bookkeeping of pass_stage1 + the launches. Results land in h_res like the three-kernel pass'. The caller has checked
 // fuse_eligible.
-int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate) {
+int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate, double *row) {
   if (c->map_n - c->map_dead <= 0) return MALIO_ERR_NO_MAP;
   if (c->N <= 0) return MALIO_ERR_NO_SCAN;
   if (int rc = map_sync_search(c)) return rc;
@@ -2364,7 +2371,7 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   hipLaunchKernelGGL(k_pass<false>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
                      (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
-  launch_final_tiles(c, sb, nullptr, gate);
+  launch_final_tiles(c, sb, nullptr, gate, row);
   prof_mark(c, "k_final_reduce");
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;
@@ -2388,11 +2395,18 @@ int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   return MALIO_OK;
 }
 
+void fuse_note(Ctx *c, bool hit);
 // the pass' results are in h_res (sums | true extrema | heavy score): did the guess hold?
 int fused_collect(Ctx *c, double *sums_out, bool *hit) {
   const int ns = sums_len(c);
   (void)sums_out;
   *hit = memcmp(c->h_res + ns, c->fuse_guess_used, sizeof(double) * 4) == 0;
+  fuse_note(c, *hit);
+  return MALIO_OK;
+}
+// bookkeeping of one speculating pass (also called by malio_measure_node, whose hit / miss is decided across the shards)
+void fuse_note(Ctx *c, bool hit_) {
+  const bool *hit = &hit_;
   // A miss stops the speculation for the rest of the update at first (3 passes); every further miss before 16 hits in a
   // row doubles that, up to FUSE_COOLDOWN_MAX: a scene that misses one guess in 25 keeps speculating (a hit is worth
   // ~2.5 us, a miss ~25 us: break-even at one in 11), one that misses one in 12 (BASELINE config 3) soon stops.
@@ -2404,7 +2418,6 @@ int fused_collect(Ctx *c, double *sums_out, bool *hit) {
     c->fuse_cooldown = c->fuse_cooldown_len;
     c->fuse_cooldown_len = std::min(2 * c->fuse_cooldown_len, FUSE_COOLDOWN_MAX);
   }
-  return MALIO_OK;
 }
 
 // Assemble the C x C normal equations from the per-LiDAR 12 x 12 blocks, apply the localization
