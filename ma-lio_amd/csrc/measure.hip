@@ -1465,7 +1465,10 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   PointOut po;
   if (converge) {
     if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
-    // (a workgroup of another shard's tiles comes back `skipped` with nothing selected: it goes on to store a zero tile)
+    if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
+      for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + blockIdx.x] = 0.0;
+      return;
+    }
   } else {  // REUSE pass: the control wave alone, lane = point
     if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
     if (threadIdx.x >= 64) return;
