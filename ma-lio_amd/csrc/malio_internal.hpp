@@ -118,13 +118,14 @@ struct PartView {
   float inv_tile = 1.f / 16.f;
 };
 __host__ __device__ inline int tile_coord(float x, float inv_tile) { return (int)floorf(x * inv_tile); }
-__host__ __device__ inline u32 tile_owner(int tx, int ty, int tz, u32 world) {
+__host__ __device__ inline u32 tile_hash(int tx, int ty, int tz) {
   u32 h = (u32)tx * 0x9E3779B1u ^ (u32)ty * 0x85EBCA77u ^ (u32)tz * 0xC2B2AE3Du;
   h ^= h >> 15;
   h *= 0x2C1B3C6Du;
   h ^= h >> 12;
-  return h % world;
+  return h;
 }
+__host__ __device__ inline u32 tile_owner(int tx, int ty, int tz, u32 world) { return tile_hash(tx, ty, tz) % world; }
 __host__ __device__ inline bool part_owns(const PartView &p, float x, float y, float z) {
   return p.world <= 1 ||
          tile_owner(tile_coord(x, p.inv_tile), tile_coord(y, p.inv_tile), tile_coord(z, p.inv_tile), (u32)p.world) == (u32)p.rank;

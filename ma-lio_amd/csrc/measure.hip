@@ -1896,7 +1896,7 @@ void publish_pack_now(Ctx *c) {
 // stays inside its buckets; the first pass reports it) and k_sort_scan publishes them.
 __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatConst qc, float inv_cf,
                                                     u32 *keys, u32 *bkt, u32 *rnk, u32 *cnt, u32 *pack_info, u32 *pack_pub,
-                                                    u32 pack_seq, int count_L) {
+                                                    u32 pack_seq, int count_L, PartView part) {
   if (pack_pub && blockIdx.x == 0) publish_pack(pack_info, pack_pub, pack_seq);  // (uniform per workgroup; under the others' work)
   int i = blockIdx.x * BLK + threadIdx.x;
   if (count_L) {  // (workgroup-uniform)
@@ -1933,7 +1933,16 @@ __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatCo
   // workgroups still work on one part of the map and the five neighbours of their queries share cache lines of the map
   // array. (A hashed bucket order balances the buckets better - the grouping is ~20 us cheaper per scan - but costs
   // every search pass 0.8 us at config 2 and 13 us in config 5's 500 m tunnel; coarser columns change nothing.)
-  const u32 b = (u32)lid * SORT_NBK + (((cy & 63u) << 6) | (cx & 63u));
+  u32 b = (u32)lid * SORT_NBK + (((cy & 63u) << 6) | (cx & 63u));
+  if (part.world > 1) {
+    // A tile shard serves the points of its own tiles: grouped by tile class first (64 classes of the ownership hash; the
+    // owner is a function of the class whenever the shard count divides 64), by 8 x 8-column patch inside the tile second,
+    // so that the points a shard owns fill whole workgroups instead of a few lanes of most workgroups (the column order
+    // above lets a 64-point block run through eight tiles: two thirds of an eighth-shard's workgroups had work).
+    const u32 th = tile_hash(tile_coord((float)pg.x, part.inv_tile), tile_coord((float)pg.y, part.inv_tile),
+                             tile_coord((float)pg.z, part.inv_tile)) & 63u;
+    b = (u32)lid * SORT_NBK + (th << 6) + (((cy & 7u) << 3) | (cx & 7u));
+  }
   keys[i] = cell;
   bkt[i] = b;
   rnk[i] = atomicAdd(&cnt[b], 1u);
@@ -2105,7 +2114,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   const bool cis = pub && c->count_in_sort;  // the counts do not exist yet: k_sort_count forms them, k_sort_scan publishes
   c->count_in_sort = false;
   hipLaunchKernelGGL(k_sort_count, grid, dim3(BLK), 0, c->stream, c->d_upload, N, qc, c->inv_cell /* == nl1.inv_cf, which exists only once the lists are built */, keys, bkt, rnk, cnt,
-                     c->d_packinfo, pub && !cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq, cis ? c->prm.lid_num : 0);
+                     c->d_packinfo, pub && !cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq, cis ? c->prm.lid_num : 0, c->part);
   hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, c->stream, cnt, offs, c->d_packinfo,
                      cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
   hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkv, tbkt);

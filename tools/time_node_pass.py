@@ -33,3 +33,10 @@ for part in ("tiles", "scan"):
         for _ in range(300):
             t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
         print("%s shard 0 of %d, %s pass: %.1f us (M %d)  fuse %s" % (part, G, name, np.median(ts) * 1e6, out.M, e.fuse_stats()))
+    e.set_profiling(True)
+    acc = {}
+    for _ in range(20):
+        fn()
+        for n, ms in e.last_kernel_times(): acc.setdefault(n, []).append(ms * 1000)
+    print("   kernels (events):", {n: round(float(np.median(v)), 1) for n, v in acc.items()})
+    e.set_profiling(False)
