@@ -1004,3 +1004,51 @@ def test_round3_entry_points_refuse_bad_arguments(capi, scenes):
     nd.map_build(sc["map"])
     assert lib.malio_node_map_total(nd.h, C.byref(n)) == 0 and n.value == sc["map"].shape[0]
     nd.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_loop_sixty_turns_equals_plain_loop(capi, scenes, monkeypatch):
+    """Sixty turns of the mapping loop the fast way - next scan staged ahead as packed records, list maintenance on its own
+    stream, map_incremental's one-read-back batch - against sixty turns the plain way (pageable points, every switch off) on a
+    small map that keeps changing on the way (in-place list updates with deletions, appends and tail-region moves): the same
+    posterior after every turn, the same map at the end, bit for bit."""
+    sc = scenes.make_scene(seed=123, N=5000, Nmap=30000, L=3)
+    scans = [scenes.make_scene(seed=123, N=5000, Nmap=30000, L=3, scan_seed=1000 + k)["scan"] for k in range(8)]
+    monkeypatch.setenv("MALIO_MAINT_STREAM", "0")
+    monkeypatch.setenv("MALIO_MAPINC_SMALL", "0")
+    plain = _fresh(capi, sc)
+    plain.map_add(sc["map"][:4], True)                 # (the switches are read by the first mutation)
+    plain.scan_set(scans[0], sc["tables"], sc["temporal_comp"])
+    plain.update_iterated(sc["state0"], sc["P0"])
+    plain.map_incremental(sc["state0"], True, None)
+    monkeypatch.setenv("MALIO_MAINT_STREAM", "1")
+    monkeypatch.setenv("MALIO_MAPINC_SMALL", "4096")
+    fast = _fresh(capi, sc)
+    fast.map_add(sc["map"][:4], True)
+    fast.scan_set(scans[0], sc["tables"], sc["temporal_comp"])
+    fast.update_iterated(sc["state0"], sc["P0"])
+    fast.map_incremental(sc["state0"], True, None)
+    pins = [capi.PinnedArray((5000, 5), np.float32) for _ in range(2)]
+    state = sc["state0"].copy()
+    rng = np.random.default_rng(0)
+    pins[0].array[:] = capi.Engine.pack_scan(scans[1])
+    fast.scan_stage(pins[0].array, True)
+    n0 = plain.map_size()
+    for k in range(1, 61):
+        scan = scans[k % 8]
+        cur = pins[(k - 1) % 2]
+        plain.scan_set(scan, sc["tables"], sc["temporal_comp"])
+        fast.scan_set_packed(cur.array, sc["tables"], sc["temporal_comp"])
+        u, v = plain.update_iterated(state, sc["P0"]), fast.update_iterated(state, sc["P0"])
+        assert np.array_equal(u["state"], v["state"]) and np.array_equal(u["P"], v["P"]), k
+        nxt = pins[k % 2]
+        fast.scan_upload_wait()
+        nxt.array[:] = capi.Engine.pack_scan(scans[(k + 1) % 8])
+        fast.scan_stage(nxt.array, True)
+        assert plain.map_incremental(u["state"], True, None) == fast.map_incremental(v["state"], True, None), k
+        state = u["state"].copy()
+        state[0:3] += rng.normal(0, 0.15, 3)            # the sensor wanders: new ground every turn
+    a, b = plain.map_get(), fast.map_get()
+    assert np.array_equal(a, b) and a.shape[0] > n0
+    da, db = plain.debug_counters(), fast.debug_counters()
+    assert da == db and da["inplace"] > 40 and da["tombstones"] > 100, da
