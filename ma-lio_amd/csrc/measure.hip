@@ -1412,8 +1412,9 @@ __global__ void __launch_bounds__(LPL == 16 ? FR16_BLK : BLK) k_final_reduce(con
 // malio_measure speculates on search passes only. In the enqueued-ahead update every unit is a k_pass unit: there the
 // three-kernel unit pays for reading the matrix form of the state through vector loads (k_rows_reduce<true>: 82 VGPRs,
 // 8.1-8.6 us) and the update gains 4-9 us.
-// Not used when queries may be deferred to k_search_tail (their planes do not exist yet when the rows are formed), on
-// map shards (NF_NOTMINE workgroups), or for the dense rows of the rows path.
+// Not used when queries may be deferred to k_search_tail (their planes do not exist yet when the rows are formed) or for the
+// dense rows of the rows path. On a map shard a workgroup of other shards' tiles stores a zero tile (malio_measure_node
+// speculates on the GLOBAL extrema of the previous pass; hit or miss is decided across the shards by the exchange).
 struct FuseArgs {
   int seg_start[MALIO_MAX_LIDAR + 1];
   int seg_blk0[MALIO_MAX_LIDAR + 1];  // first workgroup (64-point tile) of each LiDAR segment
