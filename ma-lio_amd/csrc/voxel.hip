@@ -18,7 +18,6 @@
 // Within a voxel PCL adds the points in whatever order its (unstable) integer sort left them; here the sort is
 // stable, i.e. input order - float sums can differ from a PCL build in the last bits for that reason alone.
 #include "malio_internal.hpp"
-#include <hipcub/hipcub.hpp>
 
 namespace malio {
 namespace {
@@ -93,6 +92,96 @@ __global__ void __launch_bounds__(BLK) k_vg_keys(const float *__restrict__ pts, 
   vals[i] = (u32)i;
 }
 
+// ---- stable LSD radix sort of (voxel index, point index) pairs, 8 bits per pass ---------------------------------------------
+// A wave owns a CHUNK of 1 024 consecutive pairs (all loaded up front) and walks it 64 at a time, in order: per pass one kernel counts the
+// chunk's digits (LDS atomics), one scan over the [digit][chunk] table turns the counts into positions, one kernel
+// places the pairs - a lane's rank among the earlier pairs of its digit = the chunk's running count of that digit (LDS)
+// + the lanes below it in the wave that hold the same digit (nine ballots match the digit). Stable by construction:
+// digit-major scan, chunks ascending, the walk in order. Only as many passes as the largest voxel index has bytes.
+constexpr int RS_CHUNK = 1024;
+constexpr int RS_IT = RS_CHUNK / 64;
+template <int DB>  // digit bits
+__device__ __forceinline__ unsigned long long same_digit_lanes(u32 d, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < DB; b++) {
+    const unsigned long long s = __ballot(valid && ((d >> b) & 1u));
+    m &= ((d >> b) & 1u) ? s : ~s;
+  }
+  return m;  // (meaningful in the valid lanes)
+}
+template <int DB>
+__global__ void __launch_bounds__(BLK) k_rs_hist(const u32 *__restrict__ keys, int n, int shift, u32 *hist, int nchunks) {
+  constexpr int NB = 1 << DB;
+  __shared__ u32 h[BLK / 64][NB];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * (BLK / 64) + wv;
+  for (int d = lane; d < NB; d += 64) h[wv][d] = 0;
+  if (chunk >= nchunks) return;  // (no workgroup barrier below: the waves are independent)
+  u32 key[RS_IT];  // the whole chunk's loads in flight at once: the walk below is a chain of LDS operations, not of HBM trips
+#pragma unroll
+  for (int it = 0; it < RS_IT; it++) {
+    const int i = chunk * RS_CHUNK + it * 64 + lane;
+    key[it] = i < n ? keys[i] : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < RS_IT; it++)
+    if (chunk * RS_CHUNK + it * 64 + lane < n) atomicAdd(&h[wv][(key[it] >> shift) & (NB - 1)], 1u);
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < NB; d += 64) hist[(size_t)d * nchunks + chunk] = h[wv][d];
+}
+template <int DB>
+__global__ void __launch_bounds__(BLK) k_rs_scatter(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *kout, u32 *vout,
+                                                    int n, int shift, const u32 *__restrict__ offs, int nchunks) {
+  constexpr int NB = 1 << DB;
+  __shared__ u32 run[BLK / 64][NB];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * (BLK / 64) + wv;
+  if (chunk >= nchunks) return;  // (no workgroup barrier below: the waves are independent)
+  u32 key[RS_IT], val[RS_IT];
+#pragma unroll
+  for (int it = 0; it < RS_IT; it++) {
+    const int i = chunk * RS_CHUNK + it * 64 + lane;
+    key[it] = i < n ? kin[i] : 0u, val[it] = i < n ? vin[i] : 0u;
+  }
+  for (int d = lane; d < NB; d += 64) run[wv][d] = offs[(size_t)d * nchunks + chunk];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < RS_IT; it++) {
+    const bool valid = chunk * RS_CHUNK + it * 64 + lane < n;
+    const u32 d = (key[it] >> shift) & (NB - 1);
+    const unsigned long long m = same_digit_lanes<DB>(d, valid);
+    const u32 below = (u32)__popcll(m & ((1ull << lane) - 1ull));
+    u32 base = 0;
+    if (valid) base = run[wv][d];
+    __builtin_amdgcn_wave_barrier();  // every lane has read its digit's count before a leader moves it on
+    if (valid && below == 0) run[wv][d] = base + (u32)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) kout[base + below] = key[it], vout[base + below] = val[it];
+  }
+}
+// sorts (k1, v1) by the low `bits` bits of the key (9-bit digits: three passes up to 2^27 voxels, four beyond); the result
+// is in (k1, v1) again when it returns
+static int radix_sort_pairs(Ctx *c, ArenaScope &sc, u32 *&k1, u32 *&k2, u32 *&v1, u32 *&v2, int n, int bits) {
+  constexpr int DB = 9, NB = 1 << DB;
+  const int nchunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+  const int nh = NB * nchunks;
+  u32 *hist = nullptr, *offs = nullptr, *tiles = nullptr;
+  MALIO_HIP(sc.get(&hist, (size_t)nh));
+  MALIO_HIP(sc.get(&offs, (size_t)nh));
+  MALIO_HIP(sc.get(&tiles, (size_t)(nh + 1023) / 1024 + 2));
+  const dim3 grid((nchunks + BLK / 64 - 1) / (BLK / 64));
+  for (int shift = 0; shift < bits; shift += DB) {
+    hipLaunchKernelGGL(k_rs_hist<DB>, grid, dim3(BLK), 0, c->stream, k1, n, shift, hist, nchunks);
+    if (int rc = exclusive_scan_u32(c, hist, offs, tiles, nh)) return rc;
+    hipLaunchKernelGGL(k_rs_scatter<DB>, grid, dim3(BLK), 0, c->stream, k1, v1, k2, v2, n, shift, offs, nchunks);
+    std::swap(k1, k2), std::swap(v1, v2);
+  }
+  MALIO_HIP(hipGetLastError());
+  return MALIO_OK;
+}
+
 __global__ void __launch_bounds__(BLK) k_vg_heads(const u32 *__restrict__ keys, int n, u32 *head) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i > n) return;  // head[n] = 0 so that the exclusive scan leaves the total at [n]
@@ -146,7 +235,6 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
   if (n <= 0) return MALIO_OK;
   u32 *d_mm = nullptr, *k1 = nullptr, *k2 = nullptr, *v1 = nullptr, *v2 = nullptr, *head = nullptr, *pos = nullptr,
       *first = nullptr, *tiles = nullptr;
-  char *tmp = nullptr;
   MALIO_HIP(sc.get(&d_mm, (size_t)VG_SLOTS * 6));
   u32 *mb = nullptr, *mbd = nullptr;
   MALIO_HIP(mbox(c, &mb, &mbd));
@@ -185,7 +273,8 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
     return MALIO_OK;
   }
   g.mul[0] = 1, g.mul[1] = div[0], g.mul[2] = div[0] * div[1];
-  size_t tmp_bytes = 0;
+  const long long cells_total = (long long)div[0] * div[1] * div[2];  // (<= INT_MAX: checked above on the float extents;
+                                                                        //  the int form can exceed the float form by one cell per axis)
   MALIO_HIP(sc.get(&k1, (size_t)n));
   MALIO_HIP(sc.get(&k2, (size_t)n));
   MALIO_HIP(sc.get(&v1, (size_t)n));
@@ -194,10 +283,15 @@ int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, floa
   MALIO_HIP(sc.get(&pos, (size_t)n + 1));
   MALIO_HIP(sc.get(&first, (size_t)n + 1));
   MALIO_HIP(sc.get(&tiles, (size_t)(n + 1 + 1023) / 1024 + 2));
-  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
-  MALIO_HIP(sc.get(&tmp, tmp_bytes ? tmp_bytes : 16));
   hipLaunchKernelGGL(k_vg_keys, dim3(nb), dim3(BLK), 0, c->stream, d_pts, n, g, k1, v1);
-  MALIO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k2, v1, v2, n, 0, 32, c->stream));
+  {
+    // valid keys are < cells <= INT_MAX; the key of a non-finite point is all ones: its low bits sort it behind every
+    // valid key as long as 2^bits > cells
+    int bits = 1;
+    while (bits < 32 && (1ll << bits) <= cells_total) bits++;
+    if (int rcs = radix_sort_pairs(c, sc, k1, k2, v1, v2, n, bits)) return rcs;
+    std::swap(k1, k2), std::swap(v1, v2);  // (the code below reads the sorted pairs from k2 / v2)
+  }
   hipLaunchKernelGGL(k_vg_heads, dim3((n + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, k2, n, head);
   u32 *h_nvox = mb + 1024 + VG_SLOTS * 6;
   exclusive_scan_u32(c, head, pos, tiles, n + 1, mbd + 1024 + VG_SLOTS * 6);  // the voxel count lands in the mapped buffer
