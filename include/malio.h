@@ -345,6 +345,48 @@ int malio_ieskf_step(int lid_num, int max_iteration, double limit, int iter_inde
 enum { MALIO_SCAN_ORDER_AUTO = 0, MALIO_SCAN_ORDER_SORT = 1, MALIO_SCAN_ORDER_KEEP = 2 };
 int malio_scan_order(malio_handle_t h, int mode);
 
+/* ---- per-handle options ----------------------------------------------------------------------------------------- */
+/* Everything that selects between two implementations of the same arithmetic (results are bit-identical either way) or
+ * tunes a time-out lives on the handle and is set through this call - a ROS node configures its engine from its launch
+ * file, not from the process environment. The reference has no counterpart (its knobs are compile-time: MP_PROC_NUM,
+ * CMakeLists.txt:23-25). The environment variables of the same names (MALIO_FUSE, MALIO_MAINT_STREAM, ...) are read ONCE,
+ * by malio_create, as the initial values: they exist for the A/B tools under tools/; a later malio_set_option wins.
+ *   MALIO_OPT_FUSE             1 (default): search passes run as k_pass -> k_final_reduce, speculating on the previous pass'
+ *                              extrema (laserMapping.cpp:625-628,646-647); 0: always three kernels.
+ *   MALIO_OPT_SEARCH_SKIP      1: a search pass (ekfom_data.converge, laserMapping.cpp:582-591) that is not the first one of
+ *                              its scan keeps the cached five neighbours of every point whose cache a distance certificate
+ *                              proves unchanged (exact: same sets, same order, same bits as a full search; everything else
+ *                              is searched). 0 (default): every search pass walks the lists for every point - the
+ *                              certificate needs the 6th neighbour to be farther than the 5th by twice the point's motion,
+ *                              and in a 0.5 m voxel map that gap is centimetres (1 % of the points kept
+ *                              in a real update, +1 us per pass).
+ *   MALIO_OPT_MAINT_STREAM     1 (default): list maintenance of map_add / map_incremental on a stream of its own.
+ *   MALIO_OPT_MAPINC_SMALL     cap of map_incremental's one-read-back path in points (default 4096; 0: general path always).
+ *   MALIO_OPT_GATE_PINNED      1: the gated update's control block goes through pinned host memory even under a large BAR.
+ *   MALIO_OPT_GATE_TIMEOUT_MS  how long a gate waits for the calling thread before the update falls back to the
+ *                              host-driven loop (default 200).
+ *   MALIO_OPT_SCAN_SET_SYNC    1: malio_scan_set waits for the copy out of a page-locked cloud itself.
+ *   MALIO_OPT_NL_FULL_BLOCKS   1: level-1 neighbour lists hold whole 3x3x3 blocks (takes effect at the next list build).
+ *   MALIO_OPT_DEBUG_*          test hooks: every guess of the extrema wrong / the host stalls before publishing pass 2.
+ * Returns MALIO_ERR_BAD_ARG for an unknown option or a value outside its range. */
+enum {
+  MALIO_OPT_FUSE = 1,
+  MALIO_OPT_SEARCH_SKIP = 2,
+  MALIO_OPT_MAINT_STREAM = 3,
+  MALIO_OPT_MAPINC_SMALL = 4,
+  MALIO_OPT_GATE_PINNED = 5,
+  MALIO_OPT_GATE_TIMEOUT_MS = 6,
+  MALIO_OPT_SCAN_SET_SYNC = 7,
+  MALIO_OPT_NL_FULL_BLOCKS = 8,
+  MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
+  MALIO_OPT_DEBUG_GATE_STALL_MS = 101
+};
+int malio_set_option(malio_handle_t h, int option, double value);
+int malio_get_option(malio_handle_t h, int option, double *value);
+/* After a search pass: out4 = {points of the pass, points whose cached neighbours were kept (MALIO_OPT_SEARCH_SKIP),
+ * points that walked the lists, 1 when the pass was allowed to skip at all}. */
+int malio_debug_skip_stats(malio_handle_t h, int *out4);
+
 /* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */
 /* Every entry point accepts ordinary (pageable) host memory, as the reference's std::vector / pcl clouds are. A copy
  * out of pageable memory is staged by the runtime in chunks and blocks the caller; out of page-locked memory it is one
@@ -569,6 +611,7 @@ int malio_node_scan_set_resident(malio_node_t nd, float leaf, int normal_mode, c
 int malio_node_nearest_search(malio_node_t nd, const malio_point_t *queries, int n, int k, malio_point_t *out_pts,
                               float *out_d2, int *out_count);
 int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int pass, void *user), void *user);
+int malio_node_set_option(malio_node_t nd, int option, double value); /* malio_set_option on every GPU's handle */
 int malio_node_exchange_stats(malio_node_t nd, int *stats2); /* passes that needed one / two exchanges so far */
 /* shard geometry, host code (no GPU): which shard serves each of n world points (xyz [n][3]) / whether shard `rank`
  * stores each of n map points */

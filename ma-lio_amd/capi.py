@@ -31,7 +31,11 @@ EXPORTS = [
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
     "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
     "malio_set_update_mode", "malio_localize_weight", "malio_predict_chain",
+    "malio_set_option", "malio_get_option", "malio_debug_skip_stats", "malio_node_set_option",
 ]
+# malio_set_option (include/malio.h)
+OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
+           nl_full_blocks=8, debug_fuse_bad_guess=100, debug_gate_stall_ms=101)
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
 
@@ -217,6 +221,26 @@ class Engine:
         """"device" (default): update_iterated is one enqueued chain of kernels with the filter algebra on the GPU;
         "host": one pass at a time, algebra on the calling thread."""
         self._chk(lib().malio_set_update_mode(self.h, {"device": 0, "host": 1, "gated": 2}[mode]), "malio_set_update_mode")
+
+    def set_option(self, name, value):
+        """malio_set_option: name is a key of OPT (or the numeric id)."""
+        f = lib().malio_set_option
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        self._chk(f(self.h, int(OPT.get(name, name)), float(value)), "malio_set_option(%s)" % name)
+        return self
+
+    def get_option(self, name):
+        f = lib().malio_get_option
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        v = C.c_double(0)
+        self._chk(f(self.h, int(OPT.get(name, name)), C.byref(v)), "malio_get_option(%s)" % name)
+        return v.value
+
+    def skip_stats(self):
+        """After a search pass: points, points that kept their cached neighbours, points that walked the lists, allowed."""
+        out = (C.c_int * 4)()
+        self._chk(lib().malio_debug_skip_stats(self.h, out), "malio_debug_skip_stats")
+        return dict(points=out[0], kept=out[1], walked=out[2], allowed=out[3])
 
     def last_kernel_times(self):
         names = (C.c_char_p * 16)()
@@ -942,6 +966,12 @@ class Node:
         out = np.zeros((max(n.value, 1), 12), np.float32)
         lib().malio_map_get(hh, _p(out, Point), n.value, C.byref(n))
         return out[:n.value]
+
+    def set_option(self, name, value):
+        f = lib().malio_node_set_option
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        self._chk(f(self.h, int(OPT.get(name, name)), float(value)), "malio_node_set_option(%s)" % name)
+        return self
 
     def exchange_stats(self):
         st = (C.c_int * 2)()

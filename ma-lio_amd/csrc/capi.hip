@@ -139,6 +139,99 @@ int malio_device_count(void) {
 
 const char *malio_last_error(malio_handle_t h) { return h ? h->err.c_str() : "null handle"; }
 
+// Initial option values: the environment variables of the A/B tools, read once per handle, here (include/malio.h,
+// malio_set_option).
+static void options_from_env(malio_handle_t c) {
+  auto num = [](const char *name, double *v) {
+    const char *e = getenv(name);
+    if (!e || !*e) return false;
+    *v = atof(e);
+    return true;
+  };
+  static const struct { const char *env; int opt; } tab[] = {
+      {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
+      {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
+      {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
+  for (const auto &t : tab) {
+    double v;
+    if (num(t.env, &v)) (void)malio_set_option(c, t.opt, v);  // (a value out of range is ignored)
+  }
+}
+
+int malio_set_option(malio_handle_t h, int option, double value) {
+  if (check(h) || !(value == value)) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  const bool is01 = value == 0.0 || value == 1.0;
+  switch (option) {
+    case MALIO_OPT_FUSE:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->fuse_enabled = (int)value;
+      return MALIO_OK;
+    case MALIO_OPT_SEARCH_SKIP:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_search_skip = (int)value;
+      return MALIO_OK;
+    case MALIO_OPT_MAINT_STREAM:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      if ((int)value != c->maint_enabled) {  // whatever is queued on the maintenance stream first
+        if (int rc = maint_join(c)) return rc;
+        c->maint_enabled = (int)value;
+      }
+      return MALIO_OK;
+    case MALIO_OPT_MAPINC_SMALL:
+      if (value < 0.0 || value > 1e9) return MALIO_ERR_BAD_ARG;
+      c->mapinc_small = (int)value;  // (clamped to the kernel's capacity where it is used)
+      return MALIO_OK;
+    case MALIO_OPT_GATE_PINNED:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_gate_pinned = (int)value;  // takes effect at the next update (ensure_gate_buffers)
+      return MALIO_OK;
+    case MALIO_OPT_GATE_TIMEOUT_MS:
+      if (value < 0.0 || value > 1e7) return MALIO_ERR_BAD_ARG;
+      c->gate_timeout_ticks = (long long)(value * 1e5);  // 100 MHz; 0: the default (GATE_TIMEOUT_US)
+      return MALIO_OK;
+    case MALIO_OPT_SCAN_SET_SYNC:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->scan_set_sync = (int)value;
+      return MALIO_OK;
+    case MALIO_OPT_NL_FULL_BLOCKS:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_nl_full_blocks = (int)value;  // takes effect at the next list build
+      return MALIO_OK;
+    case MALIO_OPT_DEBUG_FUSE_BAD_GUESS:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->fuse_debug_bad_guess = value != 0.0;
+      return MALIO_OK;
+    case MALIO_OPT_DEBUG_GATE_STALL_MS:
+      if (value < 0.0 || value > 1e4) return MALIO_ERR_BAD_ARG;
+      c->gate_debug_stall_ms = (int)value;
+      return MALIO_OK;
+    default:
+      c->err = "malio_set_option: unknown option";
+      return MALIO_ERR_BAD_ARG;
+  }
+}
+
+int malio_get_option(malio_handle_t h, int option, double *value) {
+  if (check(h) || !value) return MALIO_ERR_BAD_ARG;
+  const Ctx *c = h;
+  switch (option) {
+    case MALIO_OPT_FUSE: *value = c->fuse_enabled; return MALIO_OK;
+    case MALIO_OPT_SEARCH_SKIP: *value = c->opt_search_skip; return MALIO_OK;
+    case MALIO_OPT_MAINT_STREAM: *value = c->maint_enabled; return MALIO_OK;
+    case MALIO_OPT_MAPINC_SMALL: *value = c->mapinc_small; return MALIO_OK;
+    case MALIO_OPT_GATE_PINNED: *value = c->opt_gate_pinned; return MALIO_OK;
+    case MALIO_OPT_GATE_TIMEOUT_MS: *value = (double)c->gate_timeout_ticks * 1e-5; return MALIO_OK;
+    case MALIO_OPT_SCAN_SET_SYNC: *value = c->scan_set_sync; return MALIO_OK;
+    case MALIO_OPT_NL_FULL_BLOCKS: *value = c->opt_nl_full_blocks; return MALIO_OK;
+    case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
+    case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
+    default: return MALIO_ERR_BAD_ARG;
+  }
+}
+
 int malio_create(const malio_params_t *params, int device, malio_handle_t *out) {
   if (!params || !out) return MALIO_ERR_BAD_ARG;
   if (params->lid_num < 1 || params->lid_num > MALIO_MAX_LIDAR) return MALIO_ERR_BAD_ARG;
@@ -156,6 +249,7 @@ int malio_create(const malio_params_t *params, int device, malio_handle_t *out) 
     return MALIO_ERR_HIP;
   }
   c->stream = c->own_stream;
+  options_from_env(c);
   *out = c;
   return MALIO_OK;
 }
@@ -177,7 +271,7 @@ int malio_destroy(malio_handle_t h) {
   free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt), fr(c->d_del);
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
@@ -496,6 +590,7 @@ static int scan_tables(Ctx *c, const malio_pose_t *const *pose_unc, const int *p
 static int scan_reset(Ctx *c) {
   c->node_guess_valid = false;  // malio_measure_node: a new scan starts with a plain (two-exchange) pass
   c->nbr_epoch = c->map_epoch;
+  c->cert_valid = false;  // no search pass of this scan yet: nothing to keep (search_skip_begin)
   c->scan_sorted = false;
   c->last_M = -1;
   c->mm_guess_valid = false;  // the first pass of a scan runs as three kernels and leaves the first guess
@@ -631,6 +726,9 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
   int rc = measure_alloc(c);
   if (rc != MALIO_OK) return rc;
   c->seg_pending = false;
+  // what a previous scan that never reached its first pass (dropped frame, MALIO_ERR_NO_MAP) may have left armed: its
+  // counts were to be formed by the grouping's first kernel (malio_scan_set_packed) - this scan brings its own
+  c->count_in_sort = false, c->pack_publish_pending = false;
   {
     // A cloud in page-locked memory (malio_host_alloc, or any hipHostMalloc / hipHostRegister'ed buffer) is not touched
     // by this thread at all: one DMA copy of the 48-byte points and a kernel that packs them; the per-slot counts come
@@ -661,11 +759,7 @@ int malio_scan_set(malio_handle_t h, const malio_point_t *body, int n, const mal
       if (!c->ev_upload) MALIO_HIP(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
       MALIO_HIP(hipEventRecord(c->ev_upload, c->stream));
       c->upload_in_flight = true;
-      if (c->scan_set_sync < 0) {
-        const char *e = getenv("MALIO_SCAN_SET_SYNC");
-        c->scan_set_sync = (e && e[0] == '1') ? 1 : 0;
-      }
-      if (c->scan_set_sync) {
+      if (c->scan_set_sync) {  // MALIO_OPT_SCAN_SET_SYNC
         MALIO_HIP(hipEventSynchronize(c->ev_upload));
         c->upload_in_flight = false;
       }
@@ -902,7 +996,8 @@ int malio_scan_set_resident(malio_handle_t h, float leaf, int normal_mode, const
   *out_n = n;
   if (n <= 0) return MALIO_ERR_NO_SCAN;
   c->N = n;
-  c->seg_pending = false;  // (a page-locked malio_scan_set nobody ran a pass on may have left its counts pending)
+  c->seg_pending = false;  // (a page-locked malio_scan_set nobody ran a pass on may have left its counts pending,
+  c->count_in_sort = false, c->pack_publish_pending = false;  // a packed one its counting armed for the grouping)
   c->seg_start[0] = 0;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? m[l] : 0);
   int rc = measure_alloc(c);
@@ -1353,6 +1448,26 @@ int malio_debug_nfound_hist(malio_handle_t h, int *out8) {
   MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   for (unsigned char v : nf) out8[v <= 5 ? v : 7]++;
+  return MALIO_OK;
+}
+
+// Diagnostics: what the last search pass did with the cached neighbours - {points, kept (no list walk), walked, the pass was
+// allowed to keep at all}. Points of other shards count as neither.
+int malio_debug_skip_stats(malio_handle_t h, int *out4) {
+  if (check(h) || !out4) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  for (int k = 0; k < 4; k++) out4[k] = 0;
+  if (c->N <= 0 || !c->scan_sorted || !c->d_kept) return MALIO_ERR_NO_SCAN;
+  MALIO_HIP(hipSetDevice(c->device));
+  std::vector<unsigned char> kept(c->N), nf(c->N);
+  MALIO_HIP(hipMemcpyAsync(kept.data(), c->d_kept, c->N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
+  MALIO_HIP(hipStreamSynchronize(c->stream));
+  out4[0] = c->N, out4[3] = c->last_search_skip;
+  for (int i = 0; i < c->N; i++) {
+    if (kept[i]) out4[1]++;
+    else if (nf[i] <= 5) out4[2]++;
+  }
   return MALIO_OK;
 }
 

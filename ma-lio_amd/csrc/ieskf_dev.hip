@@ -443,6 +443,7 @@ __global__ void __launch_bounds__(ST_BLK) k_ieskf_step(StepArgs g) {
     dl->stamps[9] = wall_clock64();
     dl->passes += 1;
     dl->searches += was_search ? 1 : 0;
+    if (was_search) dl->search_skip = dl->skip_opt;  // its certificates exist: later search passes may keep neighbours
     if (was_search) dl->heavy = (int)g.mm[5];
     dl->last_search = was_search ? 1 : 0;
     dl->commit_prev = M > 0 ? 1 : 0;
@@ -515,6 +516,9 @@ int ieskf_update_device_begin(Ctx *c, const malio_state_t *xio, const double *Pi
   in->mm_parity = c->mm_parity ^ 1, in->dq_parity = c->dq_parity ^ 1;
   in->commit_prev = c->last_M > 0 ? 1 : 0;
   in->maximum_iter = maximum_iter, in->L = L, in->extrinsic_est_en = c->prm.extrinsic_est_en;
+  // the loop's first pass is a search pass: it may keep neighbours of an earlier search of this scan (malio_measure before
+  // the update); every later search pass of the loop may keep those of the first (k_ieskf_step arms search_skip)
+  in->search_skip = search_skip_begin(c), in->skip_opt = c->opt_search_skip;
   in->limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
   memcpy(in->tcq, c->tcq, sizeof(in->tcq)), memcpy(in->tct, c->tct, sizeof(in->tct));
   in->x = *xio, in->x_prop = *xio;
@@ -534,7 +538,6 @@ int ieskf_update_device_begin(Ctx *c, const malio_state_t *xio, const double *Pi
   const int ns_ = sums_len(c);
   g.sums = c->d_sums, g.mm = c->d_sums + ns_, g.out = c->d_loop_out;
   const size_t lds_bytes = sizeof(double) * ((size_t)4 * n * n + (size_t)C * C + C + 4 * n + 9 * (MALIO_MAX_LIDAR + 2) + 4) + sizeof(int) * n;
-  c->nbr_epoch = c->map_epoch;  // the first pass of the loop is a search pass
   c->last_M = -1;
   for (int p = 0; p <= maximum_iter; p++) {
     if (int rc = enqueue_pass_dev(c, c->d_sums, c->d_sums + ns_)) return rc;
@@ -608,11 +611,19 @@ int ensure_gate_buffers(Ctx *c) {
     MALIO_HIP(hipHostMalloc((void **)&c->h_gate, sizeof(double) * hdr + 256, hipHostMallocMapped | hipHostMallocCoherent));
     MALIO_HIP(hipHostGetDevicePointer((void **)&c->d_gate, c->h_gate, 0));
     memset(c->h_gate, 0, sizeof(double) * hdr + 256);
-    // host -> GPU direction in device memory when the CPU can store there (MALIO_GATE_PINNED=1 keeps it in pinned memory)
+    c->gate_stage.assign(hdr, 0.0);
+  }
+  // host -> GPU direction in device memory when the CPU can store there (MALIO_OPT_GATE_PINNED keeps it in pinned memory;
+  // the option may change between updates: no chain is in flight then)
+  if (c->opt_gate_pinned && c->d_cmd) {
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_cmd);
+    c->d_cmd = nullptr, c->d_cmd_tried = false;
+  }
+  if (!c->opt_gate_pinned && !c->d_cmd && !c->d_cmd_tried) {
+    c->d_cmd_tried = true;
     int large_bar = 0;
-    const char *env = getenv("MALIO_GATE_PINNED");
-    if (!(env && env[0] == '1') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess &&
-        large_bar) {
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar) {
       if (hipExtMallocWithFlags((void **)&c->d_cmd, sizeof(double) * hdr + 256, hipDeviceMallocFinegrained) == hipSuccess) {
         MALIO_HIP(hipMemset(c->d_cmd, 0, sizeof(double) * hdr + 256));
         MALIO_HIP(hipDeviceSynchronize());
@@ -621,9 +632,6 @@ int ensure_gate_buffers(Ctx *c) {
         c->d_cmd = nullptr;
       }
     }
-    c->gate_stage.assign(hdr, 0.0);
-    if (const char *e = getenv("MALIO_GATE_TIMEOUT_MS")) c->gate_timeout_ticks = (long long)(atof(e) * 1e5);  // 100 MHz
-    if (const char *e = getenv("MALIO_DEBUG_GATE_STALL_MS")) c->gate_debug_stall_ms = atoi(e);
   }
   return MALIO_OK;
 }
@@ -659,7 +667,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   // base + u + 2, the block of unit u + 1. A unit is normally the next pass of the loop; after a one-kernel pass whose
   // guess of the extrema turned out wrong it is the SAME pass again (same state, neighbours and planes kept, rows
   // weighted with the now known extrema), which the loop does not count.
-  const int max_units = 2 * (maximum_iter + 1) + 2;
+  const int max_units = 3 * (maximum_iter + 1) + 2;  // a pass, and up to two repeats of it (the attempt loop below)
   const int base = c->gate_epoch;
   c->gate_epoch += max_units + 4;
   if (c->gate_epoch > (1 << 30)) c->gate_epoch = 1;
@@ -680,13 +688,15 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       blk->converge = redo ? 0 : converge;
       blk->L = L, blk->maximum_iter = maximum_iter, blk->extrinsic_est_en = c->prm.extrinsic_est_en;
       c->mm_parity ^= 1;
-      if (blk->converge) c->dq_parity ^= 1, c->nbr_epoch = c->map_epoch;
+      if (blk->converge) c->dq_parity ^= 1, blk->search_skip = search_skip_begin(c);
       blk->mm_parity = c->mm_parity, blk->dq_parity = c->dq_parity;
       // (a repeated pass folds nothing: the pass it repeats has consumed the pending fold, and its own results are the
       // repeat's results)
       blk->commit_prev = (!redo && c->last_M > 0) ? 1 : 0;
       c->last_M = -1;
-      c->last_pass_search = blk->converge != 0;
+      // (a repeat runs in reuse form at the SAME state: what malio_scan_get reads of the repeated search pass - world4,
+      // neighbours - is untouched by it, so the pass it repeats keeps deciding where feats_down_world is read from)
+      if (!redo) c->last_pass_search = blk->converge != 0;
       memcpy(blk->mm_guess, c->mm_guess, sizeof(blk->mm_guess));
       if (c->fuse_debug_bad_guess && !redo) blk->mm_guess[0] += 1.0;
       memcpy(c->fuse_guess_used, blk->mm_guess, sizeof(blk->mm_guess));
@@ -715,7 +725,10 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   int u_enq = 1;  // units enqueued so far (unit 0 below)
   auto enqueue_unit = [&]() -> int {
     const int u = u_enq;
-    if (u >= max_units) return MALIO_ERR_BAD_ARG;
+    if (u >= max_units) {
+      c->err = "malio_update_iterated: the gated loop ran out of units (the one-kernel pass keeps missing its own extrema)";
+      return MALIO_ERR_BAD_ARG;
+    }
     g.publish = base + u + 1, g.wait_for = base + u + 2;
     // decided when the unit is enqueued, one pass ahead (the guess itself travels in the block)
     const bool fused = fuse_eligible(c, /*converge: a search pass may come*/ 1, /*need_guess*/ false);

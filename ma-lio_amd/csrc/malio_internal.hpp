@@ -206,6 +206,8 @@ struct DevLoop {
   int lastM_valid;  // accepted points of the last VALID pass (stats[2])
   int last_search;  // the last pass that ran was a search pass (feats_down_world then lives in world4)
   int maximum_iter, L, extrinsic_est_en;
+  int search_skip;  // the NEXT pass, if a search pass, may keep cached neighbours (search_wg phase A')
+  int skip_opt;     // device-resident loop: what search_skip becomes once the loop's first search pass has run
   double limit;
   double mm_guess[4];  // one-kernel pass (k_pass): the extrema the rows are weighted with, [max_u, -min_u, max_R, -min_R]
   double tcq[MALIO_MAX_LIDAR][4], tct[MALIO_MAX_LIDAR][3];  // temporal compensation of this scan (index lid - 1)
@@ -362,7 +364,7 @@ struct Ctx {
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
   hipEvent_t ev_upload = nullptr;  // recorded behind the DMA copy of a page-locked cloud (malio_scan_set): until then the
   bool upload_in_flight = false;   // caller's buffer is in use (malio_scan_upload_wait)
-  int scan_set_sync = -1;          // MALIO_SCAN_SET_SYNC=1: malio_scan_set waits for that copy itself (-1: not read yet)
+  int scan_set_sync = 0;           // MALIO_OPT_SCAN_SET_SYNC: malio_scan_set waits for that copy itself
   CellGrid gnew;     // new points of an Add_Points call grouped by downsample voxel (buffers reused)
   bool apply_pending = false;  // an in-place list update is queued, its verdict (fitted / overflowed) not read yet
   // map_apply's kernels (tombstones, kill, append, list maintenance) run on a stream of their own: the next scan's upload,
@@ -373,12 +375,12 @@ struct Ctx {
   hipEvent_t ev_maint_in = nullptr, ev_maint_done = nullptr;
   bool maint_pending = false;   // `stream` has not waited for ev_maint_done yet
   bool maint_inflight = false;  // the host has not seen ev_maint_done complete yet (arena_maint in use)
-  int maint_enabled = -1;       // MALIO_MAINT_STREAM=0: everything on `stream` (A/B)
+  int maint_enabled = 1;        // MALIO_OPT_MAINT_STREAM = 0: everything on `stream` (A/B)
   Arena arena_maint;
   ArenaScope *maint_scope = nullptr;
   Cell *d_small_table = nullptr;  // map_incremental's usual batch: voxel table + member lists of k_group_small
   u32 *d_small_orig = nullptr;
-  int mapinc_small = -1;
+  int mapinc_small = 4096;  // MALIO_OPT_MAPINC_SMALL: cap of the one-read-back path (SMALL_CAP; 0: general path always)
   u32 small_seq = 0;
   bool search_dirty = false;  // d_map_in changed; nl1/nl2 are rebuilt by the next search (map_sync_search)
   NList nl1, nl2;  // level 1: cf1 = cell_size (fast path); level 2: cf2 = 2 * cell_size >= sqrt(5) (always exact)
@@ -434,6 +436,10 @@ struct Ctx {
   float *d_world = nullptr;    // [3][N]
   float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_search phase A; k_search_tail, k_far_nearest)
   float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
+  float4 *d_cert = nullptr;    // [N] search-skip certificate (world point of the last list walk, radius free of outsiders)
+  unsigned char *d_kept = nullptr;  // [N] the last search pass kept the point's cached neighbours
+  bool cert_valid = false;     // a search pass of this scan has been queued: its certificates exist in stream order
+  int last_search_skip = 0;    // the last search pass was allowed to keep cached neighbours
   double *d_ucov = nullptr;    // [N] unit_cov
   double *d_trace = nullptr;   // [N] trace(Sigma_p) (clamp rule by selected flag)
   unsigned char *d_sel = nullptr;  // [N]
@@ -452,8 +458,12 @@ struct Ctx {
   double mm_guess[4] = {0, 0, 0, 0};  // true extrema of the last completed pass of this scan: the next pass' guess
   bool mm_guess_valid = false;
   double fuse_guess_used[4] = {0, 0, 0, 0};  // what the last k_pass launch was given
-  int fuse_enabled = -1;  // MALIO_FUSE=0 switches the one-kernel pass off (-1: environment not read yet)
-  bool fuse_debug_bad_guess = false;  // MALIO_DEBUG_FUSE_BAD_GUESS=1
+  int fuse_enabled = 1;  // MALIO_OPT_FUSE = 0 switches the one-kernel pass off
+  bool fuse_debug_bad_guess = false;  // MALIO_OPT_DEBUG_FUSE_BAD_GUESS
+  // options without a home above (malio_set_option; initial values from the environment, read once by malio_create)
+  int opt_search_skip = 0;     // MALIO_OPT_SEARCH_SKIP (off: measured at +1 us per search pass for the few points it keeps)
+  int opt_gate_pinned = 0;     // MALIO_OPT_GATE_PINNED
+  int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
   int fuse_cooldown = 0;  // eligible passes left that do NOT speculate (set by a miss, see fuse_eligible)
   int fuse_cooldown_len = 3, fuse_hits_in_row = 0;  // (FUSE_COOLDOWN_MIN; adapted by fused_collect)
   int fuse_hits = 0, fuse_misses = 0, fuse_passes = 0;
@@ -475,8 +485,9 @@ struct Ctx {
   char *d_cmd = nullptr;
   std::vector<double> gate_stage;  // the block as the host composes it, before it goes out in one piece
   int gate_epoch = 1;
-  long long gate_timeout_ticks = 0;  // MALIO_GATE_TIMEOUT_MS (0: the default)
-  int gate_debug_stall_ms = 0;       // MALIO_DEBUG_GATE_STALL_MS: the host sleeps before publishing pass 2 (tests the timeout path)
+  long long gate_timeout_ticks = 0;  // MALIO_OPT_GATE_TIMEOUT_MS in 100 MHz ticks (0: the default)
+  int gate_debug_stall_ms = 0;       // MALIO_OPT_DEBUG_GATE_STALL_MS: the host sleeps before publishing pass 2 (tests the timeout path)
+  bool d_cmd_tried = false;          // the fine-grained control block was asked for already (and refused, when d_cmd is null)
   int gate_timeouts = 0;             // updates that fell back to the host-driven loop because a gate gave up
   double gate_trace[60] = {0};  // developer aid: host-side timestamps of the last gated update
   int gate_trace_n = 0;
@@ -587,6 +598,7 @@ int reset_pass_state(Ctx *c);  // measure.hip: extrema slots, deferral counters 
 // value, or reading the device loop's control block; results land in h_res like the three-kernel pass'); afterwards:
 // *hit = the guessed extrema were the true ones (else the caller redoes the rows)
 bool fuse_eligible(Ctx *c, int converge, bool need_guess = true);
+int search_skip_begin(Ctx *c);  // a search pass is about to be queued: 1 = it may keep cached neighbours
 int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gate, double *row = nullptr);  // row: [sums | extrema words] (default: the pinned result buffer)
 void fuse_note(Ctx *c, bool hit);
 int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate);

@@ -485,13 +485,21 @@ void maint_destroy(Ctx *c) {
     c->maint_stream = nullptr;
   }
 }
-// the stream map_apply launches on: its own, entered behind everything queued on `stream` so far
+// Error paths only: k_vox_add's marks back to zero. Maintenance kernels of the failed batch may still be writing them on the
+// maintenance stream (with or without an event recorded behind them): wait for that stream first - an error path may block.
+static void clear_marks_now(Ctx *c) {
+  if (!c->d_del) return;
+  if (c->maint_stream) (void)hipStreamSynchronize(c->maint_stream);
+  (void)hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream);
+}
+// the stream map_apply launches on: its own, entered behind everything queued on `stream` so far.
+// inputs_ready = true skips the event dependency on `stream`. INVARIANT the caller then vouches for: everything the
+// maintenance kernels read (dlist, d_new, keep, rank, the marks, the totals) was written by kernels of `stream` that the HOST
+// has already seen complete - a stream synchronisation, or the sequence word their LAST kernel stores behind a
+// __threadfence_system() (mapinc_small_batch: k_scan_small_dev) - and NOTHING has been queued on `stream` since that the
+// maintenance kernels depend on. Anything added between that point and map_apply must go back to inputs_ready = false.
 static int maint_enter(Ctx *c, hipStream_t *out, bool inputs_ready) {
-  if (c->maint_enabled < 0) {
-    const char *e = getenv("MALIO_MAINT_STREAM");
-    c->maint_enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!c->maint_enabled) {
+  if (!c->maint_enabled) {  // MALIO_OPT_MAINT_STREAM
     *out = c->stream;
     return MALIO_OK;
   }
@@ -554,7 +562,7 @@ int map_rebuild_search(Ctx *c) {
   c->n_rebuilds++;
   // level 1 pruned to the points within one cell edge of each cell (nl_member) unless the map's voxel filter is so
   // coarse that k_vox_add needs the whole block (a voxel's half diagonal must stay inside the kept reach)
-  const bool prune1 = getenv("MALIO_NL_FULL_BLOCKS") == nullptr && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * c->cell;
+  const bool prune1 = !c->opt_nl_full_blocks /* MALIO_OPT_NL_FULL_BLOCKS */ && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * c->cell;
   int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1);
   if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;
@@ -721,7 +729,7 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   // From here until map_apply's kill kernel has consumed them, k_vox_add's marks are set in the persistent array: every
   // way out that does not reach that kernel clears them, or the next batch would skip those still-live map points
   // (`if (del[mi]) continue` in k_vox_add) and replay the keeper rule on a voxel with holes.
-  auto clear_marks = [&] { (void)hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream); };
+  auto clear_marks = [&] { clear_marks_now(c); };
   if (e != hipSuccess) {
     clear_marks();
     MALIO_HIP(e);
@@ -777,11 +785,8 @@ static int mapinc_small_batch(Ctx *c, ArenaScope &sc, const float4 *wp, const u3
   const float ds = (float)c->prm.filter_size_map;
   u32 *mb = nullptr, *mbd = nullptr;
   MALIO_HIP(mbox(c, &mb, &mbd));
-  if (c->mapinc_small < 0) {  // MALIO_MAPINC_SMALL=<cap>: 0 = always the general path, a small cap to exercise the fall-back (tests)
-    const char *e = getenv("MALIO_MAPINC_SMALL");
-    c->mapinc_small = e ? std::min(std::max(atoi(e), 0), SMALL_CAP) : SMALL_CAP;
-  }
-  const u32 cap = (u32)c->mapinc_small;
+  // MALIO_OPT_MAPINC_SMALL = <cap>: 0 = always the general path, a small cap to exercise the fall-back (tests)
+  const u32 cap = (u32)std::min(std::max(c->mapinc_small, 0), SMALL_CAP);
   if (!c->mapinc_small || !(ds > 0.f) || ds > 2.0f * c->cell || c->map_n <= 0) {
     MALIO_HIP(hipStreamSynchronize(c->stream));
     return MALIO_OK;
@@ -831,7 +836,7 @@ static int mapinc_small_batch(Ctx *c, ArenaScope &sc, const float4 *wp, const u3
       __builtin_ia32_pause();
     }
   }
-  auto clear_marks = [&] { (void)hipMemsetAsync(c->d_del, 0, c->cap_del, c->stream); };
+  auto clear_marks = [&] { clear_marks_now(c); };
   if (e != hipSuccess) {
     clear_marks();
     MALIO_HIP(e);

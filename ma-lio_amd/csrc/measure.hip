@@ -103,6 +103,9 @@ struct Pass1Args {
   unsigned char *sel;
   unsigned char *nfound;
   float *ny;        // [N] feats_down_body[i].normal_y as the reference would hold it (committed lazily)
+  float4 *cert;     // [N] search-skip certificate: world point of the point's last list walk, radius free of outsiders
+  unsigned char *kept;  // [N] this search pass kept the point's cached neighbours (diagnostics)
+  int skip;         // this search pass may keep cached neighbours (DEV: the control block's search_skip)
   int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
   // device loop (DEV = true instantiations): state, parities and commit_prev come from *dl, the slot sets from mm_base
   const DevLoop *dl;
@@ -110,7 +113,7 @@ struct Pass1Args {
 };
 // what a DEV kernel reads from the control block instead of from its arguments
 struct PassDyn {
-  int commit_prev, parity;
+  int commit_prev, parity, skip;
   u64 *mm_cur, *mm_next;
 };
 template <bool DEV>
@@ -118,10 +121,10 @@ __device__ __forceinline__ PassDyn pass_dyn(const Pass1Args &a) {
   PassDyn d;
   if (DEV) {
     const int mp = a.dl->mm_parity;
-    d.commit_prev = a.dl->commit_prev, d.parity = a.dl->dq_parity;
+    d.commit_prev = a.dl->commit_prev, d.parity = a.dl->dq_parity, d.skip = a.dl->search_skip;
     d.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, d.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
   } else {
-    d.commit_prev = a.commit_prev, d.parity = a.parity, d.mm_cur = a.mm_cur, d.mm_next = a.mm_next;
+    d.commit_prev = a.commit_prev, d.parity = a.parity, d.skip = a.skip, d.mm_cur = a.mm_cur, d.mm_next = a.mm_next;
   }
   return d;
 }
@@ -153,7 +156,6 @@ __device__ __forceinline__ u64 top5_key(float d2, u32 og) { return ((u64)__float
 // the largest key anybody inserts ("no candidate"): low word INVALID; as an f64 bit pattern it is the largest finite
 // double, NOT a NaN (see the f64 form of the insertion)
 constexpr u64 TOP5_MAXKEY = 0x7FEFFFFFFFFFFFFFull;
-#ifndef KS_U64KEY
 // Keys are >= +0 as integers with the sign bit clear and - d2 being a finite float - never carry an all-ones f64
 // exponent: read as DOUBLES they are positive finite numbers (denormals included, which the f64 units handle at full
 // speed) that order exactly like the integers. A sorted insertion is then five min/max pairs on the f64 pipe: 10
@@ -168,7 +170,9 @@ __device__ __forceinline__ double f64_max_raw(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
+// Returns the d2 bits (high word) of the key that fell off the end - the largest of the six: what the search-skip
+// certificate (nl_search) folds into its lower bound on the distance of everything OUTSIDE the list.
+__device__ __forceinline__ u32 top5_insert(Top5 &t, u64 key) {
   double x = __longlong_as_double((long long)key);
 #pragma unroll
   for (int k = 0; k < 5; k++) {
@@ -177,20 +181,8 @@ __device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
     x = f64_max_raw(cur, x);
     t.k[k] = (u64)__double_as_longlong(lo);
   }
+  return (u32)__double2hiint(x);
 }
-#else
-__device__ __forceinline__ void top5_insert(Top5 &t, u64 key) {
-  // The list is sorted, so the five comparisons against the key are independent of each other (no compare-exchange
-  // chain) and every slot is a two-way select on them: slot k takes its left neighbour when the key sorts before
-  // that neighbour, the key when it sorts before slot k only, and keeps its value otherwise.
-  const bool c0 = key < t.k[0], c1 = key < t.k[1], c2 = key < t.k[2], c3 = key < t.k[3], c4 = key < t.k[4];
-  t.k[4] = c3 ? t.k[3] : (c4 ? key : t.k[4]);
-  t.k[3] = c2 ? t.k[2] : (c3 ? key : t.k[3]);
-  t.k[2] = c1 ? t.k[1] : (c2 ? key : t.k[2]);
-  t.k[1] = c0 ? t.k[0] : (c1 ? key : t.k[1]);
-  t.k[0] = c0 ? key : t.k[0];
-}
-#endif
 
 // One hash probe: (start, count) of cell `key`, (0,0) when the cell is empty.
 __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 tmask, u64 key, Cell first, u32 slot,
@@ -212,9 +204,10 @@ __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 
 
 // Merge the G lane-local sorted lists into the global top-5 (identical in every lane of the group):
 // 5 rounds of a 64-bit (d2 bits | map index) min-reduction over xor-shuffles.
+// ev (in: the smallest d2 bits this lane's insertions pushed off its list; out, identical in every lane of the group):
+// the smallest d2 bits among ALL candidates of the group that are not in the merged top-5 - the sixth distance.
 template <int G>
-__device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
-  const u64 skey = top5_key(sentinel, INVALID);
+__device__ __forceinline__ void merge_group(Top5 &t, u32 &ev) {
   Top5 out;
 #pragma unroll
   for (int r = 0; r < 5; r++) {
@@ -229,9 +222,12 @@ __device__ __forceinline__ void merge_group(Top5 &t, float sentinel) {
     if (key == mn && (u32)key != INVALID) {
 #pragma unroll
       for (int k = 0; k < 4; k++) t.k[k] = t.k[k + 1];
-      t.k[4] = skey;
+      t.k[4] = TOP5_MAXKEY;
     }
   }
+  ev = min(ev, (u32)(t.k[0] >> 32));  // what is left of this lane's list did not make it either
+#pragma unroll
+  for (int sft = G / 2; sft > 0; sft >>= 1) ev = min(ev, (u32)__shfl_xor((int)ev, sft));
   t = out;
 }
 
@@ -582,12 +578,17 @@ struct NlView {
   const float4 *pts;
   float cf, inv_cf;
 };
+// lb2 (out, identical in every lane of the group): a lower bound on the SQUARED distance - as this function computes
+// distances - from the query to every map point that is not one of the returned neighbours: the smallest of (i) the
+// candidates of the list that fell off the top-5 or lie beyond limit2 and (ii) the radius the block guarantees. It is
+// what lets a later search pass keep the neighbours without walking the list again (search_wg, phase A').
 template <int G>
 __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
-                                          Top5 &t) {
+                                          Top5 &t, float &lb2) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
-  for (int k = 0; k < 5; k++) t.k[k] = top5_key(sentinel, INVALID);
+  for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
+  u32 ev = (u32)(TOP5_MAXKEY >> 32);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
   u64 key = cell_key_d((int)kxf, (int)kyf, (int)kzf);
@@ -602,29 +603,51 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
     for (int u = 0; u < 8; u++) {
       float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-      // d2 <= limit2 <=> key < sentinel key, which the list is padded with: no separate range test. A slot past the
-      // end of the list (its load was clamped to the last entry) gets the largest key and sorts after everything.
+      // A slot past the end of the list (its load was clamped to the last entry) gets the largest key and sorts after
+      // everything. The range test (d2 <= limit2) is applied to the five survivors below, not per candidate.
       const u64 key = top5_key(d2, __float_as_uint(m[u].w));
-      top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
+#ifndef KS_NO_CERT
+      ev = min(ev, top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY));
+#else  // A/B: what the certificate's bookkeeping costs the walk
+      (void)top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
+#endif
     }
   }
-  if (G > 1) merge_group<G>(t, sentinel);
+  if (G > 1) merge_group<G>(t, ev);
+  // survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count as
+  // outsiders for the bound (the list is sorted: they form its tail)
+#pragma unroll
+  for (int k = 0; k < 5; k++)
+    if (!(t.d(k) <= limit2)) {
+      ev = min(ev, (u32)(t.k[k] >> 32));
+      t.k[k] = top5_key(sentinel, INVALID);
+    }
   // radius the block guarantees: one cell edge plus the distance to the nearest face of the own cell, minus a
   // conservative allowance for the float rounding of the cell coordinates
   float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
   float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
   float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
   float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
-  return (t.og(4) != INVALID) && (t.d(4) <= g1 * g1 * 0.99999f);
+  const float g2 = g1 * g1 * 0.99999f;
+  lb2 = __uint_as_float(min(ev, __float_as_uint(g2)));  // (positive floats order like their bits; ev may be the no-candidate mark)
+  return (t.og(4) != INVALID) && (t.d(4) <= g2);
 }
+// lb2 -> the certificate's radius: a lower bound on the TRUE distance of every outsider (computed squared distances are
+// within 3e-7 relative of the true ones; sqrtf is correctly rounded)
+__device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.99999f; }
 
 // a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
+// cert_r >= 0: the neighbours come from a list walk at w - its certificate (w, radius free of outsiders) is stored for the
+// later search passes of this scan; < 0: the neighbours were kept under the stored certificate, which stays.
 __device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev, int i, const float4 w, double nb,
-                                            const u32 og[5], int nf, bool &selected, double &ucov, double &tr, float4 &pl_out,
-                                            float &pd2_out, float4 &q_out) {
+                                            const u32 og[5], int nf, float cert_r, bool &selected, double &ucov, double &tr,
+                                            float4 &pl_out, float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
   pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
+#ifndef KS_NO_CERT
+  if (cert_r >= 0.f) a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);
+#endif
 #pragma unroll
   for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
   a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
@@ -753,11 +776,18 @@ struct SearchLds {
   float4 w[SQ];
   u32 og[5][SQ];
   unsigned char nf[SQ];
+  unsigned char keep[SQ];  // phase A': the cached neighbours are certified for the new world point - no walk
+  int flags;               // what the control wave tells the others after phase A (search_wg)
+  float cr[SQ];            // certificate radius of the walk that served the query (cert_radius)
   double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
 };
 // Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns true in the control wave (with its
 // lane's PointOut filled), false in the three search waves once they have nothing left to do.
-template <bool DEV>
+// SKIP is a TAG: passes that may keep cached neighbours (phase A', decided at run time by dy.skip) and full searches run
+// the same code under two kernel names, so that every profile tells them apart. (Compiling phase A' out of the full
+// search was tried: the register allocator then spills 5 VGPRs in the list walk - 24 B of scratch - where this form
+// spills none.)
+template <bool DEV, bool SKIP>
 __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
                                           const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
   auto qidx = [&](int l) { return q0 + l; };
@@ -768,6 +798,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   // ---- phase A ----
   const int i = qidx(lane_);  // meaningful for the control wave only
   bool mine = cwave && i < qend;
+  bool keep = false;
   PH(0, 0);
   PH_ENTER();
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
@@ -789,23 +820,86 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
       }
     }
     S.w[lane_] = w;
+    // ---- phase A': may this query keep the neighbours of its last walk? (laserMapping.cpp:582-591 searches every point
+    // again whenever ekfom_data.converge is set; between two such passes of one update the iterate moves by centimetres.)
+    // The last walk of the point, at w0, left a radius r0 inside which there is no map point but the cached ones
+    // (nl_search's lb2). Every outsider is therefore farther than r = r0 - |w - w0| from the new point w. If that beats
+    // the fifth cached distance - or the acceptance radius sqrt 5 (:587), when fewer than five cached points lie inside
+    // it - the search would return exactly the cached points, ranked by their NEW distances under the order (d2, index):
+    // those are recomputed here the way the search computes them (ikd_Tree.cpp:1697, no FMA) and inserted into an empty
+    // list. Same set, same order, same bits; anything the bound cannot decide walks the lists as before.
+    if (mine && dy.skip) {
+      const float4 ce = a.cert[i];
+      const int nfo = a.nfound[i];
+      if (nfo <= 5 && ce.w > 0.f) {
+        Top5 t;
+#pragma unroll
+        for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
+        u32 id[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) id[k] = a.nbr[(size_t)k * a.N + i];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          u64 key = TOP5_MAXKEY;
+          if (id[k] != INVALID) {
+            const float4 m = a.map_in[id[k]];
+            const float ddx = w.x - m.x, ddy = w.y - m.y, ddz = w.z - m.z;
+            key = top5_key(ddx * ddx + ddy * ddy + ddz * ddz, id[k]);
+          }
+          (void)top5_insert(t, key);
+        }
+        const float ex = w.x - ce.x, ey = w.y - ce.y, ez = w.z - ce.z;
+        const float moved = sqrtf(ex * ex + ey * ey + ez * ez) * 1.00001f;
+        const float r = (ce.w - moved) * 0.9999f;  // (the slack dwarfs every rounding above: 3e-7 relative)
+        const float lim = __uint_as_float(__float_as_uint(5.0f) + 1u);
+        float need = lim;  // fewer than five inside the radius: no outsider may come inside sqrt 5
+        if (t.og(4) != INVALID && t.d(4) < lim) need = t.d(4);
+        keep = r > 0.f && r * r > need;
+        if (keep) {
+          int nf = 0;
+#pragma unroll
+          for (int k = 0; k < 5; k++) {
+            const bool in = t.og(k) != INVALID && t.d(k) <= 5.0f;
+            S.og[k][lane_] = in ? t.og(k) : INVALID;
+            nf += in ? 1 : 0;
+          }
+          S.nf[lane_] = (unsigned char)nf;
+        }
+      }
+    }
+    S.keep[lane_] = keep ? 1 : 0;
+#ifndef KS_NO_CERT
+    if (i < qend) a.kept[i] = keep ? 1 : 0;
+#endif
   }
-  if (a.part.world > 1 && !__syncthreads_or(mine ? 1 : 0)) {  // a workgroup of somebody else's tiles
-    po.selected = false, po.skipped = true;                   // (k_pass still owes the summation tree a zero tile)
-    return cwave;
+  // bit 0: a point of this workgroup is served here; bit 1: one of them has to walk the lists (only the control wave knows;
+  // __syncthreads_or would reduce !!predicate, not the bits)
+  if (cwave) {
+    const int fl = (__ballot(mine) ? 1 : 0) | (__ballot(mine && !keep) ? 2 : 0);
+    if (lane_ == 0) S.flags = fl;
   }
   __syncthreads();
+  const int flags = __builtin_amdgcn_readfirstlane(S.flags);  // (workgroup-uniform: a scalar)
+  if (a.part.world > 1 && !(flags & 1)) {      // a workgroup of somebody else's tiles
+    po.selected = false, po.skipped = true;  // (k_pass still owes the summation tree a zero tile)
+    return cwave;
+  }
   PH(0, 1);
+  if (flags & 2) {
   // ---- phase B ----
   {
     const int ql = threadIdx.x / NL1_G, sub = threadIdx.x % NL1_G;
-    const float4 ww = S.w[ql];
-    Top5 t;
-    const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t);
-    if (sub == 0) {
+    if (!S.keep[ql]) {  // (the NL1_G lanes of a query branch together: the shuffles of the merge stay inside the group)
+      const float4 ww = S.w[ql];
+      Top5 t;
+      float lb2;
+      const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
+      if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
-      S.nf[ql] = certified ? 5 : NF_PENDING;
+        for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
+        S.nf[ql] = certified ? 5 : NF_PENDING;
+        S.cr[ql] = cert_radius(lb2);
+      }
     }
   }
   __syncthreads();
@@ -850,7 +944,8 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
           if ((ord++ % KS_WAVES) != wave) continue;
           const float4 ww = S.w[l];
           Top5 t;
-          nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t);  // merged list is identical in every lane
+          float lb2;
+          nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t, lb2);  // merged list is identical in every lane
           if (lane < 5) {
             S.og[lane][l] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
           } else if (lane == 5) {
@@ -858,22 +953,31 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
 #pragma unroll
             for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
             S.nf[l] = (unsigned char)nf;
+          } else if (lane == 6) {
+            S.cr[l] = cert_radius(lb2);
           }
         }
       }
       __syncthreads();
     }
   }
+  }  // (somebody walks)
   if (!cwave) return false;
   // ---- phase C (control wave) ----
-  const int lane = lane_;
+  int lane = lane_;
+  asm volatile("" : "+v"(lane));  // the query index is formed again from here on: kept across the list walk it is the one
+  const int ic = qidx(lane);       // value the register allocator spills (8 B of scratch per lane for a 32-bit add)
   u32 og[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) og[k] = S.og[k][lane];
   const int nf = S.nf[lane];
   PH(0, 3);
-  if (mine && nf != NF_DEFERRED)
-    point_phase(a, dy.commit_prev, i, S.w[lane], S.nb[lane], og, nf, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+  // (what phase A knew is read back from LDS instead of being kept in registers across the list walk: the walk has none to spare)
+  const float4 wq = S.w[lane];
+  const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
+  if (served && nf != NF_DEFERRED)
+    point_phase(a, dy.commit_prev, ic, wq, S.nb[lane], og, nf, S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl,
+                po.pd2, po.q);
   PH(0, 8);
   return true;
 }
@@ -881,7 +985,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
 // DEV = true: one pass of the device-resident update loop (DevLoop): exits when the loop is over, runs the REUSE pass on
 // its first wave when the control block asks for one (a reuse pass then costs one launch of this grid, no second
 // kernel that would have to be enqueued and skipped), and takes state, parities and commit_prev from the block.
-template <bool DEV>
+template <bool DEV, bool SKIP>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ SearchLds S;
   if (DEV && a.dl->done) return;
@@ -900,7 +1004,7 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     return;
   }
   PointOut po;
-  if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po) || po.skipped) return;
+  if (!search_wg<DEV, SKIP>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po) || po.skipped) return;
   wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4 over this wave's 64 queries
   PH(0, 9);
   PH_EXIT();
@@ -932,7 +1036,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
       const int i = (int)a.dq[j];
       const float4 w = a.world4[i];
       Top5 t;
-      nl_search<64>(nl2, w.x, w.y, w.z, lane, 5.0f, t);
+      float lb2;
+      nl_search<64>(nl2, w.x, w.y, w.z, lane, 5.0f, t, lb2);
       if (lane == 0) {
         int nf = 0;
 #pragma unroll
@@ -948,7 +1053,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
         }
         float4 pl_, q_;
         float pd2_;
-        point_phase(a, dy.commit_prev, i, w, nb, og5, nf, selected, ucov, tr, pl_, pd2_, q_);
+        point_phase(a, dy.commit_prev, i, w, nb, og5, nf, cert_radius(lb2), selected, ucov, tr, pl_, pd2_, q_);
         if (selected) {
           nsel++;
           mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -968,7 +1073,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int i = (int)a.dq[live ? j : 0];
     const float4 w = a.world4[i];
     Top5 t;
-    nl_search<TAIL_G>(nl2, w.x, w.y, w.z, sub, 5.0f, t);
+    float lb2;
+    nl_search<TAIL_G>(nl2, w.x, w.y, w.z, sub, 5.0f, t, lb2);
     if (live && sub == 0) {
       int nf = 0;
 #pragma unroll
@@ -984,7 +1090,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       float4 pl_, q_;
       float pd2_;
-      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, selected, ucov, tr, pl_, pd2_, q_);
+      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, cert_radius(lb2), selected, ucov, tr, pl_, pd2_, q_);
       if (selected) {
         nsel++;
         mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
@@ -1437,7 +1543,7 @@ __device__ __forceinline__ int tile_entry(int ra, int cb) {  // (row, col) of th
   return a == 0 ? (cb == 1 ? 93 : 94) : 95;
 }
 
-template <bool DEV>
+template <bool DEV, bool SKIP>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE)))
 k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restrict__ dl) {
   __shared__ SearchLds S;
@@ -1450,10 +1556,10 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   PassDyn dy;
   if (DEV) {
     const int mp = dl->mm_parity;
-    dy.commit_prev = dl->commit_prev, dy.parity = dl->dq_parity;
+    dy.commit_prev = dl->commit_prev, dy.parity = dl->dq_parity, dy.skip = dl->search_skip;
     dy.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, dy.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
   } else {
-    dy.commit_prev = a.commit_prev, dy.parity = a.parity, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
+    dy.commit_prev = a.commit_prev, dy.parity = a.parity, dy.skip = a.skip, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
   }
   const int converge = DEV ? dl->converge : f.converge;
   // this workgroup's 64 points: inside ONE LiDAR segment
@@ -1465,7 +1571,7 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   const int lane = (int)(threadIdx.x & 63);
   PointOut po;
   if (converge) {
-    if (!search_wg<DEV>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
+    if (!search_wg<DEV, SKIP>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
     if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
       for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + blockIdx.x] = 0.0;
       return;
@@ -1538,7 +1644,8 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   const bool active = qi < n;
   float4 p = q[active ? qi : n - 1];
   Top5 t;
-  nl_search<NL2_G>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t);
+  float lb2_unused;
+  nl_search<NL2_G>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t, lb2_unused);
   if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {
@@ -1640,7 +1747,8 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
       }
     }
     // best K over the wave; the merged list then lives in lane 0 only, so that a further shell cannot count it twice
-    merge_group<64>(t, INFINITY);
+    u32 ev_unused = 0xFFFFFFFFu;
+    merge_group<64>(t, ev_unused);
     // everything within (3r+1) cell edges of the query's cell has been seen
     const float reach = (float)(3 * r + 1) * nl.cf - margin;
     if (t.og(K - 1) != INVALID && t.d(K - 1) <= reach * reach * 0.99999f) done = true;
@@ -1653,7 +1761,8 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
 #pragma unroll
     for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
     for (int j = lane; j < map_n; j += 64) offer(map_in[j], (u32)j);
-    merge_group<64>(t, INFINITY);
+    u32 ev_unused = 0xFFFFFFFFu;
+    merge_group<64>(t, ev_unused);
   }
   if (lane < K) far_idx[(size_t)lane * N + qi] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
   }  // needy queries of this group of 64
@@ -1798,7 +1907,7 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_dq), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
     MALIO_HIP(hipMalloc(&c->d_upload, sizeof(UploadRec) * K));
@@ -1815,6 +1924,8 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_nfound, K));
     MALIO_HIP(hipMalloc(&c->d_world4, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_ny, sizeof(float) * K));
+    MALIO_HIP(hipMalloc(&c->d_cert, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_kept, K));
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
   if (nb > c->cap_partials) {
@@ -1860,6 +1971,7 @@ int reset_pass_state(Ctx *c) {
   MALIO_HIP(hipStreamSynchronize(c->stream));
   c->mm_parity = 0, c->dq_parity = 0, c->last_M = -1;
   c->mm_guess_valid = false;
+  c->cert_valid = false;  // (the chain may have ended between a search pass' kernels: the next search walks every list)
   return MALIO_OK;
 }
 
@@ -2000,8 +2112,9 @@ __global__ void __launch_bounds__(BLK) k_sort_scatter(int n, const u32 *__restri
 // the sorted scan + the per-scan state every new scan starts from (nothing reads these arrays before the first pass)
 __device__ __forceinline__ void scan_install(const UploadRec *__restrict__ in, u32 src, int dst, int n, float4 *out_scan,
                                              u32 *out_perm, float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
-                                             float *pd2, float4 *plane) {
+                                             float *pd2, float4 *plane, float4 *cert) {
   const UploadRec r = in[src];  // src: index in the caller's cloud
+  cert[dst] = make_float4(0.f, 0.f, 0.f, 0.f);  // no certificate: the first search pass walks the lists for every point
   out_scan[dst] = make_float4(r.x, r.y, r.z, __uint_as_float(r.w));
   out_perm[dst] = src;
   out_ny[dst] = r.ny;
@@ -2015,22 +2128,22 @@ __global__ void __launch_bounds__(BLK) k_sort_place(const UploadRec *__restrict_
                                                     const u32 *__restrict__ tbkt,
                                                     const u32 *__restrict__ offs, float4 *out_scan, u32 *out_perm,
                                                     float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
-                                                    float *pd2, float4 *plane) {
+                                                    float *pd2, float4 *plane, float4 *cert) {
   int j = blockIdx.x * BLK + threadIdx.x;
   if (j >= n) return;
   const u32 b = tbkt[j], s0 = offs[b], s1 = offs[b + 1];
   const u64 mine = tkv[j];
   u32 rank = 0;
   for (u32 m = s0; m < s1; m++) rank += tkv[m] < mine ? 1u : 0u;
-  scan_install(in, (u32)mine, (int)(s0 + rank), n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane);
+  scan_install(in, (u32)mine, (int)(s0 + rank), n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane, cert);
 }
 // the upload order kept (malio_scan_order): install only
 __global__ void __launch_bounds__(BLK) k_gather_scan(const UploadRec *__restrict__ in, int n, float4 *out_scan, u32 *out_perm,
                                                      float *out_ny, unsigned char *sel, unsigned char *nfound, u32 *nbr,
-                                                     float *pd2, float4 *plane) {
+                                                     float *pd2, float4 *plane, float4 *cert) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
-  scan_install(in, (u32)i, i, n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane);
+  scan_install(in, (u32)i, i, n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane, cert);
 }
 
 void fill_quat_const(const Ctx *c, const malio_state_t *s, QuatConst &qc) {
@@ -2080,6 +2193,12 @@ int resolve_scan_segments(Ctx *c) {
   }
   c->seg_start[0] = 0;
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) c->seg_start[l + 1] = c->seg_start[l] + (l < L ? (int)info[l] : 0);
+  if (c->seg_start[L] != c->N) {  // counts that do not add up to the scan would send every per-segment kernel out of bounds
+    c->err = "malio_scan_set: the per-slot counts of the scan do not add up to its size (" + std::to_string(c->seg_start[L]) +
+             " vs " + std::to_string(c->N) + ")";
+    c->N = 0;
+    return MALIO_ERR_HIP;
+  }
   c->scan_keep_order = c->scan_order_mode == MALIO_SCAN_ORDER_KEEP && info[9] == 0;
   return MALIO_OK;
 }
@@ -2094,7 +2213,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
   if (c->scan_keep_order) {  // malio_scan_order: the upload order is kept (it is grouped by LiDAR slot)
     publish_pack_now(c);
     hipLaunchKernelGGL(k_gather_scan, grid, dim3(BLK), 0, c->stream, c->d_upload, N, c->d_scan, c->d_perm, c->d_ny,
-                       c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
+                       c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane, c->d_cert);
     c->scan_sorted = true;
     return MALIO_OK;
   }
@@ -2120,7 +2239,7 @@ static int sort_scan(Ctx *c, const QuatConst &qc) {
                      cis ? c->d_packinfo_pub : (u32 *)nullptr, c->pack_seq);
   hipLaunchKernelGGL(k_sort_scatter, grid, dim3(BLK), 0, c->stream, N, keys, bkt, rnk, offs, tkv, tbkt);
   hipLaunchKernelGGL(k_sort_place, grid, dim3(BLK), 0, c->stream, c->d_upload, N, tkv, tbkt, offs, c->d_scan, c->d_perm,
-                     c->d_ny, c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane);
+                     c->d_ny, c->d_sel, c->d_nfound, c->d_nbr, c->d_pd2, c->d_plane, c->d_cert);
   MALIO_HIP(hipGetLastError());
   c->scan_sorted = true;
   return MALIO_OK;
@@ -2141,6 +2260,7 @@ static void fill_pass1_static(Ctx *c, Pass1Args &a) {
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny;
+  a.cert = c->d_cert, a.kept = c->d_kept, a.skip = 0;
   a.mm_base = c->d_mmslots;
   a.dl = nullptr, a.mm_cur = a.mm_next = nullptr, a.parity = 0, a.commit_prev = 0;
 }
@@ -2165,6 +2285,18 @@ void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
   }
   pc.L = c->prm.lid_num, pc.extrinsic_est_en = c->prm.extrinsic_est_en;
   pc.plane_th = c->prm.plane_th, pc.cov_threshold = c->prm.cov_threshold;
+}
+
+// Bookkeeping of a SEARCH pass about to be queued: may it keep cached neighbours (search_wg, phase A')? Yes when an
+// earlier search pass of THIS scan has left its certificates and the map has not changed since (map ids in d_nbr, and
+// the "no outsider inside r" statement, belong to one epoch of the map array). From here on the certificates of this
+// pass exist in stream order.
+int search_skip_begin(Ctx *c) {
+  const int skip = (c->opt_search_skip && c->cert_valid && c->nbr_epoch == c->map_epoch) ? 1 : 0;
+  c->nbr_epoch = c->map_epoch;
+  c->cert_valid = true;
+  c->last_search_skip = skip;
+  return skip;
 }
 
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {
@@ -2194,9 +2326,9 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   if (converge) {
     c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
     a.parity = c->dq_parity;
-    c->nbr_epoch = c->map_epoch;
-    hipLaunchKernelGGL(k_search<false>, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
-                       view_of(c->nl2));
+    a.skip = search_skip_begin(c);
+    const auto kern = a.skip ? &k_search<false, true> : &k_search<false, false>;
+    hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
     prof_mark(c, "k_search");
     if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
       hipLaunchKernelGGL(k_search_tail<false>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
@@ -2233,6 +2365,11 @@ static int fill_pass2_static(Ctx *c, Pass2Args &a) {
 int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows, const GateArgs *gate) {
   Pass2Args a;
   const int nb = fill_pass2_static(c, a);
+  for (int l = 0; l < c->prm.lid_num; l++)  // k_final_reduce<4>: 64 rounds of 256 workgroup partials per LiDAR segment
+    if ((c->seg_start[l + 1] - c->seg_start[l] + BLK - 1) / BLK > 64 * 256) {
+      c->err = "malio_measure: more than 4 194 304 scan points in one LiDAR slot";
+      return MALIO_ERR_BAD_ARG;
+    }
   a.pc = c->pc;
   a.minmax4 = d_minmax4_in;
   a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
@@ -2279,8 +2416,10 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
   Pass1Args a;
   fill_pass1_static(c, a);
   a.dl = c->d_loop;
-  hipLaunchKernelGGL(k_search<true>, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1),
-                     view_of(c->nl2));
+  // (whether a search pass of the enqueued-ahead loop may keep neighbours is in the control block; the instantiation that can
+  // is used whenever the option is on)
+  const auto kern = c->opt_search_skip ? &k_search<true, true> : &k_search<true, false>;
+  hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
   if (a.defer) hipLaunchKernelGGL(k_search_tail<true>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
   Pass2Args b;
   const int nb = fill_pass2_static(c, b);
@@ -2297,15 +2436,13 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
 
 // ---- host side of the speculating pass ----------------------------------------------------------------------------------
 bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
-  if (c->fuse_enabled < 0) {
-    const char *e = getenv("MALIO_FUSE");
-    c->fuse_enabled = (e && e[0] == '0') ? 0 : 1;
-    const char *b = getenv("MALIO_DEBUG_FUSE_BAD_GUESS");  // tests: every guess is wrong, every speculating pass is redone
-    c->fuse_debug_bad_guess = b && b[0] == '1';
-  }
   if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending) return false;
   if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
   if (!c->d_tiles) return false;
+  // k_final_reduce<16> keeps one node per round of 1 024 tiles in 64 LDS slots: a LiDAR segment above 64 x 1 024 tiles (4.2 M
+  // points) takes the three-kernel pass
+  for (int l = 0; l < c->prm.lid_num; l++)
+    if ((c->seg_start[l + 1] - c->seg_start[l] + SQ - 1) / SQ > 64 * 1024) return false;
   // A wrong guess costs a pass its rows a second time (and the enqueued-ahead update a whole repeated unit, ~30 us), a
   // right one saves 1-4 us: after a miss the handle stops speculating for a number of eligible passes that grows with the
   // miss rate (fused_collect). Scenes whose extrema move with every iterate (planes of very uneven covariance: BASELINE
@@ -2369,7 +2506,7 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   c->last_pass_search = converge != 0;
   if (converge) {
     c->dq_parity ^= 1;
-    c->nbr_epoch = c->map_epoch;
+    a.skip = search_skip_begin(c);
   }
   a.parity = c->dq_parity;
   FuseArgs f;
@@ -2381,8 +2518,8 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   memcpy(f.guess, c->mm_guess, sizeof(f.guess));
   if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
   memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
-  hipLaunchKernelGGL(k_pass<false>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
-                     (const DevLoop *)nullptr);
+  const auto kern = a.skip ? &k_pass<false, true> : &k_pass<false, false>;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f, (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
   launch_final_tiles(c, sb, nullptr, gate, row);
   prof_mark(c, "k_final_reduce");
@@ -2400,8 +2537,8 @@ int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   FuseArgs f;
   SegBlocks sb;
   const int nwg = fill_fuse_static(c, f, sb);
-  hipLaunchKernelGGL(k_pass<true>, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f,
-                     (const DevLoop *)c->d_loop);
+  const auto kern = c->opt_search_skip ? &k_pass<true, true> : &k_pass<true, false>;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f, (const DevLoop *)c->d_loop);
   launch_final_tiles(c, sb, c->d_loop, gate);
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;

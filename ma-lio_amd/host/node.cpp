@@ -208,6 +208,11 @@ int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int, void *), void *use
   return MALIO_OK;
 }
 
+int malio_node_set_option(malio_node_t nd, int option, double value) {  // malio_set_option on every GPU's handle
+  if (!nd) return MALIO_ERR_BAD_ARG;
+  return nd->run([=](Worker &k) { return malio_set_option(k.h, option, value); });
+}
+
 // ---- map: every GPU is handed the whole call; a tile shard keeps its part (malio_set_partition) ----------------------
 int malio_node_map_build(malio_node_t nd, const malio_point_t *pts, int n) {
   if (!nd || !pts || n <= 0) return MALIO_ERR_BAD_ARG;

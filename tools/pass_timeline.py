@@ -24,7 +24,7 @@ groups = collections.defaultdict(list)
 for i in range(len(passes) - 1):
     p, nxt = passes[i], passes[i + 1]
     kind = tuple(k[0] for k in p)
-    if kind[0].startswith("k_pass") or kind[0].startswith("k_search<true>"):  # one kernel name, two kinds of pass
+    if kind[0].startswith("k_pass") or kind[0].startswith("k_search<true"):  # one kernel name, two kinds of pass
         kind = kind + ("[search]" if p[0][2] - p[0][1] > 18000 else "[reuse]",)
     groups[kind].append((p, nxt[0][1]))
 for shape, items in groups.items():

@@ -10,12 +10,13 @@ kernel = sys.argv[3] if len(sys.argv) > 3 else "k_pass"
 rnd = sys.argv[4] if len(sys.argv) > 4 else "round3"
 vals = {}
 for line in open(os.path.join(d, tag + "_pmc_summary.txt")):
-    m = re.match(r"\s+malio::(\w+)(<\w+>)? g\d+\s+(\{.*\})", line)
-    if m and m.group(1) == kernel and m.group(2) in (None, "<false>"):
+    m = re.match(r"\s+malio::(\w+)(<[\w, ]+>)? g\d+\s+(\{.*\})", line)
+    # (<false, false>: state in the kernel arguments, FULL search - the bench's step; <false, true> keeps cached neighbours)
+    if m and m.group(1) == kernel and m.group(2) in (None, "<false>", "<false, false>"):
         vals.update(ast.literal_eval(m.group(3)))
 avg_ns = calls = None
 for r in csv.DictReader(open(os.path.join(d, tag + "_bench_kernel_stats.csv"))):
-    if r["Name"].replace("void ", "").startswith(("malio::%s(" % kernel, "malio::%s<false>(" % kernel)):
+    if r["Name"].replace("void ", "").startswith(("malio::%s(" % kernel, "malio::%s<false>(" % kernel, "malio::%s<false, false>(" % kernel)):
         avg_ns, calls = float(r["AverageNs"]), int(r["Calls"])
 out = {
     "kernel": kernel, "workload": "city3_100k_1M, one launch",
