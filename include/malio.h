@@ -367,10 +367,6 @@ int malio_scan_order(malio_handle_t h, int mode);
  *                              host-driven loop (default 200).
  *   MALIO_OPT_SCAN_SET_SYNC    1: malio_scan_set waits for the copy out of a page-locked cloud itself.
  *   MALIO_OPT_NL_FULL_BLOCKS   1: level-1 neighbour lists hold whole 3x3x3 blocks (takes effect at the next list build).
- *   MALIO_OPT_NL8              1: the level-1 neighbour lists are kept a second time as 8-byte entries (13-bit grid position
- *                              inside the list's block of cells + 25-bit map index) and the search pass walks THOSE - half the
- *                              bytes - ranking the six best candidates again on their exact coordinates: same results, bit for
- *                              bit. 0: the search walks the 16-byte lists. Maps above 2^25 - 2 slots use the 16-byte walk.
  *   MALIO_OPT_DEBUG_*          test hooks: every guess of the extrema wrong / the host stalls before publishing pass 2.
  * Returns MALIO_ERR_BAD_ARG for an unknown option or a value outside its range. */
 enum {
@@ -382,7 +378,6 @@ enum {
   MALIO_OPT_GATE_TIMEOUT_MS = 6,
   MALIO_OPT_SCAN_SET_SYNC = 7,
   MALIO_OPT_NL_FULL_BLOCKS = 8,
-  MALIO_OPT_NL8 = 9,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
   MALIO_OPT_DEBUG_GATE_STALL_MS = 101
 };

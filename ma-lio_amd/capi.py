@@ -35,7 +35,7 @@ EXPORTS = [
 ]
 # malio_set_option (include/malio.h)
 OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
-           nl_full_blocks=8, nl8=9, debug_fuse_bad_guess=100, debug_gate_stall_ms=101)
+           nl_full_blocks=8, debug_fuse_bad_guess=100, debug_gate_stall_ms=101)
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
 

@@ -152,7 +152,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL8", MALIO_OPT_NL8}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -200,13 +200,6 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_nl_full_blocks = (int)value;  // takes effect at the next list build
       return MALIO_OK;
-    case MALIO_OPT_NL8:
-      if (!is01) return MALIO_ERR_BAD_ARG;
-      if ((int)value != c->opt_nl8) {
-        c->opt_nl8 = (int)value;
-        if (c->map_n > 0) c->search_dirty = true;  // the lists are rebuilt, with or without the compact form, by the next search
-      }
-      return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS:
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->fuse_debug_bad_guess = value != 0.0;
@@ -233,7 +226,6 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_GATE_TIMEOUT_MS: *value = (double)c->gate_timeout_ticks * 1e-5; return MALIO_OK;
     case MALIO_OPT_SCAN_SET_SYNC: *value = c->scan_set_sync; return MALIO_OK;
     case MALIO_OPT_NL_FULL_BLOCKS: *value = c->opt_nl_full_blocks; return MALIO_OK;
-    case MALIO_OPT_NL8: *value = c->opt_nl8; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
     default: return MALIO_ERR_BAD_ARG;

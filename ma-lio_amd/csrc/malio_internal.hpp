@@ -52,10 +52,6 @@ struct NList {
   size_t cap_pts = 0, cap_table = 0;
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
   bool pruned = false;    // lists hold the points within one cell edge of the cell instead of the whole 3x3x3 block
-  // Compact form of the same lists (level 1 only, what the search pass walks): entry j of a list is pts8[start + j] - the
-  // point's position on a 13-bit grid over the list's 3x3x3 block of cells and its map index in 8 bytes (nl8_encode). Null:
-  // not kept (level 2; MALIO_OPT_NL8 off).
-  u64 *pts8 = nullptr;
 };
 
 // scratch of build_nlist (open-addressing directory under construction), kept between rebuilds
@@ -74,8 +70,6 @@ struct NlDev {
   u32 bump_end;
   float inv_cf;
   int pruned;  // level 1: a list holds only the block's points within one cell edge of its cell (nl_member)
-  u64 *pts8;   // compact shadow of the lists (NList::pts8), or null
-  float cf;
 };
 
 #if defined(__HIP__)
@@ -95,24 +89,6 @@ __device__ __forceinline__ bool nl_member(int pruned, float gx, float gy, float 
               az = dz == 0 ? 0.f : (dz > 0 ? 1.f - fz : fz);
   const float reach = 1.0f + 1e-5f + 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f);
   return ax * ax + ay * ay + az * az <= reach * reach;
-}
-// ---- 8-byte list entries (NList::pts8) --------------------------------------------------------------------------------
-// A list belongs to one cell (cx, cy, cz) and holds points of the 3x3x3 block around it: [ (c - 1) cf, (c + 2) cf ) per axis.
-// Entry = 3 x 13-bit grid coordinates over that span (step 3 cf / 8192 = 0.41 mm at the default edge) | 25-bit map index:
-//   bits  0..12 qx, 13..25 qy, 26..38 qz, 39..63 map index   (all ones in the index: a tombstone)
-// The search ranks candidates on the grid (integer squared distances against the query's own grid position, one more
-// fractional bit), then re-ranks the six best on their exact coordinates from the map array: see nl_search8 (measure.hip).
-constexpr u32 NL8_TOMB = 0x1FFFFFFu;          // index field of a deleted entry
-constexpr u32 NL8_MAX_INDEX = NL8_TOMB - 1u;  // maps with more slots keep the float4 walk
-constexpr float NL8_GRID = 8192.f;
-__device__ __forceinline__ float nl8_origin(int c, float cf) { return (float)(c - 1) * cf; }  // the SAME expression on both sides
-__device__ __forceinline__ u64 nl8_encode(float x, float y, float z, int cx, int cy, int cz, float cf, u32 index) {
-  const float inv_s = NL8_GRID / (3.0f * cf);
-  const float fx = (x - nl8_origin(cx, cf)) * inv_s, fy = (y - nl8_origin(cy, cf)) * inv_s, fz = (z - nl8_origin(cz, cf)) * inv_s;
-  // (a point sits outside its block by the float rounding of its cell coordinate at most: clamped, inside the error budget)
-  const u32 qx = (u32)fminf(fmaxf(rintf(fx), 0.f), NL8_GRID - 1.f), qy = (u32)fminf(fmaxf(rintf(fy), 0.f), NL8_GRID - 1.f),
-            qz = (u32)fminf(fmaxf(rintf(fz), 0.f), NL8_GRID - 1.f);
-  return (u64)qx | ((u64)qy << 13) | ((u64)qz << 26) | ((u64)index << 39);
 }
 // cell directory hashing shared by every .hip file (measure.hip keeps identical _d copies next to its hot loops)
 __device__ __forceinline__ u64 cell_key(int ix, int iy, int iz) {
@@ -488,7 +464,6 @@ struct Ctx {
   int opt_search_skip = 0;     // MALIO_OPT_SEARCH_SKIP (off: measured at +1 us per search pass for the few points it keeps)
   int opt_gate_pinned = 0;     // MALIO_OPT_GATE_PINNED
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
-  int opt_nl8 = 1;             // MALIO_OPT_NL8: level-1 lists also as 8-byte entries, which the search pass then walks
   int fuse_cooldown = 0;  // eligible passes left that do NOT speculate (set by a miss, see fuse_eligible)
   int fuse_cooldown_len = 3, fuse_hits_in_row = 0;  // (FUSE_COOLDOWN_MIN; adapted by fused_collect)
   int fuse_hits = 0, fuse_misses = 0, fuse_passes = 0;
@@ -558,7 +533,7 @@ int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n,
 int exclusive_scan_u32_pair(Ctx *c, const u32 *inA, u32 *outA, u32 *tilesA, u32 *totalA, const u32 *inB, u32 *outB,
                             u32 *tilesB, u32 *totalB, int n);  // two scans of one length in one pair of launches
 void free_grid(CellGrid &g);
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false, bool want8 = false);
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false);
 void free_nlist(NList &nl);
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
 // the map array's share of a batch, done by a third slice of k_nl_ensure's grid: dlist[ndel] die, kept new points go to dst[rank]

@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(BLK) k_nl_count(const float4 *__restrict__ pts
 // pass B: place every point into the 27 lists (cursor = running fill count of the list)
 __global__ void __launch_bounds__(BLK) k_nl_fill(const float4 *__restrict__ pts, int n, float inv_cf,
                                                  const u64 *__restrict__ keys, const u32 *__restrict__ start, u32 *cursor,
-                                                 u32 mask, float4 *out, int pruned, u64 *out8, float cf) {
+                                                 u32 mask, float4 *out, int pruned) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
@@ -446,9 +446,7 @@ __global__ void __launch_bounds__(BLK) k_nl_fill(const float4 *__restrict__ pts,
         u64 key = cell_key(ix + dx, iy + dy, iz + dz);
         u32 s = hash_key(key) & mask;
         while (keys[s] != key) s = (s + 1) & mask;
-        const size_t at = (size_t)start[s] + atomicAdd(&cursor[s], 1u);
-        out[at] = rec;
-        if (out8) out8[at] = nl8_encode(p.x, p.y, p.z, ix + dx, iy + dy, iz + dz, cf, (u32)i);
+        out[(size_t)start[s] + atomicAdd(&cursor[s], 1u)] = rec;
       }
 }
 
@@ -465,7 +463,6 @@ void free_nl_scratch(NlScratch &s) {
 void free_nlist(NList &nl) {
   if (nl.table) (void)hipFree(nl.table);
   if (nl.pts) (void)hipFree(nl.pts);
-  if (nl.pts8) (void)hipFree(nl.pts8);
   if (nl.cap) (void)hipFree(nl.cap);
   if (nl.inc) (void)hipFree(nl.inc);
   if (nl.state) (void)hipFree(nl.state);
@@ -479,7 +476,7 @@ __global__ void __launch_bounds__(BLK) k_nl_caps(const u32 *__restrict__ cnt, u3
   u32 i = blockIdx.x * BLK + threadIdx.x;
   if (i > n) return;  // capv[n] = 0: the exclusive scan then leaves the total there
   u32 c = i < n ? cnt[i] : 0u;
-  capv[i] = c ? (c + max(NL_MIN_SLACK, c / 4) + 1u) & ~1u : 0u;  // even: every list starts on a 16-byte boundary of the 8-byte shadow
+  capv[i] = c ? c + max(NL_MIN_SLACK, c / 4) : 0u;
 }
 // scratch slots -> compact directory, with the capacity of every list next to it
 __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys, const u32 *__restrict__ cnt,
@@ -500,8 +497,7 @@ __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys
   cap[d] = capv[s];
 }
 
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned, bool want8) {
-  if (want8 && (u32)n > NL8_MAX_INDEX) want8 = false;  // the index field is 25 bits: larger maps keep the float4 walk
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned) {
   nl.cf = cf;
   nl.pruned = pruned;
   nl.inv_cf = 1.0f / nl.cf;
@@ -550,17 +546,10 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
       return MALIO_ERR_ALLOC;
     }
     MALIO_HIP(hipMalloc(&nl.pts, sizeof(float4) * nl.cap_pts));
-    if (nl.pts8) (void)hipFree(nl.pts8);
-    nl.pts8 = nullptr;
-  }
-  if (want8 && !nl.pts8) MALIO_HIP(hipMalloc(&nl.pts8, sizeof(u64) * nl.cap_pts));
-  if (!want8 && nl.pts8) {
-    (void)hipFree(nl.pts8);
-    nl.pts8 = nullptr;
   }
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));  // reuse as the fill cursor
   hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,
-                     nl.pts, pruned ? 1 : 0, nl.pts8, nl.cf);
+                     nl.pts, pruned ? 1 : 0);
   // compact directory (the fill cursors now equal the list lengths); sized for growth to load 0.7
   u32 tsize = next_pow2(std::max(1024u, 3u * h_cnt[0]));
   if ((size_t)tsize > nl.cap_table || !nl.table) {
@@ -685,7 +674,7 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
         // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
         // old storage is reclaimed by the next full rebuild
         const u32 total = cnt + need;
-        newcap = (total + max(NL_MIN_SLACK, total / 4) + 1u) & ~1u;
+        newcap = total + max(NL_MIN_SLACK, total / 4);
         st = atomicAdd(&nl.state[0], newcap);
         if (st + newcap > nl.bump_end || st + newcap < st) {
           atomicExch(&nl.state[1], 1u);
@@ -703,10 +692,7 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
     const u32 o = __shfl(old, src), d = __shfl(st, src), n = __shfl(cnt, src);
-    for (u32 j = lane; j < n; j += 64) {
-      nl.pts[(size_t)d + j] = nl.pts[(size_t)o + j];
-      if (nl.pts8) nl.pts8[(size_t)d + j] = nl.pts8[(size_t)o + j];
-    }
+    for (u32 j = lane; j < n; j += 64) nl.pts[(size_t)d + j] = nl.pts[(size_t)o + j];
   }
   if (mv) {
     nl.table[s].start = st;
@@ -743,10 +729,7 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
     atomicSub(&nl.table[s].count, 1u);
     atomicExch(&nl.state[1], 1u);
   } else {
-    const size_t at = (size_t)nl.table[s].start + pos;
-    nl.pts[at] = rec;
-    if (nl.pts8)
-      nl.pts8[at] = nl8_encode(p.x, p.y, p.z, ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1, nl.cf, og_base + rank[i]);
+    nl.pts[(size_t)nl.table[s].start + pos] = rec;
   }
 }
 // (3) a deleted map point leaves its 27 lists: the entry stays but can never be a neighbour again (x = +inf makes
@@ -787,10 +770,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
     bool hit = false;
 #pragma unroll
     for (int u = 0; u < 4; u++)
-      if (og[u] == i && j + lanes * u < cn) {
-        nl.pts[(size_t)st + j + lanes * u].x = INFINITY, hit = true;
-        if (nl.pts8) nl.pts8[(size_t)st + j + lanes * u] = ~0ull;  // (index field NL8_TOMB)
-      }
+      if (og[u] == i && j + lanes * u < cn) nl.pts[(size_t)st + j + lanes * u].x = INFINITY, hit = true;
     // one entry per list matches: once a lane of the group has found it the rest of the list need not be read
     if ((__ballot(hit) >> gsh) & gmask) break;
   }
@@ -800,7 +780,6 @@ NlDev nl_dev(const NList &nl) {
   NlDev v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state;
   v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.pruned = nl.pruned ? 1 : 0;
-  v.pts8 = nl.pts8, v.cf = nl.cf;
   return v;
 }
 

@@ -563,7 +563,7 @@ int map_rebuild_search(Ctx *c) {
   // level 1 pruned to the points within one cell edge of each cell (nl_member) unless the map's voxel filter is so
   // coarse that k_vox_add needs the whole block (a voxel's half diagonal must stay inside the kept reach)
   const bool prune1 = !c->opt_nl_full_blocks /* MALIO_OPT_NL_FULL_BLOCKS */ && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * c->cell;
-  int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1, c->opt_nl8 != 0);
+  int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1);
   if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;
 }
@@ -611,7 +611,6 @@ static int map_apply(Ctx *c, const u32 *dlist, u32 ndel, const float4 *d_new, co
     if ((size_t)c->nl1.ncells * 10 > (size_t)(c->nl1.tmask + 1) * 7 || (size_t)c->nl2.ncells * 10 > (size_t)(c->nl2.tmask + 1) * 7)
       in_place = false;
     if ((size_t)(c->nl_tomb + ndel) * 5 > (size_t)(hw - c->map_dead)) in_place = false;
-    if (c->nl1.pts8 && (size_t)hw + nadd > NL8_MAX_INDEX) in_place = false;  // (the rebuild drops the 8-byte lists: 25-bit indices)
   }
   if (ndel) {
     if (in_place) {

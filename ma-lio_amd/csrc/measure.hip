@@ -577,8 +577,6 @@ struct NlView {
   u32 tmask;
   const float4 *pts;
   float cf, inv_cf;
-  const uint4 *pts8;  // the same lists as pairs of 8-byte entries (NList::pts8; list starts are even), or null
-  float inv_s2;       // grid half-steps per metre: 2 * 8192 / (3 cf)
 };
 // lb2 (out, identical in every lane of the group): a lower bound on the SQUARED distance - as this function computes
 // distances - from the query to every map point that is not one of the returned neighbours: the smallest of (i) the
@@ -637,156 +635,6 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
 // lb2 -> the certificate's radius: a lower bound on the TRUE distance of every outsider (computed squared distances are
 // within 3e-7 relative of the true ones; sqrtf is correctly rounded)
 __device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.99999f; }
-
-// ---- the level-1 search on 8-byte list entries (NList::pts8, malio_internal.hpp: nl8_encode) ---------------------------
-// Half the bytes of the 16-byte walk, the same answer. Candidates are ranked on the list's 13-bit grid: integer squared
-// distances between the entry's grid position (doubled) and the query's own position on the doubled grid - packed with
-// the map index into the same 64-bit keys, so the insertion is the same chain of f64 min / max pairs, one pair longer:
-// the SIX best are kept, and the seventh distance (`ev`). A grid distance differs from the distance the reference
-// computes (ikd_Tree.cpp:1697, on the exact coordinates) by at most E half-steps (1 for the entry's rounding, 1/2 for
-// the query's, per axis, + the float rounding of both encodings); whenever sqrt(d7) > sqrt(d5) + 2 E every one of the
-// reference's five nearest is among the six. Those are then ranked on their EXACT coordinates, fetched from the map
-// array by the query's four lanes (the plane fit reads the same points a moment later), with the reference's arithmetic
-// under the total order (d2, map index): sets, order and bits of the 16-byte walk. The rare query the test cannot decide
-// (two candidates within a millimetre around the fifth distance) is left uncertified and served by level 2, which is exact.
-struct Top6 {
-  u64 k[6];
-};
-__device__ __forceinline__ u32 top6_insert(Top6 &t, u64 key) {
-  double x = __longlong_as_double((long long)key);
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const double cur = __longlong_as_double((long long)t.k[k]);
-    const double lo = f64_min_raw(cur, x);
-    x = f64_max_raw(cur, x);
-    t.k[k] = (u64)__double_as_longlong(lo);
-  }
-  return (u32)__double2hiint(x);
-}
-template <int Q>  // broadcast of lane Q's value inside every quad (DPP quad_perm: no LDS round trip)
-__device__ __forceinline__ u64 quad_bcast(u64 v) {
-  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-  const int lo = __builtin_amdgcn_mov_dpp((int)(u32)v, ctrl, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_mov_dpp((int)(u32)(v >> 32), ctrl, 0xF, 0xF, false);
-  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
-}
-// G = 4 lanes per query (a quad). Same contract as nl_search<4> on level 1.
-__device__ __forceinline__ bool nl_search8(const NlView &nl, const float4 *__restrict__ map_in, float wx, float wy, float wz,
-                                           int sub, float limit2, Top5 &t, float &lb2) {
-  constexpr int G = 4;
-  const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);
-  float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
-  float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
-  const int cx = (int)kxf, cy = (int)kyf, cz = (int)kzf;
-  u64 key = cell_key_d(cx, cy, cz);
-  u32 slot = hash_key_d(key) & nl.tmask;
-  u32 start, count;
-  cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
-  // the query on the doubled grid of this list's block (inside the middle third of the span)
-  const int qwx = (int)rintf((wx - nl8_origin(cx, nl.cf)) * nl.inv_s2), qwy = (int)rintf((wy - nl8_origin(cy, nl.cf)) * nl.inv_s2),
-            qwz = (int)rintf((wz - nl8_origin(cz, nl.cf)) * nl.inv_s2);
-  Top6 t6;
-#pragma unroll
-  for (int k = 0; k < 6; k++) t6.k[k] = TOP5_MAXKEY;
-  u32 ev = (u32)(TOP5_MAXKEY >> 32);
-  const uint4 *lp = nl.pts8 + (start >> 1);
-  const u32 npairs = (count + 1u) >> 1;
-#ifndef KS_NL8_LOADS
-#define KS_NL8_LOADS 8
-#endif
-  constexpr int NLD = KS_NL8_LOADS;  // 16-byte loads in flight per lane (two entries each)
-  for (u32 jp = (u32)sub; jp < npairs; jp += NLD * G) {
-    uint4 m[NLD];
-#pragma unroll
-    for (int u = 0; u < NLD; u++) m[u] = lp[min(jp + (u32)(u * G), npairs - 1)];
-#pragma unroll
-    for (int u = 0; u < NLD; u++) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const u32 lo = h ? m[u].z : m[u].x, hi = h ? m[u].w : m[u].y;
-        const int ex = (int)((lo & 0x1FFFu) << 1) - qwx, ey = (int)(((lo >> 13) & 0x1FFFu) << 1) - qwy,
-                  ez = (int)(((__builtin_amdgcn_alignbit(hi, lo, 26)) & 0x1FFFu) << 1) - qwz;
-        const u32 d2 = (u32)(ex * ex) + (u32)(ey * ey) + (u32)(ez * ez);  // < 3 * 2^28: a positive finite double's high word
-        const u32 id = hi >> 7;
-        const bool ok = 2u * (jp + (u32)(u * G)) + (u32)h < count && id != NL8_TOMB;
-        ev = min(ev, top6_insert(t6, ok ? (((u64)d2 << 32) | (u64)id) : TOP5_MAXKEY));
-      }
-    }
-  }
-  // merge over the quad: six rounds of the 64-bit min-reduction; ev: the seventh grid distance of the query
-  {
-    Top6 out;
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const u64 mine = t6.k[0];
-      u64 mn = mine;
-#pragma unroll
-      for (int sft = G / 2; sft > 0; sft >>= 1) {
-        const u64 other = __shfl_xor(mn, sft);
-        mn = other < mn ? other : mn;
-      }
-      out.k[r] = mn;
-      if (mine == mn && (u32)mine != INVALID) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) t6.k[k] = t6.k[k + 1];
-        t6.k[5] = TOP5_MAXKEY;
-      }
-    }
-    ev = min(ev, (u32)(t6.k[0] >> 32));
-#pragma unroll
-    for (int sft = G / 2; sft > 0; sft >>= 1) ev = min(ev, (u32)__shfl_xor((int)ev, sft));
-    t6 = out;
-  }
-  // can a candidate beyond the six be one of the true five?  E: grid-vs-true distance, in half-steps
-  const float E = 4.0f + 2e-7f * (fabsf(wx) + fabsf(wy) + fabsf(wz)) * nl.inv_s2;
-  const float d5g = (float)(u32)(t6.k[4] >> 32), d7g = (float)ev;  // (a missing key reads as ~2e9: larger than any grid distance)
-  const bool decided = d7g > d5g + 4.0f * E * sqrtf(d5g) + 4.0f * E * E + 1.0f;
-  // exact keys of the six: lane `sub` fetches candidates sub and sub + 4
-  u64 e0 = TOP5_MAXKEY, e1 = TOP5_MAXKEY;
-  {
-    const u32 i0 = sub == 0 ? (u32)t6.k[0] : sub == 1 ? (u32)t6.k[1] : sub == 2 ? (u32)t6.k[2] : (u32)t6.k[3];
-    const u32 i1 = sub == 0 ? (u32)t6.k[4] : sub == 1 ? (u32)t6.k[5] : INVALID;
-#ifdef KS_NL8_NORERANK  // A/B upper bound (WRONG results): what the walk alone costs with half the bytes - no exact re-rank
-    if (i0 != INVALID) e0 = top5_key((float)(u32)(t6.k[sub] >> 32) / (nl.inv_s2 * nl.inv_s2), i0);
-    if (i1 != INVALID) e1 = top5_key((float)(u32)(t6.k[4 + (sub & 1)] >> 32) / (nl.inv_s2 * nl.inv_s2), i1);
-#else
-    if (i0 != INVALID) {
-      const float4 p = map_in[i0];
-      const float ddx = wx - p.x, ddy = wy - p.y, ddz = wz - p.z;
-      e0 = top5_key(ddx * ddx + ddy * ddy + ddz * ddz, i0);  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-    }
-    if (i1 != INVALID) {
-      const float4 p = map_in[i1];
-      const float ddx = wx - p.x, ddy = wy - p.y, ddz = wz - p.z;
-      e1 = top5_key(ddx * ddx + ddy * ddy + ddz * ddz, i1);
-    }
-#endif
-  }
-#pragma unroll
-  for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
-  u32 ev2 = (u32)(TOP5_MAXKEY >> 32);  // exact d2 bits of the one of the six that is not among the five
-  ev2 = min(ev2, top5_insert(t, quad_bcast<0>(e0)));
-  ev2 = min(ev2, top5_insert(t, quad_bcast<1>(e0)));
-  ev2 = min(ev2, top5_insert(t, quad_bcast<2>(e0)));
-  ev2 = min(ev2, top5_insert(t, quad_bcast<3>(e0)));
-  ev2 = min(ev2, top5_insert(t, quad_bcast<0>(e1)));
-  ev2 = min(ev2, top5_insert(t, quad_bcast<1>(e1)));
-#pragma unroll
-  for (int k = 0; k < 5; k++)
-    if (!(t.d(k) <= limit2)) {
-      ev2 = min(ev2, (u32)(t.k[k] >> 32));
-      t.k[k] = top5_key(sentinel, INVALID);
-    }
-  float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
-  float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
-  float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
-  float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
-  const float g2 = g1 * g1 * 0.99999f;
-  // outsiders: the loser of the six (exact distance), everything from the seventh on (grid distance minus E), the rest of the map
-  const float r7 = fmaxf(sqrtf(d7g) - E, 0.f) / nl.inv_s2;
-  lb2 = __uint_as_float(min(min(ev2, __float_as_uint(r7 * r7)), __float_as_uint(g2)));
-  return decided && (t.og(4) != INVALID) && (t.d(4) <= g2);
-}
 
 // a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
@@ -1045,14 +893,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
       const float4 ww = S.w[ql];
       Top5 t;
       float lb2;
-#if defined(KS_NL8_ONLY)
-      const bool certified = nl_search8(nl1, a.map_in, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
-#elif defined(KS_NL16_ONLY)
       const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
-#else
-      const bool certified = nl1.pts8 ? nl_search8(nl1, a.map_in, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2)
-                                      : nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
-#endif
       if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
@@ -1821,7 +1662,6 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
 static NlView view_of(const NList &nl) {
   NlView v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
-  v.pts8 = reinterpret_cast<const uint4 *>(nl.pts8), v.inv_s2 = 2.0f * NL8_GRID / (3.0f * nl.cf);
   return v;
 }
 
