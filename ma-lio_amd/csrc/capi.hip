@@ -271,7 +271,7 @@ int malio_destroy(malio_handle_t h) {
   free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_dq), fr(c->d_dq_ctl), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt), fr(c->d_del);
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
@@ -1150,7 +1150,6 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
   memcpy(res + ns + 4, own + 4, sizeof(double) * 4);
   rc = finish_host(c, res, res + ns, out);
   c->last_M = out->M;
-  if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;
   if (stats2) stats2[0] = c->node_hits, stats2[1] = c->node_misses;
   return rc;
 }
@@ -1175,7 +1174,6 @@ int malio_measure_finish(malio_handle_t h, const double *sums_host, const double
   prof_end(h);
   int rc = finish_host(h, sums_host, minmax_host, out);
   h->last_M = out->M;
-  if (h->last_pass_search) h->defer_enabled = minmax_host[5] >= DEFER_SCORE_MIN;  // see malio_measure
   return rc;
 }
 
@@ -1250,9 +1248,6 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   c->last_M = out->M;
   memcpy(c->mm_guess, res + ns, sizeof(double) * 4);  // the next pass of this scan speculates on these
   c->mm_guess_valid = true;
-  // k_search_tail is launched with the next search pass only while search passes keep meeting workgroups full of
-  // uncertified queries (word 5 after the sums); without it such workgroups serve their queries themselves
-  if (converge) c->defer_enabled = res[ns + 5] >= DEFER_SCORE_MIN;
   if (want_rows && out->valid) {
     // Rows path (parity tests, M < n fallback): dense per-point rows back to the host, expanded to
     // C columns, scaled by w_loc (laserMapping.cpp:758-759), compacted in ascending original index.

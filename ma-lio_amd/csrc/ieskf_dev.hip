@@ -33,7 +33,7 @@ struct StepArgs {
   double *P_prop;      // [n*n] the propagated covariance the update started from
   double *P_proj;      // [n*n] projected P_propagated of the last valid iteration (what a loop that runs out leaves in P_)
   const double *sums;  // [L][97] of the pass that just ran (k_final_reduce)
-  const double *mm;    // its extrema words: [0..3] extrema, [5] deferral score of the search kernel
+  const double *mm;    // its extrema words: [0..3] extrema
   char *out;           // pinned host memory: DevLoop copy, then P (n*n) at OUT_P_OFF
   int last;            // the last pass the host enqueued
 };
@@ -444,7 +444,6 @@ __global__ void __launch_bounds__(ST_BLK) k_ieskf_step(StepArgs g) {
     dl->passes += 1;
     dl->searches += was_search ? 1 : 0;
     if (was_search) dl->search_skip = dl->skip_opt;  // its certificates exist: later search passes may keep neighbours
-    if (was_search) dl->heavy = (int)g.mm[5];
     dl->last_search = was_search ? 1 : 0;
     dl->commit_prev = M > 0 ? 1 : 0;
     dl->lastM = M;
@@ -462,7 +461,6 @@ __global__ void __launch_bounds__(ST_BLK) k_ieskf_step(StepArgs g) {
       dl->done = 1;
     } else {
       dl->mm_parity ^= 1;
-      if (dl->converge) dl->dq_parity ^= 1;
     }
     dl->stamps[10] = wall_clock64();
     if (ends) {
@@ -513,7 +511,7 @@ int ieskf_update_device_begin(Ctx *c, const malio_state_t *xio, const double *Pi
   DevLoop *in = reinterpret_cast<DevLoop *>(c->h_loop_in);
   memset(in, 0, sizeof(DevLoop));
   in->done = 0, in->converge = 1, in->i = -1, in->t = 0, in->status = MALIO_OK;
-  in->mm_parity = c->mm_parity ^ 1, in->dq_parity = c->dq_parity ^ 1;
+  in->mm_parity = c->mm_parity ^ 1;
   in->commit_prev = c->last_M > 0 ? 1 : 0;
   in->maximum_iter = maximum_iter, in->L = L, in->extrinsic_est_en = c->prm.extrinsic_est_en;
   // the loop's first pass is a search pass: it may keep neighbours of an earlier search of this scan (malio_measure before
@@ -560,9 +558,8 @@ int ieskf_update_device_end(Ctx *c, malio_state_t *xio, double *Pio, int *stats)
   c->stage_pending = false;
   // ---- results ----
   const DevLoop *o = reinterpret_cast<const DevLoop *>(c->h_loop_out);
-  c->mm_parity = o->mm_parity, c->dq_parity = o->dq_parity;
+  c->mm_parity = o->mm_parity;
   c->last_pass_search = o->last_search != 0;
-  c->defer_enabled = (double)o->heavy >= DEFER_SCORE_MIN;
   if (o->status == MALIO_SMALL_M_FALLBACK) {
     c->last_M = -1;  // the pass that ran folded the previous results already; the host loop starts this scan's update over
     return MALIO_SMALL_M_FALLBACK;
@@ -688,8 +685,8 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       blk->converge = redo ? 0 : converge;
       blk->L = L, blk->maximum_iter = maximum_iter, blk->extrinsic_est_en = c->prm.extrinsic_est_en;
       c->mm_parity ^= 1;
-      if (blk->converge) c->dq_parity ^= 1, blk->search_skip = search_skip_begin(c);
-      blk->mm_parity = c->mm_parity, blk->dq_parity = c->dq_parity;
+      if (blk->converge) blk->search_skip = search_skip_begin(c);
+      blk->mm_parity = c->mm_parity;
       // (a repeated pass folds nothing: the pass it repeats has consumed the pending fold, and its own results are the
       // repeat's results)
       blk->commit_prev = (!redo && c->last_M > 0) ? 1 : 0;
@@ -819,7 +816,6 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     c->last_M = mo.M;
     memcpy(c->mm_guess, res + ns_, sizeof(double) * 4);
     c->mm_guess_valid = true;
-    if (converge) c->defer_enabled = res[ns_ + 5] >= DEFER_SCORE_MIN;
     if (rc < 0) {
       rc_out = rc;
       break;

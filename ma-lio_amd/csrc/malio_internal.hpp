@@ -199,10 +199,8 @@ struct DevLoop {
   int passes, searches, lastM;
   int status;       // MALIO_OK, MALIO_SMALL_M_FALLBACK (n > M: the host redoes the update on the rows path) or < 0
   int mm_parity;    // extrema slot set the NEXT pass accumulates into (the other one is cleared by it)
-  int dq_parity;    // deferral counter set of the NEXT search pass
   int commit_prev;  // the previous pass was valid: its (sel, trace) are folded into normal_y by the next one
   int valid_any;    // a pass was valid: P_proj of the last valid iteration is what a loop that runs out leaves behind
-  int heavy;        // deferral score of the last search pass (steers the host's k_search_tail switch)
   int lastM_valid;  // accepted points of the last VALID pass (stats[2])
   int last_search;  // the last pass that ran was a search pass (feats_down_world then lives in world4)
   int maximum_iter, L, extrinsic_est_en;
@@ -434,7 +432,7 @@ struct Ctx {
   float4 *d_plane = nullptr;   // [N] pabcd
   float *d_pd2 = nullptr;      // [N]
   float *d_world = nullptr;    // [3][N]
-  float4 *d_world4 = nullptr;  // [N] world point of the search pass (k_search phase A; k_search_tail, k_far_nearest)
+  float4 *d_world4 = nullptr;  // [N] world point of the search pass (phase A of the search; k_far_nearest)
   float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
   float4 *d_cert = nullptr;    // [N] search-skip certificate (world point of the last list walk, radius free of outsiders)
   unsigned char *d_kept = nullptr;  // [N] the last search pass kept the point's cached neighbours
@@ -445,10 +443,6 @@ struct Ctx {
   unsigned char *d_sel = nullptr;  // [N]
   unsigned char *d_nfound = nullptr;  // [N]
   // reductions
-  u32 *d_dq = nullptr;       // [N] queries k_search handed to k_search_tail
-  u32 *d_dq_ctl = nullptr;   // [0..1] deferred counts, [2..3] heavy-workgroup counts, by search-pass parity
-  int dq_parity = 0;
-  bool defer_enabled = true;  // launch k_search_tail (switched by the heavy-workgroup count of the last search pass)
   bool last_pass_search = false;
   u64 *d_mmslots = nullptr;  // [2 parities][64 slots][5]: max_u, min_u, max_R, min_R (order-encoded doubles), count
   int mm_parity = 0;
@@ -478,7 +472,7 @@ struct Ctx {
   char *h_loop_in = nullptr;     // pinned: what one update uploads (DevLoop + P_prop)
   char *h_loop_out = nullptr;    // pinned, device-mapped: what the last step kernel stores (DevLoop + P)
   char *d_loop_out = nullptr;    // ... its device alias
-  u32 *d_gate_ticket = nullptr;  // (word 3 of d_dq_ctl's allocation is not used: own word, zeroed once)
+  u32 *d_gate_ticket = nullptr;  // (own allocation, zeroed once)
   char *h_gate = nullptr, *d_gate = nullptr;  // pinned + device alias: control block and sequence words of the gated loop
   // Large BAR: the host stores the control block and its sequence word straight into (fine-grained) device memory, so the
   // gate polls and copies local memory instead of reading pinned host memory across PCIe (null: no large BAR, pinned path)
@@ -593,7 +587,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
 // to d_mm_out)
 int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_sums_out, bool want_rows,
                 const GateArgs *gate = nullptr);  // gate: the last kernel announces its completion (see k_final_reduce)
-int reset_pass_state(Ctx *c);  // measure.hip: extrema slots, deferral counters and parities as a fresh handle has them
+int reset_pass_state(Ctx *c);  // measure.hip: extrema slots and parity as a fresh handle has them
 // measure.hip, the speculating pass (k_pass -> k_final_reduce<16>): may this pass run that way? launch it (arguments by
 // value, or reading the device loop's control block; results land in h_res like the three-kernel pass'); afterwards:
 // *hit = the guessed extrema were the true ones (else the caller redoes the rows)
@@ -626,10 +620,6 @@ inline hipError_t mbox(Ctx *c, u32 **out, u32 **dev = nullptr) {
 constexpr int MBOX_SMALL_SEQ = 13;  // sequence word of k_scan_small_dev (mapinc_small_batch polls it instead of synchronising the stream)
 constexpr int MBOX_APPLY_SEQ = 14;  // sequence word of k_publish_states (map_apply_finish waits for it, not for the stream)
 
-// k_search_tail costs ~17 us even for a handful of queries (launch + one dependent chain): it is only worth launching
-// when at least this many workgroups were loaded with uncertified queries (each counts 1, or 64 when more than half of
-// its queries are), i.e. when serving them in place would stretch the search kernel by more than that.
-constexpr double DEFER_SCORE_MIN = 64.0;
 constexpr int FUSE_COOLDOWN_MIN = 3, FUSE_COOLDOWN_MAX = 48;  // passes without speculation after a wrong guess (fused_collect)
 
 // host/predict.cpp
@@ -644,7 +634,7 @@ int ieskf_update_device_end(Ctx *c, malio_state_t *x, double *P, int *stats);   
 void free_dev_loop(Ctx *c);
 int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
 // measure.hip: the pass kernels of one iteration of the device loop (k_search/k_reuse by the control block's converge
-// flag, [k_search_tail], k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
+// flag, k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
 int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate = nullptr);  // gate: rides on the last kernel
 int prepare_scan_dev(Ctx *c, const malio_state_t *s);  // map lists in sync, scan sorted
 void publish_pack_now(Ctx *c);  // a one-wave kernel that publishes k_pack_raw's counts (when no grouping kernel will)

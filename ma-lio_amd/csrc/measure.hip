@@ -2,7 +2,6 @@
 // H^T R^-1 H / H^T R^-1 h accumulation of esekfom.hpp:621-635, as gfx950 kernels:
 //   k_search         a1-a3 (+a6/a8 trace) of a SEARCH pass: world transform, 5-NN on the two-level neighbour lists,
 //                    float plane fit, gates - one kernel, three phases per workgroup (see its header)
-//   k_search_tail    the level-2 searches of workgroups full of uncertified queries, spread over the GPU
 //   k_reuse          the same for a REUSE pass (neighbours and plane kept)
 //   k_rows_reduce    a5/a7/a10: Jacobian row, FIC weights, per-workgroup 16x16 f64 MFMA outer-product accumulation
 //   k_final_reduce   deterministic fixed-order sum of the workgroup partials
@@ -90,9 +89,6 @@ struct Pass1Args {
   float4 *world4;  // [N] world point of the search pass
   u64 *mm_cur;     // extrema slots this pass accumulates into (MmSlots)
   u64 *mm_next;    // the other parity: reset here for the next pass
-  u32 *dq;         // [N] queries deferred to k_search_tail
-  u32 *dq_ctl;     // [0..1] deferred count by pass parity, [2..3] workgroups with > DEFER_MIN uncertified queries
-  int parity, defer;
   PartView part;   // spatial shard this handle serves (world <= 1: everything)
   u32 *nbr;  // [5][N] ORIGINAL map indices (INVALID when fewer than 5 inside the radius)
   float4 *plane;
@@ -113,7 +109,7 @@ struct Pass1Args {
 };
 // what a DEV kernel reads from the control block instead of from its arguments
 struct PassDyn {
-  int commit_prev, parity, skip;
+  int commit_prev, skip;
   u64 *mm_cur, *mm_next;
 };
 template <bool DEV>
@@ -121,10 +117,10 @@ __device__ __forceinline__ PassDyn pass_dyn(const Pass1Args &a) {
   PassDyn d;
   if (DEV) {
     const int mp = a.dl->mm_parity;
-    d.commit_prev = a.dl->commit_prev, d.parity = a.dl->dq_parity, d.skip = a.dl->search_skip;
+    d.commit_prev = a.dl->commit_prev, d.skip = a.dl->search_skip;
     d.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, d.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
   } else {
-    d.commit_prev = a.commit_prev, d.parity = a.parity, d.skip = a.skip, d.mm_cur = a.mm_cur, d.mm_next = a.mm_next;
+    d.commit_prev = a.commit_prev, d.skip = a.skip, d.mm_cur = a.mm_cur, d.mm_next = a.mm_next;
   }
   return d;
 }
@@ -562,16 +558,20 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, const PassDyn &
 #endif
 constexpr int NL1_G = KS_G;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
 constexpr unsigned char NF_PENDING = 0xFF;
-constexpr unsigned char NF_DEFERRED = 0xFE;  // handed to k_search_tail
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
-constexpr int TAIL_BLOCKS = 2048;  // k_search_tail: 8192 waves x 4 queries = one sweep up to 32 k deferred queries (a second sweep
-                                   // costs its waves the whole search + point-phase chain again: 45 us instead of 25)
-constexpr int TAIL_G = 8;          // lanes per deferred query (level-2 lists hold ~180..900 points). Swept at config 5 with
-                                   // the tail at 4 waves per SIMD: 32 / 16 / 8 / 4 lanes -> 38.0 / 27.5 / 21.5 / 22.4 us - above
-                                   // 8 k deferred queries the kernel is bound by the number of waves, not by a walk's length
-constexpr int DEFER_MIN = 24;                // a workgroup serves up to this many uncertified queries itself (six level-2 walks
-                                             // per wave cost it less than the tail kernel costs the pass; swept at config 5:
-                                             // 8 / 12 / 16 / 24 / 32 / 48 -> 92.6 / 87.4 / 82.4 / 80.2 / 82.2 / 82.0 us per pass)
+#ifndef KS_L2G
+#define KS_L2G 4
+#endif
+// position of the n-th (0-based) set bit of m; popcount(m) > n
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll(m & ((1ull << w) - 1ull));
+    if (n >= c) n -= c, m >>= w, pos += w;
+  }
+  return pos;
+}
 struct NlView {
   const Cell *table;
   u32 tmask;
@@ -636,7 +636,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
 // within 3e-7 relative of the true ones; sqrtf is correctly rounded)
 __device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.99999f; }
 
-// a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of k_search, and k_search_tail): writes the
+// a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of the search phases): writes the
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
 // cert_r >= 0: the neighbours come from a list walk at w - its certificate (w, radius free of outsiders) is stored for the
 // later search passes of this scan; < 0: the neighbours were kept under the stored certificate, which stays.
@@ -760,7 +760,6 @@ __device__ __forceinline__ void wave_minmax_publish(const Pass1Args &a, u64 *mm_
 // others on the same CU.
 constexpr int SQ = 64;             // queries per workgroup: one per lane of wave 0 in phases A and C
 constexpr int KS_BLK = SQ * NL1_G;  // workgroup size of k_search
-constexpr int KS_WAVES = KS_BLK / 64;
 #ifndef KS_WPE
 #define KS_WPE 7
 #endif
@@ -801,10 +800,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   bool keep = false;
   PH(0, 0);
   PH_ENTER();
-  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) {  // the OTHER parity's slots and counters, for the next pass
-    mm_reset_slot(dy.mm_next, threadIdx.x);
-    if (threadIdx.x == 0) a.dq_ctl[dy.parity ^ 1] = 0, a.dq_ctl[2 + (dy.parity ^ 1)] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);  // the OTHER parity's slots, for the next pass
   if (cwave) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
@@ -906,55 +902,44 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   PH(0, 2);
   PH_NOTE(2, wall_clock64());
   PH_NOTE(3, 0);
-  // ---- level 2: the queries level 1 could not certify are served one at a time by a whole wave (64 lanes striding
-  // over the ~180..900-point level-2 list); the workgroup's 4 waves share them round-robin, so a workgroup full of
-  // unmatched queries (map frontier, thinned map) costs 16 serial searches per wave instead of 64 in wave 0 ----
+  // ---- level 2 (phase B'): the queries level 1 could not certify walk their ~180..900-point level-2 list ----
   {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     // lane <-> query, the same in every wave (a point of another shard sits at 3e9 and is never searched further)
     const bool pend = (qidx(lane) < qend) && S.nf[lane] == NF_PENDING && S.w[lane].x < 1e9f;
     unsigned long long todo = __ballot(pend);
-    // every wave must have taken its snapshot of the flags before any wave rewrites one (the serving wave stores the
-    // final count, wave 0 stores NF_DEFERRED): a wave that read s_nf late would see a different `todo`, the round-robin
-    // assignment below would differ between waves and a query could be left NF_PENDING
+    // every wave must have taken its snapshot of the flags before any group rewrites one (the serving group stores the
+    // final count): a wave that read S.nf late would see a different `todo`, the assignment of queries to groups below
+    // would differ between waves and a query could be left NF_PENDING
     __syncthreads();
     if (todo) {  // workgroup-uniform: every wave took the same snapshot
       const int npend = __popcll(todo);
       PH_NOTE(3, npend);
-      const bool heavy = npend > DEFER_MIN;
-      // steers the host's defer switch (DEFER_SCORE_MIN): a workgroup more than half full of uncertified queries
-      // would take tens of microseconds longer on its own and counts as 64, a mildly loaded one as 1
-      if (heavy && threadIdx.x == 0) atomicAdd(&a.dq_ctl[2 + dy.parity], npend > 32 ? 64u : 1u);
-      if (heavy && a.defer) {
-        // too many for this workgroup: hand them to k_search_tail, which spreads them one per wave over the GPU
-        if (wave == 0) {
-          u32 base = 0;
-          if (lane == 0) base = atomicAdd(&a.dq_ctl[dy.parity], (u32)npend);
-          base = __shfl(base, 0);
-          if (pend) {
-            a.dq[base + __popcll(todo & ((1ull << lane) - 1))] = (u32)qidx(lane);
-            S.nf[lane] = NF_DEFERRED;
-          }
-        }
-      } else {
-        int ord = 0;
-        while (todo) {
-          const int l = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          if ((ord++ % KS_WAVES) != wave) continue;
-          const float4 ww = S.w[l];
-          Top5 t;
-          float lb2;
-          nl_search<64>(nl2, ww.x, ww.y, ww.z, lane, 5.0f, t, lb2);  // merged list is identical in every lane
-          if (lane < 5) {
-            S.og[lane][l] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
-          } else if (lane == 5) {
-            int nf = 0;
+      {
+        // L2G lanes per uncertified query: the workgroup's 256 / L2G groups walk as many level-2 lists side by side - with
+        // the four lanes of level 1 ALL of a workgroup's uncertified queries in one round. Rounds 1-3 gave such a query a
+        // whole wave (a walk of two batches, but four queries at a time: a workgroup of the tunnel scene, BASELINE config 5,
+        // holds 9..64 of them and walked up to six times in a row) and handed workgroups with more than 24 to a kernel of
+        // their own, k_search_tail, behind the search (22 us), which also kept such passes off the one-kernel path.
+        // Swept at config 5 (profiles/round4/r04c_level2_groups.txt), whole search pass: 64 lanes + tail 84 us, 16 lanes + tail
+        // 75, and without any deferral 32 / 16 / 8 / 4 lanes -> 68 / 57 / 50 / 49 us; configs 1-4 do not move.
+        constexpr int L2G = KS_L2G, NGRP = KS_BLK / L2G;
+        const int grp = (int)threadIdx.x / L2G, sub = (int)threadIdx.x % L2G;
+        for (int r0 = 0; r0 < npend; r0 += NGRP) {
+          const int ord = r0 + grp;
+          if (ord < npend) {  // (the lanes of a group branch together: the shuffles of the merge stay inside it)
+            const int l = nth_set_bit(todo, ord);
+            const float4 ww = S.w[l];
+            Top5 t;
+            float lb2;
+            nl_search<L2G>(nl2, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);  // merged list is identical in every lane of the group
+            if (sub == 0) {
+              int nf = 0;
 #pragma unroll
-            for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
-            S.nf[l] = (unsigned char)nf;
-          } else if (lane == 6) {
-            S.cr[l] = cert_radius(lb2);
+              for (int k = 0; k < 5; k++) S.og[k][l] = t.og(k), nf += (t.og(k) != INVALID);
+              S.nf[l] = (unsigned char)nf;
+              S.cr[l] = cert_radius(lb2);
+            }
           }
         }
       }
@@ -975,7 +960,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   // (what phase A knew is read back from LDS instead of being kept in registers across the list walk: the walk has none to spare)
   const float4 wq = S.w[lane];
   const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
-  if (served && nf != NF_DEFERRED)
+  if (served)
     point_phase(a, dy.commit_prev, ic, wq, S.nb[lane], og, nf, S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl,
                 po.pd2, po.q);
   PH(0, 8);
@@ -1010,101 +995,6 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   PH_EXIT();
 }
 
-// Deferred level-2 work of k_search: 16 lanes per query on the level-2 list, then the first lane of each group runs
-// the point phase. Workgroups whose queries are mostly unmatched - the map frontier, a thinned map - would otherwise serialise
-// 16 such searches per wave while the rest of the GPU idles.
-// (4 waves per SIMD: 109 VGPRs without a spill, and the 4 250 waves that 17 k deferred queries need - config 5 - are one
-// generation instead of one and a half: 38.8 -> 36.4 us; 5 spills 31 VGPRs, 6 spills 79)
-template <bool DEV>
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) k_search_tail(Pass1Args a, NlView nl2) {
-  if (DEV && (a.dl->done || !a.dl->converge)) return;  // the loop is over, or this pass is a reuse pass
-  const PassDyn dy = pass_dyn<DEV>(a);
-  const QuatConst &qc = DEV ? a.dl->qc : a.qc;
-  // TAIL_G lanes per query: 64 / TAIL_G queries per wave search concurrently, then their first lanes run the point phase together
-  const int lane = threadIdx.x & 63, sub = threadIdx.x & (TAIL_G - 1);
-  const u32 grp = (blockIdx.x * BLK + threadIdx.x) / TAIL_G, ngrp = (gridDim.x * BLK) / TAIL_G;
-  const u32 cnt = a.dq_ctl[dy.parity];
-  double mxu = -INFINITY, mnu = INFINITY, mxr = -INFINITY, mnr = INFINITY;
-  u64 nsel = 0;
-  // Few deferred queries: a whole wave per query - 14 entries of a level-2 list per lane instead of 54, two batches of
-  // loads instead of seven on the chain that IS this kernel's duration (its waves all run at once: the kernel takes as
-  // long as one 16-lane walk + one point phase, whatever the number of queries).
-  const u32 nwaves = (gridDim.x * BLK) >> 6;
-  if (cnt <= nwaves) {
-    const u32 wv = (blockIdx.x * BLK + threadIdx.x) >> 6;
-    for (u32 j = wv; j < cnt; j += nwaves) {  // wave-uniform
-      const int i = (int)a.dq[j];
-      const float4 w = a.world4[i];
-      Top5 t;
-      float lb2;
-      nl_search<64>(nl2, w.x, w.y, w.z, lane, 5.0f, t, lb2);
-      if (lane == 0) {
-        int nf = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
-        bool selected;
-        double ucov, tr;
-        const u32 og5[5] = {t.og(0), t.og(1), t.og(2), t.og(3), t.og(4)};
-        double nb;
-        {
-          const float4 q = a.scan[i];
-          float wx, wy, wz;
-          world_point(qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
-        }
-        float4 pl_, q_;
-        float pd2_;
-        point_phase(a, dy.commit_prev, i, w, nb, og5, nf, cert_radius(lb2), selected, ucov, tr, pl_, pd2_, q_);
-        if (selected) {
-          nsel++;
-          mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
-          if (a.extrinsic_est_en) mxr = fmax(mxr, tr), mnr = fmin(mnr, tr);
-        }
-      }
-    }
-    if (wv >= cnt) return;
-    if (lane == 0) mm_publish(dy.mm_cur, mxu, mnu, mxr, mnr, nsel);
-    return;
-  }
-  const u32 sweeps = (cnt + ngrp - 1) / ngrp;
-  for (u32 sw = 0; sw < sweeps; sw++) {  // wave-uniform trip count: the shuffles inside need every lane
-    const u32 j = sw * ngrp + grp;
-    if (j - (u32)(lane / TAIL_G) >= cnt) break;  // none of this wave's queries exists (wave-uniform)
-    const bool live = j < cnt;
-    const int i = (int)a.dq[live ? j : 0];
-    const float4 w = a.world4[i];
-    Top5 t;
-    float lb2;
-    nl_search<TAIL_G>(nl2, w.x, w.y, w.z, sub, 5.0f, t, lb2);
-    if (live && sub == 0) {
-      int nf = 0;
-#pragma unroll
-      for (int k = 0; k < 5; k++) nf += (t.og(k) != INVALID);
-      bool selected;
-      double ucov, tr;
-      const u32 og5[5] = {t.og(0), t.og(1), t.og(2), t.og(3), t.og(4)};
-      double nb;  // |p'| of the range gate: recomputed for the few deferred queries instead of stored for all
-      {
-        const float4 q = a.scan[i];
-        float wx, wy, wz;
-        world_point(qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
-      }
-      float4 pl_, q_;
-      float pd2_;
-      point_phase(a, dy.commit_prev, i, w, nb, og5, nf, cert_radius(lb2), selected, ucov, tr, pl_, pd2_, q_);
-      if (selected) {
-        nsel++;
-        mxu = fmax(mxu, ucov), mnu = fmin(mnu, ucov);
-        if (a.extrinsic_est_en) mxr = fmax(mxr, tr), mnr = fmin(mnr, tr);
-      }
-    }
-  }
-  if (sweeps == 0) return;
-  mxu = wave_max(mxu), mnu = wave_min(mnu), mxr = wave_max(mxr), mnr = wave_min(mnr);
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) nsel += __shfl_xor(nsel, d);
-  if (lane == 0) mm_publish(dy.mm_cur, mxu, mnu, mxr, mnr, nsel);
-}
-
 // REUSE pass of the host-driven path, thread per point (the device loop runs it inside k_search<true>).
 __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
   const int i = blockIdx.x * BLK + threadIdx.x;
@@ -1120,14 +1010,13 @@ __global__ void __launch_bounds__(BLK) k_reuse(Pass1Args a) {
 __global__ void k_mm_init(u64 *slots) { mm_reset_slot(slots, threadIdx.x); }
 
 // Staged (multi-GPU) path: one wave folds the slots into [max_u, -min_u, max_R, -min_R, M] for the all-reduce.
-__global__ void __launch_bounds__(64) k_minmax_reduce(const u64 *__restrict__ slots, int extrinsic_est_en,
-                                                      const u32 *__restrict__ heavy, double *out) {
+__global__ void __launch_bounds__(64) k_minmax_reduce(const u64 *__restrict__ slots, int extrinsic_est_en, double *out) {
   double o5[5];
   mm_fold_wave(slots, extrinsic_est_en, o5);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 5; k++) out[k] = o5[k];
-    out[5] = (double)*heavy;  // not reduced across ranks: each rank steers its own defer switch
+    out[5] = 0.0;  // (word 5 of the extrema row: reserved - it carried the deferral score of rounds 1-3)
   }
 }
 
@@ -1146,15 +1035,13 @@ struct Pass2Args {
   WeightConst wc;
   const double *minmax4;  // [max_ucov, -min_ucov, max_R, -min_R] when the caller reduced them (multi-GPU), else null
   const u64 *mmslots;  // extrema slots of stage 1 (single-GPU path: folded here by the first wave)
-  const u32 *heavy;    // workgroups of the search kernel that were full of uncertified queries (this pass)
   double *mm_out;         // where workgroup 0 publishes the folded extrema + M for the host
   double *partials;       // [NSUM][pstride]: entry-major, so the final sum reads each entry's partials contiguously
   int pstride;
   double *rows;           // optional [N][14]: u[12], hs, r   (sorted order)
-  // device loop (DEV = true): the matrix form of the state, the slot parity and the deferral parity come from *dl
+  // device loop (DEV = true): the matrix form of the state and the slot parity come from *dl
   const DevLoop *dl;
   const u64 *mm_base;     // [2 parities][MM_SLOTS][5]
-  const u32 *dq_ctl;      // deferral counters ([2 + parity]: the search kernel's heavy-workgroup score)
 };
 
 // a5 + a7: weights and the 12 non-zero entries of the (c_i-scaled) Jacobian row of one accepted point
@@ -1231,7 +1118,6 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __shared__ double mm_s[5];
   if (DEV && a.dl->done) return;
   const u64 *mmslots = DEV ? a.mm_base + (size_t)a.dl->mm_parity * MM_SLOTS * 5 : a.mmslots;
-  const u32 *heavy = DEV ? a.dq_ctl + 2 + a.dl->dq_parity : a.heavy;
   const PassConst &pc = DEV ? a.dl->pc : a.pc;
   PH(1, 0);
   // this thread's point: its loads are issued before the extrema fold and the barrier behind it (nothing below needs
@@ -1257,7 +1143,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
-        a.mm_out[5] = (double)*heavy;
+        a.mm_out[5] = 0.0;
       }
     }
   } else if (threadIdx.x < 64) {
@@ -1269,7 +1155,7 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
       if (blockIdx.x == 0 && a.mm_out) {
 #pragma unroll
         for (int k = 0; k < 5; k++) a.mm_out[k] = o5[k];
-        a.mm_out[5] = (double)*heavy;
+        a.mm_out[5] = 0.0;
       }
     }
   }
@@ -1391,15 +1277,14 @@ __device__ __forceinline__ double butterfly_up(double a) {
 // LPL = leaves per lane: 4 when the leaves are k_rows_reduce's workgroup partials (each the node over 4 tiles), 16 when they
 // are the tiles of k_pass themselves - the same tree either way.
 // fold (k_pass' pass: nobody has folded the extrema slots yet): the first wave of workgroup 0 folds them and publishes
-// [max_u, -min_u, max_R, -min_R, M, heavy score] next to the sums, as k_rows_reduce does on the three-kernel path.
+// [max_u, -min_u, max_R, -min_R, M, 0] next to the sums, as k_rows_reduce does on the three-kernel path.
 // With a gate (gate.msg_seq set): the workgroup that finishes last - a ticket counter - announces the sums to the host
 // through a sequence word in pinned memory and, in the gated update loop (gate.dl set), waits for the next pass' control
 // block and installs it (gate_body): the gate costs no launch of its own.
 struct FoldArgs {
   const u64 *mmslots;  // this pass' slot set (device loop: the base of both sets, parity from the control block); null: no fold
-  const u32 *dq_ctl;   // deferral counters ([2 + parity]: heavy-workgroup score of the search kernel)
   double *mm_out;
-  int extrinsic_est_en, dq_parity;
+  int extrinsic_est_en;
 };
 constexpr int FR16_BLK = 1024;  // workgroup of k_final_reduce<16>: four (LiDAR, entry) pairs, four waves each
 template <int LPL>
@@ -1415,7 +1300,7 @@ __global__ void __launch_bounds__(LPL == 16 ? FR16_BLK : BLK) k_final_reduce(con
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 5; k++) fold.mm_out[k] = o5[k];
-      fold.mm_out[5] = (double)fold.dq_ctl[2 + (dl ? dl->dq_parity : fold.dq_parity)];
+      fold.mm_out[5] = 0.0;
     }
   }
   if (LPL == 16) {
@@ -1518,8 +1403,7 @@ __global__ void __launch_bounds__(LPL == 16 ? FR16_BLK : BLK) k_final_reduce(con
 // malio_measure speculates on search passes only. In the enqueued-ahead update every unit is a k_pass unit: there the
 // three-kernel unit pays for reading the matrix form of the state through vector loads (k_rows_reduce<true>: 82 VGPRs,
 // 8.1-8.6 us) and the update gains 4-9 us.
-// Not used when queries may be deferred to k_search_tail (their planes do not exist yet when the rows are formed) or for the
-// dense rows of the rows path. On a map shard a workgroup of other shards' tiles stores a zero tile (malio_measure_node
+// Not used for the dense rows of the rows path. On a map shard a workgroup of other shards' tiles stores a zero tile (malio_measure_node
 // speculates on the GLOBAL extrema of the previous pass; hit or miss is decided across the shards by the exchange).
 struct FuseArgs {
   int seg_start[MALIO_MAX_LIDAR + 1];
@@ -1556,10 +1440,10 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   PassDyn dy;
   if (DEV) {
     const int mp = dl->mm_parity;
-    dy.commit_prev = dl->commit_prev, dy.parity = dl->dq_parity, dy.skip = dl->search_skip;
+    dy.commit_prev = dl->commit_prev, dy.skip = dl->search_skip;
     dy.mm_cur = a.mm_base + (size_t)mp * MM_SLOTS * 5, dy.mm_next = a.mm_base + (size_t)(mp ^ 1) * MM_SLOTS * 5;
   } else {
-    dy.commit_prev = a.commit_prev, dy.parity = a.parity, dy.skip = a.skip, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
+    dy.commit_prev = a.commit_prev, dy.skip = a.skip, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
   }
   const int converge = DEV ? dl->converge : f.converge;
   // this workgroup's 64 points: inside ONE LiDAR segment
@@ -1584,7 +1468,9 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
     if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   }
+  PH(2, 0);
   wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
+  PH(2, 1);
   // ---- a5 / a7 with the guessed extrema ----
   double mm[4];
 #pragma unroll
@@ -1599,6 +1485,7 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   }
   double rc = r;
   if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+  PH(2, 2);
 #pragma unroll
   for (int k = 0; k < 12; k++) U[lane][k] = u[k];
   U[lane][12] = hs;
@@ -1609,21 +1496,37 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
 #endif
   const unsigned long long bal = __ballot(po.selected);
   __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above precede its loads below (waitcnt by the compiler)
+  PH(2, 3);
   const int prow = lane >> 4, col = lane & 15;
   const int ca = col < 12 ? col : (col < 15 ? col - 12 : 0), cb = col < 12 ? col : 12;
   f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int g = 0; g < 16; g++) {
-    const double *up = U[prow + 4 * g];
-    const double x = up[ca], w = up[13], y = up[cb];
+  // Operands of the 16 dependent MFMAs, read eight iterations ahead and formed WITHOUT branches: a lane-dependent
+  // `col < 12 ? x * w : ...` around the LDS read of w compiled into an exec-masked branch and an s_waitcnt lgkmcnt(0) in
+  // front of every MFMA - 1.3 us for this loop (phase clocks, profiles/round4) against ~0.3 us of MFMA latency. The
+  // selects below pick the same values: x * 1.0 == x bit for bit, and row 15 / columns 13-15 of the block are not read.
 #ifndef ROWS_DIVIDE
-    const double av = col < 12 ? x * w : (col < 15 ? x : 0.0);
-#else
-    const double av = col < 12 ? (w != 0.0 ? x / w : 0.0) : (col < 15 ? x : 0.0);
+  const double wsel = col < 12 ? 0.0 : 1.0;  // added to nothing: selects w or 1.0 below
 #endif
-    const double bv = col <= 12 ? y : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    double xa[8], wa[8], ya[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      const double *up = U[prow + 4 * (8 * half + g)];
+      xa[g] = up[ca], wa[g] = up[13], ya[g] = up[cb];
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      const double x = col < 15 ? xa[g] : 0.0, y = col <= 12 ? ya[g] : 0.0;
+#ifndef ROWS_DIVIDE
+      const double av = x * (col < 12 ? wa[g] : wsel);
+#else
+      const double av = col < 12 ? (wa[g] != 0.0 ? x / wa[g] : 0.0) : x;
+#endif
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y, acc, 0, 0, 0);
+    }
   }
+  PH(2, 4);
   // ---- the tile: a leaf of the summation tree, entry-major like k_rows_reduce's partials ----
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
@@ -1631,6 +1534,8 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     if (e >= 0) f.tiles[(size_t)e * f.tstride + blockIdx.x] = acc[rg];
   }
   if (lane == 0) f.tiles[(size_t)(NSUM - 1) * f.tstride + blockIdx.x] = (double)__popcll(bal);
+  PH(2, 5);
+  PH_EXIT();
 }
 
 // ---- batched Nearest_Search -----------------------------------------------------------------------
@@ -1906,7 +1811,7 @@ int measure_alloc(Ctx *c) {
     auto fr = [](void *p) {
       if (p) (void)hipFree(p);
     };
-    fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_dq), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
+    fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
         fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
@@ -1914,7 +1819,6 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_scan, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_perm, sizeof(u32) * K));
     MALIO_HIP(hipMalloc(&c->d_nbr, sizeof(u32) * 5 * K));
-    MALIO_HIP(hipMalloc(&c->d_dq, sizeof(u32) * K));
     MALIO_HIP(hipMalloc(&c->d_plane, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_pd2, sizeof(float) * K));
     MALIO_HIP(hipMalloc(&c->d_world, sizeof(float) * 3 * K));
@@ -1941,10 +1845,6 @@ int measure_alloc(Ctx *c) {
       MALIO_HIP(hipMalloc(&c->d_tiles, sizeof(double) * NSUM * c->cap_tiles));
     }
   }
-  if (!c->d_dq_ctl) {
-    MALIO_HIP(hipMalloc(&c->d_dq_ctl, sizeof(u32) * 4));
-    MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
-  }
   if (!c->d_mmslots) {
     MALIO_HIP(hipMalloc(&c->d_mmslots, sizeof(u64) * 2 * MM_SLOTS * 5));
     hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
@@ -1962,14 +1862,13 @@ int measure_alloc(Ctx *c) {
 }
 
 // After a chain of enqueued passes ended out of step with the host's bookkeeping (a gate that gave up): both extrema
-// slot sets and the deferral counters cleared, parities back to zero, no pending normal_y fold.
+// slot sets cleared, parity back to zero, no pending normal_y fold.
 int reset_pass_state(Ctx *c) {
   MALIO_HIP(hipStreamSynchronize(c->stream));
   if (c->d_mmslots) hipLaunchKernelGGL(k_mm_init, dim3(1), dim3(2 * MM_SLOTS), 0, c->stream, c->d_mmslots);
-  if (c->d_dq_ctl) MALIO_HIP(hipMemsetAsync(c->d_dq_ctl, 0, sizeof(u32) * 4, c->stream));
   if (c->d_gate_ticket) MALIO_HIP(hipMemsetAsync(c->d_gate_ticket, 0, 256, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
-  c->mm_parity = 0, c->dq_parity = 0, c->last_M = -1;
+  c->mm_parity = 0, c->last_M = -1;
   c->mm_guess_valid = false;
   c->cert_valid = false;  // (the chain may have ended between a search pass' kernels: the next search walks every list)
   return MALIO_OK;
@@ -2255,14 +2154,13 @@ static void fill_pass1_static(Ctx *c, Pass1Args &a) {
   for (int l = 0; l < MALIO_MAX_LIDAR; l++) a.unc_off[l] = c->unc_off[l], a.unc_len[l] = c->unc_len[l];
   a.plane_th = c->prm.plane_th, a.cov_threshold = c->prm.cov_threshold, a.extrinsic_est_en = c->prm.extrinsic_est_en;
   a.world4 = c->d_world4;
-  a.dq = c->d_dq, a.dq_ctl = c->d_dq_ctl, a.defer = c->defer_enabled ? 1 : 0;
   a.part = c->part;
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny;
   a.cert = c->d_cert, a.kept = c->d_kept, a.skip = 0;
   a.mm_base = c->d_mmslots;
-  a.dl = nullptr, a.mm_cur = a.mm_next = nullptr, a.parity = 0, a.commit_prev = 0;
+  a.dl = nullptr, a.mm_cur = a.mm_next = nullptr, a.commit_prev = 0;
 }
 
 // matrix form of a state for stage 2 (a5: rotation matrices of the pose, the extrinsics and the temporal compensation)
@@ -2318,29 +2216,21 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   c->mm_parity ^= 1;  // this pass accumulates into one parity and clears the other for the next pass
   a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
   a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
-  a.parity = c->dq_parity;
   a.commit_prev = c->last_M > 0 ? 1 : 0;
   c->last_M = -1;  // the fold is done by this pass; finish_host sets the new value
   const int nb = (c->N + BLK - 1) / BLK;
   c->last_pass_search = converge != 0;
   if (converge) {
-    c->dq_parity ^= 1;  // deferral counters alternate between SEARCH passes (each clears the other set)
-    a.parity = c->dq_parity;
     a.skip = search_skip_begin(c);
     const auto kern = a.skip ? &k_search<false, true> : &k_search<false, false>;
     hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
     prof_mark(c, "k_search");
-    if (a.defer) {  // only while recent search passes had workgroups full of uncertified queries (finish_host)
-      hipLaunchKernelGGL(k_search_tail<false>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
-      prof_mark(c, "k_search_tail");
-    }
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
     prof_mark(c, "k_reuse");
   }
   if (d_minmax4_out) {  // staged (multi-GPU) path: the caller all-reduces these between the stages
-    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en,
-                       (const u32 *)(c->d_dq_ctl + 2 + c->dq_parity), d_minmax4_out);
+    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(64), 0, c->stream, (const u64 *)a.mm_cur, c->prm.extrinsic_est_en, d_minmax4_out);
     prof_mark(c, "k_minmax_reduce");
   }
   MALIO_HIP(hipGetLastError());
@@ -2357,8 +2247,8 @@ static int fill_pass2_static(Ctx *c, Pass2Args &a) {
   a.wc.point_cov_max = c->prm.point_cov_max, a.wc.point_cov_min = c->prm.point_cov_min;
   a.wc.range_min = c->prm.range_min, a.wc.range_max = c->prm.range_max;
   a.partials = c->d_partials, a.pstride = (int)c->cap_partials;
-  a.rows = nullptr, a.minmax4 = nullptr, a.mmslots = nullptr, a.heavy = nullptr, a.mm_out = nullptr;
-  a.dl = nullptr, a.mm_base = c->d_mmslots, a.dq_ctl = c->d_dq_ctl;
+  a.rows = nullptr, a.minmax4 = nullptr, a.mmslots = nullptr, a.mm_out = nullptr;
+  a.dl = nullptr, a.mm_base = c->d_mmslots;
   return nb;
 }
 
@@ -2373,7 +2263,6 @@ int pass_stage2(Ctx *c, const double *d_minmax4_in, double *d_mm_out, double *d_
   a.pc = c->pc;
   a.minmax4 = d_minmax4_in;
   a.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, a.mm_out = d_mm_out;
-  a.heavy = c->d_dq_ctl + 2 + c->dq_parity;
   if (want_rows) {
     size_t need = (size_t)c->N * 14;
     if (need > c->cap_rows) {
@@ -2420,7 +2309,6 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
   // is used whenever the option is on)
   const auto kern = c->opt_search_skip ? &k_search<true, true> : &k_search<true, false>;
   hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
-  if (a.defer) hipLaunchKernelGGL(k_search_tail<true>, dim3(TAIL_BLOCKS), dim3(BLK), 0, c->stream, a, view_of(c->nl2));
   Pass2Args b;
   const int nb = fill_pass2_static(c, b);
   b.dl = c->d_loop, b.mm_out = d_mm_out;
@@ -2437,7 +2325,6 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
 // ---- host side of the speculating pass ----------------------------------------------------------------------------------
 bool fuse_eligible(Ctx *c, int converge, bool need_guess) {
   if (!c->fuse_enabled || (need_guess && !c->mm_guess_valid) || !c->scan_sorted || c->seg_pending) return false;
-  if (converge && c->defer_enabled) return false;  // queries handed to k_search_tail have no plane when the rows are formed
   if (!c->d_tiles) return false;
   // k_final_reduce<16> keeps one node per round of 1 024 tiles in 64 LDS slots: a LiDAR segment above 64 x 1 024 tiles (4.2 M
   // points) takes the three-kernel pass
@@ -2481,8 +2368,7 @@ static void launch_final_tiles(Ctx *c, const SegBlocks &sb, const DevLoop *dl, c
   if (!row) row = c->d_res;
   FoldArgs fold;
   fold.mmslots = dl ? c->d_mmslots : c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
-  fold.dq_ctl = c->d_dq_ctl, fold.mm_out = row + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
-  fold.dq_parity = c->dq_parity;
+  fold.mm_out = row + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
   hipLaunchKernelGGL(k_final_reduce<16>, dim3((c->prm.lid_num * NSUM + FR16_BLK / 256 - 1) / (FR16_BLK / 256)), dim3(FR16_BLK), 0, c->stream,
                      (const double *)c->d_tiles, (int)c->cap_tiles, sb, c->prm.lid_num, row, dl, gate ? *gate : GateArgs{}, fold);
 }
@@ -2497,18 +2383,13 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   Pass1Args a;
   fill_quat_const(c, s, a.qc);
   fill_pass1_static(c, a);
-  a.defer = 0;
   c->mm_parity ^= 1;
   a.mm_cur = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5;
   a.mm_next = c->d_mmslots + (size_t)(c->mm_parity ^ 1) * MM_SLOTS * 5;
   a.commit_prev = c->last_M > 0 ? 1 : 0;
   c->last_M = -1;
   c->last_pass_search = converge != 0;
-  if (converge) {
-    c->dq_parity ^= 1;
-    a.skip = search_skip_begin(c);
-  }
-  a.parity = c->dq_parity;
+  if (converge) a.skip = search_skip_begin(c);
   FuseArgs f;
   SegBlocks sb;
   const int nwg = fill_fuse_static(c, f, sb);
@@ -2532,7 +2413,6 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
 int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   Pass1Args a;
   fill_pass1_static(c, a);
-  a.defer = 0;
   memset(&a.qc, 0, sizeof(a.qc));
   FuseArgs f;
   SegBlocks sb;
@@ -2546,7 +2426,7 @@ int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
 }
 
 void fuse_note(Ctx *c, bool hit);
-// the pass' results are in h_res (sums | true extrema | heavy score): did the guess hold?
+// the pass' results are in h_res (sums | true extrema): did the guess hold?
 int fused_collect(Ctx *c, double *sums_out, bool *hit) {
   const int ns = sums_len(c);
   (void)sums_out;

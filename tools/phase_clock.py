@@ -6,7 +6,7 @@ import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes
 sc = scenes.make_scene(cfg=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
-e = capi.Engine(sc["params"]); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+e = capi.Engine(sc["params"]); e.set_option("fuse", 0); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
 for _ in range(20):
     e.measure(sc["state0"], True)
 e.measure(sc["state0"], True)

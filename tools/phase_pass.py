@@ -1,0 +1,36 @@
+"""Developer aid (variant built with -DMALIO_PHASE_CLOCK): phase stamps of one mid-grid workgroup of k_pass (search pass) and
+the grid-wide spread of workgroup exits.   MALIO_LIB=.../variants/phase.so python tools/phase_pass.py [cfg]"""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+ge.load_package()
+from malio_amd import capi, scenes
+sc = scenes.make_scene(cfg=int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+e = capi.Engine(sc["params"]); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+for _ in range(20):
+    e.measure(sc["state0"], True)
+out = (C.c_longlong * 64)()
+assert capi.lib().malio_debug_phase(out) == 0
+ph = np.array(out[:]).reshape(4, 16)
+n0 = ["enter", "A: transform + sync", "B: level-1 search + sync", "B': level 2 for pending", "neighbours gathered", "plane_cov", "QR",
+      "normalise+gates", "trace"]
+n2 = ["(search_wg returned)", "extrema -> slots", "point_row", "rows -> LDS", "16 MFMA", "tile stores issued"]
+t0 = ph[0][0]
+print("k_pass, mid-grid workgroup, cfg %s (us since its entry; step)" % (sys.argv[1] if len(sys.argv) > 1 else 2), e.fuse_stats())
+prev = t0
+for j in range(1, len(n0)):
+    print("   %-28s %6.2f  %6.2f" % (n0[j], (ph[0][j] - t0) / 100.0, (ph[0][j] - prev) / 100.0)); prev = ph[0][j]
+for j in range(len(n2)):
+    print("   %-28s %6.2f  %6.2f" % (n2[j], (ph[2][j] - t0) / 100.0, (ph[2][j] - prev) / 100.0)); prev = ph[2][j]
+nb = (sc["N"] + 63) // 64 + 4
+sp = (C.c_longlong * (4 * nb))()
+assert capi.lib().malio_debug_span(sp, nb) == 0
+sp = np.array(sp[:], np.int64).reshape(4, nb)
+ok = sp[1] > sp[0]
+tz = sp[0][ok].min()
+ent, ex = (sp[0][ok] - tz) / 100.0, (sp[1][ok] - tz) / 100.0
+print("grid: %d workgroups; entry median %.2f last %.2f; control-wave exit first %.2f median %.2f 90%% %.2f last %.2f us" % (
+    ok.sum(), np.median(ent), ent.max(), ex.min(), np.median(ex), np.percentile(ex, 90), ex.max()))
+tb = (sp[2][ok] - tz) / 100.0
+print("end of level-1 search: median %.2f 90%% %.2f max %.2f us" % (np.median(tb), np.percentile(tb, 90), tb.max()))
