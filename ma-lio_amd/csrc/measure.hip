@@ -1446,18 +1446,49 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     dy.commit_prev = a.commit_prev, dy.skip = a.skip, dy.mm_cur = a.mm_cur, dy.mm_next = a.mm_next;
   }
   const int converge = DEV ? dl->converge : f.converge;
-  // this workgroup's 64 points: inside ONE LiDAR segment
-  int lid = 0;
+  // this workgroup's 64 points: inside ONE LiDAR segment. `tile`: its leaf of the summation tree (position in scan order).
+  int lid = 0, tile = (int)blockIdx.x;
+  if (a.part.world > 1) {
+    // A tile shard: the points it owns come first in every LiDAR segment (k_sort_count), and the workgroups are handed
+    // out segment-interleaved - tile 0 of every LiDAR, tile 1 of every LiDAR, ... - so that ALL owned workgroups are
+    // among the first the dispatcher starts. (A 200 k-point scan is 3 125 workgroups, whose launch alone takes 5 us: in
+    // index order the owned workgroups of the last LiDAR entered 4.3 us after the first one's, on a kernel of 20 us -
+    // profiles/round4/r04d_shard_entry.txt.) Uniform arithmetic on the kernel arguments, <= MALIO_MAX_LIDAR rounds.
+    int rem = (int)blockIdx.x, base_t = 0;
+    for (int round = 0; round < MALIO_MAX_LIDAR; round++) {
+      int nact = 0, m = 0x7FFFFFFF;
 #pragma unroll
-  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
-    if (l < f.L && (int)blockIdx.x >= f.seg_blk0[l]) lid = l;
-  const int q0 = f.seg_start[lid] + ((int)blockIdx.x - f.seg_blk0[lid]) * SQ, qend = f.seg_start[lid + 1];
+      for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
+        const int left = (l < f.L ? f.seg_blk0[l + 1] - f.seg_blk0[l] : 0) - base_t;
+        if (left > 0) nact++, m = min(m, left);
+      }
+      if (nact == 0) break;
+      if (rem < m * nact) {
+        const int which = rem % nact;
+        int seen = 0;
+#pragma unroll
+        for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
+          const int left = (l < f.L ? f.seg_blk0[l + 1] - f.seg_blk0[l] : 0) - base_t;
+          if (left > 0 && seen++ == which) lid = l;
+        }
+        tile = f.seg_blk0[lid] + base_t + rem / nact;
+        break;
+      }
+      rem -= m * nact, base_t += m;
+    }
+  } else {
+#pragma unroll
+    for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+      if (l < f.L && (int)blockIdx.x >= f.seg_blk0[l]) lid = l;
+  }
+  lid = __builtin_amdgcn_readfirstlane(lid), tile = __builtin_amdgcn_readfirstlane(tile);  // (workgroup-uniform: scalars)
+  const int q0 = f.seg_start[lid] + (tile - f.seg_blk0[lid]) * SQ, qend = f.seg_start[lid + 1];
   const int lane = (int)(threadIdx.x & 63);
   PointOut po;
   if (converge) {
     if (!search_wg<DEV, SKIP>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
     if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
-      for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + blockIdx.x] = 0.0;
+      for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
       return;
     }
   } else {  // REUSE pass: the control wave alone, lane = point
@@ -1466,6 +1497,10 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     const int i = q0 + lane;
     po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
     po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
+    if (a.part.world > 1 && !__ballot(i < qend && a.nfound[i] != NF_NOTMINE)) {  // a workgroup of other shards' points: a zero tile
+      for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
+      return;
+    }
     if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   }
   PH(2, 0);
@@ -1531,9 +1566,9 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     const int e = tile_entry(prow + 4 * rg, col);
-    if (e >= 0) f.tiles[(size_t)e * f.tstride + blockIdx.x] = acc[rg];
+    if (e >= 0) f.tiles[(size_t)e * f.tstride + tile] = acc[rg];
   }
-  if (lane == 0) f.tiles[(size_t)(NSUM - 1) * f.tstride + blockIdx.x] = (double)__popcll(bal);
+  if (lane == 0) f.tiles[(size_t)(NSUM - 1) * f.tstride + tile] = (double)__popcll(bal);
   PH(2, 5);
   PH_EXIT();
 }
@@ -1947,13 +1982,22 @@ __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatCo
   // every search pass 0.8 us at config 2 and 13 us in config 5's 500 m tunnel; coarser columns change nothing.)
   u32 b = (u32)lid * SORT_NBK + (((cy & 63u) << 6) | (cx & 63u));
   if (part.world > 1) {
-    // A tile shard serves the points of its own tiles: grouped by tile class first (64 classes of the ownership hash; the
-    // owner is a function of the class whenever the shard count divides 64), by 8 x 8-column patch inside the tile second,
-    // so that the points a shard owns fill whole workgroups instead of a few lanes of most workgroups (the column order
-    // above lets a 64-point block run through eight tiles: two thirds of an eighth-shard's workgroups had work).
-    const u32 th = tile_hash(tile_coord((float)pg.x, part.inv_tile), tile_coord((float)pg.y, part.inv_tile),
-                             tile_coord((float)pg.z, part.inv_tile)) & 63u;
-    b = (u32)lid * SORT_NBK + (th << 6) + (((cy & 7u) << 3) | (cx & 7u));
+    // A tile shard serves the points of its own tiles: the points it owns under THIS state first, then everybody else's,
+    // each grouped by tile class (32 classes of the ownership hash) and by 8 x 8-column patch inside the tile, so that the
+    // points a shard owns fill whole workgroups instead of a few lanes of most workgroups (the column order above lets a
+    // 64-point block run through eight tiles: two thirds of an eighth-shard's workgroups had work) - and fill the FIRST
+    // workgroups of every LiDAR segment: a 200 k-point scan is 3 125 workgroups, more than the GPU holds at once, and an
+    // owned workgroup of the second generation started microseconds late behind workgroups that had nothing to do.
+    // (Ownership is still decided per pass, per point, from that pass' world point - search_wg phase A: a point that
+    // changes tiles with the iterate is served by its new owner wherever it sits in this order.)
+    const int tx = tile_coord((float)pg.x, part.inv_tile), ty = tile_coord((float)pg.y, part.inv_tile),
+              tz = tile_coord((float)pg.z, part.inv_tile);
+    const u32 th = tile_hash(tx, ty, tz);
+    const u32 other = tile_owner(tx, ty, tz, (u32)part.world) == (u32)part.rank ? 0u : 1u;
+    b = (u32)lid * SORT_NBK + (other << 11) + (((th >> 8) & 31u) << 6) + (((cy & 7u) << 3) | (cx & 7u));
+#ifdef KS_PART_CLASS_ORDER  // A/B: the order of round 3 (64 classes ascending, owned and foreign interleaved)
+    b = (u32)lid * SORT_NBK + ((th & 63u) << 6) + (((cy & 7u) << 3) | (cx & 7u));
+#endif
   }
   keys[i] = cell;
   bkt[i] = b;

@@ -16,9 +16,9 @@ class X:  # a one-rank local exchange
         assert capi.lib().malio_xchg_create_local(1, row, self.arr) == 0
         self.h = C.c_void_p(self.arr[0])
 for part in ("tiles", "scan"):
-    e = capi.Engine(sc["params"])
+    e = capi.Engine(sc["params"]); e.set_option("search_skip", 0)
     if part == "tiles":
-        e.set_partition(0, G, 16.0)
+        e.set_partition(0, G, float(os.environ.get("TILE", "16")))
         scan = sc["scan"]
     else:
         scan = sc["scan"][: N // G]
