@@ -457,7 +457,12 @@ __device__ __forceinline__ bool residual_gate(const float pabcd[4], float wx, fl
 
 // a6/a8: trace(Sigma_p); the index clamp differs for accepted (:694-696) and rejected (:737-739) points
 __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, int lid, int tidx, bool selected) {
-  int len = a.unc_len[lid];
+  // (selects on the kernel arguments: indexing the argument arrays with a lane's slot is a load from the argument segment,
+  // and the table entry's load waits for it - one more memory round trip on the control wave's chain)
+  int len = a.unc_len[0], off = a.unc_off[0];
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (lid == l) len = a.unc_len[l], off = a.unc_off[l];
   int k = tidx;
   if (selected) {
     if ((unsigned)k >= (unsigned)len) k = len - 2;
@@ -465,7 +470,7 @@ __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, 
     if ((unsigned)k >= (unsigned)(len - 1)) k = len - 2;
   }
   if (selected && !a.extrinsic_est_en) return 0.0;  // R(i,0) stays 0, normal_y not rewritten (:681-704)
-  return point_trace(a.unc[a.unc_off[lid] + k], q.x, q.y, q.z);
+  return point_trace(a.unc[off + k], q.x, q.y, q.z);
 }
 
 // feats_down_body[i].normal_y bookkeeping (laserMapping.cpp:699,730,741): a pass that reached the end
@@ -640,71 +645,15 @@ __device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.
 // per-point state, returns the accept flag, unit_cov and trace for the extrema.
 // cert_r >= 0: the neighbours come from a list walk at w - its certificate (w, radius free of outsiders) is stored for the
 // later search passes of this scan; < 0: the neighbours were kept under the stored certificate, which stays.
-__device__ __forceinline__ void point_phase(const Pass1Args &a, int commit_prev, int i, const float4 w, double nb,
-                                            const u32 og[5], int nf, float cert_r, bool &selected, double &ucov, double &tr,
-                                            float4 &pl_out, float &pd2_out, float4 &q_out) {
-  selected = false, ucov = 0.0, tr = 0.0;
-  pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
-#ifndef KS_NO_CERT
-  if (cert_r >= 0.f) a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);
-#endif
-#pragma unroll
-  for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
-  a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
-  commit_normal_y(a, commit_prev, i);
-  if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
-    // ---- esti_plane<float> (common_lib.h:144-190) ----
-    float A[5][3], W[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      float4 m = a.map_in[og[k]];
-      A[k][0] = m.x, A[k][1] = m.y, A[k][2] = m.z, W[k] = m.w;
-    }
-    PH(0, 4);
-    double cov_sum = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
-    if ((double)W[0] > 0.00001) {
-#pragma unroll
-      for (int k = 0; k < 5; k++) {
-        double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
-        ucov += wk * wk * (double)W[k];
-      }
-    }
-    float nv[3], pabcd[4];
-    PH(0, 5);
-    qr_solve_5x3(A, nv);
-    PH(0, 6);
-    float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-    pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
-    pabcd[3] = (float)(1.0 / (double)n);
-    bool plane_ok = true;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from L1/L2 (one live copy
-      const float4 m = a.map_in[og[k]];  // instead of two keeps the kernel at 6 waves per SIMD)
-      if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
-    }
-    pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
-    a.plane[i] = pl_out;
-    a.ucov[i] = ucov;
-    if (plane_ok) {
-      float pd2;
-      if (residual_gate(pabcd, w.x, w.y, w.z, nb, pd2)) {
-        selected = true;
-        a.pd2[i] = pd2;
-        pd2_out = pd2;
-      }
-    }
-  }
-  a.sel[i] = selected ? 1 : 0;
-  PH(0, 7);
-  const float4 q = a.scan[i];
-  q_out = q;
-  const int packed = __float_as_int(q.w);
-  tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
-  a.trace[i] = tr;
-}
-
+// q: the scan point (phase A read it; it comes back from LDS, not from HBM). nbp: this lane's five LDS slots for the
+// neighbours' coordinates - the plane fit overwrites its copy, the inlier test afterwards reads them from there instead of
+// gathering them a second time. The lazy normal_y commit of the previous pass happened in phase A (search_wg).
+// (What phase A left in LDS - world point, |p'|, scan point - is read where it is used: held in registers across the
+// plane fit it is what the register allocator spills.)
+struct SearchLds;
+__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
+                                            float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
+                                            float &pd2_out, float4 &q_out);
 // REUSE pass of one point (ekfom_data.converge == false, laserMapping.cpp:583-595): neighbours, plane and flag are kept; the
 // residual and the range gate are re-evaluated at the new state.
 __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst &qc, int commit_prev, int i, bool &selected,
@@ -778,8 +727,87 @@ struct SearchLds {
   unsigned char keep[SQ];  // phase A': the cached neighbours are certified for the new world point - no walk
   int flags;               // what the control wave tells the others after phase A (search_wg)
   float cr[SQ];            // certificate radius of the walk that served the query (cert_radius)
+  float4 q[SQ];            // the scan point as phase A read it (phase C: the row and the trace are built from it)
+  float4 nbp[5][SQ];       // phase C: the five neighbours' map points, kept across the plane fit (point_phase)
   double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
 };
+__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
+                                            float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
+                                            float &pd2_out, float4 &q_out) {
+  selected = false, ucov = 0.0, tr = 0.0;
+  pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
+#ifndef KS_NO_CERT
+  if (cert_r >= 0.f) {
+    const float4 w = S.w[lane];
+    a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);
+  }
+#endif
+#pragma unroll
+  for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
+  a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
+  if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
+    // ---- esti_plane<float> (common_lib.h:144-190) ----
+    float A[5][3], W[5];
+    {
+      float4 m[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) m[k] = a.map_in[og[k]];
+      // all five gathers in flight at once (left to itself the compiler fetched the five normal_y words one after the
+      // other, each behind a wait: four extra round trips on this wave's chain)
+      asm volatile("" : "+v"(m[0].w), "+v"(m[1].w), "+v"(m[2].w), "+v"(m[3].w), "+v"(m[4].w));
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        A[k][0] = m[k].x, A[k][1] = m[k].y, A[k][2] = m[k].z, W[k] = m[k].w;
+        S.nbp[k][lane] = m[k];
+      }
+    }
+    PH(0, 4);
+    double cov_sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
+    if ((double)W[0] > 0.00001) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
+        ucov += wk * wk * (double)W[k];
+      }
+    }
+    float nv[3], pabcd[4];
+    PH(0, 5);
+    qr_solve_5x3(A, nv);
+    PH(0, 6);
+    float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
+    pabcd[3] = (float)(1.0 / (double)n);
+    bool plane_ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from this lane's LDS slots
+      const float4 m = S.nbp[k][lane];
+      if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
+    }
+    pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+    a.plane[i] = pl_out;
+    a.ucov[i] = ucov;
+    if (plane_ok) {
+      float pd2;
+      const float4 w = S.w[lane];
+      if (residual_gate(pabcd, w.x, w.y, w.z, S.nb[lane], pd2)) {
+        selected = true;
+        a.pd2[i] = pd2;
+        pd2_out = pd2;
+      }
+    }
+  }
+  a.sel[i] = selected ? 1 : 0;
+  PH(0, 7);
+  const float4 q = S.q[lane];
+  q_out = q;
+  const int packed = __float_as_int(q.w);
+  tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
+  a.trace[i] = tr;
+}
+
+
 // Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns true in the control wave (with its
 // lane's PointOut filled), false in the three search waves once they have nothing left to do.
 // SKIP is a TAG: passes that may keep cached neighbours (phase A', decided at run time by dy.skip) and full searches run
@@ -805,14 +833,22 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
       const float4 q = a.scan[i];
+      // the lazy normal_y commit of the previous pass (commit_normal_y), done here: its two loads travel with the scan
+      // point's instead of opening phase C with two dependent round trips
+      unsigned char sel_prev = 0;
+      double trace_prev = 0.0;
+      if (dy.commit_prev) sel_prev = a.sel[i], trace_prev = a.trace[i];
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       a.world4[i] = w;
       S.nb[lane_] = nb;
+      S.q[lane_] = q;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
         mine = false;
         a.nfound[i] = NF_NOTMINE, a.sel[i] = 0;
         w = make_float4(3e9f, 3e9f, 3e9f, 0.f);  // far from every list: its search lanes find an empty cell
+      } else if (dy.commit_prev && !(sel_prev && !a.extrinsic_est_en)) {
+        a.ny[i] = (float)trace_prev;
       }
     }
     S.w[lane_] = w;
@@ -961,8 +997,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   const float4 wq = S.w[lane];
   const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
   if (served)
-    point_phase(a, dy.commit_prev, ic, wq, S.nb[lane], og, nf, S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl,
-                po.pd2, po.q);
+    point_phase(a, ic, S, lane, og, nf, S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   PH(0, 8);
   return true;
 }
