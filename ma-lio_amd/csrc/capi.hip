@@ -1459,8 +1459,8 @@ int malio_debug_skip_stats(malio_handle_t h, int *out4) {
   MALIO_HIP(hipMemcpyAsync(nf.data(), c->d_nfound, c->N, hipMemcpyDeviceToHost, c->stream));
   MALIO_HIP(hipStreamSynchronize(c->stream));
   out4[0] = c->N, out4[3] = c->last_search_skip;
-  for (int i = 0; i < c->N; i++) {
-    if (kept[i]) out4[1]++;
+  for (int i = 0; i < c->N; i++) {  // (d_kept is written by the kernels of a handle with the option on only)
+    if (c->last_search_skip && kept[i]) out4[1]++;
     else if (nf[i] <= 5) out4[2]++;
   }
   return MALIO_OK;

@@ -202,8 +202,8 @@ __device__ __forceinline__ void cell_lookup(const Cell *__restrict__ table, u32 
 // 5 rounds of a 64-bit (d2 bits | map index) min-reduction over xor-shuffles.
 // ev (in: the smallest d2 bits this lane's insertions pushed off its list; out, identical in every lane of the group):
 // the smallest d2 bits among ALL candidates of the group that are not in the merged top-5 - the sixth distance.
-template <int G>
-__device__ __forceinline__ void merge_group(Top5 &t, u32 &ev) {
+template <int G, bool CERT>
+__device__ __forceinline__ void merge_group(Top5 &t, u32 &ev, u64 refill = TOP5_MAXKEY) {
   Top5 out;
 #pragma unroll
   for (int r = 0; r < 5; r++) {
@@ -218,12 +218,14 @@ __device__ __forceinline__ void merge_group(Top5 &t, u32 &ev) {
     if (key == mn && (u32)key != INVALID) {
 #pragma unroll
       for (int k = 0; k < 4; k++) t.k[k] = t.k[k + 1];
-      t.k[4] = TOP5_MAXKEY;
+      t.k[4] = refill;
     }
   }
-  ev = min(ev, (u32)(t.k[0] >> 32));  // what is left of this lane's list did not make it either
+  if (CERT) {
+    ev = min(ev, (u32)(t.k[0] >> 32));  // what is left of this lane's list did not make it either
 #pragma unroll
-  for (int sft = G / 2; sft > 0; sft >>= 1) ev = min(ev, (u32)__shfl_xor((int)ev, sft));
+    for (int sft = G / 2; sft > 0; sft >>= 1) ev = min(ev, (u32)__shfl_xor((int)ev, sft));
+  }
   t = out;
 }
 
@@ -587,12 +589,16 @@ struct NlView {
 // distances - from the query to every map point that is not one of the returned neighbours: the smallest of (i) the
 // candidates of the list that fell off the top-5 or lie beyond limit2 and (ii) the radius the block guarantees. It is
 // what lets a later search pass keep the neighbours without walking the list again (search_wg, phase A').
-template <int G>
+// CERT = false: the walk of rounds 1-3 (the list starts out holding five (limit + 1 ulp, no index) keys, candidates beyond the
+// limit never enter it, nothing is tracked for lb2, which reads 0): every instruction per candidate counts in this loop -
+// the bookkeeping of the certificate costs the search pass 0.7 us at BASELINE config 2 (profiles/round4/r04h_*) - so only
+// the kernels of a handle with MALIO_OPT_SEARCH_SKIP on carry it.
+template <int G, bool CERT>
 __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
                                           Top5 &t, float &lb2) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
-  for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
+  for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
   u32 ev = (u32)(TOP5_MAXKEY >> 32);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
@@ -609,24 +615,24 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
       float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
       // A slot past the end of the list (its load was clamped to the last entry) gets the largest key and sorts after
-      // everything. The range test (d2 <= limit2) is applied to the five survivors below, not per candidate.
+      // everything. CERT: the range test (d2 <= limit2) is applied to the five survivors below, not per candidate; else
+      // d2 <= limit2 <=> key < the sentinel keys the list starts with: no range test at all.
       const u64 key = top5_key(d2, __float_as_uint(m[u].w));
-#ifndef KS_NO_CERT
-      ev = min(ev, top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY));
-#else  // A/B: what the certificate's bookkeeping costs the walk
-      (void)top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
-#endif
+      const u32 out = top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
+      if (CERT) ev = min(ev, out);
     }
   }
-  if (G > 1) merge_group<G>(t, ev);
-  // survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count as
-  // outsiders for the bound (the list is sorted: they form its tail)
+  if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+  // CERT: survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count
+  // as outsiders for the bound (the list is sorted: they form its tail)
+  if (CERT) {
 #pragma unroll
-  for (int k = 0; k < 5; k++)
-    if (!(t.d(k) <= limit2)) {
-      ev = min(ev, (u32)(t.k[k] >> 32));
-      t.k[k] = top5_key(sentinel, INVALID);
-    }
+    for (int k = 0; k < 5; k++)
+      if (!(t.d(k) <= limit2)) {
+        ev = min(ev, (u32)(t.k[k] >> 32));
+        t.k[k] = top5_key(sentinel, INVALID);
+      }
+  }
   // radius the block guarantees: one cell edge plus the distance to the nearest face of the own cell, minus a
   // conservative allowance for the float rounding of the cell coordinates
   float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
@@ -634,7 +640,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
   float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
   const float g2 = g1 * g1 * 0.99999f;
-  lb2 = __uint_as_float(min(ev, __float_as_uint(g2)));  // (positive floats order like their bits; ev may be the no-candidate mark)
+  lb2 = CERT ? __uint_as_float(min(ev, __float_as_uint(g2))) : 0.f;  // (positive floats order like their bits; ev may be the no-candidate mark)
   return (t.og(4) != INVALID) && (t.d(4) <= g2);
 }
 // lb2 -> the certificate's radius: a lower bound on the TRUE distance of every outsider (computed squared distances are
@@ -736,12 +742,10 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
                                             float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
   pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
-#ifndef KS_NO_CERT
   if (cert_r >= 0.f) {
     const float4 w = S.w[lane];
     a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);
   }
-#endif
 #pragma unroll
   for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
   a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
@@ -810,10 +814,9 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 
 // Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns true in the control wave (with its
 // lane's PointOut filled), false in the three search waves once they have nothing left to do.
-// SKIP is a TAG: passes that may keep cached neighbours (phase A', decided at run time by dy.skip) and full searches run
-// the same code under two kernel names, so that every profile tells them apart. (Compiling phase A' out of the full
-// search was tried: the register allocator then spills 5 VGPRs in the list walk - 24 B of scratch - where this form
-// spills none.)
+// SKIP: the kernels of a handle with MALIO_OPT_SEARCH_SKIP on - every list walk leaves its certificate, a search pass that is
+// not the first of its scan (dy.skip, decided per pass) keeps cached neighbours where the certificate allows (phase A').
+// SKIP = false is the search of rounds 1-3 with no trace of any of it.
 template <bool DEV, bool SKIP>
 __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
                                           const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
@@ -860,7 +863,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
     // it - the search would return exactly the cached points, ranked by their NEW distances under the order (d2, index):
     // those are recomputed here the way the search computes them (ikd_Tree.cpp:1697, no FMA) and inserted into an empty
     // list. Same set, same order, same bits; anything the bound cannot decide walks the lists as before.
-    if (mine && dy.skip) {
+    if (SKIP && mine && dy.skip) {
       const float4 ce = a.cert[i];
       const int nfo = a.nfound[i];
       if (nfo <= 5 && ce.w > 0.f) {
@@ -899,19 +902,26 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
         }
       }
     }
-    S.keep[lane_] = keep ? 1 : 0;
-#ifndef KS_NO_CERT
-    if (i < qend) a.kept[i] = keep ? 1 : 0;
-#endif
+    if (SKIP) {
+      S.keep[lane_] = keep ? 1 : 0;
+      if (i < qend) a.kept[i] = keep ? 1 : 0;
+    }
   }
   // bit 0: a point of this workgroup is served here; bit 1: one of them has to walk the lists (only the control wave knows;
   // __syncthreads_or would reduce !!predicate, not the bits)
-  if (cwave) {
-    const int fl = (__ballot(mine) ? 1 : 0) | (__ballot(mine && !keep) ? 2 : 0);
-    if (lane_ == 0) S.flags = fl;
+  int flags = 3;
+  if (SKIP) {
+    if (cwave) {
+      const int fl = (__ballot(mine) ? 1 : 0) | (__ballot(mine && !keep) ? 2 : 0);
+      if (lane_ == 0) S.flags = fl;
+    }
+    __syncthreads();
+    flags = __builtin_amdgcn_readfirstlane(S.flags);  // (workgroup-uniform: a scalar)
+  } else if (a.part.world > 1) {
+    flags = __syncthreads_or(mine ? 1 : 0) ? 3 : 0;
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
-  const int flags = __builtin_amdgcn_readfirstlane(S.flags);  // (workgroup-uniform: a scalar)
   if (a.part.world > 1 && !(flags & 1)) {      // a workgroup of somebody else's tiles
     po.selected = false, po.skipped = true;  // (k_pass still owes the summation tree a zero tile)
     return cwave;
@@ -921,16 +931,16 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   // ---- phase B ----
   {
     const int ql = threadIdx.x / NL1_G, sub = threadIdx.x % NL1_G;
-    if (!S.keep[ql]) {  // (the NL1_G lanes of a query branch together: the shuffles of the merge stay inside the group)
+    if (!SKIP || !S.keep[ql]) {  // (the NL1_G lanes of a query branch together: the shuffles of the merge stay inside the group)
       const float4 ww = S.w[ql];
       Top5 t;
       float lb2;
-      const bool certified = nl_search<NL1_G>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
+      const bool certified = nl_search<NL1_G, SKIP>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
       if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
         S.nf[ql] = certified ? 5 : NF_PENDING;
-        S.cr[ql] = cert_radius(lb2);
+        if (SKIP) S.cr[ql] = cert_radius(lb2);
       }
     }
   }
@@ -968,13 +978,13 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
             const float4 ww = S.w[l];
             Top5 t;
             float lb2;
-            nl_search<L2G>(nl2, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);  // merged list is identical in every lane of the group
+            nl_search<L2G, SKIP>(nl2, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);  // merged list is identical in every lane of the group
             if (sub == 0) {
               int nf = 0;
 #pragma unroll
               for (int k = 0; k < 5; k++) S.og[k][l] = t.og(k), nf += (t.og(k) != INVALID);
               S.nf[l] = (unsigned char)nf;
-              S.cr[l] = cert_radius(lb2);
+              if (SKIP) S.cr[l] = cert_radius(lb2);
             }
           }
         }
@@ -997,7 +1007,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   const float4 wq = S.w[lane];
   const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
   if (served)
-    point_phase(a, ic, S, lane, og, nf, S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+    point_phase(a, ic, S, lane, og, nf, !SKIP || S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   PH(0, 8);
   return true;
 }
@@ -1620,7 +1630,7 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   float4 p = q[active ? qi : n - 1];
   Top5 t;
   float lb2_unused;
-  nl_search<NL2_G>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t, lb2_unused);
+  nl_search<NL2_G, false>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t, lb2_unused);
   if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {
@@ -1723,7 +1733,7 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
     }
     // best K over the wave; the merged list then lives in lane 0 only, so that a further shell cannot count it twice
     u32 ev_unused = 0xFFFFFFFFu;
-    merge_group<64>(t, ev_unused);
+    merge_group<64, false>(t, ev_unused);
     // everything within (3r+1) cell edges of the query's cell has been seen
     const float reach = (float)(3 * r + 1) * nl.cf - margin;
     if (t.og(K - 1) != INVALID && t.d(K - 1) <= reach * reach * 0.99999f) done = true;
@@ -1737,7 +1747,7 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
     for (int k = 0; k < 5; k++) t.k[k] = TOP5_MAXKEY;
     for (int j = lane; j < map_n; j += 64) offer(map_in[j], (u32)j);
     u32 ev_unused = 0xFFFFFFFFu;
-    merge_group<64>(t, ev_unused);
+    merge_group<64, false>(t, ev_unused);
   }
   if (lane < K) far_idx[(size_t)lane * N + qi] = lane == 0 ? t.og(0) : lane == 1 ? t.og(1) : lane == 2 ? t.og(2) : lane == 3 ? t.og(3) : t.og(4);
   }  // needy queries of this group of 64
@@ -2271,7 +2281,7 @@ void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
 int search_skip_begin(Ctx *c) {
   const int skip = (c->opt_search_skip && c->cert_valid && c->nbr_epoch == c->map_epoch) ? 1 : 0;
   c->nbr_epoch = c->map_epoch;
-  c->cert_valid = true;
+  c->cert_valid = c->opt_search_skip != 0;  // (only the SKIP kernels leave certificates)
   c->last_search_skip = skip;
   return skip;
 }
@@ -2301,7 +2311,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   c->last_pass_search = converge != 0;
   if (converge) {
     a.skip = search_skip_begin(c);
-    const auto kern = a.skip ? &k_search<false, true> : &k_search<false, false>;
+    const auto kern = c->opt_search_skip ? &k_search<false, true> : &k_search<false, false>;
     hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
     prof_mark(c, "k_search");
   } else {
@@ -2478,7 +2488,7 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   memcpy(f.guess, c->mm_guess, sizeof(f.guess));
   if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
   memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
-  const auto kern = a.skip ? &k_pass<false, true> : &k_pass<false, false>;
+  const auto kern = c->opt_search_skip ? &k_pass<false, true> : &k_pass<false, false>;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f, (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
   launch_final_tiles(c, sb, nullptr, gate, row);

@@ -322,7 +322,9 @@ def test_full_size_configs(capi, orc, scenes, cfg):
         assert np.array_equal(x["HtRinvH"], g["HtRinvH"]) and np.array_equal(x["HtRinvh"], g["HtRinvh"]) and x["M"] == r["M"]
         assert np.abs(x["HtRinvH"] - HtH_o).max() <= 1e-10 * np.abs(HtH_o).max()
     eng.set_option("search_skip", 1)
-    e = eng.measure(sc["state0"], True)
+    e = eng.measure(sc["state0"], True)   # (the first walk with the option on leaves the certificates ...)
+    assert eng.skip_stats()["allowed"] == 0 and np.array_equal(e["HtRinvH"], g["HtRinvH"])
+    e = eng.measure(sc["state0"], True)   # (... the next search pass may use)
     assert eng.skip_stats()["kept"] > 0.9 * sc["N"] * (cfg != 5)
     assert np.array_equal(e["HtRinvH"], g["HtRinvH"]) and np.array_equal(e["HtRinvh"], g["HtRinvh"])
     eng.set_option("search_skip", 0)

@@ -9,7 +9,10 @@ from malio_amd import capi, scenes
 sc = scenes.make_scene(cfg=int(os.environ.get("CFG", "2")))
 skip = os.environ.get("SKIP", "0") == "1"
 eng = capi.Engine(sc["params"]); eng.map_build(sc["map"]); eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
-eng.set_option("search_skip", 1 if skip else 0)
+try:
+    eng.set_option("search_skip", 1 if skip else 0)
+except AttributeError:  # (a library of an earlier round, loaded through MALIO_LIB for an A/B: it has no options and never skips)
+    pass
 s2 = sc["state0"].copy(); s2[0:3] += [0.01, -0.008, 0.004]
 states = [sc["state0"], s2] if skip else [sc["state0"]]
 eng.measure(sc["state0"], True)
@@ -20,4 +23,7 @@ for k in range(20):
     eng.measure(states[k % len(states)], True)
     for n, ms in eng.last_kernel_times(): acc.setdefault(n, []).append(ms * 1000)
 print("KERNELS", {n: round(float(np.median(v)), 1) for n, v in acc.items()})
-print("SKIP", eng.skip_stats())
+try:
+    print("SKIP", eng.skip_stats())
+except AttributeError:
+    pass
