@@ -17,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <array>
 #include <thread>
 #include <vector>
 #include <sched.h>
@@ -430,10 +431,38 @@ int malio_node_measure(malio_node_t nd, const malio_state_t *s, int converge, ma
 int malio_node_update_iterated(malio_node_t nd, malio_state_t *x, double *P, double R, int *stats, double *solve_time) {
   if (!nd || !x || !P) return MALIO_ERR_BAD_ARG;
   if (solve_time) *solve_time = 0;
-  malio::PassFn pass = [nd](const malio_state_t *s, int converge, malio_measure_out_t *mo) -> int {
-    return malio_node_measure(nd, s, converge, mo);
-  };
-  return malio::ieskf_update_fn(nd->prm, pass, nullptr, nd->N, nd->pass_hook, nd->pass_hook_user, x, P, R, stats, solve_time);
+  if (nd->pass_hook) {
+    // h_dyn_share is a plain function in the reference: the hook runs on the CALLING thread before every pass, so the
+    // loop of esekfom.hpp:509 stays here and every pass is a job of its own for the workers
+    malio::PassFn pass = [nd](const malio_state_t *s, int converge, malio_measure_out_t *mo) -> int {
+      return malio_node_measure(nd, s, converge, mo);
+    };
+    return malio::ieskf_update_fn(nd->prm, pass, nullptr, nd->N, nd->pass_hook, nd->pass_hook_user, x, P, R, stats, solve_time);
+  }
+  // ONE job: every worker runs the whole loop on its own copy of (x, P) - pass, exchange, the n x n algebra - and the
+  // workers meet in the exchange of every pass and nowhere else. The reduced sums are identical on every worker bit for
+  // bit (rows added in rank order), hence so are the iterates and the posterior: worker 0's are handed out. Against a job
+  // per pass this takes the caller's thread off every pass' critical path (two hand-offs and the wake-up of n workers
+  // per pass, the algebra while every GPU idles).
+  const int n = 17 + 6 * nd->prm.lid_num;
+  std::vector<malio_state_t> xs((size_t)nd->n, *x);
+  std::vector<std::vector<double>> Ps((size_t)nd->n, std::vector<double>(P, P + (size_t)n * n));
+  std::vector<std::array<int, 4>> st((size_t)nd->n, std::array<int, 4>{0, 0, 0, 0});
+  std::vector<double> solve((size_t)nd->n, 0.0);
+  const int rc = nd->run([&](Worker &k) -> int {
+    return malio_update_iterated_node(k.h, k.x, &xs[k.rank], Ps[k.rank].data(), R, st[k.rank].data(), &solve[k.rank]);
+  });
+  if (rc != MALIO_OK) return rc;  // (MALIO_SMALL_M_FALLBACK included: x and P untouched, as on one engine)
+  for (int r = 1; r < nd->n; r++)
+    if (memcmp(&xs[r], &xs[0], sizeof(malio_state_t)) != 0 || memcmp(Ps[r].data(), Ps[0].data(), sizeof(double) * (size_t)n * n) != 0) {
+      nd->err = "malio_node_update_iterated: the workers' iterates differ (the exchange must hand every rank the same rows)";
+      return MALIO_ERR_HIP;
+    }
+  *x = xs[0];
+  memcpy(P, Ps[0].data(), sizeof(double) * (size_t)n * n);
+  if (stats) memcpy(stats, st[0].data(), sizeof(int) * 4);
+  if (solve_time) *solve_time = solve[0];
+  return MALIO_OK;
 }
 
 int malio_node_exchange_stats(malio_node_t nd, int *stats2) {
