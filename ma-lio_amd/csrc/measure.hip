@@ -2025,7 +2025,16 @@ __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatCo
   // workgroups still work on one part of the map and the five neighbours of their queries share cache lines of the map
   // array. (A hashed bucket order balances the buckets better - the grouping is ~20 us cheaper per scan - but costs
   // every search pass 0.8 us at config 2 and 13 us in config 5's 500 m tunnel; coarser columns change nothing.)
-  u32 b = (u32)lid * SORT_NBK + (((cy & 63u) << 6) | (cx & 63u));
+#ifndef KS_BKT_Z
+#define KS_BKT_Z 1
+#endif
+  // KS_BKT_Z bits of the vertical cell coordinate go into the bucket (taken from the horizontal range: 64 x 32 columns): a
+  // wall's column of cells is cut into 2^KS_BKT_Z buckets. What a full bucket costs is the same-address atomics below and
+  // k_sort_place's quadratic ranking; swept 0 / 1 / 2 / 3 bits (profiles/round4/r04i_grouping_buckets.txt): the update of a
+  // new scan 207 / 199.5 / 200 / 201 us at config 2, 434 / 421 / 426 / 421 at config 5, 176 / 172 / 173 / 172 at config 3;
+  // the steady search pass does not move.
+  constexpr u32 ZB = KS_BKT_Z, XB = 6 - ZB / 2, YB = 6 - (ZB + 1) / 2;
+  u32 b = (u32)lid * SORT_NBK + ((((cy & ((1u << YB) - 1u)) << XB) | (cx & ((1u << XB) - 1u))) << ZB) + (cz & ((1u << ZB) - 1u));
   if (part.world > 1) {
     // A tile shard serves the points of its own tiles: the points it owns under THIS state first, then everybody else's,
     // each grouped by tile class (32 classes of the ownership hash) and by 8 x 8-column patch inside the tile, so that the
@@ -2122,7 +2131,15 @@ __global__ void __launch_bounds__(BLK) k_sort_place(const UploadRec *__restrict_
   const u32 b = tbkt[j], s0 = offs[b], s1 = offs[b + 1];
   const u64 mine = tkv[j];
   u32 rank = 0;
-  for (u32 m = s0; m < s1; m++) rank += tkv[m] < mine ? 1u : 0u;
+  // (four loads in flight per step: with a trip count that differs from lane to lane the compiler waits for every load
+  // before it issues the next, and the kernel is as long as its fullest bucket's chain of round trips)
+  for (u32 m = s0; m < s1; m += 4) {
+    u64 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = tkv[min(m + (u32)u, s1 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) rank += (m + (u32)u < s1 && v[u] < mine) ? 1u : 0u;
+  }
   scan_install(in, (u32)mine, (int)(s0 + rank), n, out_scan, out_perm, out_ny, sel, nfound, nbr, pd2, plane, cert);
 }
 // the upload order kept (malio_scan_order): install only
