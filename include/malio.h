@@ -597,7 +597,9 @@ int malio_node_map_incremental(malio_node_t nd, const malio_state_t *state_point
                                const float *world_normal_y, int *out_counts3);
 /* The resident front end on the node: LiDAR `lid` is undistorted and voxel-filtered on GPU lid % n_gpus (the L clouds of a
  * scan side by side instead of one after the other), the filtered clouds are concatenated in LiDAR order on the host and
- * installed on every GPU like malio_node_scan_set. Arguments as malio_undistort_resident / malio_scan_set_resident. */
+ * installed on every GPU like malio_node_scan_set. Arguments as malio_undistort_resident / malio_scan_set_resident.
+ * malio_node_scan_set_resident CONSUMES the resident clouds of the scan whether it succeeds or not: after an error from any
+ * GPU (the filtered parts of the others are gone with the call) the caller undistorts the scan's clouds again. */
 int malio_node_undistort_resident(malio_node_t nd, int lid, const malio_point_t *pts, int n, double lidar_beg_time,
                                   const double *knot_times, const double *knot_poses, int n_knots, const double ext_q[4],
                                   const double ext_t[3], const double end_q[4], const double end_t[3],
