@@ -367,6 +367,11 @@ int malio_scan_order(malio_handle_t h, int mode);
  *                              host-driven loop (default 200).
  *   MALIO_OPT_SCAN_SET_SYNC    1: malio_scan_set waits for the copy out of a page-locked cloud itself.
  *   MALIO_OPT_NL_FULL_BLOCKS   1: level-1 neighbour lists hold whole 3x3x3 blocks (takes effect at the next list build).
+ *   MALIO_OPT_NODE_GATED       1 (default): malio_update_iterated_node / the node handle run the gated chain on every shard
+ *                              (pass 0 through malio_measure_node, then one speculating pass per unit, the shards' rows
+ *                              meeting in host memory between "sums seen" and "published"); 0: one pass at a time. Host
+ *                              exchanges only - a MALIO_NODE_XCHG_RCCL node always runs one pass at a time. Must be the
+ *                              same on every shard of a node.
  *   MALIO_OPT_DEBUG_*          test hooks: every guess of the extrema wrong / the host stalls before publishing pass 2.
  * Returns MALIO_ERR_BAD_ARG for an unknown option or a value outside its range. */
 enum {
@@ -378,8 +383,11 @@ enum {
   MALIO_OPT_GATE_TIMEOUT_MS = 6,
   MALIO_OPT_SCAN_SET_SYNC = 7,
   MALIO_OPT_NL_FULL_BLOCKS = 8,
+  MALIO_OPT_NODE_GATED = 9,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
-  MALIO_OPT_DEBUG_GATE_STALL_MS = 101
+  MALIO_OPT_DEBUG_GATE_STALL_MS = 101,
+  MALIO_OPT_DEBUG_NODE_GATED_RUNS = 102,  /* read-only (malio_get_option): updates of this shard through the gated chain ... */
+  MALIO_OPT_DEBUG_NODE_GATED_REDONE = 103 /* ... and how many of them were handed back to the pass-by-pass loop */
 };
 int malio_set_option(malio_handle_t h, int option, double value);
 int malio_get_option(malio_handle_t h, int option, double *value);

@@ -35,7 +35,8 @@ EXPORTS = [
 ]
 # malio_set_option (include/malio.h)
 OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
-           nl_full_blocks=8, debug_fuse_bad_guess=100, debug_gate_stall_ms=101)
+           nl_full_blocks=8, node_gated=9, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
+           debug_node_gated_redone=103)
 PART_SCAN, PART_TILES = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
 
@@ -972,6 +973,24 @@ class Node:
         f.argtypes = [C.c_void_p, C.c_int, C.c_double]
         self._chk(f(self.h, int(OPT.get(name, name)), float(value)), "malio_node_set_option(%s)" % name)
         return self
+
+    def set_option_rank(self, rank, name, value):
+        """one shard's handle only (tests: a stall on ONE shard)"""
+        hh = C.c_void_p()
+        self._chk(lib().malio_node_handle(self.h, int(rank), C.byref(hh)), "malio_node_handle")
+        f = lib().malio_set_option
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        self._chk(f(hh, int(OPT.get(name, name)), float(value)), "malio_set_option(%s)" % name)
+        return self
+
+    def get_option_rank(self, rank, name):
+        hh = C.c_void_p()
+        self._chk(lib().malio_node_handle(self.h, int(rank), C.byref(hh)), "malio_node_handle")
+        f = lib().malio_get_option
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        v = C.c_double(0)
+        self._chk(f(hh, int(OPT.get(name, name)), C.byref(v)), "malio_get_option(%s)" % name)
+        return v.value
 
     def exchange_stats(self):
         st = (C.c_int * 2)()

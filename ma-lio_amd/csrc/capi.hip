@@ -152,7 +152,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -200,6 +200,10 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_nl_full_blocks = (int)value;  // takes effect at the next list build
       return MALIO_OK;
+    case MALIO_OPT_NODE_GATED:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_node_gated = (int)value;
+      return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS:
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->fuse_debug_bad_guess = value != 0.0;
@@ -226,8 +230,11 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_GATE_TIMEOUT_MS: *value = (double)c->gate_timeout_ticks * 1e-5; return MALIO_OK;
     case MALIO_OPT_SCAN_SET_SYNC: *value = c->scan_set_sync; return MALIO_OK;
     case MALIO_OPT_NL_FULL_BLOCKS: *value = c->opt_nl_full_blocks; return MALIO_OK;
+    case MALIO_OPT_NODE_GATED: *value = c->opt_node_gated; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
+    case MALIO_OPT_DEBUG_NODE_GATED_RUNS: *value = c->node_gated_runs; return MALIO_OK;  // (read-only counters)
+    case MALIO_OPT_DEBUG_NODE_GATED_REDONE: *value = c->node_gated_redone; return MALIO_OK;
     default: return MALIO_ERR_BAD_ARG;
   }
 }
@@ -1159,6 +1166,18 @@ int malio_update_iterated_node(malio_handle_t h, malio_xchg_t xchg, malio_state_
   if (check(h) || !xchg || !x || !P) return MALIO_ERR_BAD_ARG;
   MALIO_HIP_H(hipSetDevice(h->device));
   if (solve_time) *solve_time = 0;
+  // The gated chain where it can run: rows exchanged through host memory (RCCL's gather is a stream operation: the gate
+  // would wait behind it), the one-kernel pass allowed, nobody watching single passes. Every shard of a node must decide
+  // this the same way: the options are the node's (malio_node_set_option), a pass hook keeps the node's loop on one thread.
+  if (h->opt_node_gated && h->update_mode == MALIO_UPDATE_GATED && malio_xchg_kind(xchg) != 2 && h->fuse_enabled && !h->pass_hook &&
+      !h->profiling && h->prm.max_iteration >= 1) {
+    malio_state_t x0 = *x;
+    const int rc = ieskf_update_gated(h, xchg, x, P, stats, solve_time);
+    h->node_gated_runs++;
+    if (rc != MALIO_SMALL_M_FALLBACK) return rc;
+    *x = x0;  // (untouched by contract; the per-pass loop below redoes the update - and reports M < n itself)
+    h->node_gated_redone++;
+  }
   return ieskf_update(h, xchg, x, P, R, stats, solve_time);
 }
 
@@ -1382,7 +1401,7 @@ int malio_update_iterated(malio_handle_t h, malio_state_t *x, double *P, double 
   // fewer accepted points than states (the M x M form of esekfom.hpp:574-582 works on rows).
   if (h->update_mode != MALIO_UPDATE_HOST && !h->pass_hook && !h->profiling) {
     if (solve_time) *solve_time = 0;
-    const int rc = h->update_mode == MALIO_UPDATE_GATED ? ieskf_update_gated(h, x, P, stats, solve_time) : ieskf_update_device(h, x, P, stats);
+    const int rc = h->update_mode == MALIO_UPDATE_GATED ? ieskf_update_gated(h, nullptr, x, P, stats, solve_time) : ieskf_update_device(h, x, P, stats);
     if (rc != MALIO_SMALL_M_FALLBACK) return rc;
   }
   return ieskf_update(h, nullptr, x, P, R, stats, solve_time);

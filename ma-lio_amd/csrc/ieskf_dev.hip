@@ -640,10 +640,27 @@ int gate_words(Ctx *c, volatile int **host_msg, int **dev_msg) {  // the GPU -> 
   return MALIO_OK;
 }
 
-int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, double *solve_time) {
+// xchg != nullptr: this handle is one shard of a node (malio_update_iterated_node). Pass 0 is then malio_measure_node's
+// (its rows need the GLOBAL extrema, which nobody has before the first exchange of a scan); from pass 1 on the chain is the
+// same as on one GPU - every unit a speculating k_pass on the node's extrema of the pass before - and what the loop does
+// between "sums seen" and "published" gains one step: the [sums | extrema] rows of all shards meet in host memory
+// (malio_xchg_reduce), every shard forms the same sums in rank order and takes the same decision - hit, or the same pass
+// again with the extrema the exchange found.
+int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pio, int *stats, double *solve_time) {
   const int L = c->prm.lid_num, n = 17 + 6 * L, maximum_iter = c->prm.max_iteration;
   const double limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
   if (int rc = prepare_scan_dev(c, xio)) return rc;
+  malio_measure_out_t mo0;
+  int rc_mo0 = MALIO_OK;
+  if (xchg) {  // before the chain's sequence numbers are drawn: malio_measure_node announces its stages through the same word
+    memset(&mo0, 0, sizeof(mo0));
+    rc_mo0 = malio_measure_node((malio_handle_t)c, xchg, xio, 1, &mo0, nullptr);
+    if (rc_mo0 < 0) return rc_mo0;
+    if (!c->scan_sorted || c->seg_pending || !c->d_tiles) {
+      c->err = "malio_update_iterated_node: the scan is not in the form the one-kernel pass reads";
+      return MALIO_ERR_BAD_ARG;
+    }
+  }
   const size_t hdr = loop_block_doubles(), nn = (size_t)DEV_NMAX * DEV_NMAX;
   if (!c->d_loopbuf) {
     MALIO_HIP(hipMalloc(&c->d_loopbuf, sizeof(double) * (hdr + 2 * nn)));
@@ -719,7 +736,7 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
   g.ticket = c->d_gate_ticket;
   g.timeout_ticks = c->gate_timeout_ticks;
   std::vector<char> unit_fused((size_t)max_units + 1, 0);
-  int u_enq = 1;  // units enqueued so far (unit 0 below)
+  int u_enq = xchg ? 0 : 1;  // units enqueued so far (one GPU: unit 0 below; a shard: its unit 0 is pass 1, launched after pass 0's algebra)
   auto enqueue_unit = [&]() -> int {
     const int u = u_enq;
     if (u >= max_units) {
@@ -728,14 +745,18 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     }
     g.publish = base + u + 1, g.wait_for = base + u + 2;
     // decided when the unit is enqueued, one pass ahead (the guess itself travels in the block)
-    const bool fused = fuse_eligible(c, /*converge: a search pass may come*/ 1, /*need_guess*/ false);
+    // (a shard's unit is always the one-kernel pass: the three-kernel unit weights its rows with the extrema it finds
+    // itself, which on a shard are not the node's)
+    const bool fused = xchg ? true : fuse_eligible(c, /*converge: a search pass may come*/ 1, /*need_guess*/ false);
     unit_fused[u] = fused ? 1 : 0;
     u_enq++;
     return fused ? enqueue_pass_fused_dev(c, &g) : enqueue_pass_dev(c, c->d_res, c->d_res + ns_, &g);
   };
   g.publish = base + 1, g.wait_for = base + 2;
-  if (int rc = pass_stage1(c, &x_, 1, nullptr)) return rc;
-  if (int rc = pass_stage2(c, nullptr, c->d_res + ns_, c->d_res, false, &g)) return rc;
+  if (!xchg) {
+    if (int rc = pass_stage1(c, &x_, 1, nullptr)) return rc;
+    if (int rc = pass_stage2(c, nullptr, c->d_res + ns_, c->d_res, false, &g)) return rc;
+  }
   P_prop.assign(Pio, Pio + (size_t)n * n);
   // ---- the loop (esekfom.hpp:509) ----
   int rc_out = MALIO_OK;
@@ -770,7 +791,8 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     if (ntr + 5 <= 60) tr[ntr++] = now_us() - t_begin;
     // the unit of THIS pass (missing only after a repeated pass used up the one that was enqueued ahead), then the unit
     // of pass p + 1, one ahead of the GPU
-    while (rc_out == MALIO_OK && (u_enq <= u || (p + 1 <= maximum_iter && u_enq <= u + 1))) rc_out = enqueue_unit();
+    const bool shard_first = xchg && p == 0;  // (a shard's pass 0 has run already: malio_measure_node above)
+    while (!shard_first && rc_out == MALIO_OK && (u_enq <= u || (p + 1 <= maximum_iter && u_enq <= u + 1))) rc_out = enqueue_unit();
     if (rc_out != MALIO_OK) {
       passes = p + 1;
       break;
@@ -781,12 +803,36 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
     solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (ntr + 3 <= 60) tr[ntr++] = now_us() - t_begin;
     const double *res = nullptr;
-    for (int attempt = 0;; attempt++) {  // the pass, and - rarely - its repeat with the right extrema
-      if (int rcw = wait_unit(u)) return rcw;
+    for (int attempt = 0; !shard_first; attempt++) {  // the pass, and - rarely - its repeat with the right extrema
+      const int rcw = wait_unit(u);
+      if (rcw && !xchg) return rcw;
       res = c->h_res;
-      if (!unit_fused[u]) break;
       bool hit = false;
-      fused_collect(c, nullptr, &hit);
+      if (xchg) {
+        // the shards' rows meet. A shard whose chain is gone (its gate gave up on this thread, or its stream failed) still
+        // comes, with an extremum no pass produces: every shard then leaves the gated loop the same way.
+        if (rcw) c->h_res[ns_] = INFINITY;
+        double E[4];
+        const int rcx = malio_xchg_reduce(xchg, c->h_res, ns_, c->fuse_guess_used, c->h_res, E, 60.0);
+        if (rcx < 0 || rcw < 0 || E[0] == INFINITY) {
+          if (!rcw) {  // this shard's chain is still there: let it drain
+            publish(u + 1, true, false);
+            if (int rcr = reset_pass_state(c)) return rcr;
+          }
+          c->node_guess_valid = false, c->node_uploaded_valid = false;
+          return rcw < 0 ? rcw : rcx < 0 ? rcx : MALIO_SMALL_M_FALLBACK;
+        }
+        hit = rcx == MALIO_OK;
+        memcpy(c->h_res + ns_, E, sizeof(E));  // the node's extrema where the one-GPU loop finds its own
+        memcpy(c->node_guess, E, sizeof(E));
+        c->node_guess_valid = true;
+        fuse_note(c, hit);
+        if (hit) c->node_hits++;
+        else c->node_misses++;
+      } else {
+        if (!unit_fused[u]) break;
+        fused_collect(c, nullptr, &hit);
+      }
       if (hit) break;
       if (attempt >= 2) {
         c->err = "malio_update_iterated: the one-kernel pass keeps missing its own extrema";
@@ -808,13 +854,19 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       passes = p + 1;
       break;
     }
-    u++;
     passes++;
     if (ntr + 2 <= 60) tr[ntr++] = now_us() - t_begin;
-    memset(&mo, 0, sizeof(mo));
-    int rc = finish_host(c, res, res + ns_, &mo);
-    c->last_M = mo.M;
-    memcpy(c->mm_guess, res + ns_, sizeof(double) * 4);
+    int rc;
+    if (shard_first) {
+      mo = mo0, rc = rc_mo0;  // (malio_measure_node has done the bookkeeping of its pass)
+      memcpy(c->mm_guess, c->node_guess, sizeof(double) * 4);
+    } else {
+      u++;
+      memset(&mo, 0, sizeof(mo));
+      rc = finish_host(c, res, res + ns_, &mo);
+      c->last_M = mo.M;
+      memcpy(c->mm_guess, res + ns_, sizeof(double) * 4);
+    }
     c->mm_guess_valid = true;
     if (rc < 0) {
       rc_out = rc;
@@ -839,7 +891,18 @@ int ieskf_update_gated(Ctx *c, malio_state_t *xio, double *Pio, int *stats, doub
       done = dn != 0;
     }
     if (c->gate_debug_stall_ms > 0 && p == 1) usleep(1000 * (useconds_t)c->gate_debug_stall_ms);
-    if (!done && i + 1 < maximum_iter) publish(u, false, false);
+    if (!done && i + 1 < maximum_iter) {
+      if (shard_first) {  // the shard's unit 0: pass 1 with its arguments by value, a gate on its last workgroup
+        g.publish = base + 1, g.wait_for = base + 2;
+        unit_fused[0] = 1, u_enq = 1;
+        if (int rcp = pass_fused(c, &x_, converge, &g, nullptr)) {
+          rc_out = rcp;
+          break;
+        }
+      } else {
+        publish(u, false, false);
+      }
+    }
     if (ntr + 1 <= 60) tr[ntr++] = now_us() - t_begin;
   }
   c->gate_trace_n = ntr;

@@ -458,6 +458,9 @@ struct Ctx {
   int opt_search_skip = 0;     // MALIO_OPT_SEARCH_SKIP (off: measured at +1 us per search pass for the few points it keeps)
   int opt_gate_pinned = 0;     // MALIO_OPT_GATE_PINNED
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
+  int opt_node_gated = 1;      // MALIO_OPT_NODE_GATED: a shard's update runs the gated chain (host exchanges only)
+  int node_gated_runs = 0;     // updates of a shard that went through the gated chain
+  int node_gated_redone = 0;   // updates the gated chain of a shard handed back to the per-pass loop
   int fuse_cooldown = 0;  // eligible passes left that do NOT speculate (set by a miss, see fuse_eligible)
   int fuse_cooldown_len = 3, fuse_hits_in_row = 0;  // (FUSE_COOLDOWN_MIN; adapted by fused_collect)
   int fuse_hits = 0, fuse_misses = 0, fuse_passes = 0;
@@ -632,7 +635,7 @@ int ieskf_update_device(Ctx *c, malio_state_t *x, double *P, int *stats);
 int ieskf_update_device_begin(Ctx *c, const malio_state_t *x, const double *P);  // enqueue everything, return
 int ieskf_update_device_end(Ctx *c, malio_state_t *x, double *P, int *stats);    // wait, hand out the results
 void free_dev_loop(Ctx *c);
-int ieskf_update_gated(Ctx *c, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
+int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *x, double *P, int *stats, double *solve_time);  // see ieskf_dev.hip
 // measure.hip: the pass kernels of one iteration of the device loop (k_search/k_reuse by the control block's converge
 // flag, k_rows_reduce, k_final_reduce), all reading their state from c->d_loop
 int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArgs *gate = nullptr);  // gate: rides on the last kernel

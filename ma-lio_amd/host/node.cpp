@@ -154,9 +154,20 @@ int malio_node_create(const malio_params_t *params, int n_gpus, const int *devic
   }
   // handles (and RCCL communicators: ncclCommInitRank is collective) are created by the threads that will use them
   const void *uidp = uid;
-  int rc = nd->run([nd, row, uidp](Worker &k) -> int {
+  // Shards that share a device share its hardware queues (4 per process by default): the gate of one shard's unit, polling
+  // at the head of a queue, would hold up another shard's unit behind it until it times out. Such a node - a test
+  // configuration; production is one shard per GPU - updates pass by pass unless MALIO_OPT_NODE_GATED is set again.
+  int most = 0;
+  for (int r = 0; r < n_gpus; r++) {
+    int same = 0;
+    for (int q = 0; q < n_gpus; q++) same += nd->w[q].device == nd->w[r].device;
+    most = same > most ? same : most;
+  }
+  const bool gated_ok = most <= 3;
+  int rc = nd->run([nd, row, uidp, gated_ok](Worker &k) -> int {
     int rc = malio_create(&nd->prm, k.device, &k.h);
     if (rc != MALIO_OK) return rc;
+    if (!gated_ok && (rc = malio_set_option(k.h, MALIO_OPT_NODE_GATED, 0.0)) != MALIO_OK) return rc;
     if (nd->partition == MALIO_PART_TILES && (rc = malio_set_partition(k.h, k.rank, nd->n, nd->tile_m)) != MALIO_OK) return rc;
     if (nd->exchange == MALIO_NODE_XCHG_RCCL) rc = malio_xchg_create_rccl(uidp, k.rank, nd->n, row, k.device, &k.x);
     return rc;

@@ -9,8 +9,12 @@ cfg, G = int(os.environ.get("CFG", "2")), int(os.environ.get("G", "3"))
 sc = scenes.make_scene(cfg=cfg)
 one = capi.Engine(sc["params"]); one.map_build(sc["map"])
 res = {}
-for part in (capi.PART_SCAN, capi.PART_TILES):
+for part, gated in ((capi.PART_SCAN, 1), (capi.PART_SCAN, 0), (capi.PART_TILES, 1), (capi.PART_TILES, 0)):
     nd = capi.Node(sc["params"], [0] * G, partition=part, tile_m=16.0)
+    if gated and G > 3:
+        nd.close()
+        continue  # (more than three shards on one device share hardware queues: the node updates pass by pass, host/node.cpp)
+    nd.set_option("node_gated", gated)  # the gated chain on every shard / one pass at a time
     nd.map_build(sc["map"])
     ts, to = [], []
     for k in range(14):
@@ -19,6 +23,7 @@ for part in (capi.PART_SCAN, capi.PART_TILES):
         one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"]); one.measure(sc["state0"], True)
         t = time.perf_counter(); u = one.update_iterated(sc["state0"], sc["P0"]); to.append(time.perf_counter() - t)
     assert v["passes"] == u["passes"] and np.abs(v["state"] - u["state"]).max() < 1e-8
-    print("cfg %d, %d %s shards on one GPU: node update %.1f us (min %.1f), one engine %.1f us, passes %d" % (
-        cfg, G, "scan" if part == capi.PART_SCAN else "tile", np.median(ts[3:]) * 1e6, min(ts) * 1e6, np.median(to[3:]) * 1e6, v["passes"]))
+    print("cfg %d, %d %s shards on one GPU, %s: node update %.1f us (min %.1f), one engine %.1f us, passes %d" % (
+        cfg, G, "scan" if part == capi.PART_SCAN else "tile", "gated chain" if gated else "pass by pass", np.median(ts[3:]) * 1e6,
+        min(ts) * 1e6, np.median(to[3:]) * 1e6, v["passes"]))
     nd.close()
