@@ -126,7 +126,7 @@ def test_node_handle_equals_single_engine(capi, scenes, partition, kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("partition", ["scan", "tiles"])
-def test_node_gated_update_same_bits_as_pass_by_pass(capi, scenes, partition):
+def test_node_gated_update_same_bits_as_pass_by_pass(capi, orc, scenes, partition):
     """MALIO_OPT_NODE_GATED: every shard runs the gated chain (pass 0 through malio_measure_node, then one speculating
     k_pass per unit, the shards' rows meeting in host memory before the next unit's block is published). Same sums, same
     decisions, same bits as the node's pass-by-pass loop - over three scans in a row (the first has no guess of the extrema,
@@ -159,6 +159,24 @@ def test_node_gated_update_same_bits_as_pass_by_pass(capi, scenes, partition):
         nd.close()
     ref = runs["passes"]
     assert ref[0][0]["passes"] >= 3
+    # ... and the gated node against the ORACLE directly (reference ikd-Tree + restated h_share_model / esekfom loop), scan by
+    # scan: same passes, same accepted points, state to 1e-8, covariance like every other update in the suite
+    o = orc.Oracle(sc["params"], threads=8, use_ref=True)
+    o.map_build(sc["map"])
+    perm = np.random.default_rng(5).permutation(sc["N"])
+    for (r, g), x0 in zip(runs["gated"], (sc["state0"], s2, sc["state0"])):
+        o.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        v = o.update_iterated(x0, sc["P0"])
+        assert (r["passes"], r["searches"], r["M"]) == (v["passes"], v["searches"], v["M"])
+        assert np.array_equal(g["selected"], o.scan_get()["selected"])
+        # (the yardstick of test_gpu_parity: what the ORACLE's own result moves by when the same points come in another order -
+        # the node adds its shards' partial sums in rank order)
+        o.scan_set(sc["scan"][perm], sc["tables"], sc["temporal_comp"])
+        w = o.update_iterated(x0, sc["P0"])
+        dg = np.sqrt(np.abs(np.diag(v["P"])))
+        floor_P = (np.abs(w["P"] - v["P"]) / (np.outer(dg, dg) + 1e-300)).max()
+        assert np.abs(r["state"] - v["state"]).max() < max(1e-8, 10 * np.abs(w["state"] - v["state"]).max())
+        assert_P_close(r["P"], v["P"], rel=max(2e-3, 10 * floor_P))
     for mode in ("gated", "gated_bad_guess", "gated_one_shard_stalls"):
         for (r, g), (r0, g0) in zip(runs[mode], ref):
             assert (r["passes"], r["searches"], r["M"]) == (r0["passes"], r0["searches"], r0["M"]), mode
