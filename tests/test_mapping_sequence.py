@@ -50,7 +50,12 @@ def _scan_from(scenes, rng, world, pos, rot, ext_q, ext_t, tc, N, L, det_range, 
 
 
 @pytest.mark.gpu
-def test_mapping_loop_over_a_sequence_of_scans(orc, capi, scenes):
+@pytest.mark.parametrize("style", ["call_by_call", "pipelined"])
+def test_mapping_loop_over_a_sequence_of_scans(orc, capi, scenes, style):
+    """style = pipelined: the loop the way bench.py's `pipelined_turn` drives it - the NEXT scan staged ahead as packed 20-byte
+    records from page-locked memory while map_incremental runs (malio_scan_stage), malio_scan_set_packed, list maintenance on
+    its own stream, cached neighbours kept where a certificate allows - checked against the ORACLE step by step like the plain
+    loop (not against another run of the library)."""
     rng = np.random.default_rng(2024)
     L, N, K, n_table = 2, 8000, 8, 10
     base = scenes.make_scene(N=2000, Nmap=20000, L=L, seed=5)      # params, tables, temporal comp, extrinsics
@@ -71,6 +76,10 @@ def test_mapping_loop_over_a_sequence_of_scans(orc, capi, scenes):
     d0 = np.linalg.norm(world[:, :3] - p0[None, :].astype(np.float32), axis=1)
     map0 = world[d0 < 22.0].copy()                                  # the map knows 22 m, the LiDARs see 35 m
     eng = capi.Engine(prm)
+    pipelined = style == "pipelined"
+    if pipelined:
+        eng.set_option("search_skip", 1)
+        pins = [capi.PinnedArray((N, 5), np.float32) for _ in range(2)]
     eng.map_build(map0)
     port = orc.VoxMap(ds)
     port.build(map0)
@@ -79,9 +88,14 @@ def test_mapping_loop_over_a_sequence_of_scans(orc, capi, scenes):
     P = scenes.init_P(L)
     post = None
     sizes = []
+    scans = [_scan_from(scenes, rng, world, *pose(k), ext_q, ext_t, tc, N, L, 35.0, n_table) for k in range(K)]
+    assert all(sc_.shape[0] == N for sc_ in scans)
+    if pipelined:
+        pins[0].array[:] = capi.Engine.pack_scan(scans[0])
+        eng.scan_stage(pins[0].array, True)
     for k in range(K):
         pos, rot = pose(k)
-        scan = _scan_from(scenes, rng, world, pos, rot, ext_q, ext_t, tc, N, L, 35.0, n_table)
+        scan = scans[k]
         # prediction: ground truth + a bounded error (stands in for the IMU propagation of laserMapping.cpp:987)
         dpos = rng.normal(size=3)
         dpos *= 0.06 / np.linalg.norm(dpos)
@@ -93,9 +107,16 @@ def test_mapping_loop_over_a_sequence_of_scans(orc, capi, scenes):
             s = scenes.unpack_state(post, L)
             offR, offT = s["offR"], s["offT"]                       # the filter keeps refining the extrinsics
         prior = scenes.pack_state(pos + dpos, scenes.q_norm(scenes.q_mul(rot, scenes.q_from_rotvec(drot))), offR, offT)
-        eng.scan_set(scan, tables, tc)
+        if pipelined:
+            eng.scan_set_packed(pins[k % 2].array, tables, tc)
+        else:
+            eng.scan_set(scan, tables, tc)
         o.scan_set(scan, tables, tc)
         u, v = eng.update_iterated(prior, P), o.update_iterated(prior, P)
+        if pipelined and k + 1 < K:   # the next scan travels while this one's map_incremental runs
+            eng.scan_upload_wait()
+            pins[(k + 1) % 2].array[:] = capi.Engine.pack_scan(scans[k + 1])
+            eng.scan_stage(pins[(k + 1) % 2].array, True)
         assert (u["passes"], u["searches"], u["M"]) == (v["passes"], v["searches"], v["M"]), "scan %d" % k
         assert np.abs(u["state"] - v["state"]).max() < 1e-8, "scan %d" % k
         conftest_assert_P(u["P"], v["P"])
