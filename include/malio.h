@@ -537,7 +537,12 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
 int malio_node_stats(malio_handle_t h, int *stats2); /* the two counters of malio_measure_node */
 /* malio_update_iterated with malio_measure_node as h_dyn_share: every rank calls it with the same x and P and gets
  * the same posterior (bit for bit). Returns MALIO_SMALL_M_FALLBACK when fewer points than states were accepted
- * (esekfom.hpp:574-582 needs the rows of every rank: not a sharded path). */
+ * (esekfom.hpp:574-582 needs the rows of every rank: not a sharded path).
+ * With a host-memory exchange (malio_xchg_create / _create_local) and MALIO_OPT_NODE_GATED on (the default) the passes after
+ * the first run as the gated chain of malio_update_iterated - enqueued one ahead, a gate between two passes - and the ranks'
+ * rows meet between a pass' sums and the next pass' control block; same results, bit for bit, as one pass at a time (what
+ * an RCCL exchange, a pass hook, per-pass profiling or MALIO_OPT_FUSE = 0 select). The option, the update mode and
+ * MALIO_OPT_FUSE must be the same on every rank: the ranks decide from them, each for itself, which loop to run. */
 int malio_update_iterated_node(malio_handle_t h, malio_xchg_t x, malio_state_t *state, double *P, double R, int *stats,
                                double *solve_time);
 
