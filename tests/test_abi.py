@@ -24,6 +24,20 @@ def test_header_symbols_exported(capi):
     assert set(syms) == set(capi.EXPORTS)
 
 
+def test_option_numbers_match_the_header(capi):
+    """capi.OPT (what tests, bench.py and the tools pass to malio_set_option) against include/malio.h's enum, both ways; the
+    environment variables malio_create reads as initial values (csrc/capi.hip) name options that exist."""
+    txt = open(os.path.join(ROOT, "include", "malio.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    enum = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"\bMALIO_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", code)}
+    assert enum == capi.OPT and len(enum) >= 12
+    src = open(os.path.join(ROOT, "ma-lio_amd", "csrc", "capi.hip")).read()
+    envs = re.findall(r'\{"MALIO_([A-Z0-9_]+)",\s*MALIO_OPT_([A-Z0-9_]+)\}', src)
+    assert len(envs) >= 9 and all(a == b and b.lower() in enum for a, b in envs), envs
+    for name in enum:  # every option is documented where it is declared
+        assert txt.count("MALIO_OPT_" + name.upper()) >= 2 or name.startswith("debug_"), name
+
+
 def test_struct_layouts(capi):
     assert C.sizeof(capi.Point) == 48          # pcl::PointXYZINormal
     assert C.sizeof(capi.Pose) == 59 * 8        # common_lib.h:57-63
