@@ -1961,7 +1961,7 @@ int reset_pass_state(Ctx *c) {
 // A full sort delivers that and more (it was one stable radix sort of 32-bit keys: 10 launches of rocprim's merge sort,
 // ~0.1 ms for 100 k points, as much as two search passes); nothing needs the cells themselves ordered. So: a bucket
 // grouping. key = (slot, cell of the world point under the first pass' state, coordinates modulo 1024: a scan wider
-// than 1152 m merely interleaves two far-apart cells); bucket = (slot, vertical column of cells modulo a 64 x 64 tile);
+// than 1152 m merely interleaves two far-apart cells); bucket = (slot, column of cells modulo a 64 x 32-column tile, lowest bit of the vertical cell coordinate);
 //   k_sort_count    key, bucket, arrival rank inside the bucket (atomic: arbitrary)
 //   k_sort_scan     exclusive scan of the bucket counts (one workgroup; clears the counts for the next scan)
 //   k_sort_scatter  points to their bucket's segment in arrival order
