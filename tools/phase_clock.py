@@ -1,7 +1,7 @@
 """Developer aid: per-phase time of one mid-grid workgroup of k_plane / k_rows_reduce (needs `make PHASE=1`)."""
 import ctypes as C, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge; ge.load_package()
 from malio_amd import scenes
 from scipy.spatial import cKDTree

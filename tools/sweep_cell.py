@@ -1,7 +1,7 @@
 """Developer aid: search-pass time vs level-1 cell edge (config 2)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes

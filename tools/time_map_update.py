@@ -1,7 +1,7 @@
 """Wall time of the map mutators at BASELINE configs[1] scale (1M-point map, one scan's additions)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes

@@ -1,7 +1,7 @@
 """Developer aid: k_search time vs scan size around the one-generation limit (256 CUs x 6 workgroups x 64 queries)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes

@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge; ge.load_package()
 from malio_amd import capi, scenes
 CFG = int(os.environ.get("CFG", "2"))

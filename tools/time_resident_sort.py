@@ -2,7 +2,7 @@
 scan sort unnecessary on the resident path? Realistic raw cloud: the scene's scan points x3 with jitter."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.load_package()
 from malio_amd import capi, scenes
