@@ -34,11 +34,15 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_ACHIEVABLE_GBS = 6300.0    # same guide: the measured streaming rate
 ALG_BYTES_SEARCH_PASS = 120.0  # algorithmic bytes per scan point of a search pass
+ALG_BYTES_REUSE_PASS = 36.0    # ... of a reuse pass
+UNDISTORT_VALU_PER_POINT = 1050.0  # k_undistort: VALU instructions on a raw point's path (static count of the ISA, tools/kres.sh)
+VALU_PEAK_TLANEINSTR = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: one VALU instruction per lane and cycle on every SIMD
 # One launch per pass from the second pass of a scan on (k_pass: a1-a10 with the extrema speculated); the
 # first pass of a scan - and every pass under MALIO_FUSE=0 - is k_search -> k_rows_reduce -> k_final_reduce.
 DOMINANT_KERNELS = ("k_pass", "k_search")
-PROFILE_ROUND, PROFILE_TAG = "round4", "r04"  # the committed rocprofv3 / PMC summaries the roofline block cites
+PROFILE_ROUND, PROFILE_TAG = "round5", "r05"  # the committed rocprofv3 / PMC summaries the roofline block cites
 
 
 class _quiet_stdout:
@@ -58,6 +62,36 @@ class _quiet_stdout:
         os.close(self._saved)
 
 
+def host_cpu():
+    """(physical cores, model name) of this host from /proc/cpuinfo - what `lscpu` prints as Core(s) x Socket(s) and
+    "Model name"; falls back to the logical count."""
+    cores, model = set(), "unknown"
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:  # a cgroup / affinity mask smaller than the machine: no more threads than CPUs we may run on
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(1, n), model
+
+
 def cpu_baseline(sc, budget_s=20.0):
     with _quiet_stdout():
         return _cpu_baseline(sc, budget_s)
@@ -70,7 +104,8 @@ def _cpu_baseline(sc, budget_s):
     `value`) and the WHOLE iterated update (BASELINE.md's >= 10x target is stated on it). `value` = points/s of the
     search pass at T = 3. Bounded: at most ~budget_s of CPU work in total."""
     from oracle import orc
-    ncpu = os.cpu_count() or 1
+    nlogical = os.cpu_count() or 1
+    ncpu, cpu_model = host_cpu()  # physical cores (SURVEY.md section 8d: "T = all physical cores"), lscpu's model string
     t0 = time.time()
     o = orc.Oracle(sc["params"], threads=3, use_ref=True)
     o.map_build(sc["map"])
@@ -101,14 +136,14 @@ def _cpu_baseline(sc, budget_s):
     o.close()  # the reference tree announces its rebuild thread's end on stdout: do it inside the quiet region
     return {
         "value": N / res[3], "unit": "points/s", "cores": 3, "kind": "reference" if is_ref else "port",
-        "host_cores": ncpu,
+        "host_cores": ncpu, "host_logical_cpus": nlogical, "host_cpu_model": cpu_model,
         "pass_ms": {"T3": res[3] * 1e3, "Tall": res[ncpu] * 1e3},
         "update_ms": {"T3": upd[3] * 1e3, "Tall": upd[ncpu] * 1e3, "passes": passes},
         "sample": "%d/%d search passes of h_share_model and up to 5 whole iterated updates (%d passes each) over the same "
                   "%d-pt scan vs %d-pt map, medians; k-NN = %s; T3 = 3 OMP threads (reference MP_PROC_NUM) -> value, "
-                  "Tall = %d threads; tree build %.1f s not counted" % (
+                  "Tall = %d threads = the host's physical cores (%s, %d logical CPUs); tree build %.1f s not counted" % (
                       reps[3], reps[ncpu], passes, N, sc["Nmap"],
-                      "reference ikd-Tree compiled from source" if is_ref else "oracle k-d tree", ncpu, build_s),
+                      "reference ikd-Tree compiled from source" if is_ref else "oracle k-d tree", ncpu, cpu_model, nlogical, build_s),
     }
 
 
@@ -140,8 +175,13 @@ def secondary_figures(eng, sc, scenes, capi, cfg_index=2):
         kms += [ms for name, ms in eng.last_kernel_times() if name == "k_undistort"]
     eng.set_profiling(False)
     k = float(np.median(kms))
+    # k_undistort's real roof is f64 VALU issue, not HBM: ~1 050 VALU instructions per raw point (three exp_se3 factors in
+    # axis-angle form) against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s
     out["undistort"] = {"raw_points": n, "kernel_ms": k, "points_per_s": n / (k * 1e-3),
-                        "hbm_frac": 32.0 * n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "hbm_frac": 32.0 * n / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "roofline": {"bound": "valu_f64", "instr_per_point": UNDISTORT_VALU_PER_POINT,
+                                     "achieved": UNDISTORT_VALU_PER_POINT * n / (k * 1e-3) / 1e12, "peak": VALU_PEAK_TLANEINSTR,
+                                     "unit": "T lane-instr/s", "frac": UNDISTORT_VALU_PER_POINT * n / (k * 1e-3) / 1e12 / VALU_PEAK_TLANEINSTR}}
     # row f-2: voxel down-sampling of that raw cloud (host buffers in and out, as the reference's filter call)
     und, _ = eng.undistort(pts, beg, kt, kT, ext_q, ext_t, q_end, p_end, imu_t, cp)
     ts = []
@@ -563,44 +603,78 @@ def main():
 
 
 def roofline_block(eng, state, args, n_points):
-    """Roofline of the dominant kernel: hipEvents on the engine's stream, same process, same workload."""
+    """Roofline of the dominant kernel, MEASURED IN THIS RUN: hipEvents recorded on the engine's stream around every kernel
+    of min(50, steps) search passes; `achieved` = algorithmic bytes per launch / the mean interval, `frac` = achieved /
+    8 TB/s. The committed rocprofv3 / PMC run of this command (profiles/) is cited beside it under its own keys - and only
+    when it was taken from THIS build (malio_build_id) and its kernel time agrees with this run's to 15 %: a stale file can
+    no longer hide a regression behind `frac`."""
     eng.set_profiling(True)
     per = {}
     for _ in range(min(50, max(10, args.steps))):
         eng.measure(state, True)
         for name, ms in eng.last_kernel_times():
             per.setdefault(name, []).append(ms)
+    # the REUSE pass (converge = 0: neighbours and plane kept): 36 algorithmic bytes per point (SURVEY.md section 8d)
+    per_reuse = {}
+    for _ in range(20):
+        eng.measure(state, False)
+        for name, ms in eng.last_kernel_times():
+            per_reuse.setdefault(name, []).append(ms)
+    eng.measure(state, True)
     eng.set_profiling(False)
     kt = {k: float(np.mean(v)) for k, v in per.items()}
     DOMINANT_KERNEL = next((k for k in DOMINANT_KERNELS if k in kt and len(per[k]) >= len(per.get("k_search", []))), "k_search")
     dom_ms = kt.get(DOMINANT_KERNEL, float("nan"))
     achieved = ALG_BYTES_SEARCH_PASS * n_points / (dom_ms * 1e-3) / 1e9
-    # PMC counters and rocprofv3's own kernel durations cannot be collected from inside this process: they come from
-    # the committed runs of this same command (profiles/README.md), and are labelled as such
-    traffic, traffic_src, rp_ms, rp_src = None, None, None, None
+    frac = achieved / HBM_PEAK_GBS
+    build_id = capi_build_id()
+    committed = {"file": None, "used": False}
     tj = os.path.join(ROOT, "profiles", PROFILE_ROUND, PROFILE_TAG + "_pmc_traffic.json")
+    traffic = None
     if args.config == 2 and os.path.exists(tj):
         tjd = json.load(open(tj))
-        traffic, traffic_src = tjd["traffic_bytes_per_launch"], "committed PMC run " + os.path.relpath(tj, ROOT)
-        rp_ms, rp_src = tjd.get("rocprof_kernel_ms"), tjd.get("rocprof_source")
-    # ONE fraction: on rocprofv3's own duration of this kernel when a committed run of this command exists (the HIP-event
-    # interval carries ~2 us of marker gap; it is kept beside it as frac_events)
-    frac_events = achieved / HBM_PEAK_GBS
-    frac_rocprof = (ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rp_ms else None
-    if frac_rocprof:
-        achieved = ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9
+        rp_ms = tjd.get("rocprof_kernel_ms")
+        committed = {"file": os.path.relpath(tj, ROOT), "build_id": tjd.get("build_id"), "rocprof_kernel_ms": rp_ms,
+                     "rocprof_source": tjd.get("rocprof_source"), "traffic_bytes_per_launch": tjd.get("traffic_bytes_per_launch"),
+                     "used": False}
+        same_build = tjd.get("build_id") == build_id
+        # (an event interval carries ~2 us of marker gap on top of rocprofv3's own duration of the kernel)
+        agrees = bool(rp_ms) and abs((dom_ms - 0.002) - rp_ms) <= 0.15 * rp_ms
+        if same_build and agrees and tjd.get("kernel") == DOMINANT_KERNEL:
+            committed["used"] = True
+            committed["frac_rocprof"] = ALG_BYTES_SEARCH_PASS * n_points / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            traffic = tjd.get("traffic_bytes_per_launch")
+            committed["frac_on_measured_traffic"] = traffic / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+        else:
+            committed["refused"] = ("taken from build %s, this library is %s" % (tjd.get("build_id"), build_id)) if not same_build \
+                else "its kernel time %.4f ms differs from this run's %.4f ms by more than 15 %%" % (rp_ms or float("nan"), dom_ms)
+    rk = {k: float(np.mean(v)) for k, v in per_reuse.items()}
+    reuse_dom = "k_reuse" if "k_reuse" in rk else next(iter(rk), None)
+    reuse = None
+    if reuse_dom:
+        r_ach = ALG_BYTES_REUSE_PASS * n_points / (rk[reuse_dom] * 1e-3) / 1e9
+        reuse = {"kernel": reuse_dom, "kernel_ms": rk[reuse_dom], "alg_bytes_per_launch": ALG_BYTES_REUSE_PASS * n_points,
+                 "achieved": r_ach, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS, "frac_of_achievable": r_ach / HBM_ACHIEVABLE_GBS,
+                 "kernel_event_ms": rk, "pass_kernels_ms": float(sum(rk.values())),
+                 "note": "malio_measure(converge = 0): the reuse pass' point-phase kernel; 36 B/point are its contract "
+                         "(query 16 + cached plane 16 + normal_y 4)"}
     return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": frac_rocprof if frac_rocprof else frac_events,
-            "frac_source": ("rocprofv3 duration of the committed run " + str(rp_src)) if frac_rocprof else "HIP events, this run",
-            "frac_events": frac_events,
-            "traffic": None,  # HBM bytes cannot be counted from inside this process: see traffic_committed_pmc
-            "traffic_committed_pmc": traffic, "traffic_source": traffic_src,
-            "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * n_points, "kernel_ms": dom_ms,
-            "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes the marker gap)",
-            "rocprof_kernel_ms": rp_ms, "rocprof_source": rp_src, "kernel_event_ms": kt,
-            # the same kernel priced on the bytes it really moved (committed PMC run) instead of the contract's: what it
-            # is bound by (DESIGN.md section 8) - not the contract's `frac`
-            "frac_on_measured_traffic": (traffic / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and rp_ms) else None}
+            "unit": "GB/s", "frac": frac,
+            "frac_source": "HIP events on the engine's stream around each launch, this run, this binary (build %s)" % build_id,
+            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS, "achievable_peak": HBM_ACHIEVABLE_GBS,
+            # HBM bytes cannot be counted from inside the process; the committed PMC run's figure, when it is of this build
+            "traffic": traffic, "traffic_source": committed["file"] if committed.get("used") else None,
+            "alg_bytes_per_launch": ALG_BYTES_SEARCH_PASS * n_points, "kernel_ms": dom_ms, "launches_timed": len(per.get(DOMINANT_KERNEL, [])),
+            "kernel_ms_source": "HIP events on the engine's stream, this run (interval includes ~2 us of marker gap)",
+            "kernel_event_ms": kt, "build_id": build_id, "committed_profile": committed, "reuse_pass": reuse}
+
+
+def capi_build_id():
+    from malio_amd import capi
+    try:
+        return capi.lib().malio_build_id().decode()
+    except AttributeError:  # (a library of an earlier round loaded through MALIO_LIB)
+        return None
 
 
 def main_virtual_shards(args, torch, capi, scenes, dev_index):

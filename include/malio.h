@@ -128,6 +128,8 @@ typedef struct malio_measure_out {
 int malio_create(const malio_params_t *params, int device, malio_handle_t *out);
 int malio_destroy(malio_handle_t h);
 const char *malio_version(void);
+/* 12 hex digits naming the sources + compiler flags this binary was built from (profiles/ record it, bench.py compares) */
+const char *malio_build_id(void);
 /* HIP devices this process can use (0: none - malio_create would return MALIO_ERR_NO_DEVICE). Asked of the library's own
  * HIP runtime: a caller that probes through a second copy of libamdhip64 (another search path, another version)
  * initialises a second runtime in the process, and the one that comes second finds no device. */

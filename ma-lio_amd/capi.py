@@ -19,7 +19,7 @@ ERR_BAD_ARG = -3
 ERR_TIMEOUT = -7
 
 EXPORTS = [
-    "malio_create", "malio_destroy", "malio_version", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
+    "malio_create", "malio_destroy", "malio_version", "malio_build_id", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_node_map_get", "malio_node_map_total", "malio_node_voxel_downsample", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
@@ -114,6 +114,7 @@ def lib():
         _share_hip_runtime_with_torch()
         _lib = C.CDLL(path)
         _lib.malio_version.restype = C.c_char_p
+        _lib.malio_build_id.restype = C.c_char_p
         _lib.malio_last_error.restype = C.c_char_p
         _lib.malio_last_error.argtypes = [C.c_void_p]
         _lib.malio_localize_weight.restype = C.c_double

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include "malio_internal.hpp"
+#include "../build/build_id.h"  // MALIO_BUILD_ID (written by the Makefile)
 #include "../host/manifold.hpp"
 
 using namespace malio;
@@ -127,6 +128,7 @@ int malio::host_stage(malio::Ctx *c, size_t bytes, void **out) {
 extern "C" {
 
 const char *malio_version(void) { return "malio-hip 0.1 (gfx950, ABI 1)"; }
+const char *malio_build_id(void) { return MALIO_BUILD_ID; }
 
 int malio_device_count(void) {
   int n = 0;
