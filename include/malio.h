@@ -198,6 +198,25 @@ int malio_decode_livox(malio_handle_t h, const unsigned char *records, int n_rec
 int malio_decode_ouster(malio_handle_t h, const unsigned char *records, int n_records, int point_filter_num, double blind,
                         float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time);
 
+/* Velodyne: the data[] of a sensor_msgs::PointCloud2 as the velodyne driver publishes it, through
+ * Preprocess::velodyne_handler (preprocess.cpp:148-212). pcl::fromROSMsg (:155) maps the message's fields BY NAME onto
+ * velodyne_ros::Point (preprocess.h:18-34: x, y, z, intensity, time - all FLOAT32 - and ring, UINT16), so the caller hands
+ * over the message's point_step and the byte offsets of those fields (sensor_msgs::PointField::offset; little-endian, no
+ * alignment assumed). off_intensity / off_time < 0: the message has no such field - the value reads 0.f. ring is not an
+ * argument: the handler reads it only in the block of :161-186, whose results (given_offset_time, yaw_first, yaw_end)
+ * nothing uses. Per point, as :189-211: curvature = time * time_unit_scale (float); every point_filter_num-th POINT (the
+ * index counts all points, :202) that lies outside the blind sphere (x*x + y*y + z*z in float > blind * blind, :204) is
+ * pushed; *maximum_time = the largest curvature pushed, or -9999 (:188,206-207; offsets may be negative: some drivers stamp
+ * relative to the END of the sweep). n_points == 0: the handler returns before it touches maximum_time (:157-158) -
+ * *out_n = 0 and *maximum_time is left as the caller had it. */
+typedef struct malio_pc2_layout {
+  int point_step;                                 /* bytes per point (sensor_msgs::PointCloud2::point_step) */
+  int off_x, off_y, off_z, off_intensity, off_time; /* byte offset of each FLOAT32 field inside a point; < 0: absent */
+} malio_pc2_layout_t;
+int malio_decode_velodyne(malio_handle_t h, const unsigned char *data, int n_points, const malio_pc2_layout_t *layout,
+                          int point_filter_num, double blind, float time_unit_scale, malio_point_t *out, int cap, int *out_n,
+                          double *maximum_time);
+
 /* ---- voxel down-sampling ------------------------------------------------ */
 /* downSizeFilterSurf.setInputCloud(cloud); downSizeFilterSurf.filter(*out)   laserMapping.cpp:93,860,968-971:
  * pcl::VoxelGrid<PointType> with its defaults (all fields averaged, min_points_per_voxel 0), leaf = filter_size_surf.

@@ -20,7 +20,7 @@ ERR_TIMEOUT = -7
 
 EXPORTS = [
     "malio_create", "malio_destroy", "malio_version", "malio_build_id", "malio_device_count", "malio_last_error", "malio_set_stream", "malio_map_build",
-    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_node_map_get", "malio_node_map_total", "malio_node_voxel_downsample", "malio_decode_livox", "malio_decode_ouster", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
+    "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_node_map_get", "malio_node_map_total", "malio_node_voxel_downsample", "malio_decode_livox", "malio_decode_ouster", "malio_decode_velodyne", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
     "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
@@ -44,6 +44,10 @@ XCHG_HOST, XCHG_RCCL = 0, 1
 class Point(C.Structure):  # malio_point_t == pcl::PointXYZINormal
     _fields_ = [(n, C.c_float) for n in ("x", "y", "z", "_pad0", "normal_x", "normal_y", "normal_z", "_pad1",
                                          "intensity", "curvature", "_pad2", "_pad3")]
+
+
+class Pc2Layout(C.Structure):  # malio_pc2_layout_t
+    _fields_ = [(n, C.c_int) for n in ("point_step", "off_x", "off_y", "off_z", "off_intensity", "off_time")]
 
 
 class Pose(C.Structure):  # malio_pose_t
@@ -342,6 +346,19 @@ class Engine:
         self._chk(lib().malio_decode_ouster(self.h, rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(point_filter_num),
                                             C.c_double(blind), C.c_float(time_unit_scale), _p(out, Point), n + 1,
                                             C.byref(m), C.byref(mt)), "malio_decode_ouster")
+        return out[:m.value].copy(), mt.value
+
+    def decode_velodyne(self, data, n_points, layout, point_filter_num, blind, time_unit_scale, maximum_time_in=-1.0):
+        """PointCloud2 data[] of a Velodyne message -> (pl_surf [m,12], maximum_time), Preprocess::velodyne_handler.
+        layout = (point_step, off_x, off_y, off_z, off_intensity, off_time) in bytes (< 0: field absent)."""
+        rec = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        n = int(n_points)
+        out = np.zeros((n + 1, 12), np.float32)
+        lay = Pc2Layout(*[int(v) for v in layout])
+        m, mt = C.c_int(0), C.c_double(maximum_time_in)
+        self._chk(lib().malio_decode_velodyne(self.h, rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, C.byref(lay),
+                                              int(point_filter_num), C.c_double(blind), C.c_float(time_unit_scale),
+                                              _p(out, Point), n + 1, C.byref(m), C.byref(mt)), "malio_decode_velodyne")
         return out[:m.value].copy(), mt.value
 
     def voxel_downsample(self, pts12, leaf, normal_mode=1):

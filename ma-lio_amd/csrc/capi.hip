@@ -550,6 +550,23 @@ int malio_decode_ouster(malio_handle_t h, const unsigned char *records, int n_re
   return decode_ouster(h, records, n_records, point_filter_num, blind, time_unit_scale, out, cap, out_n, maximum_time);
 }
 
+int malio_decode_velodyne(malio_handle_t h, const unsigned char *data, int n_points, const malio_pc2_layout_t *layout,
+                          int point_filter_num, double blind, float time_unit_scale, malio_point_t *out, int cap, int *out_n,
+                          double *maximum_time) {
+  if (check(h) || n_points < 0 || (n_points > 0 && !data) || !layout || point_filter_num < 1 || !out_n || cap < 0 ||
+      (cap > 0 && !out))
+    return MALIO_ERR_BAD_ARG;
+  const malio_pc2_layout_t &l = *layout;
+  const int need[3] = {l.off_x, l.off_y, l.off_z}, opt[2] = {l.off_intensity, l.off_time};
+  if (l.point_step < 12) return MALIO_ERR_BAD_ARG;
+  for (int k = 0; k < 3; k++)
+    if (need[k] < 0 || need[k] + 4 > l.point_step) return MALIO_ERR_BAD_ARG;
+  for (int k = 0; k < 2; k++)
+    if (opt[k] >= 0 && opt[k] + 4 > l.point_step) return MALIO_ERR_BAD_ARG;
+  if ((long long)n_points * l.point_step > 0x7FFFFFFFll * 4) return MALIO_ERR_BAD_ARG;
+  return decode_velodyne(h, data, n_points, l, point_filter_num, blind, time_unit_scale, out, cap, out_n, maximum_time);
+}
+
 int malio_voxel_downsample(malio_handle_t h, const malio_point_t *pts, int n, float leaf, int normal_mode,
                            malio_point_t *out, int cap, int *out_n) {
   if (check(h) || !out_n || n < 0 || cap < 0 || (n > 0 && !pts) || (cap > 0 && !out)) return MALIO_ERR_BAD_ARG;

@@ -6,6 +6,8 @@
 //   Ouster:               22-byte records x y z intensity (f32), ring (u16), t (u32)
 //                         file_player/src/ROSThread.cpp:947-957           ->  Preprocess::oust64_handler,
 //                         MA_LIO/src/preprocess.cpp:109-149
+//   Velodyne:             the data[] of a sensor_msgs::PointCloud2 (fields by offset, see malio_pc2_layout_t)
+//                         pcl::fromROSMsg + Preprocess::velodyne_handler, MA_LIO/src/preprocess.cpp:148-212
 // Byte/integer work bounded by HBM: one thread per record, unaligned little-endian loads, the handler's filters,
 // then an order-preserving compaction (exclusive scan of the keep flags). The handlers' sequential pieces are
 // restated in parallel form:
@@ -131,10 +133,62 @@ __global__ void __launch_bounds__(BLK) k_ouster_emit(const unsigned char *__rest
   q[10] = 0.f, q[11] = 0.f;
 }
 
+// ---- Velodyne (preprocess.cpp:148-212) ------------------------------------------------------------------------------
+// One thread per point of the message. What the handler does before its loop (:161-186: is_first / yaw_fp / yaw_last /
+// time_last, given_offset_time, yaw_first, yaw_end, layer_first) feeds nothing - the per-ring yaw interpolation FAST-LIO
+// has there was removed from MA-LIO's loop - and is not computed. maximum_time: the curvature may be NEGATIVE (drivers that
+// stamp relative to the end of the sweep), so the slots hold an order-preserving code of ALL non-NaN floats (0 = none;
+// `maximum_time < NaN` is false in the reference too, :206).
+__device__ __forceinline__ u32 f32_order_code(float f) {
+  const u32 b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // monotonic over the non-NaN floats, never 0 for them
+}
+struct VelPoint {
+  float x, y, z, intensity, curvature;
+};
+__device__ __forceinline__ VelPoint vel_point(const unsigned char *__restrict__ data, malio_pc2_layout_t lay, float time_unit_scale, int i) {
+  const unsigned char *p = data + (size_t)i * (size_t)lay.point_step;
+  VelPoint v;
+  v.x = ld_f32(p + lay.off_x), v.y = ld_f32(p + lay.off_y), v.z = ld_f32(p + lay.off_z);  // :196-198
+  v.intensity = lay.off_intensity >= 0 ? ld_f32(p + lay.off_intensity) : 0.f;               // :199
+  const float time = lay.off_time >= 0 ? ld_f32(p + lay.off_time) : 0.f;
+  v.curvature = time * time_unit_scale;                                                     // :200
+  return v;
+}
+__global__ void __launch_bounds__(BLK) k_velodyne_select(const unsigned char *__restrict__ data, int n, malio_pc2_layout_t lay,
+                                                         int pfn, double blind, float time_unit_scale, u32 *keep, u32 *tmax_code) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  u32 code = 0u;
+  bool push = false;
+  if (i < n && i % pfn == 0) {  // :202
+    const VelPoint v = vel_point(data, lay, time_unit_scale, i);
+    if ((double)(v.x * v.x + v.y * v.y + v.z * v.z) > blind * blind) {  // :204 (float sum, compared in double)
+      push = true;
+      if (v.curvature == v.curvature) code = f32_order_code(v.curvature);  // :206-207
+    }
+  }
+  if (i <= n) keep[i] = push ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) code = max(code, (u32)__shfl_xor((int)code, d));
+  if ((threadIdx.x & 63) == 0 && code) atomicMax(&tmax_code[blockIdx.x & 63], code);
+}
+__global__ void __launch_bounds__(BLK) k_velodyne_emit(const unsigned char *__restrict__ data, int n, malio_pc2_layout_t lay,
+                                                       float time_unit_scale, const u32 *__restrict__ keep,
+                                                       const u32 *__restrict__ pos, float *out12) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  const VelPoint v = vel_point(data, lay, time_unit_scale, i);
+  float *q = out12 + (size_t)pos[i] * 12;
+  q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = 1.f;
+  q[4] = 0.f, q[5] = 0.f, q[6] = 0.f, q[7] = 0.f;  // :193-195
+  q[8] = v.intensity, q[9] = v.curvature;
+  q[10] = 0.f, q[11] = 0.f;
+}
+
 // shared tail: scan of keep flags, emit, copy back; `nidx` = number of candidate indices (keep has nidx + 1 entries)
 template <class EmitFn>
 int finish_decode(Ctx *c, ArenaScope &sc, u32 *keep, int nidx, u32 *tmax_bits, EmitFn emit, malio_point_t *out, int cap,
-                  int *out_n, double *maximum_time) {
+                  int *out_n, double *maximum_time, bool order_code = false) {
   u32 *pos = nullptr, *tiles = nullptr;
   MALIO_HIP(sc.get(&pos, (size_t)nidx + 1));
   MALIO_HIP(sc.get(&tiles, (size_t)(nidx + 1 + 1023) / 1024 + 2));
@@ -147,8 +201,8 @@ int finish_decode(Ctx *c, ArenaScope &sc, u32 *keep, int nidx, u32 *tmax_bits, E
   if (maximum_time) {
     double mt = -9999;  // preprocess.cpp:78,119
     for (int k = 0; k < 64; k++)
-      if (tb[k] != 0u) {  // slots hold (float bits + 1); curvatures are >= 0, so bits order like values
-        const u32 bits = tb[k] - 1u;
+      if (tb[k] != 0u) {  // slots hold (float bits + 1): curvatures >= 0, bits order like values; or f32_order_code (Velodyne)
+        const u32 bits = order_code ? ((tb[k] & 0x80000000u) ? (tb[k] & 0x7FFFFFFFu) : ~tb[k]) : tb[k] - 1u;
         float f;
         memcpy(&f, &bits, 4);
         if (mt < (double)f) mt = (double)f;
@@ -217,6 +271,28 @@ int decode_ouster(Ctx *c, const unsigned char *rec, int n, int pfn, double blind
     hipLaunchKernelGGL(k_ouster_emit, dim3(nb), dim3(BLK), 0, c->stream, d_rec, n, time_unit_scale, keep, pos, d_out);
   };
   return finish_decode(c, sc, keep, n, tmax, emit, out, cap, out_n, maximum_time);
+}
+
+int decode_velodyne(Ctx *c, const unsigned char *data, int n, const malio_pc2_layout_t &lay, int pfn, double blind,
+                    float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time) {
+  MALIO_HIP(hipSetDevice(c->device));
+  *out_n = 0;
+  if (n <= 0) return MALIO_OK;  // :157-158: returns before maximum_time is reset - the caller's value stays
+  ArenaScope sc(c->arena);
+  unsigned char *d_data = nullptr;
+  u32 *keep = nullptr, *tmax = nullptr;
+  const size_t bytes = (size_t)n * (size_t)lay.point_step;
+  MALIO_HIP(sc.get(&d_data, bytes + 16));
+  MALIO_HIP(sc.get(&keep, (size_t)n + 1));
+  MALIO_HIP(sc.get(&tmax, 64));
+  MALIO_HIP(hipMemcpyAsync(d_data, data, bytes, hipMemcpyHostToDevice, c->stream));
+  MALIO_HIP(hipMemsetAsync(tmax, 0, sizeof(u32) * 64, c->stream));
+  const int nb = (n + 1 + BLK - 1) / BLK;
+  hipLaunchKernelGGL(k_velodyne_select, dim3(nb), dim3(BLK), 0, c->stream, d_data, n, lay, pfn, blind, time_unit_scale, keep, tmax);
+  auto emit = [&](const u32 *pos, float *d_out) {
+    hipLaunchKernelGGL(k_velodyne_emit, dim3(nb), dim3(BLK), 0, c->stream, d_data, n, lay, time_unit_scale, keep, pos, d_out);
+  };
+  return finish_decode(c, sc, keep, n, tmax, emit, out, cap, out_n, maximum_time, true);
 }
 
 }  // namespace malio

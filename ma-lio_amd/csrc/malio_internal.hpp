@@ -39,6 +39,7 @@ struct CellGrid {
 // its 3x3x3 block, the points of that block stored CONTIGUOUSLY (each map point is replicated 27 times -
 // 432 MB at 1M points: this is what the 288 GB of HBM are for). A query then needs ONE directory probe and one
 // streaming read of ~20 points instead of 27 probes and 9 scattered runs.
+constexpr size_t NL_GUARD = 1024;  // entries allocated behind NList::pts[cap_pts): a walk's last round may read (never use) them
 struct NList {
   Cell *table = nullptr;  // fine cell -> (start, count) of its neighbourhood list
   u32 tmask = 0;
@@ -576,6 +577,9 @@ int decode_livox(Ctx *c, const unsigned char *rec, int n_rec, int n_scans, int p
                  malio_point_t *out, int cap, int *out_n, double *maximum_time);
 int decode_ouster(Ctx *c, const unsigned char *rec, int n, int pfn, double blind, float time_unit_scale, malio_point_t *out,
                   int cap, int *out_n, double *maximum_time);
+
+int decode_velodyne(Ctx *c, const unsigned char *data, int n, const malio_pc2_layout_t &lay, int pfn, double blind,
+                    float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time);
 
 // voxel.hip
 int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,

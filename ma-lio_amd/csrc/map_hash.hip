@@ -545,7 +545,9 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
       c->err = "neighbour lists exceed 2^32 entries";
       return MALIO_ERR_ALLOC;
     }
-    MALIO_HIP(hipMalloc(&nl.pts, sizeof(float4) * nl.cap_pts));
+    // + NL_GUARD entries nobody owns: the pipelined walk (measure.hip, nl_search) reads whole rounds, and the last round of
+    // the array's last list may reach past its end
+    MALIO_HIP(hipMalloc(&nl.pts, sizeof(float4) * (nl.cap_pts + NL_GUARD)));
   }
   MALIO_HIP(hipMemsetAsync(cnt, 0, sizeof(u32) * tbig, c->stream));  // reuse as the fill cursor
   hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,

@@ -29,6 +29,11 @@ __device__ long long g_phase[4][16];
 // grid-wide spread of one kernel: entry and exit time of every workgroup (plain stores: same-address atomics from
 // 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
 __device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pending level-2 queries
+// the helper wave's stamps (KS_SPLIT): its lane 0 is thread 64
+#define PHH(kid, k)                                                                     \
+  do {                                                                                  \
+    if (threadIdx.x == 64 && blockIdx.x == gridDim.x / 2) g_phase[kid][k] = wall_clock64(); \
+  } while (0)
 #define PH_ENTER()                                                                    \
   do {                                                                                \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[0][blockIdx.x] = wall_clock64(); \
@@ -43,9 +48,21 @@ __device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pe
   } while (0)
 #else
 #define PH(kid, k)
+#define PHH(kid, k)
 #define PH_ENTER()
 #define PH_NOTE(row, val)
 #define PH_EXIT()
+#endif
+
+// Developer aid: attribution builds (tools/attr_variants.sh; WRONG results, timing and PMC counters only; never shipped):
+//   -DATTR_NO_GATHER  phase C takes the five neighbours' coordinates from LDS instead of gathering them from the map array
+//   -DATTR_NO_STATE   the per-point state of a search pass (74 B / point) is not stored
+//   -DATTR_WALK5      a list walk stops after the first five entries (probe and first line stay)
+//   -DATTR_NO_TILES   k_pass does not store its tile
+#ifdef ATTR_NO_STATE
+#define STATE_ST(stmt) ;
+#else
+#define STATE_ST(stmt) stmt
 #endif
 
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -449,6 +466,21 @@ __device__ __forceinline__ void world_point(const QuatConst &qc, const float4 q,
   nb = sqrt(p_body.x * p_body.x + p_body.y * p_body.y + p_body.z * p_body.z);  // p_body.norm(), :599
 }
 
+// esti_plane's plane_cov (common_lib.h:159-173): the five neighbours' normal_y W_j weighted by their distance from cov_threshold
+__device__ __forceinline__ double plane_unit_cov(double cov_threshold, const float W[5]) {
+  double ucov = 0.0, cov_sum = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) cov_sum += fabs(cov_threshold - (double)W[k]);
+  if ((double)W[0] > 0.00001) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      double wk = (cov_threshold - (double)W[k]) / cov_sum;
+      ucov += wk * wk * (double)W[k];
+    }
+  }
+  return ucov;
+}
+
 // residual + range gate (laserMapping.cpp:598-601)
 __device__ __forceinline__ bool residual_gate(const float pabcd[4], float wx, float wy, float wz, double nb,
                                               float &pd2) {
@@ -473,6 +505,23 @@ __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, 
   }
   if (selected && !a.extrinsic_est_en) return 0.0;  // R(i,0) stays 0, normal_y not rewritten (:681-704)
   return point_trace(a.unc[off + k], q.x, q.y, q.z);
+}
+
+// The same under BOTH clamp rules, before the accept flag exists (KS_SPLIT: a helper wave evaluates the trace while the
+// control wave fits the plane; the flag then picks one). trS == trace_for(.., true), trR == trace_for(.., false), bit for bit:
+// the two rules name different table entries only for the last index of a table.
+__device__ __forceinline__ void trace_both(const Pass1Args &a, const float4 q, int lid, int tidx, double &trS, double &trR) {
+  int len = a.unc_len[0], off = a.unc_off[0];
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (lid == l) len = a.unc_len[l], off = a.unc_off[l];
+  int kS = tidx, kR = tidx;
+  if ((unsigned)kS >= (unsigned)len) kS = len - 2;
+  if ((unsigned)kR >= (unsigned)(len - 1)) kR = len - 2;
+  trR = point_trace(a.unc[off + kR], q.x, q.y, q.z);
+  trS = trR;
+  if (kS != kR) trS = point_trace(a.unc[off + kS], q.x, q.y, q.z);
+  if (!a.extrinsic_est_en) trS = 0.0;  // R(i,0) stays 0 for an accepted point (:681-704)
 }
 
 // feats_down_body[i].normal_y bookkeeping (laserMapping.cpp:699,730,741): a pass that reached the end
@@ -593,7 +642,23 @@ struct NlView {
 // limit never enter it, nothing is tracked for lb2, which reads 0): every instruction per candidate counts in this loop -
 // the bookkeeping of the certificate costs the search pass 0.7 us at BASELINE config 2 (profiles/round4/r04h_*) - so only
 // the kernels of a handle with MALIO_OPT_SEARCH_SKIP on carry it.
-template <int G, bool CERT>
+// The walk of the LONG lists (level 2: 180-900 entries; PIPE) is software-pipelined (KS_PIPE, round 5): BASELINE config 5's
+// search pass -1.3 us. Under load a dependent memory round trip of this phase costs ~2 us (all workgroups of the one resident
+// generation issue the same burst at the same time); the walk of rounds 1-4 - 8 loads per lane, wait, 8 insertions, again -
+// paid every round trip and every batch of insertions one after the other. Here: rounds of THREE 16-byte loads per lane in
+// two register sets, the next round's loads issued (and pinned by a scheduling barrier: left alone the scheduler sinks them
+// behind the insertions) before this round's candidates are inserted; loads return in order, so the compiler's own
+// `s_waitcnt vmcnt(3)` in front of the insertions means "this round has arrived". What keeps it inside the 72-VGPR budget,
+// where round 3's attempt spilled: ONE 64-bit pointer per lane with the round's entries at immediate offsets - no clamped
+// index, no address per load: a lane whose list has ended keeps its pointer (it loads the same lines again and offers
+// MAXKEY), a round's entries past the end of a list read the list's slack, the next list or the guard behind the array
+// (build_nlist: NL_GUARD) and offer nothing either -, no SLP vectorisation (Makefile), three loads per round (four: 31
+// spilled VGPRs, 43 us). The loop is wave-uniform (a ballot decides). (Loads as inline assembly with hand-placed waits were
+// tried first and are a trap: the compiler copies a register set whose loads are still in flight.)
+#ifndef KS_PIPE
+#define KS_PIPE 1
+#endif
+template <int G, bool CERT, bool PIPE>
 __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
                                           Top5 &t, float &lb2) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
@@ -606,6 +671,68 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   u32 slot = hash_key_d(key) & nl.tmask;
   u32 start, count;
   cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
+#ifdef ATTR_WALK5
+  count = min(count, 5u);
+#endif
+  // (the SKIP kernels' walk - CERT: the certificate's bookkeeping rides on every insertion - stays the two-batch loop: with
+  // it the pipelined form spills 200 VGPRs; the option is off by default)
+  if constexpr (PIPE && !CERT) {
+    const float4 *lst = nl.pts + (size_t)start;
+    // one candidate slot: entry e of the list as loaded into m (a slot past the end - its load was clamped to the last entry -
+    // offers the largest key, which sorts behind everything)
+    auto offer = [&](const float4 &m, u32 e) {
+      float ddx = wx - m.x, ddy = wy - m.y, ddz = wz - m.z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+      const u64 key = top5_key(d2, __float_as_uint(m.w));
+      const u32 out = top5_insert(t, e < count ? key : TOP5_MAXKEY);
+      if (CERT) ev = min(ev, out);
+    };
+#ifndef KS_PIPE_R
+#define KS_PIPE_R 3
+#endif
+    constexpr int R = KS_PIPE_R;  // loads per lane and round
+    auto offer_round = [&](const float4 (&m)[R], u32 e) {
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        offer(m[u], e + (u32)(u * G));
+#ifdef KS_PIPE_SEQ
+        __builtin_amdgcn_sched_barrier(0);  // (one insertion after the other: interleaved they need more registers than the kernel has)
+#endif
+      }
+    };
+    const float4 *pa = lst + sub;  // this lane's entry of round a (the other entries of the round: immediates)
+    u32 j = (u32)sub;              // ... its index in the list
+    float4 a[R], b[R];
+#pragma unroll
+    for (int u = 0; u < R; u++) a[u] = pa[u * G];
+    while (true) {
+      // (wave-uniform: does any list of this wave reach into the next round?)
+      const u32 n = j + (u32)(R * G);
+      if (__ballot(n < count) == 0ull) {
+        offer_round(a, j);
+        break;
+      }
+      const float4 *pb = pa + (n < count ? R * G : 0);
+#pragma unroll
+      for (int u = 0; u < R; u++) b[u] = pb[u * G];
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads behind the insertions they are to overlap with)
+      offer_round(a, j);
+      j = n + (u32)(R * G);  // (the round after b's)
+      if (__ballot(j < count) == 0ull) {
+        offer_round(b, n);
+        break;
+      }
+      pa = pb + (j < count ? R * G : 0);
+#pragma unroll
+      for (int u = 0; u < R; u++) a[u] = pa[u * G];
+      __builtin_amdgcn_sched_barrier(0);
+      offer_round(b, n);
+    }
+  } else {
+  // The short lists of level 1 (~44 entries: two batches) keep the two-batch walk: pipelined rounds were measured 0.6-1 us
+  // SLOWER there (a round's insertions, ~1 us for the SIMD's seven waves, do not cover a ~2 us round trip; rounds of 2 / 3 / 4
+  // loads: 30.7 / 30.9 / 43 us - the last one spills - against 29.8 us), and touching the second batch's lines while the
+  // first is in flight (an L2 prefetch by 4-byte loads) changed nothing (profiles/round5/r05d_walk_variants.txt).
   for (u32 j = (u32)sub; j < count; j += 8 * G) {
     float4 m[8];
 #pragma unroll
@@ -621,6 +748,7 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
       const u32 out = top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
       if (CERT) ev = min(ev, out);
     }
+  }
   }
   if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
   // CERT: survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count
@@ -656,7 +784,11 @@ __device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.
 // gathering them a second time. The lazy normal_y commit of the previous pass happened in phase A (search_wg).
 // (What phase A left in LDS - world point, |p'|, scan point - is read where it is used: held in registers across the
 // plane fit it is what the register allocator spills.)
+// SPLIT (KS_SPLIT, the control wave of a workgroup whose second wave stays as its helper): plane, gates and their per-point
+// state only - unit_cov, the trace, their stores and the extrema are the helper's (helper_pre / helper_post): ucov and tr
+// come back untouched.
 struct SearchLds;
+template <bool SPLIT>
 __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
                                             float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
                                             float &pd2_out, float4 &q_out);
@@ -691,6 +823,32 @@ __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst 
   a.sel[i] = selected ? 1 : 0;
   tr = trace_for(a, q, lid, tidx, selected);
   a.trace[i] = tr;
+}
+// The same for the control wave of k_pass under KS_SPLIT: loads and arithmetic only. The world point, the flag and the
+// residual go back to the caller, which hands them to the helper wave through LDS; the helper stores them with the rest of
+// the per-point state (helper_post), forms the trace and folds the previous pass' normal_y.
+__device__ __forceinline__ void reuse_point_ctrl(const Pass1Args &a, const QuatConst &qc, int i, bool &selected, float4 &pl_out,
+                                                 float &pd2_out, float4 &q_out, float4 &world_out) {
+  selected = false;
+  pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f, q_out = pl_out, world_out = pl_out;
+  if (i >= a.N || a.nfound[i] == NF_NOTMINE) return;
+  const float4 q = a.scan[i];
+  const unsigned char sel_old = a.sel[i];
+  const float4 pl = a.plane[i];  // (always allocated, initialised by the scan's installation: loaded beside the flag, not behind it)
+  q_out = q;
+  float wx, wy, wz;
+  double nb;
+  world_point(qc, q, __float_as_int(q.w) & 0xFF, wx, wy, wz, nb);
+  world_out = make_float4(wx, wy, wz, 0.f);
+  if (sel_old) {
+    pl_out = pl;
+    const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
+    float pd2;
+    if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
+      selected = true;
+      pd2_out = pd2;
+    }
+  }
 }
 
 // a4 over one wave's 64 points: extrema of unit_cov / R and the count of accepted points -> one slot
@@ -736,26 +894,48 @@ struct SearchLds {
   float4 q[SQ];            // the scan point as phase A read it (phase C: the row and the trace are built from it)
   float4 nbp[5][SQ];       // phase C: the five neighbours' map points, kept across the plane fit (point_phase)
   double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
+  // KS_SPLIT: what the helper wave and the control wave hand each other across their one barrier
+  double trS[SQ], trR[SQ];  // helper -> itself: the trace under the accepted / rejected point's clamp rule (trace_both)
+  double ucv[SQ];           // helper -> itself: unit_cov of the five neighbours (esti_plane's plane_cov)
+  unsigned char selc[SQ];   // control -> helper: the accept flag
+  float4 plc[SQ];           // control -> helper: the plane (n, d) - the helper stores the per-point state
+  float pd2c[SQ];           // control -> helper: the residual
 };
+// the plane-independent factors of the a5/a7 row, formed by the helper wave of k_pass while the control wave fits the plane
+struct RowPre {
+  double X[3][SQ];  // point_this: the scan point in the IMU frame at LiDAR 0's scan end (laserMapping.cpp:660-667)
+  double cp[SQ];    // plane weight c_i (:651-656)
+  double rw[SQ];    // 1 / R_i after the FIC and the clamp of esekfom.hpp:624-626 (ROWS_DIVIDE: R_i itself)
+};
+template <bool SPLIT>
 __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
                                             float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
                                             float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
   pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
-  if (cert_r >= 0.f) {
-    const float4 w = S.w[lane];
-    a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);
-  }
+  // SPLIT: the control wave issues NO global store before its tile - on gfx9 a wave's stores and loads share one in-order
+  // counter (vmcnt), so a store in front of the neighbour gather makes the gather's wait a wait for the store's round trip
+  // too. The helper wave stores the per-point state after the barrier (helper_post), from LDS.
+  if (!SPLIT) {
+    if (cert_r >= 0.f) {
+      const float4 w = S.w[lane];
+      STATE_ST(a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);)
+    }
 #pragma unroll
-  for (int k = 0; k < 5; k++) a.nbr[(size_t)k * a.N + i] = og[k];
-  a.nfound[i] = (unsigned char)nf;  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
+    for (int k = 0; k < 5; k++) STATE_ST(a.nbr[(size_t)k * a.N + i] = og[k];)
+    STATE_ST(a.nfound[i] = (unsigned char)nf;)  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
+  }
   if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
     // ---- esti_plane<float> (common_lib.h:144-190) ----
     float A[5][3], W[5];
     {
       float4 m[5];
+#ifdef ATTR_NO_GATHER
+      for (int k = 0; k < 5; k++) m[k] = make_float4(S.w[lane].x + 0.3f * (float)(k & 1), S.w[lane].y + 0.3f * (float)(k >> 1), S.w[lane].z + 0.01f * (float)k, 0.001f);
+#else
 #pragma unroll
       for (int k = 0; k < 5; k++) m[k] = a.map_in[og[k]];
+#endif
       // all five gathers in flight at once (left to itself the compiler fetched the five normal_y words one after the
       // other, each behind a wait: four extra round trips on this wave's chain)
       asm volatile("" : "+v"(m[0].w), "+v"(m[1].w), "+v"(m[2].w), "+v"(m[3].w), "+v"(m[4].w));
@@ -766,16 +946,7 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
       }
     }
     PH(0, 4);
-    double cov_sum = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) cov_sum += fabs(a.cov_threshold - (double)W[k]);
-    if ((double)W[0] > 0.00001) {
-#pragma unroll
-      for (int k = 0; k < 5; k++) {
-        double wk = (a.cov_threshold - (double)W[k]) / cov_sum;
-        ucov += wk * wk * (double)W[k];
-      }
-    }
+    if (!SPLIT) ucov = plane_unit_cov(a.cov_threshold, W);
     float nv[3], pabcd[4];
     PH(0, 5);
     qr_solve_5x3(A, nv);
@@ -790,36 +961,47 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
       if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
     }
     pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
-    a.plane[i] = pl_out;
-    a.ucov[i] = ucov;
+    if (!SPLIT) {
+      STATE_ST(a.plane[i] = pl_out;)
+      STATE_ST(a.ucov[i] = ucov;)
+    }
     if (plane_ok) {
       float pd2;
       const float4 w = S.w[lane];
       if (residual_gate(pabcd, w.x, w.y, w.z, S.nb[lane], pd2)) {
         selected = true;
-        a.pd2[i] = pd2;
+        if (!SPLIT) STATE_ST(a.pd2[i] = pd2;)
         pd2_out = pd2;
       }
     }
   }
-  a.sel[i] = selected ? 1 : 0;
+  if (!SPLIT) STATE_ST(a.sel[i] = selected ? 1 : 0;)
   PH(0, 7);
   const float4 q = S.q[lane];
   q_out = q;
+  if (SPLIT) return;
   const int packed = __float_as_int(q.w);
   tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
-  a.trace[i] = tr;
+  STATE_ST(a.trace[i] = tr;)
 }
 
 
-// Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns true in the control wave (with its
-// lane's PointOut filled), false in the three search waves once they have nothing left to do.
+// Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns ROLE_CONTROL in the control wave (with
+// its lane's PointOut filled), ROLE_RETIRE in the search waves once they have nothing left to do - and, with KS_SPLIT,
+// ROLE_HELPER in the second wave: it stays to take the plane-independent work off the control wave's chain (helper_pre /
+// helper_post below; the caller runs them).
 // SKIP: the kernels of a handle with MALIO_OPT_SEARCH_SKIP on - every list walk leaves its certificate, a search pass that is
 // not the first of its scan (dy.skip, decided per pass) keeps cached neighbours where the certificate allows (phase A').
 // SKIP = false is the search of rounds 1-3 with no trace of any of it.
-template <bool DEV, bool SKIP>
-__device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
-                                          const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
+#ifndef KS_SPLIT
+#define KS_SPLIT 1
+#endif
+constexpr int ROLE_RETIRE = 0, ROLE_CONTROL = 1, ROLE_HELPER = 2;
+// PIPE2: the level-2 walk is the pipelined one (nl_search; not in the device loop's k_search<true, .>, whose extra reuse branch
+// makes the register allocator spill with it)
+template <bool DEV, bool SKIP, bool PIPE2>
+__device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
+                                         const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
   auto qidx = [&](int l) { return q0 + l; };
   const int lane_ = (int)(threadIdx.x & 63);
   const bool cwave = (int)(threadIdx.x >> 6) == 0;
@@ -843,7 +1025,9 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
       if (dy.commit_prev) sel_prev = a.sel[i], trace_prev = a.trace[i];
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
-      a.world4[i] = w;
+      // (KS_SPLIT: helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses
+      // its world point below and is nobody's to store later)
+      if (!KS_SPLIT || a.part.world > 1) STATE_ST(a.world4[i] = w;)
       S.nb[lane_] = nb;
       S.q[lane_] = q;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
@@ -924,7 +1108,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   }
   if (a.part.world > 1 && !(flags & 1)) {      // a workgroup of somebody else's tiles
     po.selected = false, po.skipped = true;  // (k_pass still owes the summation tree a zero tile)
-    return cwave;
+    return cwave ? ROLE_CONTROL : ROLE_RETIRE;
   }
   PH(0, 1);
   if (flags & 2) {
@@ -935,7 +1119,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
       const float4 ww = S.w[ql];
       Top5 t;
       float lb2;
-      const bool certified = nl_search<NL1_G, SKIP>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
+      const bool certified = nl_search<NL1_G, SKIP, false>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
       if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
@@ -978,7 +1162,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
             const float4 ww = S.w[l];
             Top5 t;
             float lb2;
-            nl_search<L2G, SKIP>(nl2, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);  // merged list is identical in every lane of the group
+            nl_search<L2G, SKIP, PIPE2>(nl2, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);  // merged list is identical in every lane of the group
             if (sub == 0) {
               int nf = 0;
 #pragma unroll
@@ -993,7 +1177,7 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
     }
   }
   }  // (somebody walks)
-  if (!cwave) return false;
+  if (!cwave) return (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) ? ROLE_HELPER : ROLE_RETIRE;
   // ---- phase C (control wave) ----
   int lane = lane_;
   asm volatile("" : "+v"(lane));  // the query index is formed again from here on: kept across the list walk it is the one
@@ -1007,9 +1191,86 @@ __device__ __forceinline__ bool search_wg(const Pass1Args &a, const NlView &nl1,
   const float4 wq = S.w[lane];
   const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
   if (served)
-    point_phase(a, ic, S, lane, og, nf, !SKIP || S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+    point_phase<KS_SPLIT != 0>(a, ic, S, lane, og, nf, !SKIP || S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
   PH(0, 8);
-  return true;
+  return ROLE_CONTROL;
+}
+
+// ---- KS_SPLIT: the helper wave ---------------------------------------------------------------------------------------------
+// The control wave's phase C is one dependent chain (gather -> QR -> gates -> ... -> row -> 16 MFMAs), 9.5 us of a 21 us
+// workgroup at BASELINE config 2, and three waves used to retire beside it. Everything on that chain that does not need the
+// PLANE is now the second wave's, lane = query as well:
+//   helper_pre   (while the control wave gathers and fits): the five neighbours' normal_y -> unit_cov (esti_plane's
+//                plane_cov, common_lib.h:159-173); trace(Sigma_p) under both clamp rules (trace_both); for k_pass the row's
+//                plane-independent factors - point_this (laserMapping.cpp:660-667), the plane weight c_i (:651-656) and
+//                1 / R_i after the FIC (:716-721, esekfom.hpp:624-626, for the accepted-point trace: only accepted points
+//                have rows) - left in LDS;
+//   ONE barrier  the control wave arrives with the accept flags in LDS;
+//   helper_post  picks the trace, stores unit_cov and the trace, reduces the extrema of the wave's 64 points and publishes
+//                them (a4) - while the control wave forms the plane-dependent rest of the row and the tile.
+// Every quantity is formed by the same expression on the same operands as before (one function, two callers): same bits.
+// i: the lane's point (sorted index), served: it is this workgroup's to serve; nf: its neighbour count.
+__device__ __forceinline__ void helper_unit_cov_trace(const Pass1Args &a, SearchLds &S, int lane, int i, bool served, int nf,
+                                                      const u32 og[5], const float4 q, double &ucov, double &trS) {
+  ucov = 0.0, trS = 0.0;
+  double trR = 0.0;
+  if (served) {
+    if (nf == 5) {
+      float W[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+#ifdef ATTR_NO_GATHER
+        W[k] = 0.001f;
+#else
+        W[k] = a.map_in[og[k]].w;
+#endif
+      ucov = plane_unit_cov(a.cov_threshold, W);
+    }
+    const int packed = __float_as_int(q.w);
+    trace_both(a, q, packed & 0xFF, packed >> 8, trS, trR);
+  }
+  S.ucv[lane] = ucov, S.trS[lane] = trS, S.trR[lane] = trR;
+}
+// after the barrier, SEARCH pass: flag -> trace; the point's whole per-point state (the control wave stores none of it:
+// see point_phase) - world point, certificate, neighbour ids and count, plane, unit_cov, residual, flag, trace -; a4
+template <bool SKIP>
+__device__ __forceinline__ void helper_post(const Pass1Args &a, u64 *mm_cur, SearchLds &S, int lane, int i, bool served, int nf) {
+  const bool selected = served && S.selc[lane] != 0;
+  const double ucov = S.ucv[lane];
+  const double tr = selected ? S.trS[lane] : S.trR[lane];
+  if (served) {
+    const float4 w = S.w[lane];
+    if (a.part.world <= 1) STATE_ST(a.world4[i] = w;)  // (a tile shard: phase A stored it)
+    if (SKIP && !S.keep[lane]) STATE_ST(a.cert[i] = make_float4(w.x, w.y, w.z, S.cr[lane]);)  // this pass walked: its certificate
+#pragma unroll
+    for (int k = 0; k < 5; k++) STATE_ST(a.nbr[(size_t)k * a.N + i] = S.og[k][lane];)
+    STATE_ST(a.nfound[i] = (unsigned char)nf;)  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
+    if (nf == 5) {
+      STATE_ST(a.plane[i] = S.plc[lane];)
+      STATE_ST(a.ucov[i] = ucov;)
+    }
+    if (selected) STATE_ST(a.pd2[i] = S.pd2c[lane];)
+    STATE_ST(a.sel[i] = selected ? 1 : 0;)
+    STATE_ST(a.trace[i] = tr;)
+  }
+  wave_minmax_publish(a, mm_cur, selected, ucov, tr);
+}
+// ... REUSE pass (k_pass): world point, the previous pass' lazy normal_y fold (commit_normal_y, from the flag and trace the
+// helper read BEFORE the barrier), residual, flag, trace; a4
+__device__ __forceinline__ void helper_post_reuse(const Pass1Args &a, u64 *mm_cur, SearchLds &S, int lane, int i, bool served,
+                                                  int commit_prev, unsigned char sel_old, double trace_old) {
+  const bool selected = served && S.selc[lane] != 0;
+  const double ucov = S.ucv[lane];
+  const double tr = selected ? S.trS[lane] : S.trR[lane];
+  if (served) {
+    const float4 w = S.w[lane];
+    a.world[i] = w.x, a.world[a.N + i] = w.y, a.world[2 * a.N + i] = w.z;
+    if (commit_prev && !(sel_old && !a.extrinsic_est_en)) a.ny[i] = (float)trace_old;
+    if (selected) a.pd2[i] = S.pd2c[lane];
+    a.sel[i] = selected ? 1 : 0;
+    a.trace[i] = tr;
+  }
+  wave_minmax_publish(a, mm_cur, selected, ucov, tr);
 }
 
 // DEV = true: one pass of the device-resident update loop (DevLoop): exits when the loop is over, runs the REUSE pass on
@@ -1034,8 +1295,29 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     return;
   }
   PointOut po;
-  if (!search_wg<DEV, SKIP>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po) || po.skipped) return;
+  const int role = search_wg<DEV, SKIP, (KS_PIPE != 0) && !DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po);
+  if (role == ROLE_RETIRE || po.skipped) return;
+#if KS_SPLIT
+  {
+    const int lane = (int)(threadIdx.x & 63), i = (int)blockIdx.x * SQ + lane;
+    if (role == ROLE_HELPER) {  // (see helper_unit_cov_trace)
+      const bool served = i < a.N && S.w[lane].x < 1e9f;
+      const int nf = S.nf[lane];
+      u32 og[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) og[k] = S.og[k][lane];
+      double ucov, trS;
+      helper_unit_cov_trace(a, S, lane, i, served, nf, og, S.q[lane], ucov, trS);
+      __syncthreads();
+      helper_post<SKIP>(a, dy.mm_cur, S, lane, i, served, nf);  // per-point state; a4 over this workgroup's 64 queries
+      return;
+    }
+    S.selc[lane] = po.selected ? 1 : 0, S.plc[lane] = po.pl, S.pd2c[lane] = po.pd2;
+    __syncthreads();
+  }
+#else
   wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4 over this wave's 64 queries
+#endif
   PH(0, 9);
   PH_EXIT();
 }
@@ -1096,39 +1378,53 @@ struct RowIn {
   double ucov, trace;
   float pd2;
 };
-__device__ __forceinline__ void point_row(const WeightConst &wc, int extrinsic_est_en, const PassConst &pc, const double mm[4],
-                                          const RowIn &in, int lid, double u[12], double &hs, double &r) {
-  const float4 q = in.q;
-  const float4 pl = in.pl;
-  const double max_u = mm[0], min_u = -mm[1], max_c = mm[2], min_c = -mm[3];
-  // plane weight c_i (laserMapping.cpp:651-656)
-  double cp = in.ucov;
+// (in pieces, so that k_pass' helper wave can form the plane-independent ones - row_plane_weight, row_point_imu,
+// row_point_noise - while the control wave still fits the plane: one expression per quantity whoever evaluates it)
+// plane weight c_i (laserMapping.cpp:651-656)
+__device__ __forceinline__ double row_plane_weight(const WeightConst &wc, const double mm[4], double ucov) {
+  const double max_u = mm[0], min_u = -mm[1];
+  double cp = ucov;
   if (cp == 0)
     cp = 1;
   else if (max_u == min_u)
     cp = (wc.plane_cov_max + wc.plane_cov_min) / 2;
   else
     cp = 1 / ((wc.plane_cov_max - wc.plane_cov_min) * (cp - min_u) / (max_u - min_u) + wc.plane_cov_min);
-  // geometry (:658-693)
+  return cp;
+}
+// point_this: q0 * p_be + t0, the point in the IMU frame at LiDAR 0's scan end (:658-667)
+__device__ __forceinline__ D3 row_point_imu(const PassConst &pc, int lid, D3 p) {
+  const LidarConst &lc = pc.lid[lid];
+  if (lid == 0) return mulR(pc.R0, p) + D3{pc.t0[0], pc.t0[1], pc.t0[2]};
+  D3 y = mulR(lc.Rl, p) + D3{lc.tl[0], lc.tl[1], lc.tl[2]};
+  return mulR(lc.Rtc, y) + D3{lc.ttc[0], lc.ttc[1], lc.ttc[2]};
+}
+// point noise R_i by FIC (:716-721)
+__device__ __forceinline__ double row_point_noise(const WeightConst &wc, int extrinsic_est_en, const double mm[4], double trace) {
+  const double max_c = mm[2], min_c = -mm[3];
+  double R = extrinsic_est_en ? trace : 0.0;
+  const double lo = min_c + (max_c - min_c) * wc.range_min, hi = min_c + (max_c - min_c) * wc.range_max;
+  if (R < lo)
+    R = wc.point_cov_min;
+  else if (R > hi)
+    R = wc.point_cov_max;
+  else
+    R = (wc.point_cov_max - wc.point_cov_min) * (R - lo) / ((wc.range_max - wc.range_min) * (max_c - min_c)) +
+        wc.point_cov_min;
+  return R;
+}
+// the plane-dependent rest: the 12 non-zero entries of the c_i-scaled row and its residual (:676-693,707,714-715)
+__device__ __forceinline__ void row_finish(int extrinsic_est_en, const PassConst &pc, int lid, const float4 q, const float4 pl,
+                                           float pd2, D3 X, double cp, double u[12], double &hs) {
   D3 p{(double)q.x, (double)q.y, (double)q.z};
   const LidarConst &lc = pc.lid[lid];
-  D3 X;  // q0 * p_be + t0  == point_this (IMU frame at LiDAR-0 scan end)
-  D3 p_be;
-  if (lid == 0) {
-    p_be = p;
-    X = mulR(pc.R0, p) + D3{pc.t0[0], pc.t0[1], pc.t0[2]};
-  } else {
-    D3 y = mulR(lc.Rl, p) + D3{lc.tl[0], lc.tl[1], lc.tl[2]};
-    X = mulR(lc.Rtc, y) + D3{lc.ttc[0], lc.ttc[1], lc.ttc[2]};
-    p_be = p;  // unused for lid != 0
-  }
   D3 n{(double)pl.x, (double)pl.y, (double)pl.z};
   D3 Cv = mulRt(pc.Rw, n);  // s.rot.conjugate() * norm_vec (:676)
   D3 A = cross(X, Cv);        // point_crossmat * C (:677)
   D3 B{0, 0, 0}, Cb{0, 0, 0};
   if (extrinsic_est_en) {
     if (lid == 0) {
-      B = cross(p_be, mulRt(pc.R0, Cv));  // :684
+      B = cross(p, mulRt(pc.R0, Cv));  // :684 (p_be == p for LiDAR 0)
       Cb = Cv;
     } else {
       Cb = mulRt(lc.Rtc, Cv);            // :689
@@ -1139,18 +1435,14 @@ __device__ __forceinline__ void point_row(const WeightConst &wc, int extrinsic_e
   u[3] = A.x * cp, u[4] = A.y * cp, u[5] = A.z * cp;
   u[6] = B.x * cp, u[7] = B.y * cp, u[8] = B.z * cp;
   u[9] = Cb.x * cp, u[10] = Cb.y * cp, u[11] = Cb.z * cp;
-  hs = (-1.0) * (double)in.pd2 * cp;  // :707,715
-  // point noise R_i by FIC (:716-721)
-  double R = extrinsic_est_en ? in.trace : 0.0;
-  const double lo = min_c + (max_c - min_c) * wc.range_min, hi = min_c + (max_c - min_c) * wc.range_max;
-  if (R < lo)
-    R = wc.point_cov_min;
-  else if (R > hi)
-    R = wc.point_cov_max;
-  else
-    R = (wc.point_cov_max - wc.point_cov_min) * (R - lo) / ((wc.range_max - wc.range_min) * (max_c - min_c)) +
-        wc.point_cov_min;
-  r = R;
+  hs = (-1.0) * (double)pd2 * cp;  // :707,715
+}
+__device__ __forceinline__ void point_row(const WeightConst &wc, int extrinsic_est_en, const PassConst &pc, const double mm[4],
+                                          const RowIn &in, int lid, double u[12], double &hs, double &r) {
+  const double cp = row_plane_weight(wc, mm, in.ucov);
+  const D3 X = row_point_imu(pc, lid, D3{(double)in.q.x, (double)in.q.y, (double)in.q.z});
+  row_finish(extrinsic_est_en, pc, lid, in.q, in.pl, in.pd2, X, cp, u, hs);
+  r = row_point_noise(wc, extrinsic_est_en, mm, in.trace);
 }
 
 // One workgroup = 256 consecutive sorted points of ONE LiDAR. Rows go to LDS, each wave turns its 64 rows into a
@@ -1479,6 +1771,9 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   // the 64 rows of the control wave for the MFMA operands: u[12], hs, 1/r (a_p = [u/r | u0..2 | 0], b_p = [u | hs | 0 0 0]
   // are formed when they are read: 7.7 KB instead of the two 17-double records of k_rows_reduce)
   __shared__ double U[SQ][15];
+#if KS_SPLIT
+  __shared__ RowPre RP;
+#endif
   if (DEV && dl->done) return;
   const QuatConst &qc = DEV ? dl->qc : a.qc;
   const PassConst &pc = DEV ? dl->pc : f.pc;
@@ -1522,39 +1817,134 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
       rem -= m * nact, base_t += m;
     }
   } else {
+#ifndef KS_NO_XCD_TILES
+    // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own,
+    // and a tile's 97 sums are 97 eight-byte stores into 97 different lines of the entry-major tile array - with tile ==
+    // workgroup id the 16 tiles that share a 128-byte line came from all 8 XCDs, and every L2 wrote its pieces back as
+    // partial lines at the end of the kernel (WRITE_SIZE 5.1 MB for 1.2 MB of tiles, 2.0 us of k_pass:
+    // profiles/round5/r05b_attribution.txt). Inside every block of 128 workgroup ids the XCD x = id mod 8 now forms the 16
+    // CONSECUTIVE tiles [16 x, 16 x + 16): a line is completed inside one L2; the 64-byte runs of the one-byte per-point
+    // state of neighbouring tiles merge there too. (Whole contiguous eighths of the scan per XCD were measured first:
+    // +1.9 us - an XCD then gets one LiDAR's and one neighbourhood's work, and they are not equal.) A tile keeps its position
+    // in scan order (the summation tree's leaf); the last, incomplete block of 128 keeps tile == id.
+    {
+      const int b = (int)blockIdx.x, full = (int)gridDim.x & ~127;
+      if (b < full) tile = (b & ~127) + ((b & 7) << 4) + ((b & 127) >> 3);
+    }
+#endif
 #pragma unroll
     for (int l = 1; l < MALIO_MAX_LIDAR; l++)
-      if (l < f.L && (int)blockIdx.x >= f.seg_blk0[l]) lid = l;
+      if (l < f.L && tile >= f.seg_blk0[l]) lid = l;
   }
   lid = __builtin_amdgcn_readfirstlane(lid), tile = __builtin_amdgcn_readfirstlane(tile);  // (workgroup-uniform: scalars)
   const int q0 = f.seg_start[lid] + (tile - f.seg_blk0[lid]) * SQ, qend = f.seg_start[lid + 1];
   const int lane = (int)(threadIdx.x & 63);
   PointOut po;
+  int role = ROLE_CONTROL;
   if (converge) {
-    if (!search_wg<DEV, SKIP>(a, nl1, nl2, qc, dy, S, q0, qend, po)) return;  // (the three search waves retire)
+    role = search_wg<DEV, SKIP, KS_PIPE != 0>(a, nl1, nl2, qc, dy, S, q0, qend, po);
+    if (role == ROLE_RETIRE) return;  // (the search waves retire; with KS_SPLIT the second wave stays as the helper)
     if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
       for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
       return;
     }
-  } else {  // REUSE pass: the control wave alone, lane = point
+  } else {  // REUSE pass: the control wave (and its helper), lane = point
     if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
-    if (threadIdx.x >= 64) return;
+    if (threadIdx.x >= (KS_SPLIT ? 128 : 64)) return;
+    role = threadIdx.x >= 64 ? ROLE_HELPER : ROLE_CONTROL;
     const int i = q0 + lane;
     po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
     po.pl = make_float4(0.f, 0.f, 0.f, 0.f), po.q = po.pl;
     if (a.part.world > 1 && !__ballot(i < qend && a.nfound[i] != NF_NOTMINE)) {  // a workgroup of other shards' points: a zero tile
-      for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
-      return;
+      if (role == ROLE_CONTROL)
+        for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
+      return;  // (both waves see the same ballot)
     }
+#if KS_SPLIT
+    if (role == ROLE_CONTROL) {
+      float4 wld = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < qend) reuse_point_ctrl(a, qc, i, po.selected, po.pl, po.pd2, po.q, wld);
+      S.w[lane] = wld;
+    }
+#else
     if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+#endif
   }
   PH(2, 0);
-  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
-  PH(2, 1);
   // ---- a5 / a7 with the guessed extrema ----
   double mm[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
+#if KS_SPLIT
+  if (role == ROLE_HELPER) {  // (see helper_unit_cov_trace)
+    const int i = q0 + lane;
+    bool served;
+    int nf;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    double ucov = 0.0, trS = 0.0;
+    unsigned char sel_old = 0;  // (reuse pass: what the lazy normal_y fold of the previous pass reads, commit_normal_y)
+    double trace_old = 0.0;
+    PHH(3, 0);
+    if (converge) {
+      served = i < qend && S.w[lane].x < 1e9f;
+      nf = S.nf[lane];
+      u32 og[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) og[k] = S.og[k][lane];
+      q = S.q[lane];
+      helper_unit_cov_trace(a, S, lane, i, served, nf, og, q, ucov, trS);
+    } else {  // the plane and its unit_cov are the search pass': a point accepted now has nf == 5 and a stored unit_cov
+      nf = i < qend ? (int)a.nfound[i] : 0;
+      served = i < qend && nf != NF_NOTMINE;
+      double trR = 0.0;
+      if (served) {
+        q = a.scan[i];
+        if (nf == 5) ucov = a.ucov[i];
+        if (dy.commit_prev) sel_old = a.sel[i], trace_old = a.trace[i];
+        const int packed = __float_as_int(q.w);
+        trace_both(a, q, packed & 0xFF, packed >> 8, trS, trR);
+      }
+      S.ucv[lane] = ucov, S.trS[lane] = trS, S.trR[lane] = trR;
+    }
+    PHH(3, 1);
+    // the plane-independent factors of the row, for the case the point is accepted
+    const D3 X = row_point_imu(pc, lid, D3{(double)q.x, (double)q.y, (double)q.z});
+    RP.X[0][lane] = X.x, RP.X[1][lane] = X.y, RP.X[2][lane] = X.z;
+    RP.cp[lane] = row_plane_weight(f.wc, mm, ucov);
+    double rc = row_point_noise(f.wc, a.extrinsic_est_en, mm, trS);
+    if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+#ifndef ROWS_DIVIDE
+    RP.rw[lane] = 1.0 / rc;
+#else
+    RP.rw[lane] = rc;
+#endif
+    PHH(3, 2);
+    __syncthreads();
+    PHH(3, 3);
+    if (converge)
+      helper_post<SKIP>(a, dy.mm_cur, S, lane, i, served, nf);  // per-point state; a4: the TRUE extrema of this pass
+    else
+      helper_post_reuse(a, dy.mm_cur, S, lane, i, served, dy.commit_prev, sel_old, trace_old);
+    PHH(3, 4);
+    return;
+  }
+  S.selc[lane] = po.selected ? 1 : 0, S.plc[lane] = po.pl, S.pd2c[lane] = po.pd2;
+  PH(2, 6);
+  __syncthreads();
+  PH(2, 1);
+  double u[12], hs = 0;
+#pragma unroll
+  for (int k = 0; k < 12; k++) u[k] = 0;
+  if (po.selected)
+    row_finish(a.extrinsic_est_en, pc, lid, po.q, po.pl, po.pd2, D3{RP.X[0][lane], RP.X[1][lane], RP.X[2][lane]}, RP.cp[lane], u, hs);
+  PH(2, 2);
+#pragma unroll
+  for (int k = 0; k < 12; k++) U[lane][k] = u[k];
+  U[lane][12] = hs;
+  U[lane][13] = po.selected ? RP.rw[lane] : 0.0;
+#else
+  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
+  PH(2, 1);
   double u[12], hs = 0, r = 1;
 #pragma unroll
   for (int k = 0; k < 12; k++) u[k] = 0;
@@ -1573,6 +1963,7 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   U[lane][13] = po.selected ? 1.0 / rc : 0.0;
 #else
   U[lane][13] = po.selected ? rc : 0.0;
+#endif
 #endif
   const unsigned long long bal = __ballot(po.selected);
   __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above precede its loads below (waitcnt by the compiler)
@@ -1608,12 +1999,16 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   }
   PH(2, 4);
   // ---- the tile: a leaf of the summation tree, entry-major like k_rows_reduce's partials ----
+#ifndef ATTR_NO_TILES
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     const int e = tile_entry(prow + 4 * rg, col);
     if (e >= 0) f.tiles[(size_t)e * f.tstride + tile] = acc[rg];
   }
   if (lane == 0) f.tiles[(size_t)(NSUM - 1) * f.tstride + tile] = (double)__popcll(bal);
+#else
+  if (acc[0] == 1.2345e300 && lane == 0) f.tiles[tile] = acc[1] + acc[2] + acc[3] + (double)__popcll(bal);  // (keeps the MFMAs alive)
+#endif
   PH(2, 5);
   PH_EXIT();
 }
@@ -1630,7 +2025,7 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   float4 p = q[active ? qi : n - 1];
   Top5 t;
   float lb2_unused;
-  nl_search<NL2_G, false>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t, lb2_unused);
+  nl_search<NL2_G, false, KS_PIPE != 0>(nl, p.x, p.y, p.z, sub, nl.cf * nl.cf * 0.999f, t, lb2_unused);
   if (!active || sub != 0) return;
   int c = 0;
   for (int j = 0; j < 5; j++) {

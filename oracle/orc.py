@@ -356,3 +356,15 @@ def decode_ouster(records, point_filter_num, blind, time_unit_scale):
     m = lib().orc_decode_ouster(rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, int(point_filter_num), C.c_double(blind),
                                 C.c_float(time_unit_scale), _p(out, C.c_float), n + 1, C.byref(mt))
     return out[:m].copy(), mt.value
+
+
+def decode_velodyne(data, n_points, layout, point_filter_num, blind, time_unit_scale, maximum_time_in=-1.0):
+    """Restated pcl::fromROSMsg + Preprocess::velodyne_handler (oracle/orc_decode.cpp). layout = (point_step, off_x, off_y,
+    off_z, off_intensity, off_time); maximum_time_in: the member's value before the call (kept when n_points == 0)."""
+    rec = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+    n = int(n_points)
+    out = np.zeros((n + 1, 12), np.float32)
+    mt = C.c_double(maximum_time_in)
+    m = lib().orc_decode_velodyne(rec.ctypes.data_as(C.POINTER(C.c_ubyte)), n, *[int(v) for v in layout], int(point_filter_num),
+                                  C.c_double(blind), C.c_float(time_unit_scale), _p(out, C.c_float), n + 1, C.byref(mt))
+    return out[:m].copy(), mt.value

@@ -95,3 +95,38 @@ extern "C" int orc_decode_ouster(const unsigned char *rec, int n_rec, int point_
   if (maximum_time_out) *maximum_time_out = maximum_time;
   return (int)pl_surf.size();
 }
+
+extern "C" int orc_decode_velodyne(const unsigned char *data, int n_points, int point_step, int off_x, int off_y, int off_z,
+                                   int off_intensity, int off_time, int point_filter_num, double blind, float time_unit_scale,
+                                   float *out12, int cap, double *maximum_time_io) {
+  // Preprocess::velodyne_handler, preprocess.cpp:148-212, on the message's bytes: pcl::fromROSMsg (:155) copies every field
+  // of velodyne_ros::Point (preprocess.h:18-34) from the offset the message gives for its name; a field the message lacks
+  // stays value-initialised (0).
+  std::vector<P12> pl_surf;
+  const int plsize = n_points;
+  if (plsize == 0) return 0;  // :157-158 (maximum_time keeps its previous value)
+  // :161-186 - is_first, yaw_fp, yaw_last, time_last, given_offset_time, yaw_first, yaw_end, layer_first - are written
+  // and never read again (grep: given_offset_time has no reader in MA_LIO/src): no observable effect, not restated.
+  double maximum_time = -9999;  // :188
+  for (int i = 0; i < plsize; i++) {
+    const unsigned char *b = data + (size_t)i * (size_t)point_step;
+    float x, y, z, intensity = 0.f, time = 0.f;
+    std::memcpy(&x, b + off_x, 4), std::memcpy(&y, b + off_y, 4), std::memcpy(&z, b + off_z, 4);
+    if (off_intensity >= 0) std::memcpy(&intensity, b + off_intensity, 4);
+    if (off_time >= 0) std::memcpy(&time, b + off_time, 4);
+    P12 added_pt;
+    added_pt.normal_x = 0, added_pt.normal_y = 0, added_pt.normal_z = 0;  // :193-195
+    added_pt.x = x, added_pt.y = y, added_pt.z = z;
+    added_pt.intensity = intensity;
+    added_pt.curvature = time * time_unit_scale;  // :200
+    if (i % point_filter_num == 0) {              // :202
+      if (added_pt.x * added_pt.x + added_pt.y * added_pt.y + added_pt.z * added_pt.z > (blind * blind)) {  // :204
+        if (maximum_time < added_pt.curvature) maximum_time = added_pt.curvature;
+        pl_surf.push_back(added_pt);
+      }
+    }
+  }
+  for (size_t k = 0; k < pl_surf.size() && (int)k < cap; k++) std::memcpy(out12 + k * 12, &pl_surf[k], 48);
+  if (maximum_time_io) *maximum_time_io = maximum_time;
+  return (int)pl_surf.size();
+}

@@ -15,14 +15,22 @@ assert capi.lib().malio_debug_phase(out) == 0
 ph = np.array(out[:]).reshape(4, 16)
 n0 = ["enter", "A: transform + sync", "B: level-1 search + sync", "B': level 2 for pending", "neighbours gathered", "plane_cov", "QR",
       "normalise+gates", "trace"]
-n2 = ["(search_wg returned)", "extrema -> slots", "point_row", "rows -> LDS", "16 MFMA", "tile stores issued"]
 t0 = ph[0][0]
 print("k_pass, mid-grid workgroup, cfg %s (us since its entry; step)" % (sys.argv[1] if len(sys.argv) > 1 else 2), e.fuse_stats())
 prev = t0
 for j in range(1, len(n0)):
-    print("   %-28s %6.2f  %6.2f" % (n0[j], (ph[0][j] - t0) / 100.0, (ph[0][j] - prev) / 100.0)); prev = ph[0][j]
-for j in range(len(n2)):
-    print("   %-28s %6.2f  %6.2f" % (n2[j], (ph[2][j] - t0) / 100.0, (ph[2][j] - prev) / 100.0)); prev = ph[2][j]
+    print("   %-34s %6.2f  %6.2f" % (n0[j], (ph[0][j] - t0) / 100.0, (ph[0][j] - prev) / 100.0)); prev = ph[0][j]
+# control wave behind search_wg (KS_SPLIT: hand-off to the helper, one barrier, the plane-dependent rest of the row)
+ctl = [(0, "(search_wg returned)"), (6, "flag / plane / residual -> LDS"), (1, "barrier passed"), (2, "row finished"), (3, "rows -> LDS"),
+       (4, "16 MFMA"), (5, "tile stores issued")]
+for k, name in ctl:
+    if ph[2][k] > 0:
+        print("   %-34s %6.2f  %6.2f" % (name, (ph[2][k] - t0) / 100.0, (ph[2][k] - prev) / 100.0)); prev = ph[2][k]
+hl = ["helper: starts (search over)", "helper: unit_cov + traces", "helper: row factors", "helper: barrier passed", "helper: state stored, extrema published"]
+if ph[3][0] > 0:
+    prev = ph[3][0]
+    for k, name in enumerate(hl):
+        print("   %-34s %6.2f  %6.2f" % (name, (ph[3][k] - t0) / 100.0, (ph[3][k] - prev) / 100.0)); prev = ph[3][k]
 nb = (sc["N"] + 63) // 64 + 4
 sp = (C.c_longlong * (4 * nb))()
 assert capi.lib().malio_debug_span(sp, nb) == 0

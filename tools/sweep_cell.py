@@ -7,7 +7,7 @@ ge.load_package()
 from malio_amd import capi, scenes
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sc = scenes.make_scene(cfg=cfg)
-for cs in (0.875, 0.9375, 1.0, 1.0625, 1.125, 1.25):
+for cs in [float(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0.875,0.9375,1.0,1.0625,1.125,1.25".split(","))]:
     e = capi.Engine(sc["params"], cell_size=cs)
     e.map_build(sc["map"]); e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     fn, out = e.measure_fn(sc["state0"], True)
