@@ -42,3 +42,12 @@ print("grid: %d workgroups; entry median %.2f last %.2f; control-wave exit first
     ok.sum(), np.median(ent), ent.max(), ex.min(), np.median(ex), np.percentile(ex, 90), ex.max()))
 tb = (sp[2][ok] - tz) / 100.0
 print("end of level-1 search: median %.2f 90%% %.2f max %.2f us" % (np.median(tb), np.percentile(tb, 90), tb.max()))
+# who is late?  exit time of the control wave by XCD (workgroup id mod 8), by LiDAR segment, by position in the grid
+b = np.nonzero(ok)[0]
+for name, key in (("XCD (id mod 8)", b % 8), ("grid eighth (id * 8 / n)", b * 8 // nb)):
+    print("exit by %s: " % name + "  ".join("%d: %.1f/%.1f" % (k, np.median(ex[key == k]), np.percentile(ex[key == k], 95)) for k in sorted(set(key))) + "   (median / p95 us)")
+late = b[ex > np.percentile(ex, 97)]
+print("the latest 3 %% of the workgroups: ids %s ...; XCD histogram %s" % (late[:16].tolist(), np.bincount(late % 8, minlength=8).tolist()))
+print("end of level-1 search by XCD: " + "  ".join("%d: %.1f/%.1f" % (k, np.median(tb[b % 8 == k]), np.percentile(tb[b % 8 == k], 95)) for k in range(8)))
+pend = sp[3][ok]
+print("workgroups with level-2 queries: %d; exit median with / without: %.1f / %.1f us" % ((pend > 0).sum(), np.median(ex[pend > 0]) if (pend > 0).any() else float("nan"), np.median(ex[pend == 0])))
