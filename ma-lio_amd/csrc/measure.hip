@@ -1817,17 +1817,43 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
       rem -= m * nact, base_t += m;
     }
   } else {
-#ifndef KS_NO_XCD_TILES
-    // Workgroup -> tile, XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own,
-    // and a tile's 97 sums are 97 eight-byte stores into 97 different lines of the entry-major tile array - with tile ==
-    // workgroup id the 16 tiles that share a 128-byte line came from all 8 XCDs, and every L2 wrote its pieces back as
-    // partial lines at the end of the kernel (WRITE_SIZE 5.1 MB for 1.2 MB of tiles, 2.0 us of k_pass:
-    // profiles/round5/r05b_attribution.txt). Inside every block of 128 workgroup ids the XCD x = id mod 8 now forms the 16
-    // CONSECUTIVE tiles [16 x, 16 x + 16): a line is completed inside one L2; the 64-byte runs of the one-byte per-point
-    // state of neighbouring tiles merge there too. (Whole contiguous eighths of the scan per XCD were measured first:
-    // +1.9 us - an XCD then gets one LiDAR's and one neighbourhood's work, and they are not equal.) A tile keeps its position
-    // in scan order (the summation tree's leaf); the last, incomplete block of 128 keeps tile == id.
+#ifndef KS_XCD_MODE
+#define KS_XCD_MODE 1
+#endif
+#if KS_XCD_MODE == 2
+    // Workgroup -> tile, XCD-aware. Consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own. Two
+    // things want the tiles an XCD forms chosen with care:
+    //  - a tile's 97 sums are 97 eight-byte stores into 97 different lines of the entry-major tile array; with tile == id
+    //    the 16 tiles that share a 128-byte line came from all 8 XCDs and every L2 wrote its pieces back as partial lines
+    //    at the end of the kernel (WRITE_SIZE 5.1 MB for 1.2 MB of tiles, 2.0 us of k_pass: profiles/round5/r05b);
+    //  - the scan is grouped by LiDAR, then by map column: tile k of n in LiDAR A's segment and tile k' = k n'/n in LiDAR
+    //    B's cover the same part of the map and walk the same cells' lists - on different XCDs each L2 fetched its own
+    //    copy: 44.9 MB of distinct list bytes per pass summed over the XCDs against 29.6 MB in the whole scan
+    //    (tools/cell_share.py, profiles/round5/r05i).
+    // So XCD x forms the x-th EIGHTH OF EVERY LiDAR SEGMENT (same share of every LiDAR's work for every XCD - one
+    // contiguous eighth of the whole scan per XCD was measured first and costs 1.9 us: the LiDARs' workgroups are not
+    // equally heavy): lines of the tile array are completed inside one L2, a cell's list is fetched once for the queries of
+    // all LiDARs. The ids of XCD x are x, x + 8, ...: its r-th id takes position P = (ids of lower XCDs) + r of the tiles
+    // ordered by (eighth, LiDAR, index); the eighths' sizes and the XCDs' id counts differ by at most a few tiles, which
+    // then run next door. A tile keeps its position in scan order (the summation tree's leaf); only who forms it changes.
     {
+      const int nt = (int)gridDim.x, xb = (int)blockIdx.x & 7, q8 = nt >> 3, rem = nt & 7;
+      int pos = xb * q8 + min(xb, rem) + ((int)blockIdx.x >> 3);  // a bijection of [0, nt)
+      bool found = false;
+      for (int x = 0; x < 8 && !found; x++) {
+#pragma unroll
+        for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
+          const int n = l < f.L ? f.seg_blk0[l + 1] - f.seg_blk0[l] : 0;
+          const int lo = (int)(((long long)x * n) >> 3), cnt = (int)(((long long)(x + 1) * n) >> 3) - lo;
+          if (!found) {
+            if (pos < cnt) tile = f.seg_blk0[l] + lo + pos, found = true;
+            else pos -= cnt;
+          }
+        }
+      }
+    }
+#elif KS_XCD_MODE == 1
+    {  // (measured on the way: inside every block of 128 ids XCD x forms the 16 CONSECUTIVE tiles [16 x, 16 x + 16): the write side only, -1.0 us)
       const int b = (int)blockIdx.x, full = (int)gridDim.x & ~127;
       if (b < full) tile = (b & ~127) + ((b & 7) << 4) + ((b & 127) >> 3);
     }
