@@ -649,6 +649,10 @@ int malio_node_nearest_search(malio_node_t nd, const malio_point_t *queries, int
 int malio_node_set_pass_hook(malio_node_t nd, void (*fn)(int pass, void *user), void *user);
 int malio_node_set_option(malio_node_t nd, int option, double value); /* malio_set_option on every GPU's handle */
 int malio_node_exchange_stats(malio_node_t nd, int *stats2); /* passes that needed one / two exchanges so far */
+/* Summed over the node's shards: out4 = [updates that ran the gated chain, how many of those were handed back to the
+ * pass-by-pass loop, gate time-outs (MALIO_OPT_GATE_TIMEOUT_MS), 0]. A node whose second number keeps growing has shards
+ * whose gates starve (several shards on one device, a descheduled worker thread): MALIO_OPT_NODE_GATED = 0 is cheaper. */
+int malio_node_update_stats(malio_node_t nd, int *out4);
 /* shard geometry, host code (no GPU): which shard serves each of n world points (xyz [n][3]) / whether shard `rank`
  * stores each of n map points */
 int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner);

@@ -29,7 +29,7 @@ EXPORTS = [
     "malio_xchg_reduce_stream", "malio_node_create", "malio_node_destroy", "malio_node_last_error", "malio_node_gpus",
     "malio_node_handle", "malio_node_map_build", "malio_node_map_size", "malio_node_map_add", "malio_node_map_delete_boxes",
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
-    "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_part_owner", "malio_part_stores",
+    "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_node_update_stats", "malio_part_owner", "malio_part_stores",
     "malio_set_update_mode", "malio_localize_weight", "malio_predict_chain",
     "malio_set_option", "malio_get_option", "malio_debug_skip_stats", "malio_node_set_option",
 ]
@@ -1014,6 +1014,12 @@ class Node:
         st = (C.c_int * 2)()
         lib().malio_node_exchange_stats(self.h, st)
         return int(st[0]), int(st[1])
+
+    def update_stats(self):
+        """Summed over the shards: updates through the gated chain, of those handed back to the pass-by-pass loop, gate time-outs."""
+        st = (C.c_int * 4)()
+        self._chk(lib().malio_node_update_stats(self.h, st), "malio_node_update_stats")
+        return dict(gated_runs=int(st[0]), gated_redone=int(st[1]), gate_timeouts=int(st[2]))
 
     def set_pass_hook(self, fn):
         proto = C.CFUNCTYPE(None, C.c_int, C.c_void_p)

@@ -1125,7 +1125,18 @@ int malio_measure_node(malio_handle_t h, malio_xchg_t x, const malio_state_t *s,
       MALIO_HIP(hipStreamSynchronize(c->stream));
     }
     memcpy(own + 4, res + ns + 4, sizeof(double) * 4);
-    return malio_xchg_reduce(x, res, ns, guess, res, Eout, timeout_s);
+    // word 5 of the extrema words (reserved, 0 from the kernels): which update loop this shard is in. Every shard of a node
+    // must run the same one - the gated chain and the pass-by-pass loop meet in different exchanges - and each decides it
+    // from its own handle's options: a disagreement is caught HERE, in an exchange both loops go through, by every rank
+    // at once, instead of as a 60 s time-out in the next one.
+    res[ns + 5] = c->node_mode_word;
+    const int rcx = malio_xchg_reduce(x, res, ns, guess, res, Eout, timeout_s);
+    if (rcx >= 0 && !xchg_word_agrees(x, ns + 5)) {
+      c->err = "malio_measure_node: the shards of this node run different update loops (gated chain on some, pass by pass on "
+               "others): MALIO_OPT_NODE_GATED, MALIO_OPT_FUSE, the update mode, a pass hook and profiling must be the same on every shard";
+      return MALIO_ERR_BAD_ARG;
+    }
+    return rcx;
   };
   const bool spec = c->node_guess_valid;
   // A speculating pass is ONE kernel + the final sum where the single-GPU pass is (k_pass: the rows are weighted with the
@@ -1191,13 +1202,24 @@ int malio_update_iterated_node(malio_handle_t h, malio_xchg_t xchg, malio_state_
   if (h->opt_node_gated && h->update_mode == MALIO_UPDATE_GATED && malio_xchg_kind(xchg) != 2 && h->fuse_enabled && !h->pass_hook &&
       !h->profiling && h->prm.max_iteration >= 1) {
     malio_state_t x0 = *x;
+    h->node_mode_word = 1.0;
     const int rc = ieskf_update_gated(h, xchg, x, P, stats, solve_time);
+    h->node_mode_word = 0.0;
     h->node_gated_runs++;
     if (rc != MALIO_SMALL_M_FALLBACK) return rc;
     *x = x0;  // (untouched by contract; the per-pass loop below redoes the update - and reports M < n itself)
     h->node_gated_redone++;
+    // (every shard left the chain together - the poison row - and redoes the update here: mode 1 again, so that a node whose
+    // shards all fell back does not look like a disagreement)
+    h->node_mode_word = 1.0;
+    const int rc2 = ieskf_update(h, xchg, x, P, R, stats, solve_time);
+    h->node_mode_word = 0.0;
+    return rc2;
   }
-  return ieskf_update(h, xchg, x, P, R, stats, solve_time);
+  h->node_mode_word = 2.0;
+  const int rc = ieskf_update(h, xchg, x, P, R, stats, solve_time);
+  h->node_mode_word = 0.0;
+  return rc;
 }
 
 int malio_node_stats(malio_handle_t h, int *stats2) {

@@ -785,6 +785,19 @@ int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pi
     }
     return MALIO_OK;
   };
+  // A shard-local failure BETWEEN two exchanges (a launch that failed, a chain out of units): the peers are on their way into
+  // the next exchange and would wait there for this shard until the exchange times out (60 s), their gates polling on the GPU
+  // meanwhile. This shard therefore still goes to that exchange, with the extremum no pass produces (the row a gate time-out
+  // sends): every shard leaves the gated loop in step; only this one reports an error. (Failures that follow FROM an
+  // exchange - finish_host, the n x n algebra, too few points - are functions of sums every shard holds identically: all
+  // shards take them together, nobody is left waiting.)
+  auto poison_next_exchange = [&]() {
+    if (!xchg) return;
+    double E[4];
+    c->h_res[ns_] = INFINITY;
+    (void)malio_xchg_reduce(xchg, c->h_res, ns_, c->fuse_guess_used, c->h_res, E, 60.0);
+    c->node_guess_valid = false, c->node_uploaded_valid = false;
+  };
   for (int i = -1; i < maximum_iter && !done; i++) {
     const int p = i + 1;
     searches += converge ? 1 : 0;
@@ -795,6 +808,7 @@ int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pi
     while (!shard_first && rc_out == MALIO_OK && (u_enq <= u || (p + 1 <= maximum_iter && u_enq <= u + 1))) rc_out = enqueue_unit();
     if (rc_out != MALIO_OK) {
       passes = p + 1;
+      poison_next_exchange();  // (the peers are heading for this pass' exchange)
       break;
     }
     auto t0 = std::chrono::steady_clock::now();
@@ -845,6 +859,7 @@ int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pi
       if (u_enq <= u + 1)
         if (int rc = enqueue_unit()) {
           rc_out = rc;
+          poison_next_exchange();  // (the peers took the same miss and meet again for the repeat)
           break;
         }
       publish(u + 1, false, true);
@@ -897,6 +912,7 @@ int ieskf_update_gated(Ctx *c, malio_xchg_t xchg, malio_state_t *xio, double *Pi
         unit_fused[0] = 1, u_enq = 1;
         if (int rcp = pass_fused(c, &x_, converge, &g, nullptr)) {
           rc_out = rcp;
+          poison_next_exchange();  // (the peers launched their pass 1 and wait for its rows)
           break;
         }
       } else {

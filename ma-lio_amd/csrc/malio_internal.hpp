@@ -358,6 +358,7 @@ struct Ctx {
   double node_guess[4] = {0, 0, 0, 0}, node_uploaded[4] = {0, 0, 0, 0};
   bool node_guess_valid = false, node_uploaded_valid = false;
   int node_hits = 0, node_misses = 0;
+  double node_mode_word = 0.0;  // which loop this shard's update runs (1 gated chain, 2 pass by pass; 0: a bare malio_measure_node): word 5 of its pass-0 row
   u32 *h_mbox = nullptr, *d_mbox = nullptr;  // pinned + device alias: small results for the host (counts), written
                                              // by kernels or copies; one stream sync serves all
   bool stage_pending = false;  // an async copy out of h_stage may still be in flight on `stream`
@@ -667,6 +668,9 @@ void ieskf_step_pre(int L, const malio_state_t *x, const malio_state_t *x_propag
 int ieskf_step_post(int L, int maximum_iter, double limit, int i, malio_state_t *x, const malio_state_t *x_propagated,
                     StepPre &pre, const double *HtRinvH, const double *HtRinvh, int *t_io, int *converge_out, int *done_out,
                     double *P_out);
+
+// host/node_exchange.cpp
+bool xchg_word_agrees(malio_xchg_t x, int word);
 
 // profiling helpers
 void prof_begin(Ctx *c);

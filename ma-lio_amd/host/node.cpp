@@ -154,9 +154,12 @@ int malio_node_create(const malio_params_t *params, int n_gpus, const int *devic
   }
   // handles (and RCCL communicators: ncclCommInitRank is collective) are created by the threads that will use them
   const void *uidp = uid;
-  // Shards that share a device share its hardware queues (4 per process by default): the gate of one shard's unit, polling
-  // at the head of a queue, would hold up another shard's unit behind it until it times out. Such a node - a test
-  // configuration; production is one shard per GPU - updates pass by pass unless MALIO_OPT_NODE_GATED is set again.
+  // Shards that share a device share its hardware queues (4 per process by default; every shard owns two streams): the gate
+  // of one shard's unit, polling at the head of a queue, can hold up another shard's unit behind it until it times out -
+  // correct (the time-out hands the update to the pass-by-pass loop, MALIO_OPT_GATE_TIMEOUT_MS) but slow. Two or three
+  // shards per device - the test configurations - were measured to get by (profiles/round4/r04j_node_gated.txt) and keep
+  // the gated chain; from four on the node updates pass by pass unless MALIO_OPT_NODE_GATED is set again. Production is
+  // one shard per GPU. A node that keeps falling back shows in malio_node_update_stats.
   int most = 0;
   for (int r = 0; r < n_gpus; r++) {
     int same = 0;
@@ -479,6 +482,21 @@ int malio_node_update_iterated(malio_node_t nd, malio_state_t *x, double *P, dou
 int malio_node_exchange_stats(malio_node_t nd, int *stats2) {
   if (!nd || !stats2) return MALIO_ERR_BAD_ARG;
   return malio_node_stats(nd->w[0].h, stats2);
+}
+
+int malio_node_update_stats(malio_node_t nd, int *out4) {
+  if (!nd || !out4) return MALIO_ERR_BAD_ARG;
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (int r = 0; r < nd->n; r++) {
+    double runs = 0, redone = 0;
+    int fs[4] = {0, 0, 0, 0};
+    int rc = malio_get_option(nd->w[r].h, MALIO_OPT_DEBUG_NODE_GATED_RUNS, &runs);
+    if (rc == MALIO_OK) rc = malio_get_option(nd->w[r].h, MALIO_OPT_DEBUG_NODE_GATED_REDONE, &redone);
+    if (rc == MALIO_OK) rc = malio_debug_fuse_stats(nd->w[r].h, fs);
+    if (rc != MALIO_OK) return rc;
+    out4[0] += (int)runs, out4[1] += (int)redone, out4[2] += fs[3];
+  }
+  return MALIO_OK;
 }
 
 // Side effects in the caller's scan order, merged from the GPUs: a scan shard returns its own range, a tile shard the

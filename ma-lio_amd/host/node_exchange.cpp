@@ -250,6 +250,17 @@ static int reduce_gathered(malio_xchg *x, int ns, const double *guess4, double *
 }
 
 int malio_xchg_row(malio_xchg_t x) { return x ? x->row : 0; }
+}  // extern "C"
+namespace malio {
+// did every rank send the same value in word `word` of the rows gathered last? (malio_measure_node: the update-loop mode word)
+bool xchg_word_agrees(malio_xchg_t x, int word) {
+  if (!x || word < 0 || word >= x->row || x->all.size() < (size_t)x->world * x->row) return true;
+  for (int r = 1; r < x->world; r++)
+    if (std::memcmp(&x->all[(size_t)r * x->row + word], &x->all[word], sizeof(double)) != 0) return false;
+  return true;
+}
+}  // namespace malio
+extern "C" {
 
 // Diagnostics: the latency of one malio_xchg_reduce between `world` native threads of this process on host memory (what
 // the node handle's MALIO_NODE_XCHG_HOST exchange costs a pass, without any GPU work around it): median-free mean over

@@ -156,6 +156,9 @@ def test_node_gated_update_same_bits_as_pass_by_pass(capi, orc, scenes, partitio
         runs[mode] = out
         ran = [(nd.get_option_rank(r, "debug_node_gated_runs"), nd.get_option_rank(r, "debug_node_gated_redone")) for r in range(3)]
         assert ran == [{"passes": (0, 0), "gated_one_shard_stalls": (3, 1)}.get(mode, (3, 0))] * 3, (mode, ran)
+        st = nd.update_stats()  # the same, summed over the shards, where a caller of the node can see it
+        assert (st["gated_runs"], st["gated_redone"]) == (sum(a for a, _ in ran), sum(b for _, b in ran)), (mode, st)
+        assert st["gate_timeouts"] == (1 if mode == "gated_one_shard_stalls" else 0), (mode, st)
         nd.close()
     ref = runs["passes"]
     assert ref[0][0]["passes"] >= 3
@@ -183,6 +186,32 @@ def test_node_gated_update_same_bits_as_pass_by_pass(capi, orc, scenes, partitio
             assert np.array_equal(r["state"], r0["state"]) and np.array_equal(r["P"], r0["P"]), mode
             for key in ("selected", "world", "normvec", "res_last", "nearest_cnt", "nearest", "normal_y"):
                 assert np.array_equal(g[key], g0[key]), (mode, key)
+
+
+@pytest.mark.gpu
+def test_node_shards_that_disagree_on_the_update_loop_fail_together_and_at_once(capi, scenes):
+    """Every shard decides from its OWN handle's options whether its update runs the gated chain or pass by pass; the two
+    loops meet in different exchanges. A node whose shards disagree (here: MALIO_OPT_NODE_GATED off on shard 1 only) must
+    not hang in an exchange until it times out: pass 0 goes through malio_measure_node in both loops, carries the loop's
+    mode word, and every shard sees the disagreement in that one exchange. With the option restored the node works again."""
+    import time
+    sc = scenes.make_scene(seed=322, N=3000, Nmap=60000, L=3)
+    nd = capi.Node(sc["params"], [0] * 3, partition=capi.PART_SCAN)
+    nd.map_build(sc["map"])
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    good = nd.update_iterated(sc["state0"], sc["P0"])
+    assert good["rc"] == 0
+    nd.set_option_rank(1, "node_gated", 0)
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    t = time.time()
+    with pytest.raises(capi.MalioError, match="different update loops"):
+        nd.update_iterated(sc["state0"], sc["P0"])
+    assert time.time() - t < 5.0  # (an exchange that waits for a shard that never comes gives up after 60 s)
+    nd.set_option_rank(1, "node_gated", 1)
+    nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    again = nd.update_iterated(sc["state0"], sc["P0"])
+    assert again["rc"] == 0 and np.array_equal(again["state"], good["state"]) and np.array_equal(again["P"], good["P"])
+    nd.close()
 
 
 @pytest.mark.gpu
