@@ -376,7 +376,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=0, help="BASELINE.json config number (1-based); default 2 at one GPU, 4 beyond")
-    ap.add_argument("--tile", type=float, default=16.0, help="tile edge [m] of the spatially sharded map (N > 1)")
+    ap.add_argument("--tile", type=float, default=16.0, help="edge [m] of the cubic tiles of the spatially sharded map (N > 1, variant tiles+shm)")
+    ap.add_argument("--column-tile", type=float, default=24.0, help="edge [m] of the COLUMN tiles (N > 1 headline: MALIO_TILE_COLUMNS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="N = 1 only: a proxy for the scaling run on ONE GPU - every shard of a G-way sharded BASELINE config "
@@ -732,13 +733,13 @@ def main_virtual_shards(args, torch, capi, scenes, dev_index):
     while G <= Gmax:
         entry = {}
         xus = exchange_us(G)
-        for part in ("tiles", "scan"):
+        for part in ("columns", "tiles", "scan"):
             shards = []
             for r in range(G):
                 e = capi.Engine(sc["params"], device=dev_index)
                 e.set_option("search_skip", 0)
-                if part == "tiles":
-                    e.set_partition(r, G, args.tile)
+                if part in ("tiles", "columns"):
+                    e.set_partition(r, G, args.tile if part == "tiles" else args.column_tile, columns=part == "columns")
                     e.map_build(sc["map"])
                     e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
                     e.measure(state, True)
@@ -765,10 +766,48 @@ def main_virtual_shards(args, torch, capi, scenes, dev_index):
     line = {"metric": "PROXY (one GPU, shards run one at a time): per-shard search-pass time of the G-way sharded job",
             "unit": "ms per pass", "n_gpus": 1, "virtual_shards": Gmax, "steps": steps, "warmup": args.warmup,
             "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass per step, sharded G ways" % (
-                cfg["name"], N, L, sc["Nmap"]), "tile_m": args.tile},
+                cfg["name"], N, L, sc["Nmap"]), "tile_m": args.tile, "column_tile_m": args.column_tile},
             "data": "synthetic", "curve": curve,
             "note": "not the scaling run: G GPUs' contention for the host and the RCCL collective are not in it"}
     print(json.dumps(line), flush=True)
+
+
+def replicas_leg(args, torch, dist, capi, scenes, world, rank, dev_index, fence):
+    """N independent BASELINE config-2 jobs, one per GPU (own map copy, own scan, no exchange): K steps on every rank
+    between two fences, max over ranks; aggregate = N x 100 k points / that time. Weak scaling by construction."""
+    sc2 = scenes.make_scene(cfg=2, scan_seed=None if rank == 0 else 700 + rank)
+    e = capi.Engine(sc2["params"], device=dev_index)
+    e.set_option("search_skip", 0)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.map_build(sc2["map"])
+    e.scan_set(sc2["scan"], sc2["tables"], sc2["temporal_comp"])
+    fn, out = e.measure_fn(sc2["state0"], True)
+
+    def step():
+        assert fn() >= 0
+    for _ in range(args.warmup + 2):
+        step()
+    dt, dts = timed_blocks(step, args.steps, fence, True, dist, torch)
+    del e
+    return {"workload": "one BASELINE config-2 job per GPU (100 k-pt scan vs 1 M-pt map, full search pass per step), no exchange",
+            "ms_per_step": dt / args.steps * 1e3, "value": world * sc2["N"] / (dt / args.steps), "unit": "points/s over the node",
+            "scaling": "weak", "timed_blocks": len(dts)}
+
+
+def predicted_curve(world):
+    """The one-GPU proxy's prediction for this world size (bench.py --virtual-shards, committed under profiles/): printed next
+    to the measured line so that the first real scaling run can be read against it."""
+    pj = os.path.join(ROOT, "profiles", PROFILE_ROUND, PROFILE_TAG + "_virtual_shards.json")
+    try:
+        cur = json.load(open(pj))["curve"]
+        ent = cur.get(str(world))
+        if not ent:
+            return None
+        return {"source": os.path.relpath(pj, ROOT), "one_gpu_pass_ms": cur["1"]["pass_ms"],
+                **{part: {"predicted_ms": v["predicted_ms"], "predicted_speedup_vs_one_gpu": v["predicted_speedup_vs_one_gpu"],
+                          "balance_max_over_mean": v["balance_max_over_mean"]} for part, v in ent.items()}}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backend):
@@ -817,8 +856,8 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
             e = capi.Engine(sc["params"], device=dev_index)
             e.set_option("search_skip", 0)  # the timed step repeats ONE state: a full search every time
             e.set_stream(torch.cuda.current_stream().cuda_stream)
-            if partition == "tiles":
-                e.set_partition(rank, world, args.tile)
+            if partition in ("tiles", "columns"):
+                e.set_partition(rank, world, args.tile if partition == "tiles" else args.column_tile, columns=partition == "columns")
                 e.map_build(sc["map"])
                 e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
             else:
@@ -830,7 +869,7 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
 
     def rescan(partition):
         e = engines[partition]
-        if partition == "tiles":
+        if partition in ("tiles", "columns"):
             e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
         else:
             lo, hi = N * rank // world, N * (rank + 1) // world
@@ -883,7 +922,7 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
     def emit():
         """rank 0's JSON line from whatever has been measured: RCCL tiles when that variant completed, else the
         shared-memory exchange (same sharding, same arithmetic) with the reason."""
-        head = ("tiles", "rccl") if ("tiles", "rccl") in results else ("tiles", "shm")
+        head = ("columns", "rccl") if ("columns", "rccl") in results else ("columns", "shm")
         hres = results[head]
         single = extras["single"]
         if single:
@@ -897,17 +936,19 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
             "vs_baseline": None,
             "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
             "config": {"workload": "%s: ONE %d-pt %d-LiDAR scan vs ONE %d-pt map on %d GPUs, one search pass (converge=1) per step; "
-                       "map sharded by %g m spatial tiles + 2.3 m halo, each rank serves the scan points of its tiles, "
+                       "map sharded by %g m COLUMN tiles (whole vertical columns on a lattice of owners) + 2.3 m halo, each rank serves the scan points of its tiles, "
                        "[sums | extrema] rows all-gathered over %s inside the library (one exchange per pass while the extrema of the "
                        "previous pass hold, else two), added in rank order" % (
-                           cfg["name"], N, L, sc["Nmap"], world, args.tile, "RCCL" if head[1] == "rccl" else "node shared memory"),
+                           cfg["name"], N, L, sc["Nmap"], world, args.column_tile, "RCCL" if head[1] == "rccl" else "node shared memory"),
                        "partition": head[0], "exchange": head[1], "total_points": N, "map_points": sc["Nmap"], "lidars": L,
-                       "M_accepted": hres["M_accepted"], "seed": sc["seed"], "tile_m": args.tile},
+                       "M_accepted": hres["M_accepted"], "seed": sc["seed"], "tile_m": args.column_tile, "tile_shape": "columns",
+                       "cube_tile_m": args.tile},
             "eskf": {"update_ms": hres["update_ms"], "passes": hres["update_passes"], "sharded": True,
                      "iter_ms": hres["update_ms"] / max(hres["update_passes"], 1)},
             "first_pass_ms": hres["first_pass_ms"],
             "variants": {"%s+%s" % k: v for k, v in results.items()},
             "balance": extras["balance"], "single_gpu_same_job": single, "roofline": extras["roofline"], "cpu_baseline": None,
+            "replicas": extras.get("replicas"), "predicted": predicted_curve(world),
         }
         # what carried the headline's exchange, at the top level: a silent fall-back from RCCL to shared memory must be
         # visible to whoever checks "did RCCL see N ranks"
@@ -918,10 +959,10 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
         print(json.dumps(line), flush=True)
 
     # 1. the sharded job over the shared-memory exchange: needs nothing but the node's memory, so there is always a line
-    run_variant("tiles", "shm")
+    run_variant("columns", "shm")
 
     # load balance of the tile sharding: scan points served and map points stored per rank
-    et = engines["tiles"]
+    et = engines["columns"]
     served = torch.tensor([float(et.scan_owned().sum()), float(et.map_size())], dtype=torch.float64, device="cuda")
     allsv = [torch.zeros_like(served) for _ in range(world)]
     dist.all_gather(allsv, served)
@@ -969,21 +1010,26 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
         threading.Thread(target=watchdog, daemon=True).start()
         ok = 1
         try:
-            run_variant("tiles", "rccl")
+            run_variant("columns", "rccl")
         except Exception as ex:  # (a rank that throws before its collective leaves the others to the watchdog)
-            ok, rccl_note[0] = 0, "tiles+rccl failed on rank %d: %r" % (rank, ex)
-            results.pop(("tiles", "rccl"), None)
+            ok, rccl_note[0] = 0, "columns+rccl failed on rank %d: %r" % (rank, ex)
+            results.pop(("columns", "rccl"), None)
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            results.pop(("tiles", "rccl"), None)
-            rccl_note[0] = rccl_note[0] or "tiles+rccl failed on another rank"
+            results.pop(("columns", "rccl"), None)
+            rccl_note[0] = rccl_note[0] or "columns+rccl failed on another rank"
         else:
             run_variant("scan", "rccl")
         done.set()
-    # 3. map replicated, scan cut into N shards, over shared memory
+    # 3. map replicated, scan cut into N shards, over shared memory; the cubic tiles of rounds 1-4 for comparison
     run_variant("scan", "shm")
+    run_variant("tiles", "shm")
     fence()
+    # 4. What N GPUs are FOR with this workload (one pass is latency-bound, sharding one scan buys
+    # capacity, not speed): N independent replicas - every rank its own BASELINE config-2 job (1 M-point map, its own
+    # 100 k-point scan), no exchange at all - aggregate points/s over the node.
+    extras["replicas"] = replicas_leg(args, torch, dist, capi, scenes, world, rank, dev_index, fence)
     if rank == 0:
         emit()
     dist.barrier()

@@ -580,6 +580,12 @@ int malio_update_iterated_node(malio_handle_t h, malio_xchg_t x, malio_state_t *
  *     and results equal those of one handle holding the whole map (tests/test_partition.py).
  * malio_scan_get then only holds values for the served points: malio_scan_owned tells which (1 = served here). */
 int malio_set_partition(malio_handle_t h, int rank, int world, float tile_m);
+/* ... with the tiles' shape: MALIO_TILE_CUBES (what malio_set_partition sets) or MALIO_TILE_COLUMNS - a tile is the whole
+ * vertical column over its tile_m x tile_m square: it has no neighbour above or below, so a shard's halo is the 2.3 m rim
+ * around its squares only. On a ground vehicle's map (a few tens of metres high, hundreds wide) 8 shards then store 1.8 x the
+ * map instead of 2.6 x (profiles/round5/r05_tile_shards.txt); ownership, exactness and the balance are as for cubes. */
+enum { MALIO_TILE_CUBES = 0, MALIO_TILE_COLUMNS = 1 };
+int malio_set_partition_shape(malio_handle_t h, int rank, int world, float tile_m, int shape);
 int malio_scan_owned(malio_handle_t h, uint8_t *owned);
 
 /* ---- several GPUs behind ONE handle, called from ONE thread ("multi-GPU handled inside") ------------- */
@@ -590,12 +596,14 @@ int malio_scan_owned(malio_handle_t h, uint8_t *owned);
  *   MALIO_PART_SCAN   map replicated on every GPU, the scan cut into n_gpus contiguous shards
  *   MALIO_PART_TILES  map sharded by spatial tiles of edge tile_m (0 = 16 m) with a halo, every GPU is handed the whole
  *                     scan and serves the points of its own tiles (malio_set_partition; BASELINE config 4)
+ *   MALIO_PART_COLUMNS  the same with column-shaped tiles (malio_set_partition_shape, MALIO_TILE_COLUMNS): no halo above and
+ *                     below a tile - the shape to use for a map that is much wider than it is high
  * exchange: how the per-pass [sums | extrema] rows (2.4 KB per GPU) meet - MALIO_NODE_XCHG_HOST: through host memory (the
  * rows are consumed by the host: the n x n filter algebra runs on the caller's thread), MALIO_NODE_XCHG_RCCL:
  * ncclAllGather over xGMI on the GPUs' streams. Either way the rows are added in GPU order: results do not depend on
  * timing, and equal those of one GPU given the whole scan and map up to the order of the final additions. */
 typedef struct malio_node *malio_node_t;
-enum { MALIO_PART_SCAN = 0, MALIO_PART_TILES = 1 };
+enum { MALIO_PART_SCAN = 0, MALIO_PART_TILES = 1, MALIO_PART_COLUMNS = 2 };
 enum { MALIO_NODE_XCHG_HOST = 0, MALIO_NODE_XCHG_RCCL = 1 };
 int malio_node_create(const malio_params_t *params, int n_gpus, const int *devices, int partition, int exchange,
                       float tile_m, malio_node_t *out);
@@ -657,6 +665,10 @@ int malio_node_update_stats(malio_node_t nd, int *out4);
  * stores each of n map points */
 int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner);
 int malio_part_stores(const float *xyz, int n, int rank, int world, float tile_m, float filter_size_map, uint8_t *out_stores);
+/* ... for either tile shape (MALIO_TILE_CUBES: the two above) */
+int malio_part_owner_shape(const float *xyz, int n, int world, float tile_m, int shape, int *out_owner);
+int malio_part_stores_shape(const float *xyz, int n, int rank, int world, float tile_m, int shape, float filter_size_map,
+                            uint8_t *out_stores);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Names/durations [ms] of the kernels of the last malio_measure / stage call, from hipEvents recorded

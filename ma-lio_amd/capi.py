@@ -23,7 +23,7 @@ EXPORTS = [
     "malio_map_size", "malio_nearest_search", "malio_map_add", "malio_map_delete_boxes", "malio_map_get", "malio_map_incremental", "malio_map_incremental_select", "malio_node_map_incremental", "malio_node_undistort_resident", "malio_node_scan_set_resident", "malio_node_nearest_search", "malio_node_map_get", "malio_node_map_total", "malio_node_voxel_downsample", "malio_decode_livox", "malio_decode_ouster", "malio_decode_velodyne", "malio_voxel_downsample", "malio_undistort_resident", "malio_scan_set_resident", "malio_scan_set", "malio_scan_set_packed", "malio_scan_upload_wait", "malio_scan_stage",
     "malio_measure", "malio_scan_get", "malio_update_iterated", "malio_update_iterated_begin", "malio_update_iterated_end", "malio_undistort", "malio_sums_len",
     "malio_measure_stage1", "malio_measure_stage2", "malio_measure_finish", "malio_last_kernel_times",
-    "malio_set_profiling", "malio_set_partition", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
+    "malio_set_profiling", "malio_set_partition", "malio_set_partition_shape", "malio_part_owner_shape", "malio_part_stores_shape", "malio_scan_owned", "malio_set_pass_hook", "malio_ieskf_step", "malio_predict", "malio_host_alloc", "malio_host_free", "malio_result_buffer", "malio_scan_order", "malio_measure_stage2_emit", "malio_xchg_create", "malio_xchg_all_gather", "malio_xchg_reduce", "malio_xchg_row", "malio_measure_node", "malio_node_stats", "malio_update_iterated_node", "malio_xchg_unlink", "malio_xchg_destroy", "malio_debug_counters", "malio_debug_fuse_stats", "malio_debug_nfound_hist", "malio_spline_feed", "malio_spline_get_pose",
     "malio_compound_pose_cov", "malio_compound_inv_pose_cov", "malio_eval_point_uncertainty",
     "malio_xchg_create_local", "malio_debug_xchg_latency", "malio_rccl_unique_id", "malio_xchg_create_rccl", "malio_xchg_device_row", "malio_xchg_kind",
     "malio_xchg_reduce_stream", "malio_node_create", "malio_node_destroy", "malio_node_last_error", "malio_node_gpus",
@@ -37,7 +37,8 @@ EXPORTS = [
 OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
            nl_full_blocks=8, node_gated=9, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
            debug_node_gated_redone=103)
-PART_SCAN, PART_TILES = 0, 1
+PART_SCAN, PART_TILES, PART_COLUMNS = 0, 1, 2  # (COLUMNS: tiles that are whole vertical columns, no halo above / below)
+TILE_CUBES, TILE_COLUMNS = 0, 1
 XCHG_HOST, XCHG_RCCL = 0, 1
 
 
@@ -563,9 +564,10 @@ class Engine:
                                        _p(out["normvec"], C.c_float)), "malio_scan_get")
         return out
 
-    def set_partition(self, rank, world, tile_m=0.0):
-        """malio_set_partition: this handle becomes spatial shard `rank` of `world` (call before map_build)."""
-        self._chk(lib().malio_set_partition(self.h, int(rank), int(world), C.c_float(tile_m)), "malio_set_partition")
+    def set_partition(self, rank, world, tile_m=0.0, columns=False):
+        """malio_set_partition[_shape]: this handle becomes spatial shard `rank` of `world` (call before map_build)."""
+        self._chk(lib().malio_set_partition_shape(self.h, int(rank), int(world), C.c_float(tile_m), TILE_COLUMNS if columns else TILE_CUBES),
+                  "malio_set_partition_shape")
 
     def scan_owned(self):
         out = np.zeros(self.N, np.uint8)
@@ -798,21 +800,22 @@ def rccl_unique_id():
     return bytes(buf.raw)
 
 
-def part_owner(xyz, world, tile_m=0.0):
-    """malio_part_owner for an [n,3] float32 array: the shard that serves a world point."""
+def part_owner(xyz, world, tile_m=0.0, columns=False):
+    """malio_part_owner[_shape] for an [n,3] float32 array: the shard that serves a world point."""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     out = np.zeros(xyz.shape[0], np.int32)
-    rc = lib().malio_part_owner(_p(xyz, C.c_float), xyz.shape[0], int(world), C.c_float(tile_m), _p(out, C.c_int))
+    rc = lib().malio_part_owner_shape(_p(xyz, C.c_float), xyz.shape[0], int(world), C.c_float(tile_m),
+                                      TILE_COLUMNS if columns else TILE_CUBES, _p(out, C.c_int))
     assert rc == OK
     return out
 
 
-def part_stores(xyz, rank, world, tile_m=0.0, filter_size_map=0.5):
-    """malio_part_stores for an [n,3] float32 array: whether shard `rank` keeps a map point (own tiles + halo)."""
+def part_stores(xyz, rank, world, tile_m=0.0, filter_size_map=0.5, columns=False):
+    """malio_part_stores[_shape] for an [n,3] float32 array: whether shard `rank` keeps a map point (own tiles + halo)."""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     out = np.zeros(xyz.shape[0], np.uint8)
-    rc = lib().malio_part_stores(_p(xyz, C.c_float), xyz.shape[0], int(rank), int(world), C.c_float(tile_m),
-                                 C.c_float(filter_size_map), _p(out, C.c_uint8))
+    rc = lib().malio_part_stores_shape(_p(xyz, C.c_float), xyz.shape[0], int(rank), int(world), C.c_float(tile_m),
+                                       TILE_COLUMNS if columns else TILE_CUBES, C.c_float(filter_size_map), _p(out, C.c_uint8))
     assert rc == OK
     return out.astype(bool)
 

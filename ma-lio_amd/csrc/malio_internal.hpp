@@ -107,8 +107,10 @@ __device__ __forceinline__ u32 hash_key(u64 k) {  // 32-bit multiplicative mix (
 }
 #endif
 
-// Spatial sharding of the map across `world` handles (BASELINE config 4): space is cut into cubic tiles,
-// a tile belongs to the shard its hashed coordinates name. A shard stores the map points of its own tiles plus a halo
+// Spatial sharding of the map across `world` handles (BASELINE config 4): space is cut into tiles - cubes of
+// edge tile_m, or (PartView::columns, the shape a ground vehicle's map wants: round 5) vertical columns over tile_m squares,
+// which have no neighbours above or below and therefore no halo there: 8 shards of BASELINE config 4 store 1.8 x the map
+// instead of 2.6 x (profiles/round5/r05_tile_shards.txt) -, a tile belongs to the shard its hashed coordinates name. A shard stores the map points of its own tiles plus a halo
 // (every point whose voxel box, grown by PART_HALO, touches an owned tile) and serves the scan points whose world point
 // of the SEARCH pass lies in an owned tile. PART_HALO > sqrt(5) m: every neighbour the reference can accept
 // (pointSearchSqDis[4] <= 5, laserMapping.cpp:587) of an owned query is in the shard, so its result equals the one an
@@ -117,6 +119,8 @@ constexpr float PART_HALO = 2.3f;
 struct PartView {
   int rank = 0, world = 1;  // world <= 1: not partitioned
   float inv_tile = 1.f / 16.f;
+  int columns = 0;  // MALIO_TILE_COLUMNS: a tile is the whole vertical column over its (x, y) square - no halo above or below it
+  int lat_k = 5;    // columns: owner = (tx + lat_k ty) mod world (part_lattice_k)
 };
 __host__ __device__ inline int tile_coord(float x, float inv_tile) { return (int)floorf(x * inv_tile); }
 __host__ __device__ inline u32 tile_hash(int tx, int ty, int tz) {
@@ -127,20 +131,42 @@ __host__ __device__ inline u32 tile_hash(int tx, int ty, int tz) {
   return h;
 }
 __host__ __device__ inline u32 tile_owner(int tx, int ty, int tz, u32 world) { return tile_hash(tx, ty, tz) % world; }
+// vertical tile coordinate under the partition's shape (columns: every height is tile 0)
+__host__ __device__ inline int part_tz(const PartView &p, float z) { return p.columns ? 0 : tile_coord(z, p.inv_tile); }
+// Who owns tile (tx, ty, tz)? Cubes: the hash above. Columns: the lattice (tx + k ty) mod world - a scan covers ~150 columns
+// of 16 m, too few for a hash to balance over 8 shards (max / mean points served 1.45); on the lattice every run of `world`
+// columns along x holds one of each shard and the rows are shifted by k: 1.04 at 16 m, 1.05 at 24 m
+// (profiles/round5/r05_tile_shards.txt). k: the smallest of 5, 3, 7, 11, 13 that shares no factor with `world`.
+inline int part_lattice_k(int world) {
+  const int cand[5] = {5, 3, 7, 11, 13};
+  for (int c = 0; c < 5; c++) {
+    int a = cand[c], b = world;
+    while (b) { const int t = a % b; a = b, b = t; }
+    if (a == 1) return cand[c];
+  }
+  return 1;
+}
+__host__ __device__ inline u32 part_tile_owner(const PartView &p, int tx, int ty, int tz) {
+  if (!p.columns) return tile_owner(tx, ty, tz, (u32)p.world);
+  const long long v = ((long long)tx + (long long)p.lat_k * (long long)ty) % (long long)p.world;
+  return (u32)(v < 0 ? v + p.world : v);
+}
+__host__ __device__ inline u32 part_owner_of(const PartView &p, float x, float y, float z) {
+  return part_tile_owner(p, tile_coord(x, p.inv_tile), tile_coord(y, p.inv_tile), part_tz(p, z));
+}
 __host__ __device__ inline bool part_owns(const PartView &p, float x, float y, float z) {
-  return p.world <= 1 ||
-         tile_owner(tile_coord(x, p.inv_tile), tile_coord(y, p.inv_tile), tile_coord(z, p.inv_tile), (u32)p.world) == (u32)p.rank;
+  return p.world <= 1 || part_owner_of(p, x, y, z) == (u32)p.rank;
 }
 // does the box [c - r, c + r] touch a tile of this shard? (at most 8 tiles while 2 r < tile edge)
 __host__ __device__ inline bool part_touches(const PartView &p, float cx, float cy, float cz, float r) {
   if (p.world <= 1) return true;
   const int x0 = tile_coord(cx - r, p.inv_tile), x1 = tile_coord(cx + r, p.inv_tile);
   const int y0 = tile_coord(cy - r, p.inv_tile), y1 = tile_coord(cy + r, p.inv_tile);
-  const int z0 = tile_coord(cz - r, p.inv_tile), z1 = tile_coord(cz + r, p.inv_tile);
+  const int z0 = part_tz(p, cz - r), z1 = part_tz(p, cz + r);
   for (int z = z0; z <= z1; z++)
     for (int y = y0; y <= y1; y++)
       for (int x = x0; x <= x1; x++)
-        if (tile_owner(x, y, z, (u32)p.world) == (u32)p.rank) return true;
+        if (part_tile_owner(p, x, y, z) == (u32)p.rank) return true;
   return false;
 }
 // a map point is stored by every shard its down-sampling voxel (edge fs; the point itself when fs <= 0) reaches: all

@@ -2466,9 +2466,9 @@ __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatCo
     // (Ownership is still decided per pass, per point, from that pass' world point - search_wg phase A: a point that
     // changes tiles with the iterate is served by its new owner wherever it sits in this order.)
     const int tx = tile_coord((float)pg.x, part.inv_tile), ty = tile_coord((float)pg.y, part.inv_tile),
-              tz = tile_coord((float)pg.z, part.inv_tile);
+              tz = part_tz(part, (float)pg.z);
     const u32 th = tile_hash(tx, ty, tz);
-    const u32 other = tile_owner(tx, ty, tz, (u32)part.world) == (u32)part.rank ? 0u : 1u;
+    const u32 other = part_tile_owner(part, tx, ty, tz) == (u32)part.rank ? 0u : 1u;
     b = (u32)lid * SORT_NBK + (other << 11) + (((th >> 8) & 31u) << 6) + (((cy & 7u) << 3) | (cx & 7u));
 #ifdef KS_PART_CLASS_ORDER  // A/B: the order of round 3 (64 classes ascending, owned and foreign interleaved)
     b = (u32)lid * SORT_NBK + ((th & 63u) << 6) + (((cy & 7u) << 3) | (cx & 7u));

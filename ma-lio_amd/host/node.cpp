@@ -41,6 +41,7 @@ struct Worker {
 struct malio_node {
   malio_params_t prm{};
   int n = 0, partition = MALIO_PART_SCAN, exchange = MALIO_NODE_XCHG_HOST;
+  int columns = 0;  // MALIO_PART_COLUMNS: partition == MALIO_PART_TILES with column-shaped tiles
   float tile_m = 0.f;
   std::vector<Worker> w;
   std::string err;
@@ -121,7 +122,9 @@ extern "C" {
 int malio_node_create(const malio_params_t *params, int n_gpus, const int *devices, int partition, int exchange,
                       float tile_m, malio_node_t *out) {
   if (!params || !out || n_gpus < 1 || n_gpus > 64) return MALIO_ERR_BAD_ARG;
-  if (partition != MALIO_PART_SCAN && partition != MALIO_PART_TILES) return MALIO_ERR_BAD_ARG;
+  if (partition != MALIO_PART_SCAN && partition != MALIO_PART_TILES && partition != MALIO_PART_COLUMNS) return MALIO_ERR_BAD_ARG;
+  const int columns = partition == MALIO_PART_COLUMNS ? 1 : 0;  // (from here on "tiles" of either shape: nd->columns says which)
+  if (columns) partition = MALIO_PART_TILES;
   if (exchange != MALIO_NODE_XCHG_HOST && exchange != MALIO_NODE_XCHG_RCCL) return MALIO_ERR_BAD_ARG;
   *out = nullptr;
   // The HIP runtime is initialised HERE, on the calling thread, before any worker exists: when this call is the first
@@ -134,7 +137,7 @@ int malio_node_create(const malio_params_t *params, int n_gpus, const int *devic
     if (d < 0 || d >= ndev) return MALIO_ERR_NO_DEVICE;
   }
   malio_node *nd = new malio_node();
-  nd->prm = *params, nd->n = n_gpus, nd->partition = partition, nd->exchange = exchange, nd->tile_m = tile_m;
+  nd->prm = *params, nd->n = n_gpus, nd->partition = partition, nd->columns = columns, nd->exchange = exchange, nd->tile_m = tile_m;
   nd->w.resize(n_gpus);
   const int row = params->lid_num * 97 + MALIO_MINMAX_LEN;
   std::vector<malio_xchg_t> xs(n_gpus, nullptr);
@@ -171,7 +174,9 @@ int malio_node_create(const malio_params_t *params, int n_gpus, const int *devic
     int rc = malio_create(&nd->prm, k.device, &k.h);
     if (rc != MALIO_OK) return rc;
     if (!gated_ok && (rc = malio_set_option(k.h, MALIO_OPT_NODE_GATED, 0.0)) != MALIO_OK) return rc;
-    if (nd->partition == MALIO_PART_TILES && (rc = malio_set_partition(k.h, k.rank, nd->n, nd->tile_m)) != MALIO_OK) return rc;
+    if (nd->partition == MALIO_PART_TILES &&
+        (rc = malio_set_partition_shape(k.h, k.rank, nd->n, nd->tile_m, nd->columns ? MALIO_TILE_COLUMNS : MALIO_TILE_CUBES)) != MALIO_OK)
+      return rc;
     if (nd->exchange == MALIO_NODE_XCHG_RCCL) rc = malio_xchg_create_rccl(uidp, k.rank, nd->n, row, k.device, &k.x);
     return rc;
   });
@@ -272,7 +277,8 @@ int malio_node_map_get(malio_node_t nd, malio_point_t *out, int cap, int *out_n)
     std::vector<malio_point_t> all((size_t)std::max(n, 1));
     if ((r = malio_map_get(k.h, all.data(), n, &n)) != MALIO_OK) return r;
     malio::PartView pv;
-    pv.rank = k.rank, pv.world = G, pv.inv_tile = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : 16.f);
+    pv.rank = k.rank, pv.world = G, pv.inv_tile = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : (nd->columns ? 24.f : 16.f)), pv.columns = nd->columns;
+    pv.lat_k = malio::part_lattice_k(G);
     for (int i = 0; i < n; i++)
       if (all[i].x < 1e8f && malio::part_owns(pv, all[i].x, all[i].y, all[i].z)) part[k.rank].push_back(all[i]);  // (1e9: an empty shard's placeholder)
     return MALIO_OK;
@@ -403,11 +409,11 @@ int malio_node_nearest_search(malio_node_t nd, const malio_point_t *queries, int
     nd->err = "malio_node_nearest_search: search radius 2 * cell_size exceeds the halo of a tile shard";
     return MALIO_ERR_BAD_ARG;
   }
-  const float inv = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : 16.f);
+  malio::PartView pv;
+  pv.rank = 0, pv.world = G, pv.inv_tile = 1.0f / (nd->tile_m > 0.f ? nd->tile_m : (nd->columns ? 24.f : 16.f)), pv.columns = nd->columns;
+  pv.lat_k = malio::part_lattice_k(G);
   std::vector<std::vector<int>> idx(G);
-  for (int i = 0; i < n; i++)
-    idx[malio::tile_owner(malio::tile_coord(queries[i].x, inv), malio::tile_coord(queries[i].y, inv),
-                          malio::tile_coord(queries[i].z, inv), (unsigned)G)].push_back(i);
+  for (int i = 0; i < n; i++) idx[malio::part_owner_of(pv, queries[i].x, queries[i].y, queries[i].z)].push_back(i);
   return nd->run([&](Worker &w) -> int {
     const std::vector<int> &mine = idx[w.rank];
     const int m = (int)mine.size();
@@ -596,17 +602,26 @@ int malio_node_map_incremental(malio_node_t nd, const malio_state_t *state_point
 
 // ---- shard geometry (host code: tests, and callers that want to know where a point lives) -------------------------
 int malio_part_owner(const float *xyz, int n, int world, float tile_m, int *out_owner) {
-  if (!xyz || !out_owner || n < 0 || world < 1) return MALIO_ERR_BAD_ARG;
-  const float inv = 1.0f / (tile_m > 0.f ? tile_m : 16.f);
-  for (int i = 0; i < n; i++)
-    out_owner[i] = (int)malio::tile_owner(malio::tile_coord(xyz[3 * i], inv), malio::tile_coord(xyz[3 * i + 1], inv),
-                                          malio::tile_coord(xyz[3 * i + 2], inv), (unsigned)world);
+  return malio_part_owner_shape(xyz, n, world, tile_m, MALIO_TILE_CUBES, out_owner);
+}
+int malio_part_owner_shape(const float *xyz, int n, int world, float tile_m, int shape, int *out_owner) {
+  if (!xyz || !out_owner || n < 0 || world < 1 || (shape != MALIO_TILE_CUBES && shape != MALIO_TILE_COLUMNS)) return MALIO_ERR_BAD_ARG;
+  malio::PartView p;
+  p.rank = 0, p.world = world, p.inv_tile = 1.0f / (tile_m > 0.f ? tile_m : (shape == MALIO_TILE_COLUMNS ? 24.f : 16.f)), p.columns = shape == MALIO_TILE_COLUMNS;
+  p.lat_k = malio::part_lattice_k(world);
+  for (int i = 0; i < n; i++) out_owner[i] = (int)malio::part_owner_of(p, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
   return MALIO_OK;
 }
 int malio_part_stores(const float *xyz, int n, int rank, int world, float tile_m, float filter_size_map, uint8_t *out_stores) {
-  if (!xyz || !out_stores || n < 0 || world < 1 || rank < 0 || rank >= world) return MALIO_ERR_BAD_ARG;
+  return malio_part_stores_shape(xyz, n, rank, world, tile_m, MALIO_TILE_CUBES, filter_size_map, out_stores);
+}
+int malio_part_stores_shape(const float *xyz, int n, int rank, int world, float tile_m, int shape, float filter_size_map,
+                            uint8_t *out_stores) {
+  if (!xyz || !out_stores || n < 0 || world < 1 || rank < 0 || rank >= world || (shape != MALIO_TILE_CUBES && shape != MALIO_TILE_COLUMNS))
+    return MALIO_ERR_BAD_ARG;
   malio::PartView p;
-  p.rank = rank, p.world = world, p.inv_tile = 1.0f / (tile_m > 0.f ? tile_m : 16.f);
+  p.rank = rank, p.world = world, p.inv_tile = 1.0f / (tile_m > 0.f ? tile_m : (shape == MALIO_TILE_COLUMNS ? 24.f : 16.f)), p.columns = shape == MALIO_TILE_COLUMNS;
+  p.lat_k = malio::part_lattice_k(world);
   for (int i = 0; i < n; i++) out_stores[i] = malio::part_stores(p, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], filter_size_map) ? 1 : 0;
   return MALIO_OK;
 }

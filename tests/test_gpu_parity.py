@@ -605,16 +605,18 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(capi, scenes):
     assert res.returncode == 0, res.stderr[-2000:]
     js = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["value"] > 0
-    assert js["config"]["partition"] == "tiles" and js["config"]["exchange"] == "shm"
+    assert js["config"]["partition"] == "columns" and js["config"]["exchange"] == "shm"  # (gloo ranks on one GPU: no RCCL leg)
     sc = scenes.make_scene(cfg=3)
     eng = capi.Engine(sc["params"])
     eng.map_build(sc["map"])
     eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     M = eng.measure(sc["state0"], True)["M"]
     assert js["config"]["M_accepted"] == M
-    assert set(js["variants"]) == {"tiles+shm", "scan+shm"}
+    assert set(js["variants"]) == {"columns+shm", "tiles+shm", "scan+shm"}
     assert all(v["M_accepted"] == M and v["first_pass_ms"] > 0 for v in js["variants"].values())
     assert sum(js["balance"]["scan_points_served"]) == sc["N"]
+    # the replicas leg: one BASELINE config-2 job per rank, no exchange, aggregate over the node
+    assert js["replicas"]["scaling"] == "weak" and js["replicas"]["value"] > 0 and js["replicas"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
@@ -636,7 +638,7 @@ def test_bench_rccl_leg_failure_still_prints_the_line():
     assert res.returncode == 0, res.stderr[-2000:]
     js = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert js["n_gpus"] == 2 and js["config"]["exchange"] == "shm" and js["value"] > 0
-    assert "rccl_note" in js and "tiles+rccl" not in js["variants"]
+    assert "rccl_note" in js and "columns+rccl" not in js["variants"]
     assert js["roofline"] and js["single_gpu_same_job"]["ms_per_step"] > 0
 
 

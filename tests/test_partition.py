@@ -10,8 +10,13 @@ import pytest
 from conftest import assert_P_close
 
 
+def _part(capi, name):
+    return {"scan": capi.PART_SCAN, "tiles": capi.PART_TILES, "columns": capi.PART_COLUMNS}[name]
+
+
+@pytest.mark.parametrize("columns", [False, True], ids=["cubes", "columns"])
 @pytest.mark.parametrize("world,tile", [(2, 0.0), (3, 12.0), (8, 16.0), (8, 32.0)])
-def test_every_acceptable_neighbour_is_shard_local(capi, orc, scenes, world, tile):
+def test_every_acceptable_neighbour_is_shard_local(capi, orc, scenes, world, tile, columns):
     from scipy.spatial import cKDTree
     sc = scenes.make_scene(seed=301, N=6000, Nmap=120000, L=3)
     m = sc["map"][:, :3].astype(np.float32)
@@ -21,9 +26,13 @@ def test_every_acceptable_neighbour_is_shard_local(capi, orc, scenes, world, til
     t = tile if tile > 0 else 16.0
     q[:500, 0] = np.round(q[:500, 0] / t) * t                      # exactly on a tile face
     q[500:1000, 1] = np.nextafter(np.round(q[500:1000, 1] / t) * t, -np.inf).astype(np.float32)  # one ulp below it
-    owner = capi.part_owner(q, world, tile)
+    owner = capi.part_owner(q, world, tile, columns)
     assert set(np.unique(owner)) <= set(range(world)) and len(np.unique(owner)) == world
-    stores = np.stack([capi.part_stores(m, r, world, tile, 0.5) for r in range(world)])  # [world, Nmap]
+    if columns:  # a column owns every height over its square
+        q_up = q.copy()
+        q_up[:, 2] += 37.0
+        assert np.array_equal(capi.part_owner(q_up, world, tile, True), owner)
+    stores = np.stack([capi.part_stores(m, r, world, tile, 0.5, columns) for r in range(world)])  # [world, Nmap]
     assert stores.any(0).all()                                       # every map point lives somewhere
     tree = cKDTree(m.astype(np.float64))
     nb = tree.query_ball_point(q.astype(np.float64), np.sqrt(5.0) + 1e-3)
@@ -38,9 +47,10 @@ def test_every_acceptable_neighbour_is_shard_local(capi, orc, scenes, world, til
     assert same.sum() > 100 and np.array_equal(stores[:, a], stores[:, b])
     # replication: a point is stored by at most the 8 shards around a tile corner; on average (16 + 2 x 2.55)^3 / 16^3 = 2.3
     # copies at the default edge when the neighbouring tiles all belong to other shards, 1.6 at 32 m
-    assert stores.sum(0).max() <= min(8, world)
+    # columns: no tile above or below - at most the 4 shards around a column's edge, (16 + 2 x 2.55)^2 / 16^2 = 1.74 copies
+    assert stores.sum(0).max() <= min(4 if columns else 8, world)
     if world == 8:
-        assert stores.sum() / len(m) < (2.6 if tile == 16.0 else 1.9)
+        assert stores.sum() / len(m) < ((2.6 if tile == 16.0 else 1.9) if not columns else (1.8 if tile == 16.0 else 1.45))
 
 
 def test_shard_local_5nn_equals_reference_tree(capi, orc, scenes):
@@ -76,7 +86,7 @@ def _single(capi, sc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("partition", ["scan", "tiles"])
+@pytest.mark.parametrize("partition", ["scan", "tiles", "columns"])
 @pytest.mark.parametrize("kw", [dict(seed=311, N=6000, Nmap=150000, L=3), dict(seed=312, N=4000, Nmap=90000, L=2, map_unc=True),
                                 dict(seed=313, N=5000, Nmap=120000, L=3, kind="tunnel", det_range=500.0)],
                          ids=lambda k: "s%d" % k["seed"])
@@ -84,10 +94,9 @@ def test_node_handle_equals_single_engine(capi, scenes, partition, kw):
     sc = scenes.make_scene(**kw)
     one = _single(capi, sc)
     G = 3
-    nd = capi.Node(sc["params"], [0] * G, partition=capi.PART_TILES if partition == "tiles" else capi.PART_SCAN,
-                   tile_m=12.0)
+    nd = capi.Node(sc["params"], [0] * G, partition=_part(capi, partition), tile_m=12.0)
     nd.map_build(sc["map"])
-    if partition == "tiles":
+    if partition != "scan":
         sizes = nd.map_sizes()
         assert max(sizes) < sc["Nmap"] and sum(sizes) >= sc["Nmap"]
     nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
@@ -258,17 +267,20 @@ def test_tile_shards_map_mutations(capi, scenes):
 
 
 @pytest.mark.gpu
-def test_config4_tile_sharded_8_shards_equals_single_engine(capi, scenes):
+@pytest.mark.parametrize("shape", ["tiles", "columns"])
+def test_config4_tile_sharded_8_shards_equals_single_engine(capi, scenes, shape):
     """BASELINE.json configs[3] at FULL size the way the driver's scaling run executes it: the 8 M-point map cut into 16 m
     hashed tiles over 8 shards (here all on GPU 0, one after the other through the node handle), the 200 k-point scan
     served by the shard that owns each point's tile - against ONE engine that holds the whole map. Flags, planes,
     neighbours and Nearest_Points point for point; the sums to their summation order (per-shard partial sums)."""
     sc = scenes.make_scene(cfg=4)
     one = _single(capi, sc)
-    nd = capi.Node(sc["params"], [0] * 8, partition=capi.PART_TILES, tile_m=16.0)
+    nd = capi.Node(sc["params"], [0] * 8, partition=_part(capi, shape), tile_m=16.0)
     nd.map_build(sc["map"])
     sizes = nd.map_sizes()
     assert max(sizes) < 0.5 * sc["Nmap"] and sum(sizes) >= sc["Nmap"]  # every shard holds its tiles + halo only
+    # (cubes of 16 m store 2.6 x the map between them - the halo above and below every tile is most of it -, columns 1.8 x)
+    assert sum(sizes) < (2.7 if shape == "tiles" else 1.9) * sc["Nmap"], sizes
     nd.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     s2 = sc["state0"].copy()
     s2[0:3] += [0.012, -0.02, 0.006]

@@ -14,7 +14,7 @@ OBJS=$(ls build/csrc/*.o build/host/*.o | grep -v "build/${SRC}.o")
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c $SRC -o build/variants/$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so $OBJS build/variants/$name.o -lrt -lpthread -L/opt/rocm/lib -lrccl ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so $OBJS build/variants/$name.o -lrt -lpthread -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib ) &
 done
 wait
 ls -la variants
