@@ -658,22 +658,26 @@ struct NlView {
 #ifndef KS_PIPE
 #define KS_PIPE 1
 #endif
+// the directory probe alone: (start, count) of the list of the cell that holds (wx, wy, wz); (0, 0): no such cell
+__device__ __forceinline__ void nl_probe(const NlView &nl, float wx, float wy, float wz, u32 &start, u32 &count) {
+  const float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
+  const u64 key = cell_key_d((int)floorf(gx), (int)floorf(gy), (int)floorf(gz));
+  const u32 slot = hash_key_d(key) & nl.tmask;
+  cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
+#ifdef ATTR_WALK5
+  count = min(count, 5u);
+#endif
+}
+// the walk of a list whose (start, count) are known
 template <int G, bool CERT, bool PIPE>
-__device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
-                                          Top5 &t, float &lb2) {
+__device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, float wz, int sub, float limit2, u32 start, u32 count,
+                                        Top5 &t, float &lb2) {
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
   for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
   u32 ev = (u32)(TOP5_MAXKEY >> 32);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
-  u64 key = cell_key_d((int)kxf, (int)kyf, (int)kzf);
-  u32 slot = hash_key_d(key) & nl.tmask;
-  u32 start, count;
-  cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
-#ifdef ATTR_WALK5
-  count = min(count, 5u);
-#endif
   // (the SKIP kernels' walk - CERT: the certificate's bookkeeping rides on every insertion - stays the two-batch loop: with
   // it the pipelined form spills 200 VGPRs; the option is off by default)
   if constexpr (PIPE && !CERT) {
@@ -770,6 +774,18 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
   const float g2 = g1 * g1 * 0.99999f;
   lb2 = CERT ? __uint_as_float(min(ev, __float_as_uint(g2))) : 0.f;  // (positive floats order like their bits; ev may be the no-candidate mark)
   return (t.og(4) != INVALID) && (t.d(4) <= g2);
+}
+// (Measured and not kept, profiles/round5/r05l_probe_and_order.txt: the G lanes of a query loading the 2 G directory slots behind
+// the home slot in one trip - a wave of 16 queries otherwise waits for its unluckiest linear probe: 93 % of the waves need a
+// second dependent slot, 56 % a third - costs k_pass +1.4 us at config 2: twice the probe's requests outweigh the saved trips;
+// and the level-1 probe moved into phase A with the queries handed to phase B sorted by the number of batches they need
+// (a wave walks as many batches as its longest list: 2.8 where a query alone needs 1.9): -25 % candidate slots, +0.5 us.)
+template <int G, bool CERT, bool PIPE>
+__device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
+                                          Top5 &t, float &lb2) {
+  u32 start, count;
+  nl_probe(nl, wx, wy, wz, start, count);
+  return nl_walk<G, CERT, PIPE>(nl, wx, wy, wz, sub, limit2, start, count, t, lb2);
 }
 // lb2 -> the certificate's radius: a lower bound on the TRUE distance of every outsider (computed squared distances are
 // within 3e-7 relative of the true ones; sqrtf is correctly rounded)
@@ -892,7 +908,8 @@ struct SearchLds {
   int flags;               // what the control wave tells the others after phase A (search_wg)
   float cr[SQ];            // certificate radius of the walk that served the query (cert_radius)
   float4 q[SQ];            // the scan point as phase A read it (phase C: the row and the trace are built from it)
-  float4 nbp[5][SQ];       // phase C: the five neighbours' map points, kept across the plane fit (point_phase)
+  float4 (*nbp)[SQ];       // phase C: [5][SQ] - the five neighbours' map points, kept across the plane fit (point_phase); the
+                           // kernel's own LDS (k_pass: the storage of its row staging U, which is written after the fit)
   double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
   // KS_SPLIT: what the helper wave and the control wave hand each other across their one barrier
   double trS[SQ], trR[SQ];  // helper -> itself: the trace under the accepted / rejected point's clamp rule (trace_both)
@@ -913,6 +930,7 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
                                             float &pd2_out, float4 &q_out) {
   selected = false, ucov = 0.0, tr = 0.0;
   pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
+  float4 (*const nbp)[SQ] = S.nbp;
   // SPLIT: the control wave issues NO global store before its tile - on gfx9 a wave's stores and loads share one in-order
   // counter (vmcnt), so a store in front of the neighbour gather makes the gather's wait a wait for the store's round trip
   // too. The helper wave stores the per-point state after the barrier (helper_post), from LDS.
@@ -942,7 +960,7 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         A[k][0] = m[k].x, A[k][1] = m[k].y, A[k][2] = m[k].z, W[k] = m[k].w;
-        S.nbp[k][lane] = m[k];
+        nbp[k][lane] = m[k];
       }
     }
     PH(0, 4);
@@ -957,7 +975,7 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
     bool plane_ok = true;
 #pragma unroll
     for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from this lane's LDS slots
-      const float4 m = S.nbp[k][lane];
+      const float4 m = nbp[k][lane];
       if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
     }
     pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
@@ -1279,6 +1297,8 @@ __device__ __forceinline__ void helper_post_reuse(const Pass1Args &a, u64 *mm_cu
 template <bool DEV, bool SKIP>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ SearchLds S;
+  __shared__ float4 s_nbp[5][SQ];
+  if (threadIdx.x == 0) S.nbp = s_nbp;  // (read by the control wave in phase C, behind the barriers of phases A and B)
   if (DEV && a.dl->done) return;
   const QuatConst &qc = DEV ? a.dl->qc : a.qc;
   const PassDyn dy = pass_dyn<DEV>(a);
@@ -1771,6 +1791,7 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   // the 64 rows of the control wave for the MFMA operands: u[12], hs, 1/r (a_p = [u/r | u0..2 | 0], b_p = [u | hs | 0 0 0]
   // are formed when they are read: 7.7 KB instead of the two 17-double records of k_rows_reduce)
   __shared__ double U[SQ][15];
+  if (threadIdx.x == 0) S.nbp = reinterpret_cast<float4 (*)[SQ]>(&U[0][0]);  // (5 KB of U's 7.5: the fit is over before a row is staged)
 #if KS_SPLIT
   __shared__ RowPre RP;
 #endif
