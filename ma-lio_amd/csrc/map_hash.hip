@@ -469,14 +469,19 @@ void free_nlist(NList &nl) {
   nl = NList();
 }
 
-// capacity of a list built with `cnt` entries: room for a quarter more, at least NL_MIN_SLACK
+// capacity of a list built with `cnt` entries: room for a quarter more, at least NL_MIN_SLACK - rounded up to whole 128-byte
+// lines (8 entries): capacities are what the lists' starts are the prefix sums of (and what the tail's bump cursor advances
+// by), so every list STARTS on a line. A 44-entry list then lies in 6 lines instead of 6.5 on average, and the 64 bytes a
+// query's four lanes load per instruction never straddle two - what the search pass is short of is outstanding L1 misses
+// per CU (profiles/round5/r05n_tcp_counters.txt), and every line is one.
 constexpr u32 NL_MIN_SLACK = 8;
+__host__ __device__ inline u32 nl_capacity(u32 cnt) { return (cnt + max(NL_MIN_SLACK, cnt / 4) + 7u) & ~7u; }
 constexpr int NL_MAX_PROBES = 1024;  // linear-probe bound of the incremental kernels (a full directory must not hang them)
 __global__ void __launch_bounds__(BLK) k_nl_caps(const u32 *__restrict__ cnt, u32 *capv, u32 n) {
   u32 i = blockIdx.x * BLK + threadIdx.x;
   if (i > n) return;  // capv[n] = 0: the exclusive scan then leaves the total there
   u32 c = i < n ? cnt[i] : 0u;
-  capv[i] = c ? c + max(NL_MIN_SLACK, c / 4) : 0u;
+  capv[i] = c ? nl_capacity(c) : 0u;
 }
 // scratch slots -> compact directory, with the capacity of every list next to it
 __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys, const u32 *__restrict__ cnt,
@@ -676,7 +681,7 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
         // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
         // old storage is reclaimed by the next full rebuild
         const u32 total = cnt + need;
-        newcap = total + max(NL_MIN_SLACK, total / 4);
+        newcap = nl_capacity(total);
         st = atomicAdd(&nl.state[0], newcap);
         if (st + newcap > nl.bump_end || st + newcap < st) {
           atomicExch(&nl.state[1], 1u);
