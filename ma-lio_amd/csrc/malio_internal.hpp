@@ -73,6 +73,11 @@ struct NlDev {
   int pruned;  // level 1: a list holds only the block's points within one cell edge of its cell (nl_member)
 };
 
+// NL_REACH: how far from a cell (in cell edges) a point may lie and still be in the cell's PRUNED list; the certificate of a
+// search in that list is NL_REACH x cf + (distance to the nearest face). 1: every point within one cell edge (rounds 2-4).
+#ifndef NL_REACH
+#define NL_REACH 1.0f
+#endif
 #if defined(__HIP__)
 // Which of the 27 lists around a point's own cell hold it. Unpruned: all of them (the list of a cell is the whole 3x3x3
 // block around it). Pruned (level 1): only the cells the point is within one cell edge of. A search in cell c certifies
@@ -88,7 +93,7 @@ __device__ __forceinline__ bool nl_member(int pruned, float gx, float gy, float 
   const float fx = gx - (float)ix, fy = gy - (float)iy, fz = gz - (float)iz;
   const float ax = dx == 0 ? 0.f : (dx > 0 ? 1.f - fx : fx), ay = dy == 0 ? 0.f : (dy > 0 ? 1.f - fy : fy),
               az = dz == 0 ? 0.f : (dz > 0 ? 1.f - fz : fz);
-  const float reach = 1.0f + 1e-5f + 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f);
+  const float reach = NL_REACH + 1e-5f + 6e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f);
   return ax * ax + ay * ay + az * az <= reach * reach;
 }
 // cell directory hashing shared by every .hip file (measure.hip keeps identical _d copies next to its hot loops)

@@ -562,7 +562,7 @@ int map_rebuild_search(Ctx *c) {
   c->n_rebuilds++;
   // level 1 pruned to the points within one cell edge of each cell (nl_member) unless the map's voxel filter is so
   // coarse that k_vox_add needs the whole block (a voxel's half diagonal must stay inside the kept reach)
-  const bool prune1 = !c->opt_nl_full_blocks /* MALIO_OPT_NL_FULL_BLOCKS */ && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * c->cell;
+  const bool prune1 = !c->opt_nl_full_blocks /* MALIO_OPT_NL_FULL_BLOCKS */ && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * NL_REACH * c->cell;
   int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1);
   if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;

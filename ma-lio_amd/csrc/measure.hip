@@ -633,6 +633,7 @@ struct NlView {
   u32 tmask;
   const float4 *pts;
   float cf, inv_cf;
+  float reach_cf;  // the radius around the query's CELL the list is complete for: cf, or NL_REACH x cf for a pruned list
 };
 // lb2 (out, identical in every lane of the group): a lower bound on the SQUARED distance - as this function computes
 // distances - from the query to every map point that is not one of the returned neighbours: the smallest of (i) the
@@ -770,7 +771,7 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
   float fx = gx - kxf, fy = gy - kyf, fz = gz - kzf;
   float margin = 3e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz) + 3.0f) * nl.cf;
   float fmin_ = fminf(fminf(fminf(fx, 1.f - fx), fminf(fy, 1.f - fy)), fminf(fz, 1.f - fz));
-  float g1 = nl.cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
+  float g1 = nl.reach_cf + fmaxf(fmin_ * nl.cf - margin, 0.f) - margin;
   const float g2 = g1 * g1 * 0.99999f;
   lb2 = CERT ? __uint_as_float(min(ev, __float_as_uint(g2))) : 0.f;  // (positive floats order like their bits; ev may be the no-candidate mark)
   return (t.og(4) != INVALID) && (t.d(4) <= g2);
@@ -1877,6 +1878,12 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     {  // (measured on the way: inside every block of 128 ids XCD x forms the 16 CONSECUTIVE tiles [16 x, 16 x + 16): the write side only, -1.0 us)
       const int b = (int)blockIdx.x, full = (int)gridDim.x & ~127;
       if (b < full) tile = (b & ~127) + ((b & 7) << 4) + ((b & 127) >> 3);
+#ifndef KS_NO_REVERSE
+      // ... and in REVERSE scan order: the launch hands out ~1 600 workgroups over ~1 us, lowest id first, and the workgroups
+      // that finish last are those of the sparser LiDARs at the END of the scan (fewer queries share a cell: more distinct
+      // lines to fetch per workgroup, profiles/round5/r05h) - they now enter first.
+      if (b < full) tile = full - 1 - tile;
+#endif
     }
 #endif
 #pragma unroll
@@ -2089,6 +2096,7 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
 static NlView view_of(const NList &nl) {
   NlView v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
+  v.reach_cf = nl.pruned ? NL_REACH * nl.cf : nl.cf;
   return v;
 }
 
