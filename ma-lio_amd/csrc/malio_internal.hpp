@@ -261,13 +261,13 @@ struct alignas(16) UncEntry {
 // Gate between two passes of the gated update loop (csrc/ieskf_dev.hip): announce the finished pass to the host, wait for
 // the control block of the next one, copy it into the DevLoop the pass kernels read.
 struct GateArgs {
-  DevLoop *dl;
-  const double *cmd;   // pinned, or device memory the host stores into: the control block, DevLoop layout (rounded up to 256 B) ...
-  const int *cmd_seq;  // ... and the word the host stores LAST (release)
-  int *msg_seq;        // pinned: sequence word the GPU publishes
-  u32 *ticket;         // device counter of the kernel the gate rides on (k_final_reduce: its last workgroup is the gate)
-  int publish, wait_for, ndoubles;
-  long long timeout_ticks;  // 100 MHz ticks the gate waits for the host (0: GATE_TIMEOUT_US)
+  DevLoop *dl = nullptr;
+  const double *cmd = nullptr;   // pinned, or device memory the host stores into: the control block, DevLoop layout (rounded up to 256 B) ...
+  const int *cmd_seq = nullptr;  // ... and the word the host stores LAST (release)
+  int *msg_seq = nullptr;        // pinned: sequence word the GPU publishes
+  u32 *ticket = nullptr;         // device counter of the kernel the gate rides on (k_final_reduce: its last workgroup is the gate)
+  int publish = 0, wait_for = 0, ndoubles = 0;
+  long long timeout_ticks = 0;  // 100 MHz ticks the gate waits for the host (0: GATE_TIMEOUT_US)
 };
 constexpr long long GATE_TIMEOUT_US = 200000;  // default; MALIO_GATE_TIMEOUT_MS overrides it per handle
 #if defined(__HIP__)
