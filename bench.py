@@ -11,12 +11,14 @@ over one fused multi-LiDAR scan that is already resident in HBM, against the res
 N = 1 workload: BASELINE.json configs[1] - City 3-LiDAR 100k-point scan vs 1M-point map (the configuration the metric
 is quoted on).
 N > 1 (strong scaling): BASELINE.json configs[3] - ONE 200k-point 3-LiDAR scan vs ONE 8M-point map on N GPUs. Headline:
-the map sharded by spatial tiles with a halo (malio_set_partition), every rank serves the scan points of its own tiles,
-the [97 L sums | extrema] rows of SURVEY.md §8(e) all-gathered over RCCL inside the library (malio_measure_node on an
-RCCL exchange), added in rank order. The line also carries the three other combinations (exchange through node shared
-memory; map replicated + scan cut into N contiguous shards), the first (two-exchange) pass of a scan, the sharded
-iterated update, the load balance of the tiles and - rank 0 - the same job on one GPU. Barriers and the max-over-ranks
-timing use the process group (RCCL).
+the map sharded by COLUMN tiles with a halo (malio_set_partition_shape, MALIO_TILE_COLUMNS: whole vertical columns on a
+lattice of owners), every rank serves the scan points of its own tiles, the [97 L sums | extrema] rows of SURVEY.md §8(e)
+all-gathered over RCCL inside the library (malio_measure_node on an RCCL exchange), added in rank order. The line also
+carries the other combinations (exchange through node shared memory; the cubic tiles of rounds 1-4; map replicated + scan
+cut into N contiguous shards), the first (two-exchange) pass of a scan, the sharded iterated update, the load balance of the
+tiles, rank 0's same job on one GPU, `replicas` (N independent config-2 jobs, one per GPU, no exchange: aggregate points/s -
+what N GPUs are for with this workload) and `predicted` (the one-GPU proxy's figures for this N, profiles/). Barriers and
+the max-over-ranks timing use the process group (RCCL).
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields). The CPU oracle is used only for
 the `cpu_baseline` leg (rank 0, N = 1), never inside the timed GPU region.

@@ -37,7 +37,7 @@ struct dyn_share_datastruct {
 
 // One GPU (malio_create) or all GPUs of the node behind one handle (malio_node_create, include/malio.h): the classes below
 // call malio_xxx or malio_node_xxx accordingly, so a loop written against them runs on either. The environment can
-// turn a plain Handle into a node without touching the caller: MALIO_NODE="<gpus>[,scan|tiles[,rccl]]" (every shard on
+// turn a plain Handle into a node without touching the caller: MALIO_NODE="<gpus>[,scan|tiles|columns[,rccl]]" (every shard on
 // `device` when MALIO_NODE_SAME_DEVICE=1: the single-GPU test boxes).
 class Handle {
  public:
@@ -45,11 +45,12 @@ class Handle {
     if (const char *e = std::getenv("MALIO_NODE")) {
       const int g = std::atoi(e);
       if (g >= 1) {
-        const bool tiles = std::strstr(e, "tiles") != nullptr, rccl = std::strstr(e, "rccl") != nullptr;
+        const bool tiles = std::strstr(e, "tiles") != nullptr, columns = std::strstr(e, "columns") != nullptr, rccl = std::strstr(e, "rccl") != nullptr;
         const char *same = std::getenv("MALIO_NODE_SAME_DEVICE");
         std::vector<int> dev(g);
         for (int r = 0; r < g; r++) dev[r] = (same && same[0] == '1') ? device : r;
-        init_node(g, dev.data(), tiles ? MALIO_PART_TILES : MALIO_PART_SCAN, rccl ? MALIO_NODE_XCHG_RCCL : MALIO_NODE_XCHG_HOST, 0.f);
+        init_node(g, dev.data(), columns ? MALIO_PART_COLUMNS : tiles ? MALIO_PART_TILES : MALIO_PART_SCAN,
+                  rccl ? MALIO_NODE_XCHG_RCCL : MALIO_NODE_XCHG_HOST, 0.f);
         return;
       }
     }
