@@ -388,6 +388,10 @@ int malio_scan_order(malio_handle_t h, int mode);
  *                              host-driven loop (default 200).
  *   MALIO_OPT_SCAN_SET_SYNC    1: malio_scan_set waits for the copy out of a page-locked cloud itself.
  *   MALIO_OPT_NL_FULL_BLOCKS   1: level-1 neighbour lists hold whole 3x3x3 blocks (takes effect at the next list build).
+ *   MALIO_OPT_NL_SORTED        1 (default): level-1 neighbour lists are kept in order of distance from their cell's centre, so a
+ *                              query's walk ends after the first 32 entries when those prove the rest irrelevant (exact: the
+ *                              same five neighbours); 0: unordered lists, walked whole (rounds 2-4). Takes effect at the
+ *                              next list build.
  *   MALIO_OPT_NODE_GATED       1 (default): malio_update_iterated_node / the node handle run the gated chain on every shard
  *                              (pass 0 through malio_measure_node, then one speculating pass per unit, the shards' rows
  *                              meeting in host memory between "sums seen" and "published"); 0: one pass at a time. Host
@@ -405,6 +409,7 @@ enum {
   MALIO_OPT_SCAN_SET_SYNC = 7,
   MALIO_OPT_NL_FULL_BLOCKS = 8,
   MALIO_OPT_NODE_GATED = 9,
+  MALIO_OPT_NL_SORTED = 10,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
   MALIO_OPT_DEBUG_GATE_STALL_MS = 101,
   MALIO_OPT_DEBUG_NODE_GATED_RUNS = 102,  /* read-only (malio_get_option): updates of this shard through the gated chain ... */
@@ -415,6 +420,9 @@ int malio_get_option(malio_handle_t h, int option, double *value);
 /* After a search pass: out4 = {points of the pass, points whose cached neighbours were kept (MALIO_OPT_SEARCH_SKIP),
  * points that walked the lists, 1 when the pass was allowed to skip at all}. */
 int malio_debug_skip_stats(malio_handle_t h, int *out4);
+/* The level-1 neighbour lists as the next search would find them: out4 = {lists, lists flagged as ordered (MALIO_OPT_NL_SORTED),
+ * flagged lists that are NOT in order (always 0), live entries}. Builds stale lists first. */
+int malio_debug_list_order(malio_handle_t h, long long *out4);
 
 /* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */
 /* Every entry point accepts ordinary (pageable) host memory, as the reference's std::vector / pcl clouds are. A copy

@@ -31,11 +31,11 @@ EXPORTS = [
     "malio_node_scan_set", "malio_node_measure", "malio_node_update_iterated", "malio_node_scan_get",
     "malio_node_set_pass_hook", "malio_node_exchange_stats", "malio_node_update_stats", "malio_part_owner", "malio_part_stores",
     "malio_set_update_mode", "malio_localize_weight", "malio_predict_chain",
-    "malio_set_option", "malio_get_option", "malio_debug_skip_stats", "malio_node_set_option",
+    "malio_set_option", "malio_get_option", "malio_debug_skip_stats", "malio_debug_list_order", "malio_node_set_option",
 ]
 # malio_set_option (include/malio.h)
 OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
-           nl_full_blocks=8, node_gated=9, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
+           nl_full_blocks=8, node_gated=9, nl_sorted=10, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
            debug_node_gated_redone=103)
 PART_SCAN, PART_TILES, PART_COLUMNS = 0, 1, 2  # (COLUMNS: tiles that are whole vertical columns, no halo above / below)
 TILE_CUBES, TILE_COLUMNS = 0, 1
@@ -248,6 +248,12 @@ class Engine:
         out = (C.c_int * 4)()
         self._chk(lib().malio_debug_skip_stats(self.h, out), "malio_debug_skip_stats")
         return dict(points=out[0], kept=out[1], walked=out[2], allowed=out[3])
+
+    def list_order(self):
+        """The level-1 neighbour lists as the next search finds them: lists, flagged ordered, flagged but NOT ordered, entries."""
+        out = (C.c_longlong * 4)()
+        self._chk(lib().malio_debug_list_order(self.h, out), "malio_debug_list_order")
+        return dict(lists=out[0], ordered=out[1], broken=out[2], entries=out[3])
 
     def last_kernel_times(self):
         names = (C.c_char_p * 16)()

@@ -154,7 +154,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -202,6 +202,10 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_nl_full_blocks = (int)value;  // takes effect at the next list build
       return MALIO_OK;
+    case MALIO_OPT_NL_SORTED:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_nl_sorted = (int)value;  // takes effect at the next list build
+      return MALIO_OK;
     case MALIO_OPT_NODE_GATED:
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_node_gated = (int)value;
@@ -232,6 +236,7 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_GATE_TIMEOUT_MS: *value = (double)c->gate_timeout_ticks * 1e-5; return MALIO_OK;
     case MALIO_OPT_SCAN_SET_SYNC: *value = c->scan_set_sync; return MALIO_OK;
     case MALIO_OPT_NL_FULL_BLOCKS: *value = c->opt_nl_full_blocks; return MALIO_OK;
+    case MALIO_OPT_NL_SORTED: *value = c->opt_nl_sorted; return MALIO_OK;
     case MALIO_OPT_NODE_GATED: *value = c->opt_node_gated; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
@@ -1528,6 +1533,18 @@ int malio_debug_skip_stats(malio_handle_t h, int *out4) {
     else if (nf[i] <= 5) out4[2]++;
   }
   return MALIO_OK;
+}
+
+// Diagnostics: the level-1 neighbour lists as the next search would find them - {lists, lists flagged "in order of distance from
+// the cell centre", flagged lists that are NOT, live entries}. out4[2] != 0 would be a bug (a search may end early in a flagged list).
+int malio_debug_list_order(malio_handle_t h, long long *out4) {
+  if (check(h) || !out4) return MALIO_ERR_BAD_ARG;
+  Ctx *c = h;
+  for (int k = 0; k < 4; k++) out4[k] = 0;
+  MALIO_HIP(hipSetDevice(c->device));
+  if (int rc = map_sync_search(c)) return rc;  // (lists that a change of the map left stale are built first; queued maintenance is waited for)
+  if (!c->nl1.table) return MALIO_OK;
+  return nl_check_order(c, c->nl1, out4);
 }
 
 int malio_set_pass_hook(malio_handle_t h, void (*fn)(int, void *), void *user) {

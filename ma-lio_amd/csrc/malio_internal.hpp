@@ -39,6 +39,12 @@ struct CellGrid {
 // its 3x3x3 block, the points of that block stored CONTIGUOUSLY (each map point is replicated 27 times -
 // 432 MB at 1M points: this is what the 288 GB of HBM are for). A query then needs ONE directory probe and one
 // streaming read of ~20 points instead of 27 probes and 9 scattered runs.
+// Level-1 lists are kept SORTED by the distance of their entries from the centre of the list's cell (round 5, map_hash.hip:
+// k_nl_sort): a query that has seen the first 32 entries knows a lower bound on the distance of everything behind them and
+// mostly need not read on (measure.hip: nl_walk, EARLY). The top bit of Cell::count says "this list is sorted"; every reader of a
+// neighbour list's count masks it. (The voxel grids' Cells never carry it.)
+constexpr u32 NL_SORTED = 0x80000000u, NL_COUNT = 0x7FFFFFFFu;
+constexpr u32 NL_SORT_MAX = 256;    // longer lists stay unsorted (and are walked whole): one wave sorts a list in registers
 constexpr size_t NL_GUARD = 1024;  // entries allocated behind NList::pts[cap_pts): a walk's last round may read (never use) them
 struct NList {
   Cell *table = nullptr;  // fine cell -> (start, count) of its neighbourhood list
@@ -47,12 +53,14 @@ struct NList {
   float4 *pts = nullptr;  // [cap_pts] x, y, z, bits(map index); a deleted point's entries carry x = +inf
   u32 *cap = nullptr;     // [table size] capacity of every list (count + slack): room for incremental inserts
   u32 *inc = nullptr;     // [table size] entries the batch being applied brings to each list (zero between batches)
-  u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells
+  u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells, [3] lists on `work`
+  u32 *work = nullptr;    // [table size] (sorted level only) directory slots of the lists the batch being applied appends to
   size_t total = 0;       // entries reserved by the lists built last (capacities)
   size_t entries = 0;     // live entries at build time (27 per point for whole blocks; ~20.6 when pruned)
   size_t cap_pts = 0, cap_table = 0;
   float cf = 0.75f, inv_cf = 1.f / 0.75f;
   bool pruned = false;    // lists hold the points within one cell edge of the cell instead of the whole 3x3x3 block
+  bool sorted = false;    // lists are kept sorted by distance from the cell centre (NL_SORTED)
 };
 
 // scratch of build_nlist (open-addressing directory under construction), kept between rebuilds
@@ -67,9 +75,10 @@ struct NlDev {
   Cell *table;
   u32 tmask;
   float4 *pts;
-  u32 *cap, *inc, *state;
+  u32 *cap, *inc, *state, *work;
   u32 bump_end;
-  float inv_cf;
+  float inv_cf, cf;
+  int sorted;
   int pruned;  // level 1: a list holds only the block's points within one cell edge of its cell (nl_member)
 };
 
@@ -491,6 +500,7 @@ struct Ctx {
   int opt_search_skip = 0;     // MALIO_OPT_SEARCH_SKIP (off: measured at +1 us per search pass for the few points it keeps)
   int opt_gate_pinned = 0;     // MALIO_OPT_GATE_PINNED
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
+  int opt_nl_sorted = 1;       // MALIO_OPT_NL_SORTED
   int opt_node_gated = 1;      // MALIO_OPT_NODE_GATED: a shard's update runs the gated chain (host exchanges only)
   int node_gated_runs = 0;     // updates of a shard that went through the gated chain
   int node_gated_redone = 0;   // updates the gated chain of a shard handed back to the per-pass loop
@@ -563,8 +573,9 @@ int exclusive_scan_u32(Ctx *c, const u32 *d_in, u32 *d_out, u32 *d_tiles, int n,
 int exclusive_scan_u32_pair(Ctx *c, const u32 *inA, u32 *outA, u32 *tilesA, u32 *totalA, const u32 *inB, u32 *outB,
                             u32 *tilesB, u32 *totalB, int n);  // two scans of one length in one pair of launches
 void free_grid(CellGrid &g);
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false);
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned = false, bool sorted = false);
 void free_nlist(NList &nl);
+int nl_check_order(Ctx *c, NList &nl, long long out4[4]);  // diagnostics: lists, flagged sorted, flagged but out of order, live entries
 // incremental maintenance of one level (kernels in map_hash.hip); overflow is reported through nl.state[1]
 // the map array's share of a batch, done by a third slice of k_nl_ensure's grid: dlist[ndel] die, kept new points go to dst[rank]
 struct MapSide {

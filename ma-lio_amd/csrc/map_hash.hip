@@ -465,6 +465,7 @@ void free_nlist(NList &nl) {
   if (nl.pts) (void)hipFree(nl.pts);
   if (nl.cap) (void)hipFree(nl.cap);
   if (nl.inc) (void)hipFree(nl.inc);
+  if (nl.work) (void)hipFree(nl.work);
   if (nl.state) (void)hipFree(nl.state);
   nl = NList();
 }
@@ -502,9 +503,92 @@ __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys
   cap[d] = capv[s];
 }
 
-int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned) {
+
+// ---- level-1 lists sorted by distance from the cell centre (round 5) -------------------------------------------------
+// What a search pass is short of is outstanding L1 misses per CU (profiles/round5/r05n_tcp_counters.txt): every 128-byte line
+// of a list a query reads is one. A list in ARBITRARY order must be read whole. In order of distance from the centre of its
+// cell, a query that has read the first 32 entries knows that everything behind them lies at least as far from the centre
+// as the farthest one it has seen, r - and so at least r - |query - centre| from the query (triangle inequality); if the
+// fifth distance so far is smaller, the rest cannot change the result (measure.hip: nl_walk<.., EARLY>; 96 % of the queries
+// of BASELINE config 2 stop there: 4.1 lines of list per query instead of 6.2).
+// One wave sorts one list in registers: up to four entries per lane, every entry's final position = the number of entries
+// that sort before it under (distance, position) - n shuffles, no scratch, in place (every lane holds its entries before
+// any lane stores). Tombstones (x = +inf: their distance is +inf) go to the end. Lists above NL_SORT_MAX entries are left
+// as they are, unflagged. work == nullptr: every list of the directory (after a build); else the lists work[0 .. *nwork)
+// (the ones a batch appended to: k_nl_place).
+__device__ __forceinline__ float nl_centre_d2(const float4 &e, float cx, float cy, float cz) {
+  const float dx = e.x - cx, dy = e.y - cy, dz = e.z - cz;
+  return dx * dx + dy * dy + dz * dz;  // == measure.hip: nl_walk's r2 of the entries it has read
+}
+__global__ void __launch_bounds__(BLK) k_nl_sort(NlDev nl, const u32 *__restrict__ work, const u32 *__restrict__ nwork) {
+  const int lane = threadIdx.x & 63;
+  const u32 wave = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
+  const u32 nitems = work ? *nwork : nl.tmask + 1;
+  for (u32 base = wave * 64; base < nitems; base += nwaves * 64) {
+    // 64 candidates per wave and round: directory slots (most are empty) or entries of the work list
+    u32 s = 0, cnt = 0;
+    bool todo = false;
+    if (base + lane < nitems) {
+      s = work ? work[base + lane] : base + lane;
+      const Cell c = nl.table[s];
+      cnt = c.count & NL_COUNT;
+      todo = c.key != EMPTY_KEY && cnt > 1 && cnt <= NL_SORT_MAX;
+      if (c.key != EMPTY_KEY && cnt <= 1) nl.table[s].count = cnt | NL_SORTED;  // (nothing to order)
+    }
+    unsigned long long m = __ballot(todo);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const u32 slot = __shfl(s, src), n = __shfl(cnt, src);
+      const Cell c = nl.table[slot];
+      const u64 B = 1ull << 20;
+      const float cx = ((float)((int)(c.key & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+                  cy = ((float)((int)((c.key >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+                  cz = ((float)((int)((c.key >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
+      float4 *lst = nl.pts + (size_t)c.start;
+      constexpr int K = NL_SORT_MAX / 64;
+      float4 e[K];
+      float key[K];
+      u32 rank[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const u32 idx = (u32)lane + 64u * k;
+        key[k] = INFINITY, rank[k] = 0;
+        if (idx < n) {
+          e[k] = lst[idx];
+          key[k] = nl_centre_d2(e[k], cx, cy, cz);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < K; kk++) {
+        if (64u * kk >= n) break;  // (wave-uniform)
+        const u32 lim = min(64u, n - 64u * kk);
+        for (u32 jj = 0; jj < lim; jj++) {
+          const float kj = __shfl(key[kk], (int)jj);
+          const u32 j = 64u * kk + jj;
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            const u32 idx = (u32)lane + 64u * k;
+            rank[k] += (kj < key[k] || (kj == key[k] && j < idx)) ? 1u : 0u;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const u32 idx = (u32)lane + 64u * k;
+        if (idx < n) lst[rank[k]] = e[k];
+      }
+      if (lane == 0) nl.table[slot].count = n | NL_SORTED;
+    }
+  }
+}
+
+NlDev nl_dev(const NList &nl);
+
+int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pruned, bool sorted) {
   nl.cf = cf;
   nl.pruned = pruned;
+  nl.sorted = sorted;
   nl.inv_cf = 1.0f / nl.cf;
   // scratch table: halo cells are a few times the occupied ones; 8 slots per point keeps the load low
   u32 tbig = next_pow2((u32)std::max(4096, 8 * n));
@@ -558,7 +642,10 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
   hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(BLK), 0, c->stream, d_in, n, nl.inv_cf, keys, start, cnt, tbig - 1,
                      nl.pts, pruned ? 1 : 0);
   // compact directory (the fill cursors now equal the list lengths); sized for growth to load 0.7
-  u32 tsize = next_pow2(std::max(1024u, 3u * h_cnt[0]));
+#ifndef NL_DIR_X
+#define NL_DIR_X 3u
+#endif
+  u32 tsize = next_pow2(std::max(1024u, NL_DIR_X * h_cnt[0]));
   if ((size_t)tsize > nl.cap_table || !nl.table) {
     if (nl.table) (void)hipFree(nl.table);
     if (nl.cap) (void)hipFree(nl.cap);
@@ -568,7 +655,10 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
     MALIO_HIP(hipMalloc(&nl.cap, sizeof(u32) * nl.cap_table));
     if (nl.inc) (void)hipFree(nl.inc);
     MALIO_HIP(hipMalloc(&nl.inc, sizeof(u32) * nl.cap_table));
+    if (nl.work) (void)hipFree(nl.work);
+    nl.work = nullptr;
   }
+  if (sorted && !nl.work) MALIO_HIP(hipMalloc(&nl.work, sizeof(u32) * nl.cap_table));
   if (!nl.state) MALIO_HIP(hipMalloc(&nl.state, sizeof(u32) * 4));
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
   MALIO_HIP(hipMemsetAsync(nl.cap, 0, sizeof(u32) * tsize, c->stream));
@@ -577,8 +667,11 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
                      nl.table, nl.cap, tsize - 1);
   const u32 h_state[4] = {(u32)used, 0u, h_cnt[0], 0u};  // bump cursor, overflow flag, cells, -
   MALIO_HIP(hipMemcpyAsync(nl.state, h_state, sizeof(h_state), hipMemcpyHostToDevice, c->stream));
-  MALIO_HIP(hipStreamSynchronize(c->stream));
   nl.tmask = tsize - 1, nl.ncells = h_cnt[0], nl.total = used, nl.entries = (size_t)27 * (size_t)n;
+  if (sorted)
+    hipLaunchKernelGGL(k_nl_sort, dim3(std::min<u32>(8192u, (tsize + BLK - 1) / BLK)), dim3(BLK), 0, c->stream, nl_dev(nl),
+                       (const u32 *)nullptr, (const u32 *)nullptr);
+  MALIO_HIP(hipStreamSynchronize(c->stream));
   MALIO_HIP(hipGetLastError());
   return MALIO_OK;
 }
@@ -605,6 +698,7 @@ __global__ void __launch_bounds__(BLK) k_nl_ensure(const float4 *__restrict__ ne
   const NlDev nl = blockIdx.y ? nl_b : nl_a;
   // 32 lanes per point, one of its 27 cells each
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (t == 0) nl.state[3] = 0;  // the batch's work list of touched lists (k_nl_place fills it, k_nl_sort consumes it) starts empty
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
   if (i >= m || cidx >= 27 || !keep[i]) return;
   float4 p = newp[i];
@@ -676,7 +770,8 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
   if (live) {
     const u32 need = atomicExch(&nl.inc[s], 0u);
     if (need != 0) {
-      cnt = nl.table[s].count;
+      cnt = nl.table[s].count & NL_COUNT;
+      if (nl.sorted) nl.work[atomicAdd(&nl.state[3], 1u)] = s;  // exactly one lane per touched list is here: k_nl_sort puts it in order again
       if (cnt + need > nl.cap[s]) {
         // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
         // old storage is reclaimed by the next full rebuild
@@ -732,6 +827,7 @@ __global__ void __launch_bounds__(BLK) k_nl_append(const float4 *__restrict__ ne
     s = (s + 1) & nl.tmask;
   }
   u32 pos = atomicAdd(&nl.table[s].count, 1u);
+  if (pos & NL_SORTED) atomicAnd(&nl.table[s].count, NL_COUNT), pos &= NL_COUNT;  // no longer in order (k_nl_sort follows)
   if (pos >= nl.cap[s]) {  // list full: undo, the host rebuilds the lists from the map array
     atomicSub(&nl.table[s].count, 1u);
     atomicExch(&nl.state[1], 1u);
@@ -767,7 +863,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
     if (k == EMPTY_KEY) return;  // cannot happen for a point that was inserted
     s = (s + 1) & nl.tmask;
   }
-  const u32 st = nl.table[s].start, cn = nl.table[s].count;
+  const u32 st = nl.table[s].start, cn = nl.table[s].count & NL_COUNT;
   const int gsh = (threadIdx.x & 63) & ~(int)(lanes - 1);  // first lane of this group inside the wave
   const unsigned long long gmask = lanes == 64 ? ~0ull : 0xFFFFull;
   for (u32 j = (u32)sub; j < cn; j += lanes * 4) {  // 4 independent loads in flight per lane
@@ -785,9 +881,49 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
 
 NlDev nl_dev(const NList &nl) {
   NlDev v;
-  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state;
-  v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.pruned = nl.pruned ? 1 : 0;
+  v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state, v.work = nl.work;
+  v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.cf = nl.cf, v.pruned = nl.pruned ? 1 : 0, v.sorted = nl.sorted ? 1 : 0;
   return v;
+}
+
+
+// diagnostics (malio_debug_list_order): one thread per directory slot - out[0] lists, [1] lists flagged NL_SORTED, [2] flagged
+// lists whose live entries are NOT in order of distance from the cell centre, [3] live entries
+__global__ void __launch_bounds__(BLK) k_nl_check(NlDev nl, unsigned long long *out) {
+  const u32 s = blockIdx.x * BLK + threadIdx.x;
+  if (s > nl.tmask) return;
+  const Cell c = nl.table[s];
+  if (c.key == EMPTY_KEY) return;
+  const u32 n = c.count & NL_COUNT;
+  const u64 B = 1ull << 20;
+  const float cx = ((float)((int)(c.key & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cy = ((float)((int)((c.key >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cz = ((float)((int)((c.key >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
+  float last = 0.f;
+  u32 live = 0;
+  bool bad = false;
+  for (u32 j = 0; j < n; j++) {
+    const float d = nl_centre_d2(nl.pts[(size_t)c.start + j], cx, cy, cz);
+    if (!(d < INFINITY)) continue;  // a tombstone
+    live++;
+    if (d < last) bad = true;
+    last = d;
+  }
+  atomicAdd(&out[0], 1ull);
+  if (c.count & NL_SORTED) atomicAdd(&out[1], 1ull);
+  if ((c.count & NL_SORTED) && bad) atomicAdd(&out[2], 1ull);
+  atomicAdd(&out[3], (unsigned long long)live);
+}
+int nl_check_order(Ctx *c, NList &nl, long long out4[4]) {
+  unsigned long long *d = nullptr;
+  MALIO_HIP(hipMalloc(&d, sizeof(unsigned long long) * 4));
+  MALIO_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * 4, c->stream));
+  hipLaunchKernelGGL(k_nl_check, dim3((nl.tmask + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl_dev(nl), d);
+  hipError_t e = hipMemcpyAsync(out4, d, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  MALIO_HIP(e);
+  return MALIO_OK;
 }
 
 void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_new, const u32 *keep, int m,
@@ -803,6 +939,14 @@ void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
   const long long th = (long long)m * 32;
   hipLaunchKernelGGL(k_nl_append, dim3((unsigned)((th + BLK - 1) / BLK), 2), dim3(BLK), 0, st, d_new, keep, rank,
                      og_base, m, nl_dev(nl_a), nl_dev(nl_b));
+  // the lists of the sorted level this batch appended to, in order again (one wave per list; the work list's length is on the
+  // device: a grid that covers a typical batch in one round, the rest by striding)
+  if (nl_a.sorted) {
+    const NlDev a = nl_dev(nl_a);
+    const long long lists = std::min<long long>((long long)m * 27, (long long)nl_a.tmask + 1);
+    hipLaunchKernelGGL(k_nl_sort, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (lists * 64 + BLK - 1) / BLK))),
+                       dim3(BLK), 0, st, a, (const u32 *)a.work, (const u32 *)(a.state + 3));
+  }
 }
 void nl_tombstone(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d_map, const u32 *dlist, int ndel) {
   const long long th = (long long)ndel * 27 * 64;  // (level 2's need; the level-1 half of the grid leaves early)

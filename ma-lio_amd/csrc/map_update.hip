@@ -33,7 +33,7 @@ __device__ __forceinline__ bool vox_find(const Cell *__restrict__ table, u32 tma
   while (true) {
     Cell e = table[s];
     if (e.key == key) {
-      start = e.start, count = e.count;
+      start = e.start, count = e.count & NL_COUNT;  // (a level-1 neighbour list's count carries NL_SORTED)
       return true;
     }
     if (e.key == EMPTY_KEY) return false;
@@ -563,7 +563,7 @@ int map_rebuild_search(Ctx *c) {
   // level 1 pruned to the points within one cell edge of each cell (nl_member) unless the map's voxel filter is so
   // coarse that k_vox_add needs the whole block (a voxel's half diagonal must stay inside the kept reach)
   const bool prune1 = !c->opt_nl_full_blocks /* MALIO_OPT_NL_FULL_BLOCKS */ && (float)c->prm.filter_size_map * 0.8660254f <= 0.95f * NL_REACH * c->cell;
-  int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1);
+  int rc = build_nlist(c, c->d_map_in, c->map_n, c->cell, c->nl1, prune1, c->opt_nl_sorted != 0 /* MALIO_OPT_NL_SORTED */);
   if (rc == MALIO_OK) rc = build_nlist(c, c->d_map_in, c->map_n, std::max(2.0f * c->cell, 2.25f), c->nl2);
   return rc;
 }

@@ -28,7 +28,7 @@ __device__ long long g_phase[4][16];
   } while (0)
 // grid-wide spread of one kernel: entry and exit time of every workgroup (plain stores: same-address atomics from
 // 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
-__device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pending level-2 queries
+__device__ long long g_span[12][8192];  // entry, exit, end of level-1 search, pending level-2 queries; 4-7: each wave's own end of the level-1 search, 8-11: ... of its directory probe
 // the helper wave's stamps (KS_SPLIT): its lane 0 is thread 64
 #define PHH(kid, k)                                                                     \
   do {                                                                                  \
@@ -42,6 +42,10 @@ __device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pe
   do {                                                                                \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[row][blockIdx.x] = (val);       \
   } while (0)
+#define PH_WAVE(row0)                                                                  \
+  do {                                                                                 \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) g_span[(row0) + (threadIdx.x >> 6)][blockIdx.x] = wall_clock64(); \
+  } while (0)
 #define PH_EXIT()                                                                     \
   do {                                                                                \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[1][blockIdx.x] = wall_clock64(); \
@@ -51,6 +55,7 @@ __device__ long long g_span[4][8192];  // entry, exit, end of level-1 search, pe
 #define PHH(kid, k)
 #define PH_ENTER()
 #define PH_NOTE(row, val)
+#define PH_WAVE(row0)
 #define PH_EXIT()
 #endif
 
@@ -614,6 +619,9 @@ __device__ __forceinline__ void block_minmax(const Pass1Args &a, const PassDyn &
 #endif
 constexpr int NL1_G = KS_G;  // lanes per query on the level-1 lists (~45 candidates, 8 loads in flight per lane)
 constexpr unsigned char NF_PENDING = 0xFF;
+#ifndef KS_EARLY
+#define KS_EARLY 1
+#endif
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
 #ifndef KS_L2G
 #define KS_L2G 4
@@ -666,19 +674,53 @@ __device__ __forceinline__ void nl_probe(const NlView &nl, float wx, float wy, f
   const u32 slot = hash_key_d(key) & nl.tmask;
   cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
 #ifdef ATTR_WALK5
-  count = min(count, 5u);
+  count = min(count & NL_COUNT, 5u);
 #endif
 }
 // the walk of a list whose (start, count) are known
-template <int G, bool CERT, bool PIPE>
+// count: as the directory holds it (NL_SORTED in its top bit).
+// EARLY (level 1, round 5): a list flagged NL_SORTED is in order of distance from the centre of its cell (map_hash.hip:
+// k_nl_sort). Its first batch - 8 G entries: four 128-byte lines - is read as ever; everything behind it lies at least as
+// far from the centre as the farthest entry of the batch, r, hence at least r - |query - centre| from the query. If the fifth
+// distance so far is below that, no unread entry can enter the five (nor tie with one: the margins below dwarf the float
+// rounding of all three distances, 3e-7 relative) and the walk ends: the lines that are never requested are what the search
+// pass is short of (outstanding L1 misses per CU). Otherwise (2.5 % of the queries at BASELINE config 2: the ones near a corner
+// of their cell) the same lanes read the rest of the list on top of what they have.
+template <int G, bool CERT, bool PIPE, bool EARLY = false>
 __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, float wz, int sub, float limit2, u32 start, u32 count,
                                         Top5 &t, float &lb2) {
+  const bool in_order = (count & NL_SORTED) != 0;
+  count &= NL_COUNT;
+  const bool cut = EARLY && in_order && count > (u32)(8 * G);  // (the G lanes of a query agree)
+  const u32 cn = cut ? (u32)(8 * G) : count;                   // entries this walk reads
+  float r2 = 0.f;  // cut: squared distance from the cell centre of this lane's LAST entry of the batch (0: a tombstone)
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
   for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
   u32 ev = (u32)(TOP5_MAXKEY >> 32);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
+  auto batch = [&](u32 j) {  // 8 entries of this lane, the first one at j
+    float4 m[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
+    if (EARLY) {  // (a cut list is longer than the batch: entry sub + 7 G exists; a tombstone's x is +inf)
+      const float cdx = m[7].x - (kxf + 0.5f) * nl.cf, cdy = m[7].y - (kyf + 0.5f) * nl.cf, cdz = m[7].z - (kzf + 0.5f) * nl.cf;
+      const float c2 = cdx * cdx + cdy * cdy + cdz * cdz;  // == map_hash.hip: nl_centre_d2
+      r2 = c2 < INFINITY ? c2 : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
+      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
+      // A slot past the end of the list (its load was clamped to the last entry) gets the largest key and sorts after
+      // everything. CERT: the range test (d2 <= limit2) is applied to the five survivors below, not per candidate; else
+      // d2 <= limit2 <=> key < the sentinel keys the list starts with: no range test at all.
+      const u64 key = top5_key(d2, __float_as_uint(m[u].w));
+      const u32 out = top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
+      if (CERT) ev = min(ev, out);
+    }
+  };
   // (the SKIP kernels' walk - CERT: the certificate's bookkeeping rides on every insertion - stays the two-batch loop: with
   // it the pipelined form spills 200 VGPRs; the option is off by default)
   if constexpr (PIPE && !CERT) {
@@ -738,24 +780,28 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
   // SLOWER there (a round's insertions, ~1 us for the SIMD's seven waves, do not cover a ~2 us round trip; rounds of 2 / 3 / 4
   // loads: 30.7 / 30.9 / 43 us - the last one spills - against 29.8 us), and touching the second batch's lines while the
   // first is in flight (an L2 prefetch by 4-byte loads) changed nothing (profiles/round5/r05d_walk_variants.txt).
-  for (u32 j = (u32)sub; j < count; j += 8 * G) {
-    float4 m[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
-      float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
-      // A slot past the end of the list (its load was clamped to the last entry) gets the largest key and sorts after
-      // everything. CERT: the range test (d2 <= limit2) is applied to the five survivors below, not per candidate; else
-      // d2 <= limit2 <=> key < the sentinel keys the list starts with: no range test at all.
-      const u64 key = top5_key(d2, __float_as_uint(m[u].w));
-      const u32 out = top5_insert(t, j + (u32)(u * G) < count ? key : TOP5_MAXKEY);
-      if (CERT) ev = min(ev, out);
-    }
-  }
+  for (u32 j = (u32)sub; j < cn; j += 8 * G) batch(j);
   }
   if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+  if (EARLY && cut) {
+#pragma unroll
+    for (int sft = G / 2; sft > 0; sft >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, sft));  // (any entry that was read bounds the unread ones)
+    const float qx = wx - (kxf + 0.5f) * nl.cf, qy = wy - (kyf + 0.5f) * nl.cf, qz = wz - (kzf + 0.5f) * nl.cf;
+    const float lo = sqrtf(r2) * 0.9999f - sqrtf(qx * qx + qy * qy + qz * qz) * 1.0001f - 1e-6f;
+    const float b2 = lo * lo * 0.9999f;  // every unread entry is farther than this (squared)
+    if (lo > 0.f && t.og(4) != INVALID && t.d(4) < b2) {
+      if (CERT) ev = min(ev, __float_as_uint(b2));  // the unread entries are outsiders as well
+    } else {
+      // not settled (2.5 % of the queries of BASELINE config 2: the ones near a corner of their cell): the rest of the list, on
+      // top of what the group has - the merged five stay in the group's first lane, the others start empty again
+      if (sub != 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
+      }
+      for (u32 j = (u32)(8 * G + sub); j < count; j += 8 * G) batch(j);
+      if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+    }
+  }
   // CERT: survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count
   // as outsiders for the bound (the list is sorted: they form its tail)
   if (CERT) {
@@ -781,12 +827,12 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
 // second dependent slot, 56 % a third - costs k_pass +1.4 us at config 2: twice the probe's requests outweigh the saved trips;
 // and the level-1 probe moved into phase A with the queries handed to phase B sorted by the number of batches they need
 // (a wave walks as many batches as its longest list: 2.8 where a query alone needs 1.9): -25 % candidate slots, +0.5 us.)
-template <int G, bool CERT, bool PIPE>
+template <int G, bool CERT, bool PIPE, bool EARLY = false>
 __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, float wz, int sub, float limit2,
                                           Top5 &t, float &lb2) {
   u32 start, count;
   nl_probe(nl, wx, wy, wz, start, count);
-  return nl_walk<G, CERT, PIPE>(nl, wx, wy, wz, sub, limit2, start, count, t, lb2);
+  return nl_walk<G, CERT, PIPE, EARLY>(nl, wx, wy, wz, sub, limit2, start, count, t, lb2);
 }
 // lb2 -> the certificate's radius: a lower bound on the TRUE distance of every outsider (computed squared distances are
 // within 3e-7 relative of the true ones; sqrtf is correctly rounded)
@@ -1138,7 +1184,16 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       const float4 ww = S.w[ql];
       Top5 t;
       float lb2;
-      const bool certified = nl_search<NL1_G, SKIP, false>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
+#ifdef MALIO_PHASE_CLOCK
+      u32 st_, cn_;
+      nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
+      asm volatile("" ::"v"(st_), "v"(cn_));
+      PH_WAVE(8);
+      const bool certified = nl_walk<NL1_G, SKIP, false, KS_EARLY != 0>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, st_, cn_, t, lb2);
+      PH_WAVE(4);
+#else
+      const bool certified = nl_search<NL1_G, SKIP, false, KS_EARLY != 0>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
+#endif
       if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) S.og[k][ql] = t.og(k);
@@ -1607,9 +1662,9 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
 extern "C" int malio_debug_phase(long long *out64) {
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
 }
-extern "C" int malio_debug_span(long long *out, int n) {  // [4][n]: rows of g_span for workgroups 0..n-1
+extern "C" int malio_debug_span(long long *out, int n) {  // [12][n]: rows of g_span for workgroups 0..n-1
   if (n > 8192) return -1;
-  for (int r = 0; r < 4; r++)
+  for (int r = 0; r < 12; r++)
     if (hipMemcpyFromSymbol(out + (size_t)r * n, HIP_SYMBOL(g_span), sizeof(long long) * n, sizeof(long long) * 8192 * r) != hipSuccess)
       return -1;
   return 0;
@@ -1882,7 +1937,15 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
       // ... and in REVERSE scan order: the launch hands out ~1 600 workgroups over ~1 us, lowest id first, and the workgroups
       // that finish last are those of the sparser LiDARs at the END of the scan (fewer queries share a cell: more distinct
       // lines to fetch per workgroup, profiles/round5/r05h) - they now enter first.
+#ifndef KS_NO_TAIL_LIGHT
+      // The ids past the last whole block of 128 are handed out LAST and land as a SEVENTH workgroup on CUs that hold six (1 564
+      // workgroups over 256 CUs at BASELINE config 2): these were the kernel's last workgroups to leave - by 2 us, whatever the
+      // rest gained (profiles/round5/r05p_*). They take the scan's FIRST tiles (the densest LiDAR: the lightest), everything
+      // else moves up.
+      tile = b < full ? (int)gridDim.x - 1 - tile : b - full;
+#else
       if (b < full) tile = full - 1 - tile;
+#endif
 #endif
     }
 #endif
@@ -2168,6 +2231,7 @@ __global__ void __launch_bounds__(BLK) k_far_nearest(int N, const float4 *__rest
           u64 key = cell_key_d(cx + 3 * a, cy + 3 * b, cz + 3 * c);
           u32 slot = hash_key_d(key) & nl.tmask;
           cell_lookup(nl.table, nl.tmask, key, nl.table[slot], slot, start, count);
+          count &= NL_COUNT;
         }
       }
       unsigned long long m = __ballot(count > 0);

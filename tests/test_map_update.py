@@ -288,6 +288,10 @@ def test_gpu_in_place_list_updates_equal_a_full_rebuild(orc, capi, scenes):
         _, d2_new, cnt_new = fresh.nearest_search(q, 5)
         np.testing.assert_array_equal(d2_inc, d2_new)
         np.testing.assert_array_equal(cnt_inc, cnt_new)
+        # the level-1 lists a batch appended to are put back in order of distance from their cell's centre (k_nl_sort):
+        # a search may end early in every list that says so
+        lo = eng.list_order()
+        assert lo["broken"] == 0 and lo["ordered"] >= 0.999 * lo["lists"], lo
     after = eng.debug_counters()
     assert after["rebuilds"] == before["rebuilds"], "the changes were meant to fit in place"
     assert after["inplace"] >= before["inplace"] + 12 and after["tombstones"] > 0
@@ -310,3 +314,41 @@ def test_gpu_in_place_list_updates_equal_a_full_rebuild(orc, capi, scenes):
     _, d2_new, _ = fresh.nearest_search(q, 5)
     np.testing.assert_array_equal(d2_inc, d2_new)
     assert eng.debug_counters()["rebuilds"] > after["rebuilds"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [1, 3, 5])
+def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scenes, cfg):
+    """MALIO_OPT_NL_SORTED (default on): the level-1 lists in order of distance from the cell centre let a walk end after
+    its first 32 entries when those prove the rest irrelevant. Same five neighbours, same order, same bits as the whole
+    walk over unordered lists (rounds 2-4) - through a search pass, an iterated update and a map that changed in place."""
+    sc = scenes.make_scene(cfg=cfg)
+    res = []
+    for srt in (1, 0):
+        eng = capi.Engine(sc["params"])
+        eng.set_option("nl_sorted", srt)
+        eng.map_build(sc["map"])
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        lo = eng.list_order()
+        assert lo["broken"] == 0
+        assert (lo["ordered"] >= 0.999 * lo["lists"]) if srt else (lo["ordered"] == 0), lo
+        m = eng.measure(sc["state0"], True)
+        sg = eng.scan_get()
+        u = eng.update_iterated(sc["state0"], sc["P0"])
+        na, nn, ret = eng.map_incremental(u["state"], True, np.full(sc["N"], 0.001, np.float32))
+        lo2 = eng.list_order()
+        assert lo2["broken"] == 0 and ((lo2["ordered"] >= 0.999 * lo2["lists"]) if srt else (lo2["ordered"] == 0)), lo2
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        m2 = eng.measure(u["state"], True)
+        sg2 = eng.scan_get()
+        res.append((m, sg, u, (na, nn, ret), m2, sg2, lo["entries"], lo2["entries"]))
+    a, b = res
+    assert a[3] == b[3] and a[6] == b[6] and a[7] == b[7]
+    for k in (1, 5):
+        for f in ("selected", "nearest", "res_last", "normvec"):
+            if f in a[k]:
+                np.testing.assert_array_equal(a[k][f], b[k][f], err_msg=f)
+    assert a[0]["M"] == b[0]["M"] and a[4]["M"] == b[4]["M"]
+    np.testing.assert_array_equal(a[0]["HtRinvH"], b[0]["HtRinvH"])
+    np.testing.assert_array_equal(a[4]["HtRinvH"], b[4]["HtRinvH"])
+    np.testing.assert_array_equal(a[2]["state"], b[2]["state"])

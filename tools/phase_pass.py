@@ -32,9 +32,9 @@ if ph[3][0] > 0:
     for k, name in enumerate(hl):
         print("   %-34s %6.2f  %6.2f" % (name, (ph[3][k] - t0) / 100.0, (ph[3][k] - prev) / 100.0)); prev = ph[3][k]
 nb = (sc["N"] + 63) // 64 + 4
-sp = (C.c_longlong * (4 * nb))()
+sp = (C.c_longlong * (12 * nb))()
 assert capi.lib().malio_debug_span(sp, nb) == 0
-sp = np.array(sp[:], np.int64).reshape(4, nb)
+sp = np.array(sp[:], np.int64).reshape(12, nb)
 ok = sp[1] > sp[0]
 tz = sp[0][ok].min()
 ent, ex = (sp[0][ok] - tz) / 100.0, (sp[1][ok] - tz) / 100.0
@@ -50,4 +50,23 @@ late = b[ex > np.percentile(ex, 97)]
 print("the latest 3 %% of the workgroups: ids %s ...; XCD histogram %s" % (late[:16].tolist(), np.bincount(late % 8, minlength=8).tolist()))
 print("end of level-1 search by XCD: " + "  ".join("%d: %.1f/%.1f" % (k, np.median(tb[b % 8 == k]), np.percentile(tb[b % 8 == k], 95)) for k in range(8)))
 pend = sp[3][ok]
+print("pending queries per workgroup (level 2 + level 1 again): mean %.2f" % pend.mean())
 print("workgroups with level-2 queries: %d; exit median with / without: %.1f / %.1f us" % ((pend > 0).sum(), np.median(ex[pend > 0]) if (pend > 0).any() else float("nan"), np.median(ex[pend == 0])))
+
+# per wave: end of the directory probe / of the level-1 walk (us since the first workgroup's entry); the workgroup waits for its slowest wave
+pr = (sp[8:12][:, ok] - tz) / 100.0
+wk = (sp[4:8][:, ok] - tz) / 100.0
+en = ent
+print("directory probe (from entry): median of wave means %.2f; slowest wave of a workgroup: median %.2f p90 %.2f max %.2f" % (
+    np.median(pr.mean(0) - en), np.median(pr.max(0) - en), np.percentile(pr.max(0) - en, 90), (pr.max(0) - en).max()))
+d = wk - pr
+print("walk after the probe, per wave: median %.2f p90 %.2f max %.2f; slowest wave of a workgroup: median %.2f p90 %.2f max %.2f" % (
+    np.median(d), np.percentile(d, 90), d.max(), np.median(d.max(0)), np.percentile(d.max(0), 90), d.max(0).max()))
+print("spread inside a workgroup (slowest - fastest wave at the end of the walk): median %.2f p90 %.2f max %.2f" % (
+    np.median(wk.max(0) - wk.min(0)), np.percentile(wk.max(0) - wk.min(0), 90), (wk.max(0) - wk.min(0)).max()))
+lt = tb > np.percentile(tb, 95)
+print("the 5 %% of workgroups whose level-1 search ends last: probe (slowest wave) median %.2f, walk (slowest wave) median %.2f, spread median %.2f; the others: %.2f / %.2f / %.2f" % (
+    np.median((pr.max(0) - en)[lt]), np.median(d.max(0)[lt]), np.median((wk.max(0) - wk.min(0))[lt]),
+    np.median((pr.max(0) - en)[~lt]), np.median(d.max(0)[~lt]), np.median((wk.max(0) - wk.min(0))[~lt])))
+if os.environ.get("PHASE_DUMP"):
+    np.save(os.environ["PHASE_DUMP"], sp)
