@@ -429,6 +429,11 @@ def main():
     # neighbours a certificate proves unchanged - is OFF, which is also the library's default (it keeps too few points to
     # pay: `search_skip` and `eskf.update_ms_search_skip` below price it).
     eng.set_option("search_skip", 0)
+    # ... and EVERY point probes the directory: MALIO_OPT_PROBE_CACHE (the library's default: a search pass reuses the
+    # directory probe of the point's previous search pass while the point stays in its cell) is OFF for the headline, for
+    # `new_state`, `cold` and the roofline block - a step that repeats one state would otherwise never probe. `probe_cache`
+    # below prices it; the whole updates of `eskf` run with the library's defaults.
+    eng.set_option("probe_cache", 0)
     fast, fast_out = eng.measure_fn(state, True)  # ctypes call with pre-built structs: no Python in the loop
 
     def step():
@@ -478,6 +483,15 @@ def main():
     new_state = {"ms_per_step": dt_ns / args.steps * 1e3, "value": N / (dt_ns / args.steps),
                  "extrema_guess_hits": f1["hits"] - f0["hits"], "extrema_guess_misses": f1["misses"] - f0["misses"],
                  "note": "full search, 16 states within ~1 cm / 0.06 deg of each other in turn"}
+    # ---- ... with MALIO_OPT_PROBE_CACHE on (the library's default): the second search pass of an update ----
+    eng.set_option("probe_cache", 1)
+    for _ in range(32):
+        step_new_state()
+    dt_pc, _ = timed_blocks(step_new_state, args.steps, fence, False, dist, torch, min_total=200, min_blocks=3)
+    probe_cache = {"ms_per_step": dt_pc / args.steps * 1e3, "value": N / (dt_pc / args.steps),
+                   "note": "same 16 states, MALIO_OPT_PROBE_CACHE on: a point that is still in the cell of its last search pass "
+                           "reuses that pass' directory probe (the same list: bit-identical results)"}
+    eng.set_option("probe_cache", 0)
     # ---- ... and with MALIO_OPT_SEARCH_SKIP on: what the second search pass of an update costs ----
     eng.set_option("search_skip", 1)
     for _ in range(32):
@@ -518,6 +532,7 @@ def main():
     # update_ms is the update of a NEW scan, as a mapping loop gets it: the once-per-scan grouping and a first pass over
     # lists nobody touched are inside. update_ms_resident keeps both out (a malio_measure before the timed call - the
     # figure rounds 1-3 printed as update_ms); *_search_skip: MALIO_OPT_SEARCH_SKIP on.
+    eng.set_option("probe_cache", 1)  # (library defaults for the whole updates)
     upd, upd_result = eng.update_iterated_fn(state, sc["P0"])  # the C call with pre-built arguments
     scans = [scenes.make_scene(cfg=args.config, scan_seed=950 + k)["scan"] for k in range(4)]
 
@@ -558,11 +573,12 @@ def main():
                     "*_search_skip: MALIO_OPT_SEARCH_SKIP on, skip_fraction_last_search = points of the update's second "
                     "search pass that kept their cached neighbours"}
 
+    eng.set_option("probe_cache", 0)  # (the headline's pass)
     roofline = roofline_block(eng, state, args, N)
     # the same pass as three kernels (MALIO_OPT_FUSE = 0 handle), same process, same scan: what k_pass replaces
     try:
         e3 = capi.Engine(sc["params"], device=dev_index)
-        e3.set_option("fuse", 0).set_option("search_skip", 0)
+        e3.set_option("fuse", 0).set_option("search_skip", 0).set_option("probe_cache", 0)
         e3.set_stream(torch.cuda.current_stream().cuda_stream)
         e3.map_build(sc["map"])
         e3.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
@@ -589,12 +605,12 @@ def main():
         "value": value, "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "timed_blocks": blocks,
         "ms_per_step_minmax": [min(dts) / args.steps * 1e3, max(dts) / args.steps * 1e3],
-        "new_state": new_state, "search_skip": search_skip,
+        "new_state": new_state, "probe_cache": probe_cache, "search_skip": search_skip,
         "cold": cold, "higher_is_better": True, "scaling": None,  # one GPU: nothing scales on this line (--gpus N: "strong")
         "vs_baseline": None,
         "dtype": "f32 (5-NN, plane fit) + f64 (transform, Jacobian, normal equations)", "data": "synthetic",
         "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step" % (
-            cfg["name"], N, L, sc["Nmap"]), "step": "full search: MALIO_OPT_SEARCH_SKIP off", "points_per_gpu": N,
+            cfg["name"], N, L, sc["Nmap"]), "step": "full search: MALIO_OPT_SEARCH_SKIP off, MALIO_OPT_PROBE_CACHE off", "points_per_gpu": N,
             "map_points": sc["Nmap"], "lidars": L,
             "M_accepted": int(out.M), "seed": sc["seed"]},
         "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
@@ -726,6 +742,7 @@ def main_virtual_shards(args, torch, capi, scenes, dev_index):
     steps = max(50, min(args.steps, 200))
     one = capi.Engine(sc["params"], device=dev_index)
     one.set_option("search_skip", 0)  # every timed pass below is a FULL search (one state repeated)
+    one.set_option("probe_cache", 0)
     one.map_build(sc["map"])
     one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     ms1, k1, kn1, M1 = time_pass(one, steps)
@@ -740,6 +757,7 @@ def main_virtual_shards(args, torch, capi, scenes, dev_index):
             for r in range(G):
                 e = capi.Engine(sc["params"], device=dev_index)
                 e.set_option("search_skip", 0)
+                e.set_option("probe_cache", 0)
                 if part in ("tiles", "columns"):
                     e.set_partition(r, G, args.tile if part == "tiles" else args.column_tile, columns=part == "columns")
                     e.map_build(sc["map"])
@@ -780,6 +798,7 @@ def replicas_leg(args, torch, dist, capi, scenes, world, rank, dev_index, fence)
     sc2 = scenes.make_scene(cfg=2, scan_seed=None if rank == 0 else 700 + rank)
     e = capi.Engine(sc2["params"], device=dev_index)
     e.set_option("search_skip", 0)
+    e.set_option("probe_cache", 0)
     e.set_stream(torch.cuda.current_stream().cuda_stream)
     e.map_build(sc2["map"])
     e.scan_set(sc2["scan"], sc2["tables"], sc2["temporal_comp"])
@@ -857,6 +876,7 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
         if partition not in engines:
             e = capi.Engine(sc["params"], device=dev_index)
             e.set_option("search_skip", 0)  # the timed step repeats ONE state: a full search every time
+            e.set_option("probe_cache", 0)
             e.set_stream(torch.cuda.current_stream().cuda_stream)
             if partition in ("tiles", "columns"):
                 e.set_partition(rank, world, args.tile if partition == "tiles" else args.column_tile, columns=partition == "columns")
@@ -978,6 +998,7 @@ def main_sharded(args, torch, dist, capi, scenes, world, rank, dev_index, backen
     if rank == 0:  # the same job on ONE GPU (the strong-scaling baseline), outside everybody's timed regions
         e1 = capi.Engine(sc["params"], device=dev_index)
         e1.set_option("search_skip", 0)
+        e1.set_option("probe_cache", 0)
         e1.map_build(sc["map"])
         e1.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
         f1, _ = e1.measure_fn(state, True)

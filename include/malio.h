@@ -392,6 +392,9 @@ int malio_scan_order(malio_handle_t h, int mode);
  *                              query's walk ends after the first 32 entries when those prove the rest irrelevant (exact: the
  *                              same five neighbours); 0: unordered lists, walked whole (rounds 2-4). Takes effect at the
  *                              next list build.
+ *   MALIO_OPT_PROBE_CACHE      1 (default): a search pass remembers every point's level-1 directory probe (cell, list start and
+ *                              length); the next search pass of the same scan - the lists unchanged - reuses it for every point
+ *                              that is still in its cell (exact: the same list) instead of probing the directory again.
  *   MALIO_OPT_NODE_GATED       1 (default): malio_update_iterated_node / the node handle run the gated chain on every shard
  *                              (pass 0 through malio_measure_node, then one speculating pass per unit, the shards' rows
  *                              meeting in host memory between "sums seen" and "published"); 0: one pass at a time. Host
@@ -410,6 +413,7 @@ enum {
   MALIO_OPT_NL_FULL_BLOCKS = 8,
   MALIO_OPT_NODE_GATED = 9,
   MALIO_OPT_NL_SORTED = 10,
+  MALIO_OPT_PROBE_CACHE = 11,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
   MALIO_OPT_DEBUG_GATE_STALL_MS = 101,
   MALIO_OPT_DEBUG_NODE_GATED_RUNS = 102,  /* read-only (malio_get_option): updates of this shard through the gated chain ... */

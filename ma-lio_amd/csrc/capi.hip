@@ -154,7 +154,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_PROBE_CACHE", MALIO_OPT_PROBE_CACHE}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -206,6 +206,10 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_nl_sorted = (int)value;  // takes effect at the next list build
       return MALIO_OK;
+    case MALIO_OPT_PROBE_CACHE:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_probe_cache = (int)value;
+      return MALIO_OK;
     case MALIO_OPT_NODE_GATED:
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_node_gated = (int)value;
@@ -237,6 +241,7 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_SCAN_SET_SYNC: *value = c->scan_set_sync; return MALIO_OK;
     case MALIO_OPT_NL_FULL_BLOCKS: *value = c->opt_nl_full_blocks; return MALIO_OK;
     case MALIO_OPT_NL_SORTED: *value = c->opt_nl_sorted; return MALIO_OK;
+    case MALIO_OPT_PROBE_CACHE: *value = c->opt_probe_cache; return MALIO_OK;
     case MALIO_OPT_NODE_GATED: *value = c->opt_node_gated; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
@@ -285,7 +290,7 @@ int malio_destroy(malio_handle_t h) {
   free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
+  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept), fr(c->d_pcache);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt), fr(c->d_del);
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
@@ -626,6 +631,7 @@ static int scan_reset(Ctx *c) {
   c->node_guess_valid = false;  // malio_measure_node: a new scan starts with a plain (two-exchange) pass
   c->nbr_epoch = c->map_epoch;
   c->cert_valid = false;  // no search pass of this scan yet: nothing to keep (search_skip_begin)
+  c->probe_valid = false;
   c->scan_sorted = false;
   c->last_M = -1;
   c->mm_guess_valid = false;  // the first pass of a scan runs as three kernels and leaves the first guess

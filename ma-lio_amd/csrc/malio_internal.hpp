@@ -476,6 +476,8 @@ struct Ctx {
   float *d_world = nullptr;    // [3][N]
   float4 *d_world4 = nullptr;  // [N] world point of the search pass (phase A of the search; k_far_nearest)
   float *d_ny = nullptr;       // [N] normal_y state (see commit_normal_y)
+  uint4 *d_pcache = nullptr;   // [N] probe cache: cell key, start, count of the point's last level-1 directory probe (measure.hip, phase B)
+  bool probe_valid = false;    // a search pass of this scan has filled d_pcache (search_skip_begin)
   float4 *d_cert = nullptr;    // [N] search-skip certificate (world point of the last list walk, radius free of outsiders)
   unsigned char *d_kept = nullptr;  // [N] the last search pass kept the point's cached neighbours
   bool cert_valid = false;     // a search pass of this scan has been queued: its certificates exist in stream order
@@ -501,6 +503,7 @@ struct Ctx {
   int opt_gate_pinned = 0;     // MALIO_OPT_GATE_PINNED
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
   int opt_nl_sorted = 1;       // MALIO_OPT_NL_SORTED
+  int opt_probe_cache = 1;     // MALIO_OPT_PROBE_CACHE
   int opt_node_gated = 1;      // MALIO_OPT_NODE_GATED: a shard's update runs the gated chain (host exchanges only)
   int node_gated_runs = 0;     // updates of a shard that went through the gated chain
   int node_gated_redone = 0;   // updates the gated chain of a shard handed back to the per-pass loop

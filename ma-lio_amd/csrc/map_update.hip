@@ -535,6 +535,7 @@ int map_rebuild_search(Ctx *c) {
   if (int rcj = maint_join(c)) return rcj;
   if (int rc = map_apply_finish(c)) return rc;
   c->search_dirty = false;
+  c->probe_valid = false;  // (the lists move: no cached directory probe survives a rebuild)
   if (c->map_dead > 0 && c->map_n > 0) {
     ArenaScope sc(c->arena);
     u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr;

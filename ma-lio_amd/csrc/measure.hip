@@ -28,7 +28,8 @@ __device__ long long g_phase[4][16];
   } while (0)
 // grid-wide spread of one kernel: entry and exit time of every workgroup (plain stores: same-address atomics from
 // 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
-__device__ long long g_span[12][8192];  // entry, exit, end of level-1 search, pending level-2 queries; 4-7: each wave's own end of the level-1 search, 8-11: ... of its directory probe
+__device__ long long g_span[14][8192];  // 12: HW_ID, 13: XCC_ID of the workgroup's first wave
+//  // entry, exit, end of level-1 search, pending level-2 queries; 4-7: each wave's own end of the level-1 search, 8-11: ... of its directory probe
 // the helper wave's stamps (KS_SPLIT): its lane 0 is thread 64
 #define PHH(kid, k)                                                                     \
   do {                                                                                  \
@@ -36,7 +37,11 @@ __device__ long long g_span[12][8192];  // entry, exit, end of level-1 search, p
   } while (0)
 #define PH_ENTER()                                                                    \
   do {                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_span[0][blockIdx.x] = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                       \
+      g_span[0][blockIdx.x] = wall_clock64();                                          \
+      g_span[12][blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);              \
+      g_span[13][blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20);             \
+    }                                                                                  \
   } while (0)
 #define PH_NOTE(row, val)                                                             \
   do {                                                                                \
@@ -123,7 +128,9 @@ struct Pass1Args {
   float *ny;        // [N] feats_down_body[i].normal_y as the reference would hold it (committed lazily)
   float4 *cert;     // [N] search-skip certificate: world point of the point's last list walk, radius free of outsiders
   unsigned char *kept;  // [N] this search pass kept the point's cached neighbours (diagnostics)
-  int skip;         // this search pass may keep cached neighbours (DEV: the control block's search_skip)
+  uint4 *pcache;    // [N] the point's last level-1 directory probe: cell key (2 words), start and count of the list (search_wg, phase B)
+  int skip;         // bit 0: this search pass may keep cached neighbours, bit 1: pcache holds probes of this scan against the
+                    // lists as they are (DEV: the control block's search_skip)
   int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
   // device loop (DEV = true instantiations): state, parities and commit_prev come from *dl, the slot sets from mm_base
   const DevLoop *dl;
@@ -622,6 +629,9 @@ constexpr unsigned char NF_PENDING = 0xFF;
 #ifndef KS_EARLY
 #define KS_EARLY 1
 #endif
+#ifndef KS_PCACHE
+#define KS_PCACHE 1
+#endif
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
 #ifndef KS_L2G
 #define KS_L2G 4
@@ -954,6 +964,7 @@ struct SearchLds {
   unsigned char keep[SQ];  // phase A': the cached neighbours are certified for the new world point - no walk
   int flags;               // what the control wave tells the others after phase A (search_wg)
   float cr[SQ];            // certificate radius of the walk that served the query (cert_radius)
+  uint4 pc[SQ];            // the point's cached directory probe (phase A read it with the scan point: one coalesced load)
   float4 q[SQ];            // the scan point as phase A read it (phase C: the row and the trace are built from it)
   float4 (*nbp)[SQ];       // phase C: [5][SQ] - the five neighbours' map points, kept across the plane fit (point_phase); the
                            // kernel's own LDS (k_pass: the storage of its row staging U, which is written after the fit)
@@ -1088,6 +1099,13 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       unsigned char sel_prev = 0;
       double trace_prev = 0.0;
       if (dy.commit_prev) sel_prev = a.sel[i], trace_prev = a.trace[i];
+      // The level-1 directory probe of the point's LAST search pass (round 5): between two search passes of one update the
+      // iterate moves by centimetres and 99 % of the points stay in their cell - their list is where it was. 16 bytes per
+      // point in one coalesced load here, against a dependent round trip to a line of the directory of its own per query
+      // in phase B (3 - 4 us of that phase under load, a fifth of its lines). ~0: no entry (no real key has bit 63 set).
+      uint4 pcv = make_uint4(~0u, ~0u, 0u, 0u);
+      if (KS_PCACHE && (dy.skip & 2)) pcv = a.pcache[i];
+      S.pc[lane_] = pcv;
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       // (KS_SPLIT: helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses
@@ -1112,7 +1130,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
     // it - the search would return exactly the cached points, ranked by their NEW distances under the order (d2, index):
     // those are recomputed here the way the search computes them (ikd_Tree.cpp:1697, no FMA) and inserted into an empty
     // list. Same set, same order, same bits; anything the bound cannot decide walks the lists as before.
-    if (SKIP && mine && dy.skip) {
+    if (SKIP && mine && (dy.skip & 1)) {
       const float4 ce = a.cert[i];
       const int nfo = a.nfound[i];
       if (nfo <= 5 && ce.w > 0.f) {
@@ -1184,15 +1202,26 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       const float4 ww = S.w[ql];
       Top5 t;
       float lb2;
-#ifdef MALIO_PHASE_CLOCK
       u32 st_, cn_;
-      nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
+      if (KS_PCACHE) {
+        const uint4 pcv = S.pc[ql];
+        const u64 key = cell_key_d((int)floorf(ww.x * nl1.inv_cf), (int)floorf(ww.y * nl1.inv_cf), (int)floorf(ww.z * nl1.inv_cf));  // == nl_probe's
+        if (pcv.x == (u32)key && pcv.y == (u32)(key >> 32)) {
+          st_ = pcv.z, cn_ = pcv.w;
+        } else {
+          nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
+          if (sub == 0) a.pcache[qidx(ql)] = make_uint4((u32)key, (u32)(key >> 32), st_, cn_);
+        }
+      } else {
+        nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
+      }
+#ifdef MALIO_PHASE_CLOCK
       asm volatile("" ::"v"(st_), "v"(cn_));
       PH_WAVE(8);
+#endif
       const bool certified = nl_walk<NL1_G, SKIP, false, KS_EARLY != 0>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, st_, cn_, t, lb2);
+#ifdef MALIO_PHASE_CLOCK
       PH_WAVE(4);
-#else
-      const bool certified = nl_search<NL1_G, SKIP, false, KS_EARLY != 0>(nl1, ww.x, ww.y, ww.z, sub, 5.0f, t, lb2);
 #endif
       if (sub == 0) {
 #pragma unroll
@@ -1662,9 +1691,9 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
 extern "C" int malio_debug_phase(long long *out64) {
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(long long) * 64) == hipSuccess ? 0 : -1;
 }
-extern "C" int malio_debug_span(long long *out, int n) {  // [12][n]: rows of g_span for workgroups 0..n-1
+extern "C" int malio_debug_span(long long *out, int n) {  // [14][n]: rows of g_span for workgroups 0..n-1
   if (n > 8192) return -1;
-  for (int r = 0; r < 12; r++)
+  for (int r = 0; r < 14; r++)
     if (hipMemcpyFromSymbol(out + (size_t)r * n, HIP_SYMBOL(g_span), sizeof(long long) * n, sizeof(long long) * 8192 * r) != hipSuccess)
       return -1;
   return 0;
@@ -2406,7 +2435,7 @@ int measure_alloc(Ctx *c) {
       if (p) (void)hipFree(p);
     };
     fr(c->d_scan), fr(c->d_perm), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2), fr(c->d_world), fr(c->d_ucov),
-        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept);
+        fr(c->d_trace), fr(c->d_sel), fr(c->d_nfound), fr(c->d_upload), fr(c->d_world4), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept), fr(c->d_pcache);
     c->cap_scan = N + N / 8 + 1024;
     size_t K = c->cap_scan;
     MALIO_HIP(hipMalloc(&c->d_upload, sizeof(UploadRec) * K));
@@ -2423,6 +2452,7 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_world4, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_ny, sizeof(float) * K));
     MALIO_HIP(hipMalloc(&c->d_cert, sizeof(float4) * K));
+    MALIO_HIP(hipMalloc(&c->d_pcache, sizeof(uint4) * K));
     MALIO_HIP(hipMalloc(&c->d_kept, K));
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
@@ -2465,6 +2495,7 @@ int reset_pass_state(Ctx *c) {
   c->mm_parity = 0, c->last_M = -1;
   c->mm_guess_valid = false;
   c->cert_valid = false;  // (the chain may have ended between a search pass' kernels: the next search walks every list)
+  c->probe_valid = false;
   return MALIO_OK;
 }
 
@@ -2778,7 +2809,7 @@ static void fill_pass1_static(Ctx *c, Pass1Args &a) {
   a.nbr = c->d_nbr, a.plane = c->d_plane, a.pd2 = c->d_pd2, a.world = c->d_world, a.ucov = c->d_ucov;
   a.trace = c->d_trace, a.sel = c->d_sel, a.nfound = c->d_nfound;
   a.ny = c->d_ny;
-  a.cert = c->d_cert, a.kept = c->d_kept, a.skip = 0;
+  a.cert = c->d_cert, a.kept = c->d_kept, a.pcache = c->d_pcache, a.skip = 0;
   a.mm_base = c->d_mmslots;
   a.dl = nullptr, a.mm_cur = a.mm_next = nullptr, a.commit_prev = 0;
 }
@@ -2809,12 +2840,17 @@ void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
 // earlier search pass of THIS scan has left its certificates and the map has not changed since (map ids in d_nbr, and
 // the "no outsider inside r" statement, belong to one epoch of the map array). From here on the certificates of this
 // pass exist in stream order.
+// Bit 1 of the result: the probe cache (Pass1Args::pcache) holds entries of an earlier search pass of this scan against the
+// lists as they are (every change of the lists goes with a change of the map array); without it the pass ignores the cache
+// and writes every entry.
 int search_skip_begin(Ctx *c) {
   const int skip = (c->opt_search_skip && c->cert_valid && c->nbr_epoch == c->map_epoch) ? 1 : 0;
+  const int probes = (c->opt_probe_cache && c->probe_valid && c->nbr_epoch == c->map_epoch) ? 2 : 0;
   c->nbr_epoch = c->map_epoch;
   c->cert_valid = c->opt_search_skip != 0;  // (only the SKIP kernels leave certificates)
+  c->probe_valid = true;
   c->last_search_skip = skip;
-  return skip;
+  return skip | probes;
 }
 
 int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_out) {

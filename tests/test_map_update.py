@@ -352,3 +352,52 @@ def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scen
     np.testing.assert_array_equal(a[0]["HtRinvH"], b[0]["HtRinvH"])
     np.testing.assert_array_equal(a[4]["HtRinvH"], b[4]["HtRinvH"])
     np.testing.assert_array_equal(a[2]["state"], b[2]["state"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [1, 5])
+def test_gpu_cached_directory_probes_change_nothing(capi, scenes, cfg):
+    """MALIO_OPT_PROBE_CACHE (default on): a search pass reuses the level-1 directory probe of the point's last search
+    pass while the point stays in its cell. Same lists, same neighbours, same bits - across passes at moving states, a
+    state that moves every point into another cell, a map that changes under the scan, and a new scan."""
+    sc = scenes.make_scene(cfg=cfg)
+    rng = np.random.default_rng(5)
+    states = [np.array(sc["state0"], np.float64)]
+    for k in range(3):
+        st = states[0].copy()
+        st[:3] += rng.normal(0, 0.01, 3)
+        states.append(st)
+    far = states[0].copy()
+    far[:3] += (1.7, -2.3, 0.4)   # every point lands in another cell: every cached probe must be refused
+    states.append(far)
+    states.append(states[1])
+    new = sc["map"][rng.integers(0, sc["map"].shape[0], 3000)].copy()
+    new[:, :3] += rng.normal(0, 0.3, size=(3000, 3)).astype(np.float32)
+    res = []
+    for on in (1, 0):
+        eng = capi.Engine(sc["params"])
+        eng.set_option("probe_cache", on)
+        eng.map_build(sc["map"])
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        out = []
+        for st in states:
+            m = eng.measure(st, True)
+            g = eng.scan_get()
+            out.append((m["M"], m["HtRinvH"].copy(), g["nearest"].copy(), g["selected"].copy(), g["res_last"].copy()))
+        eng.map_add(new, True)                       # lists appended to in place (some move): the cache must not survive
+        m = eng.measure(states[1], True)
+        g = eng.scan_get()
+        out.append((m["M"], m["HtRinvH"].copy(), g["nearest"].copy(), g["selected"].copy(), g["res_last"].copy()))
+        u = eng.update_iterated(sc["state0"], sc["P0"])
+        eng.scan_set(sc["scan"][::2].copy(), sc["tables"], sc["temporal_comp"])   # a new scan: other points in the slots
+        m = eng.measure(states[2], True)
+        g = eng.scan_get()
+        out.append((m["M"], m["HtRinvH"].copy(), g["nearest"].copy(), g["selected"].copy(), g["res_last"].copy()))
+        res.append((out, u["state"].copy()))
+    (a, ua), (b, ub) = res
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0], k
+        for i in range(1, 5):
+            np.testing.assert_array_equal(x[i], y[i], err_msg="step %d field %d" % (k, i))
+    np.testing.assert_array_equal(ua, ub)

@@ -32,9 +32,9 @@ if ph[3][0] > 0:
     for k, name in enumerate(hl):
         print("   %-34s %6.2f  %6.2f" % (name, (ph[3][k] - t0) / 100.0, (ph[3][k] - prev) / 100.0)); prev = ph[3][k]
 nb = (sc["N"] + 63) // 64 + 4
-sp = (C.c_longlong * (12 * nb))()
+sp = (C.c_longlong * (14 * nb))()
 assert capi.lib().malio_debug_span(sp, nb) == 0
-sp = np.array(sp[:], np.int64).reshape(12, nb)
+sp = np.array(sp[:], np.int64).reshape(14, nb)
 ok = sp[1] > sp[0]
 tz = sp[0][ok].min()
 ent, ex = (sp[0][ok] - tz) / 100.0, (sp[1][ok] - tz) / 100.0
