@@ -632,6 +632,9 @@ constexpr unsigned char NF_PENDING = 0xFF;
 #ifndef KS_PCACHE
 #define KS_PCACHE 1
 #endif
+#ifndef KS_NB
+#define KS_NB 8  // 16-byte loads per lane and batch of the level-1 walk (x NL1_G lanes: the entries a sorted list's walk reads before it may stop)
+#endif
 constexpr unsigned char NF_NOTMINE = 0xFD;   // partitioned handle: the point's tile belongs to another shard
 #ifndef KS_L2G
 #define KS_L2G 4
@@ -701,8 +704,8 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
                                         Top5 &t, float &lb2) {
   const bool in_order = (count & NL_SORTED) != 0;
   count &= NL_COUNT;
-  const bool cut = EARLY && in_order && count > (u32)(8 * G);  // (the G lanes of a query agree)
-  const u32 cn = cut ? (u32)(8 * G) : count;                   // entries this walk reads
+  const bool cut = EARLY && in_order && count > (u32)(KS_NB * G);  // (the G lanes of a query agree)
+  const u32 cn = cut ? (u32)(KS_NB * G) : count;                   // entries this walk reads
   float r2 = 0.f;  // cut: squared distance from the cell centre of this lane's LAST entry of the batch (0: a tombstone)
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
 #pragma unroll
@@ -710,17 +713,18 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
   u32 ev = (u32)(TOP5_MAXKEY >> 32);
   float gx = wx * nl.inv_cf, gy = wy * nl.inv_cf, gz = wz * nl.inv_cf;
   float kxf = floorf(gx), kyf = floorf(gy), kzf = floorf(gz);
-  auto batch = [&](u32 j) {  // 8 entries of this lane, the first one at j
-    float4 m[8];
+  constexpr int NB = KS_NB;  // loads per lane and batch
+  auto batch = [&](u32 j) {  // NB entries of this lane, the first one at j
+    float4 m[NB];
 #pragma unroll
-    for (int u = 0; u < 8; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
+    for (int u = 0; u < NB; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
     if (EARLY) {  // (a cut list is longer than the batch: entry sub + 7 G exists; a tombstone's x is +inf)
-      const float cdx = m[7].x - (kxf + 0.5f) * nl.cf, cdy = m[7].y - (kyf + 0.5f) * nl.cf, cdz = m[7].z - (kzf + 0.5f) * nl.cf;
+      const float cdx = m[NB - 1].x - (kxf + 0.5f) * nl.cf, cdy = m[NB - 1].y - (kyf + 0.5f) * nl.cf, cdz = m[NB - 1].z - (kzf + 0.5f) * nl.cf;
       const float c2 = cdx * cdx + cdy * cdy + cdz * cdz;  // == map_hash.hip: nl_centre_d2
       r2 = c2 < INFINITY ? c2 : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < NB; u++) {
       float ddx = wx - m[u].x, ddy = wy - m[u].y, ddz = wz - m[u].z;
       float d2 = ddx * ddx + ddy * ddy + ddz * ddz;  // calc_dist, ikd_Tree.cpp:1697 (no FMA)
       // A slot past the end of the list (its load was clamped to the last entry) gets the largest key and sorts after
@@ -790,7 +794,7 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
   // SLOWER there (a round's insertions, ~1 us for the SIMD's seven waves, do not cover a ~2 us round trip; rounds of 2 / 3 / 4
   // loads: 30.7 / 30.9 / 43 us - the last one spills - against 29.8 us), and touching the second batch's lines while the
   // first is in flight (an L2 prefetch by 4-byte loads) changed nothing (profiles/round5/r05d_walk_variants.txt).
-  for (u32 j = (u32)sub; j < cn; j += 8 * G) batch(j);
+  for (u32 j = (u32)sub; j < cn; j += NB * G) batch(j);
   }
   if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
   if (EARLY && cut) {
@@ -808,7 +812,7 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
 #pragma unroll
         for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
       }
-      for (u32 j = (u32)(8 * G + sub); j < count; j += 8 * G) batch(j);
+      for (u32 j = (u32)(NB * G + sub); j < count; j += NB * G) batch(j);
       if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
     }
   }
@@ -1971,6 +1975,10 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
       // workgroups over 256 CUs at BASELINE config 2): these were the kernel's last workgroups to leave - by 2 us, whatever the
       // rest gained (profiles/round5/r05p_*). They take the scan's FIRST tiles (the densest LiDAR: the lightest), everything
       // else moves up.
+      // (Dealing the tiles to the CUs by weight - the dispatcher is round-robin: workgroup b runs on XCD (b & 7), CU slot
+      // ((b >> 3) & 31) - so that every CU fetches the same number of lists, the CUs with a workgroup more the lightest ones:
+      // loads 254 .. 266 per CU instead of 246 .. 301, and the same 28 us: what is left of the tail is not systematic,
+      // profiles/round5/r05q_placement.txt.)
       tile = b < full ? (int)gridDim.x - 1 - tile : b - full;
 #else
       if (b < full) tile = full - 1 - tile;
