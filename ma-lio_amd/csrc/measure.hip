@@ -1245,11 +1245,11 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
     // lane <-> query, the same in every wave (a point of another shard sits at 3e9 and is never searched further)
     const bool pend = (qidx(lane) < qend) && S.nf[lane] == NF_PENDING && S.w[lane].x < 1e9f;
     unsigned long long todo = __ballot(pend);
-    // every wave must have taken its snapshot of the flags before any group rewrites one (the serving group stores the
-    // final count): a wave that read S.nf late would see a different `todo`, the assignment of queries to groups below
-    // would differ between waves and a query could be left NF_PENDING
-    __syncthreads();
-    if (todo) {  // workgroup-uniform: every wave took the same snapshot
+    if (todo) {  // workgroup-uniform: nothing writes S.nf between the barrier above and the one below
+      // every wave must have taken its snapshot of the flags before any group rewrites one (the serving group stores the
+      // final count): a wave that read S.nf late would see a different `todo`, the assignment of queries to groups below
+      // would differ between waves and a query could be left NF_PENDING
+      __syncthreads();
       const int npend = __popcll(todo);
       PH_NOTE(3, npend);
       {
@@ -1715,10 +1715,23 @@ extern "C" int malio_debug_span(long long *out, int n) {  // [14][n]: rows of g_
 struct SegBlocks {
   int b[MALIO_MAX_LIDAR + 1];
 };
+// (round 5: on DPP row operations like wave_max - after every step the lanes of a group hold the same bits, so any lane of the
+// partner group stands for the partner of the xor step, and IEEE addition commutes: lane 63 ends with the bits of the xor
+// butterfly's ((((a0 + a1) + (a2 + a3)) + ...): read back and returned to every lane. Twelve LDS-crossbar round trips less per call.)
 __device__ __forceinline__ double butterfly_up(double a) {
+#ifndef KS_NO_DPP
+  a += dpp_f64<0xB1, 0xF>(a);   // quad_perm [1,0,3,2]
+  a += dpp_f64<0x4E, 0xF>(a);   // quad_perm [2,3,0,1]
+  a += dpp_f64<0x141, 0xF>(a);  // row_half_mirror
+  a += dpp_f64<0x140, 0xF>(a);  // row_mirror
+  a += dpp_f64<0x142, 0xA>(a);  // row_bcast:15 into rows 1 and 3 (the other rows' values are not used from here on)
+  a += dpp_f64<0x143, 0xC>(a);  // row_bcast:31 into rows 2 and 3
+  return readlane63_f64(a);
+#else
 #pragma unroll
   for (int sft = 1; sft < 64; sft <<= 1) a += __shfl_xor(a, sft);
   return a;
+#endif
 }
 // LPL = leaves per lane: 4 when the leaves are k_rows_reduce's workgroup partials (each the node over 4 tiles), 16 when they
 // are the tiles of k_pass themselves - the same tree either way.
