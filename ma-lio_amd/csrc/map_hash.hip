@@ -520,65 +520,85 @@ __device__ __forceinline__ float nl_centre_d2(const float4 &e, float cx, float c
   const float dx = e.x - cx, dy = e.y - cy, dz = e.z - cz;
   return dx * dx + dy * dy + dz * dz;  // == measure.hip: nl_walk's r2 of the entries it has read
 }
+// one list of n <= 64 K entries, by the whole wave: K entries per lane (the usual list: K = 1)
+template <int K>
+__device__ __forceinline__ void nl_sort_body(float4 *lst, u32 n, float cx, float cy, float cz, int lane) {
+  float4 e[K];
+  float key[K];
+  u32 rank[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const u32 idx = (u32)lane + 64u * k;
+    key[k] = INFINITY, rank[k] = 0;
+    if (idx < n) {
+      e[k] = lst[idx];
+      key[k] = nl_centre_d2(e[k], cx, cy, cz);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < K; kk++) {
+    if (64u * kk >= n) break;  // (wave-uniform)
+    const u32 lim = min(64u, n - 64u * kk);
+    for (u32 jj = 0; jj < lim; jj++) {
+      // entry j's key to everybody: a scalar (v_readlane with a uniform lane index; a shuffle is an LDS-crossbar round trip
+      // per entry and made this kernel 68 us for a batch's ~10 k lists)
+      const float kj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key[kk]), (int)jj));
+      const u32 j = 64u * kk + jj;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const u32 idx = (u32)lane + 64u * k;
+        rank[k] += (kj < key[k] || (kj == key[k] && j < idx)) ? 1u : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const u32 idx = (u32)lane + 64u * k;
+    if (idx < n) lst[rank[k]] = e[k];
+  }
+}
+// (slot: the list's directory slot; every lane of the wave calls with the same slot)
+__device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, int lane) {
+  const Cell c = nl.table[slot];
+  const u32 n = c.count & NL_COUNT;
+  if (c.key == EMPTY_KEY) return;
+  if (n <= 1) {
+    if (lane == 0) nl.table[slot].count = n | NL_SORTED;  // (nothing to order)
+    return;
+  }
+  if (n > NL_SORT_MAX) return;  // stays as it is, unflagged (k_nl_append cleared the flag if it had one)
+  const u64 B = 1ull << 20;
+  const float cx = ((float)((int)(c.key & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cy = ((float)((int)((c.key >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cz = ((float)((int)((c.key >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
+  float4 *lst = nl.pts + (size_t)c.start;
+  static_assert(NL_SORT_MAX == 256, "the dispatch below covers 64 / 128 / 256 entries");
+  if (n <= 64) nl_sort_body<1>(lst, n, cx, cy, cz, lane);
+  else if (n <= 128) nl_sort_body<2>(lst, n, cx, cy, cz, lane);
+  else nl_sort_body<4>(lst, n, cx, cy, cz, lane);
+  if (lane == 0) nl.table[slot].count = n | NL_SORTED;
+}
 __global__ void __launch_bounds__(BLK) k_nl_sort(NlDev nl, const u32 *__restrict__ work, const u32 *__restrict__ nwork) {
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
-  const u32 nitems = work ? *nwork : nl.tmask + 1;
+  if (work) {  // a batch's work list: one list per wave and round
+    const u32 nitems = *nwork;
+    for (u32 item = wave; item < nitems; item += nwaves) nl_sort_list(nl, work[item], lane);
+    return;
+  }
+  // the whole directory: 64 slots per wave and round, most of them empty - the occupied ones one after the other
+  const u32 nitems = nl.tmask + 1;
   for (u32 base = wave * 64; base < nitems; base += nwaves * 64) {
-    // 64 candidates per wave and round: directory slots (most are empty) or entries of the work list
-    u32 s = 0, cnt = 0;
     bool todo = false;
     if (base + lane < nitems) {
-      s = work ? work[base + lane] : base + lane;
-      const Cell c = nl.table[s];
-      cnt = c.count & NL_COUNT;
-      todo = c.key != EMPTY_KEY && cnt > 1 && cnt <= NL_SORT_MAX;
-      if (c.key != EMPTY_KEY && cnt <= 1) nl.table[s].count = cnt | NL_SORTED;  // (nothing to order)
+      const Cell c = nl.table[base + lane];
+      todo = c.key != EMPTY_KEY;
     }
     unsigned long long m = __ballot(todo);
     while (m) {
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const u32 slot = __shfl(s, src), n = __shfl(cnt, src);
-      const Cell c = nl.table[slot];
-      const u64 B = 1ull << 20;
-      const float cx = ((float)((int)(c.key & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
-                  cy = ((float)((int)((c.key >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
-                  cz = ((float)((int)((c.key >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
-      float4 *lst = nl.pts + (size_t)c.start;
-      constexpr int K = NL_SORT_MAX / 64;
-      float4 e[K];
-      float key[K];
-      u32 rank[K];
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        const u32 idx = (u32)lane + 64u * k;
-        key[k] = INFINITY, rank[k] = 0;
-        if (idx < n) {
-          e[k] = lst[idx];
-          key[k] = nl_centre_d2(e[k], cx, cy, cz);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < K; kk++) {
-        if (64u * kk >= n) break;  // (wave-uniform)
-        const u32 lim = min(64u, n - 64u * kk);
-        for (u32 jj = 0; jj < lim; jj++) {
-          const float kj = __shfl(key[kk], (int)jj);
-          const u32 j = 64u * kk + jj;
-#pragma unroll
-          for (int k = 0; k < K; k++) {
-            const u32 idx = (u32)lane + 64u * k;
-            rank[k] += (kj < key[k] || (kj == key[k] && j < idx)) ? 1u : 0u;
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        const u32 idx = (u32)lane + 64u * k;
-        if (idx < n) lst[rank[k]] = e[k];
-      }
-      if (lane == 0) nl.table[slot].count = n | NL_SORTED;
+      nl_sort_list(nl, base + (u32)src, lane);
     }
   }
 }
@@ -766,12 +786,12 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
   }
   // exactly one lane per touched cell sees the batch's total for that cell (and clears it)
   u32 cnt = 0, old = 0, st = 0, newcap = 0;
-  bool mv = false;
+  bool mv = false, owner = false;
   if (live) {
     const u32 need = atomicExch(&nl.inc[s], 0u);
     if (need != 0) {
       cnt = nl.table[s].count & NL_COUNT;
-      if (nl.sorted) nl.work[atomicAdd(&nl.state[3], 1u)] = s;  // exactly one lane per touched list is here: k_nl_sort puts it in order again
+      owner = true;  // exactly one lane per touched list is here
       if (cnt + need > nl.cap[s]) {
         // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
         // old storage is reclaimed by the next full rebuild
@@ -787,9 +807,31 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
       }
     }
   }
+  const int lane = threadIdx.x & 63;
+  // The touched lists of the sorted level go on the batch's work list (k_nl_sort puts them in order again). ONE global atomic
+  // per workgroup: the slots are counted per wave (ballot), summed in LDS, reserved by thread 0 - a returning atomic per
+  // wave on the one counter (~1 000 of them for a scan's batch) made this kernel 17 us instead of 9.
+  __shared__ u32 s_wcnt[BLK / 64], s_wbase;
+  {
+    const unsigned long long ow = __ballot(owner && nl.sorted);
+    const int wv = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_wcnt[wv] = (u32)__popcll(ow);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u32 tot = 0;
+#pragma unroll
+      for (int w = 0; w < BLK / 64; w++) tot += s_wcnt[w];
+      s_wbase = tot ? atomicAdd(&nl.state[3], tot) : 0u;
+    }
+    __syncthreads();
+    if (owner && nl.sorted) {
+      u32 off = s_wbase;
+      for (int w = 0; w < wv; w++) off += s_wcnt[w];
+      nl.work[off + (u32)__popcll(ow & ((1ull << lane) - 1ull))] = s;
+    }
+  }
   // the lists that move are copied by the whole wave, one after the other (a level-2 list has hundreds of entries)
   unsigned long long todo = __ballot(mv);
-  const int lane = threadIdx.x & 63;
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
@@ -944,7 +986,8 @@ void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
   if (nl_a.sorted) {
     const NlDev a = nl_dev(nl_a);
     const long long lists = std::min<long long>((long long)m * 27, (long long)nl_a.tmask + 1);
-    hipLaunchKernelGGL(k_nl_sort, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (lists * 64 + BLK - 1) / BLK))),
+    // (grid: a typical batch - 1 600 new points, ~8 k lists - in two rounds of one list per wave)
+    hipLaunchKernelGGL(k_nl_sort, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (lists * 64 + BLK - 1) / BLK))),
                        dim3(BLK), 0, st, a, (const u32 *)a.work, (const u32 *)(a.state + 3));
   }
 }

@@ -10,7 +10,9 @@ e = capi.Engine(sc["params"]); e.map_build(sc["map"]); e.scan_set(sc["scan"], sc
 s2 = sc["state0"].copy(); s2[0:3] += [0.01, -0.008, 0.004]
 fs, _ = e.measure_fn(sc["state0"], True); fs2, _ = e.measure_fn(s2, True); fr, _ = e.measure_fn(sc["state0"], False)
 e.set_option("search_skip", 0)
+e.set_option("probe_cache", 0)   # the bench's headline step: every point probes the directory
 for _ in range(300): fs()
+e.set_option("probe_cache", 1)   # (library default from here on)
 e.set_option("search_skip", 1)
 for k in range(300): (fs2 if k & 1 else fs)()
 print("skip", e.skip_stats())
