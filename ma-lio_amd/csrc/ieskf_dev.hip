@@ -516,7 +516,7 @@ int ieskf_update_device_begin(Ctx *c, const malio_state_t *xio, const double *Pi
   in->maximum_iter = maximum_iter, in->L = L, in->extrinsic_est_en = c->prm.extrinsic_est_en;
   // the loop's first pass is a search pass: it may keep neighbours of an earlier search of this scan (malio_measure before
   // the update); every later search pass of the loop may keep those of the first (k_ieskf_step arms search_skip)
-  in->search_skip = search_skip_begin(c), in->skip_opt = c->opt_search_skip;
+  in->search_skip = search_skip_begin(c), in->skip_opt = c->opt_search_skip | (c->opt_probe_cache ? 6 : 0);  // (bits: search_skip_begin)
   in->limit = c->prm.limit > 0 ? c->prm.limit : 0.001;
   memcpy(in->tcq, c->tcq, sizeof(in->tcq)), memcpy(in->tct, c->tct, sizeof(in->tct));
   in->x = *xio, in->x_prop = *xio;

@@ -130,7 +130,7 @@ struct Pass1Args {
   unsigned char *kept;  // [N] this search pass kept the point's cached neighbours (diagnostics)
   uint4 *pcache;    // [N] the point's last level-1 directory probe: cell key (2 words), start and count of the list (search_wg, phase B)
   int skip;         // bit 0: this search pass may keep cached neighbours, bit 1: pcache holds probes of this scan against the
-                    // lists as they are (DEV: the control block's search_skip)
+                    // lists as they are, bit 2: this pass writes its probes to pcache (DEV: the control block's search_skip)
   int commit_prev;  // the previous pass was valid: fold its (sel, trace) into ny before overwriting them
   // device loop (DEV = true instantiations): state, parities and commit_prev come from *dl, the slot sets from mm_base
   const DevLoop *dl;
@@ -1214,7 +1214,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
           st_ = pcv.z, cn_ = pcv.w;
         } else {
           nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
-          if (sub == 0) a.pcache[qidx(ql)] = make_uint4((u32)key, (u32)(key >> 32), st_, cn_);
+          if (sub == 0 && (dy.skip & 4)) a.pcache[qidx(ql)] = make_uint4((u32)key, (u32)(key >> 32), st_, cn_);
         }
       } else {
         nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
@@ -2862,14 +2862,14 @@ void fill_pass_const(const Ctx *c, const malio_state_t *s, PassConst &pc) {
 // the "no outsider inside r" statement, belong to one epoch of the map array). From here on the certificates of this
 // pass exist in stream order.
 // Bit 1 of the result: the probe cache (Pass1Args::pcache) holds entries of an earlier search pass of this scan against the
-// lists as they are (every change of the lists goes with a change of the map array); without it the pass ignores the cache
-// and writes every entry.
+// lists as they are (every change of the lists goes with a change of the map array); without it the pass ignores the cache.
+// Bit 2: the pass writes the probes it makes (MALIO_OPT_PROBE_CACHE on).
 int search_skip_begin(Ctx *c) {
   const int skip = (c->opt_search_skip && c->cert_valid && c->nbr_epoch == c->map_epoch) ? 1 : 0;
-  const int probes = (c->opt_probe_cache && c->probe_valid && c->nbr_epoch == c->map_epoch) ? 2 : 0;
+  const int probes = c->opt_probe_cache ? ((c->probe_valid && c->nbr_epoch == c->map_epoch) ? 6 : 4) : 0;  // 4: this pass fills the cache
   c->nbr_epoch = c->map_epoch;
   c->cert_valid = c->opt_search_skip != 0;  // (only the SKIP kernels leave certificates)
-  c->probe_valid = true;
+  c->probe_valid = c->opt_probe_cache != 0;
   c->last_search_skip = skip;
   return skip | probes;
 }
