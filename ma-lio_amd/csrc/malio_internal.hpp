@@ -54,7 +54,9 @@ struct NList {
   u32 *cap = nullptr;     // [table size] capacity of every list (count + slack): room for incremental inserts
   u32 *inc = nullptr;     // [table size] entries the batch being applied brings to each list (zero between batches)
   u32 *state = nullptr;   // device: [0] bump cursor into the tail of pts, [1] overflow flag, [2] cells, [3] lists on `work`
-  u32 *work = nullptr;    // [table size] (sorted level only) directory slots of the lists the batch being applied appends to
+  u32 *work = nullptr;    // [work_cap][8] (sorted level only) the lists the batch being applied appends to: slot, count word before the
+                          // batch, count after it, start | cell key (2 words), - , -  (k_nl_place -> k_nl_sort); grown by nl_ensure
+  size_t work_cap = 0;
   size_t total = 0;       // entries reserved by the lists built last (capacities)
   size_t entries = 0;     // live entries at build time (27 per point for whole blocks; ~20.6 when pruned)
   size_t cap_pts = 0, cap_table = 0;
@@ -76,7 +78,7 @@ struct NlDev {
   u32 tmask;
   float4 *pts;
   u32 *cap, *inc, *state, *work;
-  u32 bump_end;
+  u32 bump_end, work_cap;
   float inv_cf, cf;
   int sorted;
   int pruned;  // level 1: a list holds only the block's points within one cell edge of its cell (nl_member)

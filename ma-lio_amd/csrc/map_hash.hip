@@ -557,33 +557,92 @@ __device__ __forceinline__ void nl_sort_body(float4 *lst, u32 n, float cx, float
     if (idx < n) lst[rank[k]] = e[k];
   }
 }
-// (slot: the list's directory slot; every lane of the wave calls with the same slot)
-__device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, int lane) {
-  const Cell c = nl.table[slot];
-  const u32 n = c.count & NL_COUNT;
-  if (c.key == EMPTY_KEY) return;
+// A list that WAS in order (its first n0 entries) and got a few entries appended: the tail's entries are ranked among all, the
+// prefix entries move up by the number of tail entries that sort before them - a compare and a ballot per tail entry instead of a
+// compare per pair (a scan's batch touches ~20 k lists with one to three new entries each: 31 -> ~10 us for the kernel, which
+// sits between a scan's map update and the next scan's first search). false: a tombstone in the prefix (its key is +inf wherever
+// it stands: the prefix is not in order by key) - the caller sorts from scratch.
+template <int K>
+__device__ __forceinline__ bool nl_merge_body(float4 *lst, u32 n0, u32 n, float cx, float cy, float cz, int lane) {
+  float4 e[K];
+  float key[K];
+  u32 rank[K];
+  bool tomb = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const u32 idx = (u32)lane + 64u * k;
+    key[k] = INFINITY, rank[k] = idx;  // a prefix entry keeps its place among the prefix entries
+    if (idx < n) {
+      e[k] = lst[idx];
+      key[k] = nl_centre_d2(e[k], cx, cy, cz);
+      tomb |= idx < n0 && !(key[k] < INFINITY);
+    }
+  }
+  if (__ballot(tomb)) return false;
+  for (u32 t = n0; t < n; t++) {  // (wave-uniform; at most NL_MERGE_MAX rounds)
+    const int tl = (int)(t & 63u);
+    float kt = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if ((t >> 6) == (u32)k) kt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key[k]), tl));
+    u32 before = 0;  // entries that sort before entry t: its final position
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const u32 idx = (u32)lane + 64u * k;
+      const bool live = idx < n;
+      before += (u32)__popcll(__ballot(live && (key[k] < kt || (key[k] == kt && idx < t))));
+      if (live && idx < n0 && kt < key[k]) rank[k] += 1;  // (a tie leaves the older entry in front)
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if ((u32)lane + 64u * k == t) rank[k] = before;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const u32 idx = (u32)lane + 64u * k;
+    if (idx < n && rank[k] != idx) lst[rank[k]] = e[k];
+  }
+  return true;
+}
+constexpr u32 NL_MERGE_MAX = 8;  // more new entries than that: sorted from scratch
+// (slot: the list's directory slot, old: its count word before the batch's appends - 0: unknown -, key / start / n: the cell and
+// the list as they are now; every lane of the wave calls with the same values)
+__device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, u32 old, u64 ckey, u32 cstart, u32 n, int lane) {
+  if (ckey == EMPTY_KEY) return;
   if (n <= 1) {
     if (lane == 0) nl.table[slot].count = n | NL_SORTED;  // (nothing to order)
     return;
   }
   if (n > NL_SORT_MAX) return;  // stays as it is, unflagged (k_nl_append cleared the flag if it had one)
   const u64 B = 1ull << 20;
-  const float cx = ((float)((int)(c.key & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
-              cy = ((float)((int)((c.key >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
-              cz = ((float)((int)((c.key >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
-  float4 *lst = nl.pts + (size_t)c.start;
+  const float cx = ((float)((int)(ckey & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cy = ((float)((int)((ckey >> 21) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf,
+              cz = ((float)((int)((ckey >> 42) & 0x1FFFFF) - (int)B) + 0.5f) * nl.cf;
+  float4 *lst = nl.pts + (size_t)cstart;
   static_assert(NL_SORT_MAX == 256, "the dispatch below covers 64 / 128 / 256 entries");
-  if (n <= 64) nl_sort_body<1>(lst, n, cx, cy, cz, lane);
-  else if (n <= 128) nl_sort_body<2>(lst, n, cx, cy, cz, lane);
-  else nl_sort_body<4>(lst, n, cx, cy, cz, lane);
+  const u32 n0 = old & NL_COUNT;
+  bool done = false;
+  if ((old & NL_SORTED) && n0 >= 1 && n0 < n && n - n0 <= NL_MERGE_MAX) {
+    if (n <= 64) done = nl_merge_body<1>(lst, n0, n, cx, cy, cz, lane);
+    else if (n <= 128) done = nl_merge_body<2>(lst, n0, n, cx, cy, cz, lane);
+    else done = nl_merge_body<4>(lst, n0, n, cx, cy, cz, lane);
+  }
+  if (!done) {
+    if (n <= 64) nl_sort_body<1>(lst, n, cx, cy, cz, lane);
+    else if (n <= 128) nl_sort_body<2>(lst, n, cx, cy, cz, lane);
+    else nl_sort_body<4>(lst, n, cx, cy, cz, lane);
+  }
   if (lane == 0) nl.table[slot].count = n | NL_SORTED;
 }
 __global__ void __launch_bounds__(BLK) k_nl_sort(NlDev nl, const u32 *__restrict__ work, const u32 *__restrict__ nwork) {
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
   if (work) {  // a batch's work list: one list per wave and round
-    const u32 nitems = *nwork;
-    for (u32 item = wave; item < nitems; item += nwaves) nl_sort_list(nl, work[item], lane);
+    const u32 nitems = min(*nwork, nl.work_cap);
+    for (u32 item = wave; item < nitems; item += nwaves) {
+      const uint4 w0 = ((const uint4 *)work)[2 * (size_t)item], w1 = ((const uint4 *)work)[2 * (size_t)item + 1];
+      nl_sort_list(nl, w0.x, w0.y, (u64)w1.x | ((u64)w1.y << 32), w0.w, w0.z, lane);
+    }
     return;
   }
   // the whole directory: 64 slots per wave and round, most of them empty - the occupied ones one after the other
@@ -598,7 +657,8 @@ __global__ void __launch_bounds__(BLK) k_nl_sort(NlDev nl, const u32 *__restrict
     while (m) {
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
-      nl_sort_list(nl, base + (u32)src, lane);
+      const Cell c = nl.table[base + (u32)src];
+      nl_sort_list(nl, base + (u32)src, 0u, c.key, c.start, c.count & NL_COUNT, lane);
     }
   }
 }
@@ -675,10 +735,7 @@ int build_nlist(Ctx *c, const float4 *d_in, int n, float cf, NList &nl, bool pru
     MALIO_HIP(hipMalloc(&nl.cap, sizeof(u32) * nl.cap_table));
     if (nl.inc) (void)hipFree(nl.inc);
     MALIO_HIP(hipMalloc(&nl.inc, sizeof(u32) * nl.cap_table));
-    if (nl.work) (void)hipFree(nl.work);
-    nl.work = nullptr;
   }
-  if (sorted && !nl.work) MALIO_HIP(hipMalloc(&nl.work, sizeof(u32) * nl.cap_table));
   if (!nl.state) MALIO_HIP(hipMalloc(&nl.state, sizeof(u32) * 4));
   hipLaunchKernelGGL(k_clear_table, dim3((tsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, nl.table, tsize);
   MALIO_HIP(hipMemsetAsync(nl.cap, 0, sizeof(u32) * tsize, c->stream));
@@ -762,12 +819,14 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
   const int i = (int)(t >> 5), cidx = (int)(t & 31);
   bool live = i < m && cidx < 27 && keep[i] != 0;
   u32 s = 0;
+  u64 mykey = 0;
   if (live) {
     float4 p = newp[i];
     const float gx = p.x * nl.inv_cf, gy = p.y * nl.inv_cf, gz = p.z * nl.inv_cf;
     int ix = (int)floorf(gx), iy = (int)floorf(gy), iz = (int)floorf(gz);
     live = nl_member(nl.pruned, gx, gy, gz, ix, iy, iz, cidx % 3 - 1, (cidx / 3) % 3 - 1, cidx / 9 - 1);
     u64 key = cell_key(ix + cidx % 3 - 1, iy + (cidx / 3) % 3 - 1, iz + cidx / 9 - 1);
+    mykey = key;
     s = hash_key(key) & nl.tmask;
     int probes = 0;
     while (live) {
@@ -785,12 +844,14 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
     return;
   }
   // exactly one lane per touched cell sees the batch's total for that cell (and clears it)
-  u32 cnt = 0, old = 0, st = 0, newcap = 0;
+  u32 cnt = 0, rawcnt = 0, newcnt = 0, old = 0, st = 0, newcap = 0;
   bool mv = false, owner = false;
   if (live) {
     const u32 need = atomicExch(&nl.inc[s], 0u);
     if (need != 0) {
-      cnt = nl.table[s].count & NL_COUNT;
+      rawcnt = nl.table[s].count;  // (the batch's entries are appended by the next kernel: the length and the flag BEFORE it)
+      cnt = rawcnt & NL_COUNT;
+      newcnt = cnt + need;
       owner = true;  // exactly one lane per touched list is here
       if (cnt + need > nl.cap[s]) {
         // new cell, or a list that outgrew its slack (the map frontier): move it to the tail with fresh slack; the
@@ -827,7 +888,13 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
     if (owner && nl.sorted) {
       u32 off = s_wbase;
       for (int w = 0; w < wv; w++) off += s_wcnt[w];
-      nl.work[off + (u32)__popcll(ow & ((1ull << lane) - 1ull))] = s;
+      // (everything k_nl_sort needs of the list: it then reads the item and the entries - no trip to the directory)
+      const u32 at = off + (u32)__popcll(ow & ((1ull << lane) - 1ull));
+      if (at < nl.work_cap) {
+        uint4 *w = (uint4 *)nl.work + 2 * (size_t)at;
+        w[0] = make_uint4(s, rawcnt, newcnt, mv ? st : nl.table[s].start);
+        w[1] = make_uint4((u32)mykey, (u32)(mykey >> 32), 0u, 0u);
+      }
     }
   }
   // the lists that move are copied by the whole wave, one after the other (a level-2 list has hundreds of entries)
@@ -924,6 +991,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
 NlDev nl_dev(const NList &nl) {
   NlDev v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cap = nl.cap, v.inc = nl.inc, v.state = nl.state, v.work = nl.work;
+  v.work_cap = (u32)nl.work_cap;
   v.bump_end = (u32)nl.cap_pts, v.inv_cf = nl.inv_cf, v.cf = nl.cf, v.pruned = nl.pruned ? 1 : 0, v.sorted = nl.sorted ? 1 : 0;
   return v;
 }
@@ -972,6 +1040,18 @@ void nl_ensure(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
                const MapSide &side) {
   const long long th = (long long)m * 32;
   const dim3 grid((unsigned)((th + BLK - 1) / BLK), 2);
+  if (nl_a.sorted) {
+    // the batch's work list (k_nl_place -> k_nl_sort): at most one item per (point, cell) pair; grown here, rarely (hipFree waits
+    // for whatever still reads the old one). A list that finds no room on it stays unflagged - walked whole - until a rebuild.
+    const size_t want = (size_t)std::min<long long>((long long)m * 27, 4ll << 20);
+    if (want > nl_a.work_cap) {
+      if (nl_a.work) (void)hipFree(nl_a.work);
+      nl_a.work = nullptr, nl_a.work_cap = 0;
+      const size_t cap = std::max<size_t>(want + want / 2, (size_t)1 << 16);
+      if (hipMalloc(&nl_a.work, sizeof(u32) * 8 * cap) == hipSuccess) nl_a.work_cap = cap;
+      else (void)hipGetLastError();
+    }
+  }
   const NlDev a = nl_dev(nl_a), b = nl_dev(nl_b);
   hipLaunchKernelGGL(k_nl_ensure, dim3(grid.x, 3), dim3(BLK), 0, st, d_new, keep, m, a, b, side);
   hipLaunchKernelGGL(k_nl_place, grid, dim3(BLK), 0, st, d_new, keep, m, a, b, 1);
@@ -983,11 +1063,11 @@ void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
                      og_base, m, nl_dev(nl_a), nl_dev(nl_b));
   // the lists of the sorted level this batch appended to, in order again (one wave per list; the work list's length is on the
   // device: a grid that covers a typical batch in one round, the rest by striding)
-  if (nl_a.sorted) {
+  if (nl_a.sorted && nl_a.work) {
     const NlDev a = nl_dev(nl_a);
     const long long lists = std::min<long long>((long long)m * 27, (long long)nl_a.tmask + 1);
     // (grid: a typical batch - 1 600 new points, ~8 k lists - in two rounds of one list per wave)
-    hipLaunchKernelGGL(k_nl_sort, dim3((unsigned)std::max<long long>(1, std::min<long long>(1024, (lists * 64 + BLK - 1) / BLK))),
+    hipLaunchKernelGGL(k_nl_sort, dim3((unsigned)std::max<long long>(1, std::min<long long>(2048, (lists * 64 + BLK - 1) / BLK))),
                        dim3(BLK), 0, st, a, (const u32 *)a.work, (const u32 *)(a.state + 3));
   }
 }
