@@ -861,6 +861,7 @@ __global__ void __launch_bounds__(BLK) k_nl_place(const float4 *__restrict__ new
         st = atomicAdd(&nl.state[0], newcap);
         if (st + newcap > nl.bump_end || st + newcap < st) {
           atomicExch(&nl.state[1], 1u);
+          owner = false;  // (no room: the list keeps its length, the host rebuilds - nothing for k_nl_sort here)
         } else {
           mv = true;
           old = nl.table[s].start;

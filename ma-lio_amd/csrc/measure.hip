@@ -655,6 +655,7 @@ struct NlView {
   const float4 *pts;
   float cf, inv_cf;
   float reach_cf;  // the radius around the query's CELL the list is complete for: cf, or NL_REACH x cf for a pruned list
+  int early;       // walks of an ordered list may end after the first batch (nl_walk, EARLY): set for scans that fill the GPU
 };
 // lb2 (out, identical in every lane of the group): a lower bound on the SQUARED distance - as this function computes
 // distances - from the query to every map point that is not one of the returned neighbours: the smallest of (i) the
@@ -704,7 +705,7 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
                                         Top5 &t, float &lb2) {
   const bool in_order = (count & NL_SORTED) != 0;
   count &= NL_COUNT;
-  const bool cut = EARLY && in_order && count > (u32)(KS_NB * G);  // (the G lanes of a query agree)
+  const bool cut = EARLY && nl.early && in_order && count > (u32)(KS_NB * G);  // (the G lanes of a query agree)
   const u32 cn = cut ? (u32)(KS_NB * G) : count;                   // entries this walk reads
   float r2 = 0.f;  // cut: squared distance from the cell centre of this lane's LAST entry of the batch (0: a tombstone)
   const float sentinel = __uint_as_float(__float_as_uint(limit2) + 1u);  // next float above the limit
@@ -718,7 +719,7 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
     float4 m[NB];
 #pragma unroll
     for (int u = 0; u < NB; u++) m[u] = nl.pts[(size_t)start + min(j + (u32)(u * G), count - 1)];
-    if (EARLY) {  // (a cut list is longer than the batch: entry sub + 7 G exists; a tombstone's x is +inf)
+    if (EARLY && cut) {  // (a cut list is longer than the batch: entry sub + 7 G exists; a tombstone's x is +inf)
       const float cdx = m[NB - 1].x - (kxf + 0.5f) * nl.cf, cdy = m[NB - 1].y - (kyf + 0.5f) * nl.cf, cdz = m[NB - 1].z - (kzf + 0.5f) * nl.cf;
       const float c2 = cdx * cdx + cdy * cdy + cdz * cdz;  // == map_hash.hip: nl_centre_d2
       r2 = c2 < INFINITY ? c2 : 0.f;
@@ -789,15 +790,22 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
       __builtin_amdgcn_sched_barrier(0);
       offer_round(b, n);
     }
+    if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
   } else {
   // The short lists of level 1 (~44 entries: two batches) keep the two-batch walk: pipelined rounds were measured 0.6-1 us
   // SLOWER there (a round's insertions, ~1 us for the SIMD's seven waves, do not cover a ~2 us round trip; rounds of 2 / 3 / 4
   // loads: 30.7 / 30.9 / 43 us - the last one spills - against 29.8 us), and touching the second batch's lines while the
   // first is in flight (an L2 prefetch by 4-byte loads) changed nothing (profiles/round5/r05d_walk_variants.txt).
-  for (u32 j = (u32)sub; j < cn; j += NB * G) batch(j);
-  }
-  if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
-  if (EARLY && cut) {
+  // ONE copy of the batch and of the merge in the code (the continuation as a second inlined copy made the kernel 1.3 us
+  // slower on lists that are not cut at all - its instruction footprint): a loop of at most two turns, the second one only for
+  // the lanes of a cut list whose first batch settled nothing.
+  u32 j = (u32)sub, end = cn;
+  bool again = EARLY && cut;  // (the G lanes of a query agree on everything that steers this loop)
+  while (true) {
+    for (; j < end; j += NB * G) batch(j);
+    if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+    if (!(EARLY && again)) break;
+    again = false;
 #pragma unroll
     for (int sft = G / 2; sft > 0; sft >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, sft));  // (any entry that was read bounds the unread ones)
     const float qx = wx - (kxf + 0.5f) * nl.cf, qy = wy - (kyf + 0.5f) * nl.cf, qz = wz - (kzf + 0.5f) * nl.cf;
@@ -805,16 +813,16 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
     const float b2 = lo * lo * 0.9999f;  // every unread entry is farther than this (squared)
     if (lo > 0.f && t.og(4) != INVALID && t.d(4) < b2) {
       if (CERT) ev = min(ev, __float_as_uint(b2));  // the unread entries are outsiders as well
-    } else {
-      // not settled (2.5 % of the queries of BASELINE config 2: the ones near a corner of their cell): the rest of the list, on
-      // top of what the group has - the merged five stay in the group's first lane, the others start empty again
-      if (sub != 0) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
-      }
-      for (u32 j = (u32)(NB * G + sub); j < count; j += NB * G) batch(j);
-      if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+      break;
     }
+    // not settled (2.5 % of the queries of BASELINE config 2: the ones near a corner of their cell): the rest of the list, on
+    // top of what the group has - the merged five stay in the group's first lane, the others start empty again
+    if (sub != 0) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) t.k[k] = CERT ? TOP5_MAXKEY : top5_key(sentinel, INVALID);
+    }
+    j = (u32)(NB * G + sub), end = count;
+  }
   }
   // CERT: survivors beyond the limit are not results: they read (sentinel, INVALID) as an empty slot always has, and count
   // as outsiders for the bound (the list is sorted: they form its tail)
@@ -2206,10 +2214,18 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   out_cnt[qi] = c;
 }
 
-static NlView view_of(const NList &nl) {
+// n_queries: the scan the view is for. Ending a walk early saves LINES - what a full GPU's level-1 search queues for (DESIGN.md
+// section 3.7) - and costs the unsettled queries a dependent trip: on a scan that leaves most CUs with one workgroup or none
+// (BASELINE config 1: 157 workgroups) there is no queue to shorten and the trip is all there is (+1.2 us per pass, measured) -
+// such a scan walks its lists whole. (A tile shard serves 1 / world of its scan's points: that is its n_queries.)
+#ifndef KS_EARLY_MIN_QUERIES
+#define KS_EARLY_MIN_QUERIES 32768  // 512 workgroups: two per CU
+#endif
+static NlView view_of(const NList &nl, int n_queries = 0) {
   NlView v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
   v.reach_cf = nl.pruned ? NL_REACH * nl.cf : nl.cf;
+  v.early = n_queries >= KS_EARLY_MIN_QUERIES ? 1 : 0;
   return v;
 }
 
@@ -2900,7 +2916,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   if (converge) {
     a.skip = search_skip_begin(c);
     const auto kern = c->opt_search_skip ? &k_search<false, true> : &k_search<false, false>;
-    hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
+    hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2));
     prof_mark(c, "k_search");
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
@@ -2985,7 +3001,7 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
   // (whether a search pass of the enqueued-ahead loop may keep neighbours is in the control block; the instantiation that can
   // is used whenever the option is on)
   const auto kern = c->opt_search_skip ? &k_search<true, true> : &k_search<true, false>;
-  hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2));
+  hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2));
   Pass2Args b;
   const int nb = fill_pass2_static(c, b);
   b.dl = c->d_loop, b.mm_out = d_mm_out;
@@ -3077,7 +3093,7 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
   memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
   const auto kern = c->opt_search_skip ? &k_pass<false, true> : &k_pass<false, false>;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f, (const DevLoop *)nullptr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2), f, (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
   launch_final_tiles(c, sb, nullptr, gate, row);
   prof_mark(c, "k_final_reduce");
@@ -3095,7 +3111,7 @@ int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   SegBlocks sb;
   const int nwg = fill_fuse_static(c, f, sb);
   const auto kern = c->opt_search_skip ? &k_pass<true, true> : &k_pass<true, false>;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1), view_of(c->nl2), f, (const DevLoop *)c->d_loop);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2), f, (const DevLoop *)c->d_loop);
   launch_final_tiles(c, sb, c->d_loop, gate);
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;

@@ -401,3 +401,34 @@ def test_gpu_cached_directory_probes_change_nothing(capi, scenes, cfg):
         for i in range(1, 5):
             np.testing.assert_array_equal(x[i], y[i], err_msg="step %d field %d" % (k, i))
     np.testing.assert_array_equal(ua, ub)
+
+
+@pytest.mark.gpu
+def test_gpu_ordered_lists_on_a_dense_and_on_a_tiny_map(capi, scenes):
+    """Lists above 256 entries stay unordered and unflagged (walked whole); a map of a handful of points has lists of one or two
+    entries; neither may change a neighbour. Same answers with MALIO_OPT_NL_SORTED on and off."""
+    sc = scenes.make_scene(cfg=1)
+    rng = np.random.default_rng(3)
+    dense = sc["map"][:20000].copy()
+    c = sc["map"][rng.integers(0, sc["map"].shape[0]), :3]
+    dense[:, :3] = (c + rng.uniform(-2.5, 2.5, size=(20000, 3))).astype(np.float32)   # 160 points per m^3: lists of ~2 000 entries
+    big = np.concatenate([sc["map"], dense])
+    tiny = sc["map"][:7].copy()
+    qs = np.concatenate([dense[:2000, :6] * 0 + dense[:2000, :6], sc["map"][:2000, :6]]).astype(np.float32)
+    for mp, expect_unflagged in ((big, True), (tiny, False)):
+        res = []
+        for srt in (1, 0):
+            eng = capi.Engine(sc["params"])
+            eng.set_option("nl_sorted", srt)
+            eng.map_build(mp)
+            lo = eng.list_order()
+            assert lo["broken"] == 0
+            if srt:
+                assert (lo["ordered"] < lo["lists"]) if expect_unflagged else (lo["ordered"] == lo["lists"]), lo
+            eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            m = eng.measure(sc["state0"], True)
+            g = eng.scan_get()
+            res.append((m["M"], g["nearest"].copy(), g["selected"].copy(), g["res_last"].copy()))
+        assert res[0][0] == res[1][0]
+        for k in (1, 2, 3):
+            np.testing.assert_array_equal(res[0][k], res[1][k])
