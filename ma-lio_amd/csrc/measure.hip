@@ -1104,6 +1104,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);  // the OTHER parity's slots, for the next pass
   if (cwave) {
     float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 pcv = make_uint4(~0u, ~0u, 0u, 0u);  // the point's cached directory probe; ~0: none (no real key has bit 63 set)
     if (mine) {
       const float4 q = a.scan[i];
       // the lazy normal_y commit of the previous pass (commit_normal_y), done here: its two loads travel with the scan
@@ -1114,10 +1115,8 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       // The level-1 directory probe of the point's LAST search pass (round 5): between two search passes of one update the
       // iterate moves by centimetres and 99 % of the points stay in their cell - their list is where it was. 16 bytes per
       // point in one coalesced load here, against a dependent round trip to a line of the directory of its own per query
-      // in phase B (3 - 4 us of that phase under load, a fifth of its lines). ~0: no entry (no real key has bit 63 set).
-      uint4 pcv = make_uint4(~0u, ~0u, 0u, 0u);
+      // in phase B (3 - 4 us of that phase under load, a fifth of its lines).
       if (KS_PCACHE && (dy.skip & 2)) pcv = a.pcache[i];
-      S.pc[lane_] = pcv;
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
       // (KS_SPLIT: helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses
@@ -1134,6 +1133,10 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       }
     }
     S.w[lane_] = w;
+    // (EVERY lane of the tile: a lane past the end of its LiDAR segment searches at (0, 0, 0) like any other, and whatever an earlier
+    // workgroup - of another handle, another map - left in this LDS must not pass for its cached probe: it did, in scenes around the
+    // origin, and the walk of a list that is not there faulted)
+    S.pc[lane_] = pcv;
     // ---- phase A': may this query keep the neighbours of its last walk? (laserMapping.cpp:582-591 searches every point
     // again whenever ekfom_data.converge is set; between two such passes of one update the iterate moves by centimetres.)
     // The last walk of the point, at w0, left a radius r0 inside which there is no map point but the cached ones
@@ -1222,7 +1225,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
           st_ = pcv.z, cn_ = pcv.w;
         } else {
           nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);
-          if (sub == 0 && (dy.skip & 4)) a.pcache[qidx(ql)] = make_uint4((u32)key, (u32)(key >> 32), st_, cn_);
+          if (sub == 0 && (dy.skip & 4) && qidx(ql) < qend) a.pcache[qidx(ql)] = make_uint4((u32)key, (u32)(key >> 32), st_, cn_);
         }
       } else {
         nl_probe(nl1, ww.x, ww.y, ww.z, st_, cn_);

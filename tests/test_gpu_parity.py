@@ -1256,3 +1256,37 @@ def test_options_api(capi, scenes):
             eng.set_option(name, bad)
     eng.set_option("fuse", 0).set_option("nl_full_blocks", 1)
     assert eng.get_option("fuse") == 0 and eng.get_option("nl_full_blocks") == 1
+
+
+@pytest.mark.gpu
+def test_partial_tiles_do_not_take_another_handles_cached_probe(capi, scenes):
+    """A tile's lanes past the end of their LiDAR segment search at (0, 0, 0) like any query. Their cached-probe slot in LDS
+    (MALIO_OPT_PROBE_CACHE) must be written for them too: what an earlier workgroup - of another handle with a bigger map -
+    left there once passed for the probe of the cell around the origin, and the walk of a list that does not exist in THIS
+    handle's array faulted (round 5, found by running the suite in a loop). Regression: a big scene's search passes, then a
+    small handle whose segments do not fill their last tiles, repeatedly; results equal those with the option off."""
+    big = scenes.make_scene(seed=611, N=60000, Nmap=600000, L=3)
+    eb = capi.Engine(big["params"])
+    eb.map_build(big["map"])
+    eb.scan_set(big["scan"], big["tables"], big["temporal_comp"])
+    for _ in range(3):
+        eb.measure(big["state0"], True)
+    small = scenes.make_scene(seed=612, N=5000 + 17, Nmap=20000, L=3)
+    ref = None
+    for on in (0, 1, 1, 1):
+        e = capi.Engine(small["params"])
+        e.set_option("probe_cache", on)
+        e.map_build(small["map"])
+        for k in range(6):
+            e.scan_set(small["scan"], small["tables"], small["temporal_comp"])
+            m1 = e.measure(small["state0"], True)
+            m2 = e.measure(small["state0"], True)
+            eb.measure(big["state0"], True)   # (keeps the big handle's entries coming through the CUs' LDS)
+        g = e.scan_get()
+        cur = (m1["M"], m2["M"], m2["HtRinvH"].copy(), g["nearest"].copy(), g["selected"].copy())
+        if ref is None:
+            ref = cur
+        else:
+            assert cur[0] == ref[0] and cur[1] == ref[1]
+            for a, b in zip(cur[2:], ref[2:]):
+                np.testing.assert_array_equal(a, b)
