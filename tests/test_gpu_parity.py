@@ -1263,8 +1263,10 @@ def test_partial_tiles_do_not_take_another_handles_cached_probe(capi, scenes):
     """A tile's lanes past the end of their LiDAR segment search at (0, 0, 0) like any query. Their cached-probe slot in LDS
     (MALIO_OPT_PROBE_CACHE) must be written for them too: what an earlier workgroup - of another handle with a bigger map -
     left there once passed for the probe of the cell around the origin, and the walk of a list that does not exist in THIS
-    handle's array faulted (round 5, found by running the suite in a loop). Regression: a big scene's search passes, then a
-    small handle whose segments do not fill their last tiles, repeatedly; results equal those with the option off."""
+    handle's array faulted (round 5, found by running the suite in a loop: 5 runs of 8 aborted). The fault needed the leftover
+    of a query in the cell around the origin on the same CU, so this does not reproduce it on demand (the kernel before the fix
+    passes it too): a big scene's search passes, then a small handle whose segments do not fill their last tiles, repeatedly;
+    results equal those with the option off."""
     big = scenes.make_scene(seed=611, N=60000, Nmap=600000, L=3)
     eb = capi.Engine(big["params"])
     eb.map_build(big["map"])
