@@ -395,6 +395,10 @@ int malio_scan_order(malio_handle_t h, int mode);
  *   MALIO_OPT_PROBE_CACHE      1 (default): a search pass remembers every point's level-1 directory probe (cell, list start and
  *                              length); the next search pass of the same scan - the lists unchanged - reuses it for every point
  *                              that is still in its cell (exact: the same list) instead of probing the directory again.
+ *   MALIO_OPT_EARLY_MIN_QUERIES  a walk of an ordered level-1 list ends early only in scans of at least this many queries
+ *                              (default 32 768: below that the GPU has no queue of list lines to shorten and an unsettled
+ *                              query's second trip is all there is; a tile shard counts the points it serves). 0: always -
+ *                              the setting the edge-case tests run, and what a node of many small shards may want.
  *   MALIO_OPT_NODE_GATED       1 (default): malio_update_iterated_node / the node handle run the gated chain on every shard
  *                              (pass 0 through malio_measure_node, then one speculating pass per unit, the shards' rows
  *                              meeting in host memory between "sums seen" and "published"); 0: one pass at a time. Host
@@ -414,6 +418,7 @@ enum {
   MALIO_OPT_NODE_GATED = 9,
   MALIO_OPT_NL_SORTED = 10,
   MALIO_OPT_PROBE_CACHE = 11,
+  MALIO_OPT_EARLY_MIN_QUERIES = 12,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
   MALIO_OPT_DEBUG_GATE_STALL_MS = 101,
   MALIO_OPT_DEBUG_NODE_GATED_RUNS = 102,  /* read-only (malio_get_option): updates of this shard through the gated chain ... */

@@ -154,7 +154,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_PROBE_CACHE", MALIO_OPT_PROBE_CACHE}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_PROBE_CACHE", MALIO_OPT_PROBE_CACHE}, {"MALIO_EARLY_MIN_QUERIES", MALIO_OPT_EARLY_MIN_QUERIES}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -214,6 +214,10 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_node_gated = (int)value;
       return MALIO_OK;
+    case MALIO_OPT_EARLY_MIN_QUERIES:
+      if (value < 0.0 || value > 2e9) return MALIO_ERR_BAD_ARG;
+      c->opt_early_min_queries = (int)value;  // (read when a search pass is queued)
+      return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS:
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->fuse_debug_bad_guess = value != 0.0;
@@ -243,6 +247,7 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_NL_SORTED: *value = c->opt_nl_sorted; return MALIO_OK;
     case MALIO_OPT_PROBE_CACHE: *value = c->opt_probe_cache; return MALIO_OK;
     case MALIO_OPT_NODE_GATED: *value = c->opt_node_gated; return MALIO_OK;
+    case MALIO_OPT_EARLY_MIN_QUERIES: *value = c->opt_early_min_queries; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
     case MALIO_OPT_DEBUG_NODE_GATED_RUNS: *value = c->node_gated_runs; return MALIO_OK;  // (read-only counters)

@@ -330,6 +330,9 @@ struct Arena {
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
     if (e == hipSuccess) extra.push_back(q);
+#ifdef MALIO_POISON
+    if (e == hipSuccess) (void)hipMemset(q, 0xFF, bytes);
+#endif
     *out = q;
     return e;
   }
@@ -345,12 +348,25 @@ struct ArenaScope {  // allocations made through a scope die with it
   size_t mark, want_mark;
   explicit ArenaScope(Arena &ar) : a(ar), mark(ar.off), want_mark(ar.want) { a.depth++; }
   ~ArenaScope() {
+#ifdef MALIO_POISON
+    // developer build (make POISON=1): what a scope hands back reads as 0xFF.. from then on - a kernel that still uses a
+    // temporary of a scope that has ended, or slack nobody wrote, computes with NaNs / indices of 4 G instead of with whatever
+    // the last user left there. Blocking on purpose (the queued kernels of this scope finish first).
+    if (a.base && a.off > mark) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(a.base + mark, 0xFF, a.off - mark);
+      (void)hipDeviceSynchronize();
+    }
+#endif
     a.off = mark;
     if (--a.depth == 0) {
       if (!a.extra.empty()) {  // the block was too small: grow it for the next call
         const size_t need = a.want + a.want / 2;
         a.release_all();
         if (hipMalloc((void **)&a.base, need) == hipSuccess) a.cap = need;
+#ifdef MALIO_POISON
+        if (a.cap) (void)hipMemset(a.base, 0xFF, a.cap);
+#endif
       }
       a.want = 0;
     } else {
@@ -506,6 +522,7 @@ struct Ctx {
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
   int opt_nl_sorted = 1;       // MALIO_OPT_NL_SORTED
   int opt_probe_cache = 1;     // MALIO_OPT_PROBE_CACHE
+  int opt_early_min_queries = 32768;  // MALIO_OPT_EARLY_MIN_QUERIES: scans of at least this many queries end walks of ordered lists early (measure.hip, view_l1)
   int opt_node_gated = 1;      // MALIO_OPT_NODE_GATED: a shard's update runs the gated chain (host exchanges only)
   int node_gated_runs = 0;     // updates of a shard that went through the gated chain
   int node_gated_redone = 0;   // updates the gated chain of a shard handed back to the per-pass loop

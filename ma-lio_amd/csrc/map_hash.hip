@@ -518,7 +518,10 @@ __global__ void __launch_bounds__(BLK) k_nl_compact(const u64 *__restrict__ keys
 // (the ones a batch appended to: k_nl_place).
 __device__ __forceinline__ float nl_centre_d2(const float4 &e, float cx, float cy, float cz) {
   const float dx = e.x - cx, dy = e.y - cy, dz = e.z - cz;
-  return dx * dx + dy * dy + dz * dz;  // == measure.hip: nl_walk's r2 of the entries it has read
+  const float d2 = dx * dx + dy * dy + dz * dz;  // == measure.hip: nl_walk's r2 of the entries it has read
+  // (a non-finite key - a tombstone's +inf, or a NaN coordinate somebody put into the map - sorts behind everything: ranking by
+  // comparison needs a total order, and a NaN would compare false both ways and collide with another entry's rank)
+  return d2 < INFINITY ? d2 : INFINITY;
 }
 // one list of n <= 64 K entries, by the whole wave: K entries per lane (the usual list: K = 1)
 template <int K>

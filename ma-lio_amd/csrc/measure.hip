@@ -75,6 +75,25 @@ __device__ long long g_span[14][8192];  // 12: HW_ID, 13: XCC_ID of the workgrou
 #define STATE_ST(stmt) stmt
 #endif
 
+// Developer aid (make POISON=1 -> -DMALIO_POISON; never shipped): the hand-off structures the waves of a workgroup pass each
+// other through LDS start every kernel as 0x7FC0DEAD words - a quiet NaN as a float, (NaN, NaN) halves as a double, 2.1 G as a
+// map index (beyond every array: the access faults), 0xAD as a neighbour count - instead of what the previous workgroup on the
+// CU left there, which is usually a plausible value of the right kind (the probe-cache fault of round 5 was exactly that: a lane
+// without a point used a neighbouring workgroup's leftovers as its cached directory probe). The whole GPU suite runs green on this
+// build (tools/loop_suite.sh poison).
+#ifdef MALIO_POISON
+template <class T>
+__device__ __forceinline__ void poison_lds(T &obj) {
+  u32 *p = reinterpret_cast<u32 *>(&obj);
+  for (int k = (int)threadIdx.x; k < (int)(sizeof(T) / 4); k += (int)blockDim.x) p[k] = 0x7FC0DEADu;
+}
+#define POISON_LDS(obj) poison_lds(obj)
+#define POISON_SYNC() __syncthreads()
+#else
+#define POISON_LDS(obj)
+#define POISON_SYNC()
+#endif
+
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 cross(D3 a, D3 b) {
@@ -1205,6 +1224,12 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
     __syncthreads();
   }
   if (a.part.world > 1 && !(flags & 1)) {      // a workgroup of somebody else's tiles
+    // Nobody probes here, so nobody would overwrite these points' cached probes: entries of an earlier scan - another map epoch -
+    // would pass for this scan's as soon as one of the points crosses into an owned tile with a matching cell key. They are
+    // marked empty instead (a lane of a workgroup that does search overwrites its entry in phase B, owned or not).
+#ifndef KS_NO_PCACHE_MARK  // (A/B switch of tests/test_partition.py::test_tile_shard_forgets_cached_probes_of_an_earlier_scan: the kernel before the fix)
+    if (KS_PCACHE && cwave && (dy.skip & 4) && i < qend) a.pcache[i] = make_uint4(~0u, ~0u, 0u, 0u);
+#endif
     po.selected = false, po.skipped = true;  // (k_pass still owes the summation tree a zero tile)
     return cwave ? ROLE_CONTROL : ROLE_RETIRE;
   }
@@ -1398,6 +1423,9 @@ template <bool DEV, bool SKIP>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE))) k_search(Pass1Args a, NlView nl1, NlView nl2) {
   __shared__ SearchLds S;
   __shared__ float4 s_nbp[5][SQ];
+  POISON_LDS(S);
+  POISON_LDS(s_nbp);
+  POISON_SYNC();
   if (threadIdx.x == 0) S.nbp = s_nbp;  // (read by the control wave in phase C, behind the barriers of phases A and B)
   if (DEV && a.dl->done) return;
   const QuatConst &qc = DEV ? a.dl->qc : a.qc;
@@ -1573,6 +1601,11 @@ __global__ void __launch_bounds__(BLK) k_rows_reduce(Pass2Args a) {
   __shared__ double SB[BLK][17];  // b_p: u, hs, 0 0 0                                           (+1 pad)
   __shared__ double DW[BLK / 64][16][16];
   __shared__ double mm_s[5];
+  POISON_LDS(SA);
+  POISON_LDS(SB);
+  POISON_LDS(DW);
+  POISON_LDS(mm_s);
+  POISON_SYNC();
   if (DEV && a.dl->done) return;
   const u64 *mmslots = DEV ? a.mm_base + (size_t)a.dl->mm_parity * MM_SLOTS * 5 : a.mmslots;
   const PassConst &pc = DEV ? a.dl->pc : a.pc;
@@ -1904,10 +1937,14 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   // the 64 rows of the control wave for the MFMA operands: u[12], hs, 1/r (a_p = [u/r | u0..2 | 0], b_p = [u | hs | 0 0 0]
   // are formed when they are read: 7.7 KB instead of the two 17-double records of k_rows_reduce)
   __shared__ double U[SQ][15];
-  if (threadIdx.x == 0) S.nbp = reinterpret_cast<float4 (*)[SQ]>(&U[0][0]);  // (5 KB of U's 7.5: the fit is over before a row is staged)
 #if KS_SPLIT
   __shared__ RowPre RP;
+  POISON_LDS(RP);
 #endif
+  POISON_LDS(S);
+  POISON_LDS(U);
+  POISON_SYNC();
+  if (threadIdx.x == 0) S.nbp = reinterpret_cast<float4 (*)[SQ]>(&U[0][0]);  // (5 KB of U's 7.5: the fit is over before a row is staged)
   if (DEV && dl->done) return;
   const QuatConst &qc = DEV ? dl->qc : a.qc;
   const PassConst &pc = DEV ? dl->pc : f.pc;
@@ -2217,19 +2254,21 @@ __global__ void __launch_bounds__(BLK) k_nearest(const float4 *__restrict__ q, i
   out_cnt[qi] = c;
 }
 
-// n_queries: the scan the view is for. Ending a walk early saves LINES - what a full GPU's level-1 search queues for (DESIGN.md
-// section 3.7) - and costs the unsettled queries a dependent trip: on a scan that leaves most CUs with one workgroup or none
-// (BASELINE config 1: 157 workgroups) there is no queue to shorten and the trip is all there is (+1.2 us per pass, measured) -
-// such a scan walks its lists whole. (A tile shard serves 1 / world of its scan's points: that is its n_queries.)
-#ifndef KS_EARLY_MIN_QUERIES
-#define KS_EARLY_MIN_QUERIES 32768  // 512 workgroups: two per CU
-#endif
-static NlView view_of(const NList &nl, int n_queries = 0) {
+// early: ending a walk early saves LINES - what a full GPU's level-1 search queues for - and costs the
+// unsettled queries a dependent trip: on a scan that leaves most CUs with one workgroup or none (BASELINE config 1: 157
+// workgroups) there is no queue to shorten and the trip is all there is (+1.2 us per pass, measured) - such a scan walks its
+// lists whole. The threshold is the handle's (MALIO_OPT_EARLY_MIN_QUERIES, default 32 768 = 512 workgroups: two per CU; 0: every
+// scan cuts - what the edge-case tests run); a tile shard serves 1 / world of its scan's points: that is its number of queries.
+static NlView view_of(const NList &nl, int early = 0) {
   NlView v;
   v.table = nl.table, v.tmask = nl.tmask, v.pts = nl.pts, v.cf = nl.cf, v.inv_cf = nl.inv_cf;
   v.reach_cf = nl.pruned ? NL_REACH * nl.cf : nl.cf;
-  v.early = n_queries >= KS_EARLY_MIN_QUERIES ? 1 : 0;
+  v.early = early;
   return v;
+}
+static NlView view_l1(const Ctx *c) {
+  const int nq = c->part.world > 1 ? c->N / c->part.world : c->N;
+  return view_of(c->nl1, nq >= c->opt_early_min_queries ? 1 : 0);
 }
 
 int nearest_search(Ctx *c, const float4 *d_q, int n, int k, u32 *d_idx, float *d_d2, int *d_cnt) {
@@ -2494,6 +2533,15 @@ int measure_alloc(Ctx *c) {
     MALIO_HIP(hipMalloc(&c->d_cert, sizeof(float4) * K));
     MALIO_HIP(hipMalloc(&c->d_pcache, sizeof(uint4) * K));
     MALIO_HIP(hipMalloc(&c->d_kept, K));
+#ifdef MALIO_POISON
+    {  // (the per-point state a scan starts from is what its installation writes - scan_install - not what the allocator returned)
+      struct { void *p; size_t b; } arr[] = {{c->d_upload, sizeof(UploadRec) * K}, {c->d_scan, sizeof(float4) * K}, {c->d_perm, sizeof(u32) * K},
+        {c->d_nbr, sizeof(u32) * 5 * K}, {c->d_plane, sizeof(float4) * K}, {c->d_pd2, sizeof(float) * K}, {c->d_world, sizeof(float) * 3 * K},
+        {c->d_ucov, sizeof(double) * K}, {c->d_trace, sizeof(double) * K}, {c->d_sel, K}, {c->d_nfound, K}, {c->d_world4, sizeof(float4) * K},
+        {c->d_ny, sizeof(float) * K}, {c->d_cert, sizeof(float4) * K}, {c->d_pcache, sizeof(uint4) * K}, {c->d_kept, K}};
+      for (auto &x : arr) MALIO_HIP(hipMemset(x.p, 0xFF, x.b));
+    }
+#endif
   }
   size_t nb = (N + BLK - 1) / BLK + MALIO_MAX_LIDAR;
   if (nb > c->cap_partials) {
@@ -2919,7 +2967,7 @@ int pass_stage1(Ctx *c, const malio_state_t *s, int converge, double *d_minmax4_
   if (converge) {
     a.skip = search_skip_begin(c);
     const auto kern = c->opt_search_skip ? &k_search<false, true> : &k_search<false, false>;
-    hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2));
+    hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_l1(c), view_of(c->nl2));
     prof_mark(c, "k_search");
   } else {
     hipLaunchKernelGGL(k_reuse, dim3(nb), dim3(BLK), 0, c->stream, a);
@@ -3004,7 +3052,7 @@ int enqueue_pass_dev(Ctx *c, double *d_sums_out, double *d_mm_out, const GateArg
   // (whether a search pass of the enqueued-ahead loop may keep neighbours is in the control block; the instantiation that can
   // is used whenever the option is on)
   const auto kern = c->opt_search_skip ? &k_search<true, true> : &k_search<true, false>;
-  hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2));
+  hipLaunchKernelGGL(kern, dim3((c->N + SQ - 1) / SQ), dim3(KS_BLK), 0, c->stream, a, view_l1(c), view_of(c->nl2));
   Pass2Args b;
   const int nb = fill_pass2_static(c, b);
   b.dl = c->d_loop, b.mm_out = d_mm_out;
@@ -3096,7 +3144,7 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
   memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
   const auto kern = c->opt_search_skip ? &k_pass<false, true> : &k_pass<false, false>;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2), f, (const DevLoop *)nullptr);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_l1(c), view_of(c->nl2), f, (const DevLoop *)nullptr);
   prof_mark(c, "k_pass");
   launch_final_tiles(c, sb, nullptr, gate, row);
   prof_mark(c, "k_final_reduce");
@@ -3114,7 +3162,7 @@ int enqueue_pass_fused_dev(Ctx *c, const GateArgs *gate) {
   SegBlocks sb;
   const int nwg = fill_fuse_static(c, f, sb);
   const auto kern = c->opt_search_skip ? &k_pass<true, true> : &k_pass<true, false>;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_of(c->nl1, c->part.world > 1 ? c->N / c->part.world : c->N), view_of(c->nl2), f, (const DevLoop *)c->d_loop);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(KS_BLK), 0, c->stream, a, view_l1(c), view_of(c->nl2), f, (const DevLoop *)c->d_loop);
   launch_final_tiles(c, sb, c->d_loop, gate);
   MALIO_HIP(hipGetLastError());
   c->fuse_passes++;

@@ -74,14 +74,29 @@ CASES = [
 ]
 
 
+# MALIO_OPT_EARLY_MIN_QUERIES: the walk of an ordered level-1 list ends after its first 32 entries (measure.hip: nl_walk<.., EARLY>)
+# only in scans of >= 32 768 queries by default - every edge scene below is smaller. "cut" runs them with the threshold at 0:
+# the early exit, its continuation for unsettled queries and the cached probes against the ORACLE (whose search has no early
+# exit to get wrong, ikd_Tree.cpp:426-461) at a 1 000 m origin, with four LiDARs, in the 800 m tunnel, with map_unc, ...
+EARLY = pytest.mark.parametrize("early", [None, 0], ids=["whole", "cut"])
+
+
+def early_opts(early, **more):
+    o = dict(more)
+    if early is not None:
+        o["early_min_queries"] = early
+    return o
+
+
+@EARLY
 @pytest.mark.parametrize("skip", [0, 1], ids=["walk", "skip"])
 @pytest.mark.parametrize("kw", CASES, ids=lambda k: "s%d" % k["seed"])
-def test_pass_and_update_parity(capi, orc, scenes, kw, skip):
+def test_pass_and_update_parity(capi, orc, scenes, kw, skip, early):
     """skip = 1: MALIO_OPT_SEARCH_SKIP on - the later search passes keep cached neighbours where a certificate allows."""
     kw = dict(kw)
     yardstick = kw.pop("yardstick", False)
     sc = scenes.make_scene(**kw)
-    eng, o = make_pair(capi, orc, sc, opts={"search_skip": skip})
+    eng, o = make_pair(capi, orc, sc, opts=early_opts(early, search_skip=skip))
     compare_pass(eng, o, sc["state0"], True)
     s2 = sc["state0"].copy()
     s2[0:3] += [0.012, -0.02, 0.006]
@@ -175,7 +190,8 @@ def test_short_loops_all_modes(capi, orc, scenes, max_iteration):
         assert np.array_equal(eng.scan_get()["selected"], o.scan_get()["selected"])
 
 
-def test_table_index_clamps(capi, orc, scenes):
+@EARLY
+def test_table_index_clamps(capi, orc, scenes, early):
     """normal_x outside the table / negative: the two different clamps of laserMapping.cpp:694-696 vs :737-739."""
     sc = scenes.make_scene(seed=211, N=1500, Nmap=30000, L=3, n_table=6)
     scan = sc["scan"]
@@ -183,7 +199,7 @@ def test_table_index_clamps(capi, orc, scenes):
     scan[1::7, 4] = 9.3    # >= size   : both clamp to size-2
     scan[2::7, 4] = -1.0   # negative  : unsigned compare -> size-2
     scan[3::7, 4] = -0.4   # int(-0.4) == 0
-    eng, o = make_pair(capi, orc, sc)
+    eng, o = make_pair(capi, orc, sc, opts=early_opts(early))
     compare_pass(eng, o, sc["state0"], True)
 
 
@@ -248,7 +264,8 @@ def test_valid_then_invalid_passes_leave_projected_P(capi, orc, scenes):
     assert np.abs(v["P"] - sc["P0"]).max() < 1e-3 * np.abs(sc["P0"]).max()  # ... and not a posterior either
 
 
-def test_tiny_map_and_small_M_fallback(capi, orc, scenes):
+@EARLY
+def test_tiny_map_and_small_M_fallback(capi, orc, scenes, early):
     """Fewer accepted points than state dimensions -> esekfom.hpp:574-582 (K via the M x M system)."""
     sc = scenes.make_scene(seed=213, N=400, Nmap=6000, L=1)
     # keep only a 3 m patch of the map: a handful of scan points find 5 neighbours
@@ -256,7 +273,7 @@ def test_tiny_map_and_small_M_fallback(capi, orc, scenes):
     keep = np.linalg.norm(sc["map"][:, :3] - c[None, :].astype(np.float32), axis=1) < 1.6
     sc["map"] = sc["map"][keep]
     assert 5 < keep.sum() < 200
-    eng, o = make_pair(capi, orc, sc)
+    eng, o = make_pair(capi, orc, sc, opts=early_opts(early))
     g, r = compare_pass(eng, o, sc["state0"], True)
     assert 0 < r["M"] < 23
     eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
@@ -267,7 +284,7 @@ def test_tiny_map_and_small_M_fallback(capi, orc, scenes):
     assert_P_close(u["P"], v["P"])
     # a map with fewer than 5 points accepts nothing
     sc["map"] = sc["map"][:4]
-    eng, o = make_pair(capi, orc, sc)
+    eng, o = make_pair(capi, orc, sc, opts=early_opts(early))
     g, r = compare_pass(eng, o, sc["state0"], True)
     assert not g["valid"]
 

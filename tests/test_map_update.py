@@ -317,8 +317,8 @@ def test_gpu_in_place_list_updates_equal_a_full_rebuild(orc, capi, scenes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [1, 3, 5])
-def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scenes, cfg):
+@pytest.mark.parametrize("cfg,early", [(1, None), (1, 0), (3, None), (5, None)], ids=["cfg1", "cfg1-cut", "cfg3", "cfg5"])
+def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scenes, cfg, early):
     """MALIO_OPT_NL_SORTED (default on): the level-1 lists in order of distance from the cell centre let a walk end after
     its first 32 entries when those prove the rest irrelevant. Same five neighbours, same order, same bits as the whole
     walk over unordered lists (rounds 2-4) - through a search pass, an iterated update and a map that changed in place."""
@@ -327,6 +327,8 @@ def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scen
     for srt in (1, 0):
         eng = capi.Engine(sc["params"])
         eng.set_option("nl_sorted", srt)
+        if early is not None:  # (config 1's 10 k points are below the default threshold: both engines would walk whole lists)
+            eng.set_option("early_min_queries", early)
         eng.map_build(sc["map"])
         eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
         lo = eng.list_order()

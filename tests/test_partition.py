@@ -90,11 +90,18 @@ def _single(capi, sc):
 @pytest.mark.parametrize("kw", [dict(seed=311, N=6000, Nmap=150000, L=3), dict(seed=312, N=4000, Nmap=90000, L=2, map_unc=True),
                                 dict(seed=313, N=5000, Nmap=120000, L=3, kind="tunnel", det_range=500.0)],
                          ids=lambda k: "s%d" % k["seed"])
-def test_node_handle_equals_single_engine(capi, scenes, partition, kw):
+@pytest.mark.parametrize("early", [None, 0], ids=["whole", "cut"])
+def test_node_handle_equals_single_engine(capi, scenes, partition, kw, early):
+    """early = 0 (MALIO_OPT_EARLY_MIN_QUERIES): walks of ordered lists end early on the shards and on the single engine, whatever
+    the scan's size - the early exit and the cached probes on tile / column shards, where whole workgroups serve nobody."""
     sc = scenes.make_scene(**kw)
-    one = _single(capi, sc)
+    one = capi.Engine(sc["params"], device=0)
     G = 3
     nd = capi.Node(sc["params"], [0] * G, partition=_part(capi, partition), tile_m=12.0)
+    if early is not None:
+        one.set_option("early_min_queries", early), nd.set_option("early_min_queries", early)
+    one.map_build(sc["map"])
+    one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
     nd.map_build(sc["map"])
     if partition != "scan":
         sizes = nd.map_sizes()
@@ -487,3 +494,62 @@ def test_node_resident_front_end_and_nearest_search(capi, scenes, partition):
     with pytest.raises(RuntimeError):  # the resident clouds were consumed
         nd.scan_set_resident(leaf, sc["tables"], sc["temporal_comp"])
     nd.close()
+
+
+@pytest.mark.gpu
+def test_tile_shard_forgets_cached_probes_of_an_earlier_scan(capi, scenes):
+    """MALIO_OPT_PROBE_CACHE on a tile shard (round-5 advisor finding). A workgroup whose 64 points all belong to other shards
+    leaves the search at once and probes nothing - so nothing overwrote its points' cached probes, and entries of an EARLIER scan,
+    against another map, passed for this scan's as soon as the points crossed into an owned tile of the same cell key between two
+    search passes of one update. Staged here: scan A on map A fills the cache; the map is rebuilt (every list moves); the same
+    points, installed again, first land a whole number of tiles AND of 8-cell patches away (36 m: same grouping order, tiles of the
+    other shard - every workgroup leaves early), then back where scan A had them: same cell keys as the stale entries. The second
+    search pass must find what an unpartitioned engine on map B finds."""
+    sc = scenes.make_scene(seed=315, N=6000, Nmap=150000, L=3)
+    world, tile = 2, 12.0
+    one = capi.Engine(sc["params"])
+    one.map_build(sc["map"])
+    one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+    one.measure(sc["state0"], True)
+    w = one.scan_get()["world"]
+    t = np.floor(w / tile).astype(np.int64)
+    inner = (np.abs(w / tile - np.round(w / tile)) > 1.0 / tile).all(1)  # a metre away from every tile face
+    keys, cnt = np.unique(t[inner], axis=0, return_counts=True)
+    pick = inner & (t == keys[np.argmax(cnt)]).all(1)
+    assert pick.sum() >= 200
+    scan = sc["scan"][pick]
+    r0 = int(capi.part_owner(w[pick][:1], world, tile)[0])
+    assert (capi.part_owner(w[pick], world, tile) == r0).all()
+    shift = None
+    for k in (1, -1, 2, -2, 3, -3, 4, -4):
+        for ax in (0, 1):
+            d = np.zeros(3)
+            d[ax] = 36.0 * k
+            if (capi.part_owner((w[pick] + d).astype(np.float32), world, tile) != r0).all():
+                shift = d
+                break
+        if shift is not None:
+            break
+    assert shift is not None
+    away = sc["state0"].copy()
+    away[0:3] += shift
+    mapB = sc["map"][np.random.default_rng(4).random(sc["Nmap"]) < 0.7]  # (every list starts somewhere else)
+    e = capi.Engine(sc["params"])
+    e.set_partition(r0, world, tile)
+    e.set_option("early_min_queries", 0)
+    e.map_build(sc["map"])
+    e.scan_set(scan, sc["tables"], sc["temporal_comp"])
+    assert e.measure(sc["state0"], True)["M"] > 100  # scan A: every probe cached
+    e.map_build(mapB)
+    e.scan_set(scan, sc["tables"], sc["temporal_comp"])
+    assert e.measure(away, True)["M"] == 0 and not e.scan_owned().any()  # nobody's points here: every workgroup leaves early
+    got = e.measure(sc["state0"], True)
+    ref = capi.Engine(sc["params"])
+    ref.map_build(mapB)
+    ref.scan_set(scan, sc["tables"], sc["temporal_comp"])
+    want = ref.measure(sc["state0"], True)
+    assert e.scan_owned().all() and got["M"] == want["M"] > 100
+    a, b = e.scan_get(), ref.scan_get()
+    for f in ("nearest_cnt", "nearest", "selected", "normvec", "res_last"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.abs(got["HtRinvH"] - want["HtRinvH"]).max() <= 1e-12 * np.abs(want["HtRinvH"]).max()  # (a shard groups its scan differently: summation order)
