@@ -380,6 +380,8 @@ def main():
     ap.add_argument("--config", type=int, default=0, help="BASELINE.json config number (1-based); default 2 at one GPU, 4 beyond")
     ap.add_argument("--tile", type=float, default=16.0, help="edge [m] of the cubic tiles of the spatially sharded map (N > 1, variant tiles+shm)")
     ap.add_argument("--column-tile", type=float, default=24.0, help="edge [m] of the COLUMN tiles (N > 1 headline: MALIO_TILE_COLUMNS)")
+    ap.add_argument("--map-order", choices=["raster", "shuffled"], default="raster",
+                    help="order the synthetic map is handed to malio_map_build in: as generated (surface by surface, raster) or shuffled (what a map that grew scan by scan looks like to the gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="N = 1 only: a proxy for the scaling run on ONE GPU - every shard of a G-way sharded BASELINE config "
@@ -418,6 +420,8 @@ def main():
     cfg = scenes.CONFIGS[args.config]
     sc = scenes.make_scene(cfg=args.config)
     N, L = sc["N"], sc["L"]
+    if args.map_order == "shuffled":  # (same point set; the line says so under config.map_order)
+        sc["map"] = sc["map"][np.random.default_rng(77).permutation(sc["Nmap"])]
 
     eng = capi.Engine(sc["params"], device=dev_index)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -612,7 +616,8 @@ def main():
         "config": {"workload": "%s: %d-pt %d-LiDAR scan vs %d-pt map, one search pass (converge=1) per step" % (
             cfg["name"], N, L, sc["Nmap"]), "step": "full search: MALIO_OPT_SEARCH_SKIP off, MALIO_OPT_PROBE_CACHE off", "points_per_gpu": N,
             "map_points": sc["Nmap"], "lidars": L,
-            "M_accepted": int(out.M), "seed": sc["seed"]},
+            "M_accepted": int(out.M), "seed": sc["seed"],
+            "map_order": args.map_order + " as handed to malio_map_build (the library keeps its copy in cell order: MALIO_OPT_MAP_CELL_ORDER)"},
         "eskf": eskf, "secondary": secondary, "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)

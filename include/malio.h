@@ -395,6 +395,12 @@ int malio_scan_order(malio_handle_t h, int mode);
  *   MALIO_OPT_PROBE_CACHE      1 (default): a search pass remembers every point's level-1 directory probe (cell, list start and
  *                              length); the next search pass of the same scan - the lists unchanged - reuses it for every point
  *                              that is still in its cell (exact: the same list) instead of probing the directory again.
+ *   MALIO_OPT_MAP_CELL_ORDER   1 (default): a (re)build of the search structures also puts the map array into cell order (columns of
+ *                              level-1 cells, in the order the scan's grouping visits them), so that the five neighbours a query gathers for its plane fit share one
+ *                              or two 128-byte lines whatever order the map was handed over or grew in; points added since
+ *                              sit behind, in arrival order, until the next rebuild. Same neighbours either way (exact ties
+ *                              of two map points' distances - (d2, slot) order - may resolve differently); malio_map_get and
+ *                              the keeper rule's ties keep speaking of insertion order. Takes effect at the next rebuild.
  *   MALIO_OPT_EARLY_MIN_QUERIES  a walk of an ordered level-1 list ends early only in scans of at least this many queries
  *                              (default 32 768: below that the GPU has no queue of list lines to shorten and an unsettled
  *                              query's second trip is all there is; a tile shard counts the points it serves). 0: always -
@@ -419,6 +425,7 @@ enum {
   MALIO_OPT_NL_SORTED = 10,
   MALIO_OPT_PROBE_CACHE = 11,
   MALIO_OPT_EARLY_MIN_QUERIES = 12,
+  MALIO_OPT_MAP_CELL_ORDER = 13,
   MALIO_OPT_DEBUG_FUSE_BAD_GUESS = 100,
   MALIO_OPT_DEBUG_GATE_STALL_MS = 101,
   MALIO_OPT_DEBUG_NODE_GATED_RUNS = 102,  /* read-only (malio_get_option): updates of this shard through the gated chain ... */

@@ -35,7 +35,7 @@ EXPORTS = [
 ]
 # malio_set_option (include/malio.h)
 OPT = dict(fuse=1, search_skip=2, maint_stream=3, mapinc_small=4, gate_pinned=5, gate_timeout_ms=6, scan_set_sync=7,
-           nl_full_blocks=8, node_gated=9, nl_sorted=10, probe_cache=11, early_min_queries=12, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
+           nl_full_blocks=8, node_gated=9, nl_sorted=10, probe_cache=11, early_min_queries=12, map_cell_order=13, debug_fuse_bad_guess=100, debug_gate_stall_ms=101, debug_node_gated_runs=102,
            debug_node_gated_redone=103)
 PART_SCAN, PART_TILES, PART_COLUMNS = 0, 1, 2  # (COLUMNS: tiles that are whole vertical columns, no halo above / below)
 TILE_CUBES, TILE_COLUMNS = 0, 1

@@ -154,7 +154,7 @@ static void options_from_env(malio_handle_t c) {
       {"MALIO_FUSE", MALIO_OPT_FUSE}, {"MALIO_SEARCH_SKIP", MALIO_OPT_SEARCH_SKIP}, {"MALIO_MAINT_STREAM", MALIO_OPT_MAINT_STREAM},
       {"MALIO_MAPINC_SMALL", MALIO_OPT_MAPINC_SMALL}, {"MALIO_GATE_PINNED", MALIO_OPT_GATE_PINNED},
       {"MALIO_GATE_TIMEOUT_MS", MALIO_OPT_GATE_TIMEOUT_MS}, {"MALIO_SCAN_SET_SYNC", MALIO_OPT_SCAN_SET_SYNC},
-      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_PROBE_CACHE", MALIO_OPT_PROBE_CACHE}, {"MALIO_EARLY_MIN_QUERIES", MALIO_OPT_EARLY_MIN_QUERIES}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
+      {"MALIO_NL_FULL_BLOCKS", MALIO_OPT_NL_FULL_BLOCKS}, {"MALIO_NL_SORTED", MALIO_OPT_NL_SORTED}, {"MALIO_PROBE_CACHE", MALIO_OPT_PROBE_CACHE}, {"MALIO_EARLY_MIN_QUERIES", MALIO_OPT_EARLY_MIN_QUERIES}, {"MALIO_MAP_CELL_ORDER", MALIO_OPT_MAP_CELL_ORDER}, {"MALIO_NODE_GATED", MALIO_OPT_NODE_GATED}, {"MALIO_DEBUG_FUSE_BAD_GUESS", MALIO_OPT_DEBUG_FUSE_BAD_GUESS},
       {"MALIO_DEBUG_GATE_STALL_MS", MALIO_OPT_DEBUG_GATE_STALL_MS}};
   for (const auto &t : tab) {
     double v;
@@ -214,6 +214,10 @@ int malio_set_option(malio_handle_t h, int option, double value) {
       if (!is01) return MALIO_ERR_BAD_ARG;
       c->opt_node_gated = (int)value;
       return MALIO_OK;
+    case MALIO_OPT_MAP_CELL_ORDER:
+      if (!is01) return MALIO_ERR_BAD_ARG;
+      c->opt_map_cell_order = (int)value;  // takes effect at the next rebuild
+      return MALIO_OK;
     case MALIO_OPT_EARLY_MIN_QUERIES:
       if (value < 0.0 || value > 2e9) return MALIO_ERR_BAD_ARG;
       c->opt_early_min_queries = (int)value;  // (read when a search pass is queued)
@@ -248,6 +252,7 @@ int malio_get_option(malio_handle_t h, int option, double *value) {
     case MALIO_OPT_PROBE_CACHE: *value = c->opt_probe_cache; return MALIO_OK;
     case MALIO_OPT_NODE_GATED: *value = c->opt_node_gated; return MALIO_OK;
     case MALIO_OPT_EARLY_MIN_QUERIES: *value = c->opt_early_min_queries; return MALIO_OK;
+    case MALIO_OPT_MAP_CELL_ORDER: *value = c->opt_map_cell_order; return MALIO_OK;
     case MALIO_OPT_DEBUG_FUSE_BAD_GUESS: *value = c->fuse_debug_bad_guess ? 1.0 : 0.0; return MALIO_OK;
     case MALIO_OPT_DEBUG_GATE_STALL_MS: *value = c->gate_debug_stall_ms; return MALIO_OK;
     case MALIO_OPT_DEBUG_NODE_GATED_RUNS: *value = c->node_gated_runs; return MALIO_OK;  // (read-only counters)
@@ -295,7 +300,7 @@ int malio_destroy(malio_handle_t h) {
   free_dev_loop(c);
   c->arena.release_all();
   for (auto &rc : c->res) fr(rc.d);
-  fr(c->d_map_in), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept), fr(c->d_pcache);
+  fr(c->d_map_in), fr(c->d_map_ord), fr(c->d_world4), fr(c->d_mmslots), fr(c->d_ny), fr(c->d_cert), fr(c->d_kept), fr(c->d_pcache);
   fr(c->d_map_alt), fr(c->d_raw), fr(c->d_packinfo), fr(c->d_sort_cnt), fr(c->d_del);
   if (c->h_packinfo) (void)hipHostFree(c->h_packinfo);
   fr(c->d_upload), fr(c->d_scan), fr(c->d_perm), fr(c->d_unc), fr(c->d_nbr), fr(c->d_plane), fr(c->d_pd2);
@@ -425,6 +430,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
     MALIO_HIP(hipStreamSynchronize(c->stream));  // (the arena's temporaries are handed back with this scope)
     c->map_n = (int)need;
     c->map_dead = 0;
+    c->map_sorted_n = 0;  // (as uploaded: insertion order)
     c->map_epoch++;
     int rc = map_rebuild_search(c);
     (void)hipStreamSynchronize(c->stream);
@@ -440,6 +446,7 @@ int malio_map_build(malio_handle_t h, const malio_point_t *pts, int n) {
   MALIO_HIP(hipMemcpyAsync(c->d_map_in, stage, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   c->map_n = n;
   c->map_dead = 0;
+  c->map_sorted_n = 0;  // (as uploaded: insertion order)
   c->map_epoch++;
   int rc = map_rebuild_search(c);
   (void)hipStreamSynchronize(c->stream);
@@ -541,9 +548,20 @@ int malio_map_get(malio_handle_t h, malio_point_t *out, int cap, int *out_n) {
   if (int rcj = maint_join(c)) return rcj;
   std::vector<float4> mp((size_t)c->map_n);
   MALIO_HIP(hipMemcpyAsync(mp.data(), c->d_map_in, sizeof(float4) * mp.size(), hipMemcpyDeviceToHost, c->stream));
+  // "map order" is INSERTION order, whatever order the slots are kept in (the array's first map_sorted_n slots are in cell order
+  // since the last rebuild, d_map_ord holds their ranks): slot_of[rank] first, then the ranks in turn
+  std::vector<u32> slot_of;
+  if (c->map_sorted_n > 0) {
+    std::vector<u32> ord((size_t)c->map_sorted_n);
+    MALIO_HIP(hipMemcpyAsync(ord.data(), c->d_map_ord, sizeof(u32) * ord.size(), hipMemcpyDeviceToHost, c->stream));
+    MALIO_HIP(hipStreamSynchronize(c->stream));
+    slot_of.resize(ord.size());
+    for (size_t i = 0; i < ord.size(); i++) slot_of[ord[i]] = (u32)i;
+  }
   MALIO_HIP(hipStreamSynchronize(c->stream));
   int k = 0;
-  for (size_t i = 0; i < mp.size() && k < cap; i++) {
+  for (size_t e = 0; e < mp.size() && k < cap; e++) {
+    const size_t i = e < slot_of.size() ? slot_of[e] : e;
     if (std::isinf(mp[i].x)) continue;  // deleted slot
     malio_point_t p;
     memset(&p, 0, sizeof(p));

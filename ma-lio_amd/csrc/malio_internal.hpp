@@ -445,6 +445,13 @@ struct Ctx {
   float4 *d_map_in = nullptr;  // [map_n] map array: x y z normal_y, slot index = map id (plane fit + Nearest_Points)
   float4 *d_map_alt = nullptr;  // compaction target of map_add / map_delete_boxes (swapped with d_map_in)
   size_t cap_map_in = 0, cap_map_alt = 0;
+  // The map array in CELL ORDER (round 6, MALIO_OPT_MAP_CELL_ORDER): a rebuild leaves slots [0, map_sorted_n) sorted by their
+  // level-1 cell, columns of cells in the scan grouping's order (map_update.hip: map_rebuild_search), so that the five neighbours a query gathers for its plane fit
+  // share one or two 128-byte lines; d_map_ord[slot] is the slot's rank in INSERTION order (what "lowest map index" means to the
+  // keeper rule's ties, k_vox_add, and the order malio_map_get hands the map out in). Slots appended since are their own rank.
+  u32 *d_map_ord = nullptr;
+  size_t cap_map_ord = 0;
+  int map_sorted_n = 0;
   unsigned char *d_del = nullptr;  // per-slot "deleted by this batch" marks of the voxel update; all zero between calls (k_map_kill_list clears what it kills)
   size_t cap_del = 0;
   int map_dead = 0;  // slots of d_map_in[0, map_n) that hold a deleted point (x = +inf)
@@ -522,6 +529,7 @@ struct Ctx {
   int opt_nl_full_blocks = 0;  // MALIO_OPT_NL_FULL_BLOCKS
   int opt_nl_sorted = 1;       // MALIO_OPT_NL_SORTED
   int opt_probe_cache = 1;     // MALIO_OPT_PROBE_CACHE
+  int opt_map_cell_order = 1;  // MALIO_OPT_MAP_CELL_ORDER (takes effect at the next rebuild)
   int opt_early_min_queries = 32768;  // MALIO_OPT_EARLY_MIN_QUERIES: scans of at least this many queries end walks of ordered lists early (measure.hip, view_l1)
   int opt_node_gated = 1;      // MALIO_OPT_NODE_GATED: a shard's update runs the gated chain (host exchanges only)
   int node_gated_runs = 0;     // updates of a shard that went through the gated chain
@@ -647,6 +655,7 @@ int decode_velodyne(Ctx *c, const unsigned char *data, int n, const malio_pc2_la
                     float time_unit_scale, malio_point_t *out, int cap, int *out_n, double *maximum_time);
 
 // voxel.hip
+int radix_sort_pairs_u32(Ctx *c, ArenaScope &sc, u32 *&k1, u32 *&k2, u32 *&v1, u32 *&v2, int n, int bits);  // voxel.hip
 int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,
                          int *out_n, bool *passthrough);
 int voxel_downsample(Ctx *c, const malio_point_t *pts, int n, float leaf, int normal_mode, malio_point_t *out, int cap,

@@ -47,9 +47,15 @@ __device__ __forceinline__ float calc_dist3(float ax, float ay, float az, float 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// (the map array is kept in cell order, see map_rebuild_search)
+// A slot's rank in insertion order: the side array for the slots the last rebuild sorted, the slot itself for what was
+// appended since.
+__device__ __forceinline__ u32 map_ord(const u32 *__restrict__ ord, u32 nsorted, u32 slot) { return slot < nsorted ? ord[slot] : slot; }
+
 struct Winner {
   float x, y, z, cov, dist;
-  u32 rank;  // 0 = the new point, 1 + map index = stored point, 0xFFFFFFFF = the new point kept earlier in this call
+  u32 rank;  // 0 = the new point, 1 + rank in insertion order = stored point, 0xFFFFFFFF = the new point kept earlier in this call
+  u32 slot;  // a stored point's slot in the map array
   bool near;
 };
 
@@ -69,7 +75,8 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
                                                  const float4 *__restrict__ lpts, float linv_cf,
                                                  const float4 *__restrict__ mapp, int have_map, float ds,
                                                  unsigned char *del, u32 *dlist, u32 *addf,
-                                                 u32 *counters /*[0] adds [1] deletions*/) {
+                                                 u32 *counters /*[0] adds [1] deletions*/,
+                                                 const u32 *__restrict__ ord, u32 nsorted /* map_ord: "lowest map index" = first inserted */) {
   u32 slot = blockIdx.x * BLK + threadIdx.x;
   if (slot >= ntsize) return;
   Cell nc = ntable[slot];
@@ -102,7 +109,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
       vox_find(ltable, ltmask, key, es, ec);
     }
     Winner w;
-    w.x = p.x, w.y = p.y, w.z = p.z, w.cov = p.w, w.rank = 0;
+    w.x = p.x, w.y = p.y, w.z = p.z, w.cov = p.w, w.rank = 0, w.slot = 0xFFFFFFFFu;
     w.dist = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
     w.near = w.dist < near_th;
     u32 inbox = 0;
@@ -133,7 +140,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
         else
           cand_overflow = true;
         Winner b;
-        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = mapp[mi].w, b.rank = 1u + mi;
+        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = mapp[mi].w, b.rank = 1u + map_ord(ord, nsorted, mi), b.slot = mi;
         b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
         b.near = b.dist < near_th;
         if (displaces(w, b)) w = b;
@@ -144,7 +151,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
       if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
         inbox++;
         Winner b;
-        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = q.w, b.rank = NONE;
+        b.x = q.x, b.y = q.y, b.z = q.z, b.cov = q.w, b.rank = NONE, b.slot = 0xFFFFFFFFu;
         b.dist = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
         b.near = b.dist < near_th;
         if (displaces(w, b)) w = b;
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
       if (!cand_overflow) {
         for (int k = 0; k < nc; k++) {
           const u32 mi = cand[k];
-          if (w.rank == 1u + mi) continue;
+          if (w.slot == mi) continue;
           del[mi] = 1;
           dlist[atomicAdd(&counters[1], 1u)] = mi;  // order is irrelevant: every entry is tombstoned independently
         }
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(BLK) k_vox_add(const Cell *__restrict__ ntable
           if (!(bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z))
             continue;
           const u32 mi = __float_as_uint(q.w);
-          if (del[mi] || w.rank == 1u + mi) continue;
+          if (del[mi] || w.slot == mi) continue;
           del[mi] = 1;
           dlist[atomicAdd(&counters[1], 1u)] = mi;
         }
@@ -410,6 +417,43 @@ __global__ void __launch_bounds__(BLK) k_alive_flags(const float4 *__restrict__ 
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i <= n) keep[i] = (i < n && !isinf(mapp[i].x)) ? 1u : 0u;  // keep[n] = 0: the scan leaves the total at [n]
 }
+// ---- the map array in cell order (round 6) ------------------------------------------------------------------------------
+// keep[rank in insertion order] = the slot is alive; keep[n] = 0 (the scan leaves the total there)
+__global__ void __launch_bounds__(BLK) k_alive_by_ord(const float4 *__restrict__ mapp, int n, const u32 *__restrict__ ord, u32 nsorted,
+                                                      u32 *keep) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i == n) keep[n] = 0u;
+  if (i < n) keep[map_ord(ord, nsorted, (u32)i)] = isinf(mapp[i].x) ? 0u : 1u;
+}
+// the alive slots back in insertion order, packed
+__global__ void __launch_bounds__(BLK) k_compact_by_ord(const float4 *__restrict__ mapp, int n, const u32 *__restrict__ ord, u32 nsorted,
+                                                        const u32 *__restrict__ kpos, float4 *dst) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = mapp[i];
+  if (!isinf(p.x)) dst[kpos[map_ord(ord, nsorted, (u32)i)]] = p;
+}
+// Sort key: the point's level-1 cell as (cy, cx, cz) - columns of cells, x running fastest: the order the scan's grouping hands
+// the queries to the workgroups in (measure.hip: k_sort_count - bucket = column, cy major), so that the 64 queries of a
+// workgroup gather their neighbours from ONE stretch of the array. Measured on the CPU (tools/gather_lines.py, BASELINE config
+// 2, distinct 128-byte lines of the map array per 64-query workgroup): 80 - 83 in this order, 92 by Morton code, 78 in the
+// raster order the synthetic scene happens to be generated in - and 247 for the same map shuffled, which is what a map that
+// grew scan by scan looks like to the gather. 10 + 10 + 7 bits (1 152 m x 1 152 m x 144 m; beyond that the key wraps and two
+// far-apart cells interleave, which costs those cells' lines their locality and nothing else); ties keep insertion order.
+__global__ void __launch_bounds__(BLK) k_cell_keys(const float4 *__restrict__ mapp, int n, float inv_cf, u32 *keys, u32 *vals) {
+  int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = mapp[i];
+  const u32 cx = (u32)(int)floorf(p.x * inv_cf) & 1023u, cy = (u32)(int)floorf(p.y * inv_cf) & 1023u, cz = (u32)(int)floorf(p.z * inv_cf) & 127u;
+  keys[i] = (cy << 17) | (cx << 7) | cz;
+  vals[i] = (u32)i;
+}
+__global__ void __launch_bounds__(BLK) k_map_permute(const float4 *__restrict__ src, const u32 *__restrict__ vals, int n, float4 *dst, u32 *ord) {
+  int j = blockIdx.x * BLK + threadIdx.x;
+  if (j >= n) return;
+  const u32 v = vals[j];
+  dst[j] = src[v], ord[j] = v;
+}
 __global__ void __launch_bounds__(BLK) k_fill_u32(u32 *p, u32 v, int n) {
   int i = blockIdx.x * BLK + threadIdx.x;
   if (i < n) p[i] = v;
@@ -536,26 +580,56 @@ int map_rebuild_search(Ctx *c) {
   if (int rc = map_apply_finish(c)) return rc;
   c->search_dirty = false;
   c->probe_valid = false;  // (the lists move: no cached directory probe survives a rebuild)
-  if (c->map_dead > 0 && c->map_n > 0) {
+  // (1) back to insertion order with the deleted slots swept out (indices change) - nothing to do for an array that IS in
+  // insertion order and has no dead slot (a fresh malio_map_build)
+  if ((c->map_dead > 0 || c->map_sorted_n > 0) && c->map_n > 0) {
     ArenaScope sc(c->arena);
     u32 *keep = nullptr, *kpos = nullptr, *tiles = nullptr;
     const int n0 = c->map_n;
     MALIO_HIP(sc.get(&keep, (size_t)n0 + 1));
     MALIO_HIP(sc.get(&kpos, (size_t)n0 + 1));
     MALIO_HIP(sc.get(&tiles, (size_t)(n0 + 1 + 1023) / 1024 + 2));
-    hipLaunchKernelGGL(k_alive_flags, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, keep);
+    hipLaunchKernelGGL(k_alive_by_ord, dim3((n0 + 1 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, (const u32 *)c->d_map_ord,
+                       (u32)c->map_sorted_n, keep);
     exclusive_scan_u32(c, keep, kpos, tiles, n0 + 1);
     u32 alive = 0;
     MALIO_HIP(hipMemcpyAsync(&alive, kpos + n0, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     MALIO_HIP(hipStreamSynchronize(c->stream));
     int rc = ensure_alt(c, (size_t)alive + (size_t)alive / 4 + 4096);
     if (rc != MALIO_OK) return rc;
-    hipLaunchKernelGGL(k_compact, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, keep, kpos, n0,
-                       (const u32 *)nullptr, c->d_map_alt);
+    hipLaunchKernelGGL(k_compact_by_ord, dim3((n0 + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n0, (const u32 *)c->d_map_ord,
+                       (u32)c->map_sorted_n, kpos, c->d_map_alt);
     MALIO_HIP(hipStreamSynchronize(c->stream));
     swap_maps(c);
     c->map_n = (int)alive;
     c->map_dead = 0;
+    c->map_sorted_n = 0;
+    c->map_epoch++;
+  }
+  // (2) into cell order (k_cell_keys); the lists below are built from the array as it then stands, so their entries, the
+  // neighbour ids of the search passes and the gather all speak of the new slots
+  if (c->opt_map_cell_order && c->map_n > 1) {
+    ArenaScope sc(c->arena);
+    const int n = c->map_n;
+    u32 *k1 = nullptr, *k2 = nullptr, *v1 = nullptr, *v2 = nullptr;
+    MALIO_HIP(sc.get(&k1, (size_t)n));
+    MALIO_HIP(sc.get(&k2, (size_t)n));
+    MALIO_HIP(sc.get(&v1, (size_t)n));
+    MALIO_HIP(sc.get(&v2, (size_t)n));
+    hipLaunchKernelGGL(k_cell_keys, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, n, 1.0f / c->cell, k1, v1);
+    if (int rcs = radix_sort_pairs_u32(c, sc, k1, k2, v1, v2, n, 27)) return rcs;
+    int rc = ensure_alt(c, (size_t)n + (size_t)n / 4 + 4096);
+    if (rc != MALIO_OK) return rc;
+    if ((size_t)n > c->cap_map_ord) {
+      if (c->d_map_ord) (void)hipFree(c->d_map_ord);
+      c->d_map_ord = nullptr;
+      c->cap_map_ord = (size_t)n + (size_t)n / 4 + 4096;
+      MALIO_HIP(hipMalloc(&c->d_map_ord, sizeof(u32) * c->cap_map_ord));
+    }
+    hipLaunchKernelGGL(k_map_permute, dim3((n + BLK - 1) / BLK), dim3(BLK), 0, c->stream, c->d_map_in, (const u32 *)v1, n, c->d_map_alt, c->d_map_ord);
+    MALIO_HIP(hipStreamSynchronize(c->stream));  // (the sort's temporaries go back to the arena with this scope)
+    swap_maps(c);
+    c->map_sorted_n = n;
     c->map_epoch++;
   }
   c->nl_tomb = 0;
@@ -720,7 +794,7 @@ int map_add_pair_dev(Ctx *c, const float4 *d_new, int m_ds, int m_plain, int *ou
   const u32 ntsize = gnew.tmask + 1;
   hipLaunchKernelGGL(k_vox_add, dim3((ntsize + BLK - 1) / BLK), dim3(BLK), 0, c->stream, gnew.table, ntsize, gnew.orig,
                      d_new, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, hw > 0 ? 1 : 0, ds, del,
-                     dlist, addf, counters);
+                     dlist, addf, counters, (const u32 *)c->d_map_ord, (u32)c->map_sorted_n);
   // kept points (both parts) | return value of the down-sampling call | deleted map points: stored into the host's
   // mapped buffer by the scan's last kernel
   u32 *h_tot = mb + 8;
@@ -820,7 +894,7 @@ static int mapinc_small_batch(Ctx *c, ArenaScope &sc, const float4 *wp, const u3
                      c->d_small_orig, addf, info, cap);
   hipLaunchKernelGGL(k_vox_add, dim3(SMALL_TS / BLK), dim3(BLK), 0, c->stream, c->d_small_table, (u32)SMALL_TS,
                      c->d_small_orig, d_add, c->nl1.table, c->nl1.tmask, c->nl1.pts, c->nl1.inv_cf, c->d_map_in, 1, ds, c->d_del,
-                     dlist, addf, counters);
+                     dlist, addf, counters, (const u32 *)c->d_map_ord, (u32)c->map_sorted_n);
   if (++c->small_seq == 0) c->small_seq = 1;
   hipLaunchKernelGGL(k_scan_small_dev, dim3(1), dim3(1024), 0, c->stream, addf, apos, info + 1, mbd + 8, counters, 2,
                      mbd + MBOX_SMALL_SEQ, c->small_seq);

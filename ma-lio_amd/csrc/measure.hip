@@ -513,10 +513,11 @@ __device__ __forceinline__ double plane_unit_cov(double cov_threshold, const flo
 }
 
 // residual + range gate (laserMapping.cpp:598-601)
-__device__ __forceinline__ bool residual_gate(const float pabcd[4], float wx, float wy, float wz, double nb,
+// snb = sqrt(|p'|) (the callers form it where it is off the plane fit's dependent chain: phase A of a search pass)
+__device__ __forceinline__ bool residual_gate(const float pabcd[4], float wx, float wy, float wz, double snb,
                                               float &pd2) {
   pd2 = pabcd[0] * wx + pabcd[1] * wy + pabcd[2] * wz + pabcd[3];
-  float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(nb));
+  float s = (float)(1 - 0.9 * (double)fabsf(pd2) / snb);
   return (double)s > 0.1;
 }
 
@@ -918,7 +919,7 @@ __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst 
     const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
     ucov = a.ucov[i];
     float pd2;
-    if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
+    if (residual_gate(pabcd, wx, wy, wz, sqrt(nb), pd2)) {
       selected = true;
       a.pd2[i] = pd2;
       pd2_out = pd2;
@@ -948,7 +949,7 @@ __device__ __forceinline__ void reuse_point_ctrl(const Pass1Args &a, const QuatC
     pl_out = pl;
     const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
     float pd2;
-    if (residual_gate(pabcd, wx, wy, wz, nb, pd2)) {
+    if (residual_gate(pabcd, wx, wy, wz, sqrt(nb), pd2)) {
       selected = true;
       pd2_out = pd2;
     }
@@ -999,7 +1000,7 @@ struct SearchLds {
   float4 q[SQ];            // the scan point as phase A read it (phase C: the row and the trace are built from it)
   float4 (*nbp)[SQ];       // phase C: [5][SQ] - the five neighbours' map points, kept across the plane fit (point_phase); the
                            // kernel's own LDS (k_pass: the storage of its row staging U, which is written after the fit)
-  double nb[SQ];  // |p'| of phase A, consumed by the range gate in phase C
+  double nb[SQ];  // sqrt(|p'|) of phase A, consumed by the range gate in phase C
   // KS_SPLIT: what the helper wave and the control wave hand each other across their one barrier
   double trS[SQ], trR[SQ];  // helper -> itself: the trace under the accepted / rejected point's clamp rule (trace_both)
   double ucv[SQ];           // helper -> itself: unit_cov of the five neighbours (esti_plane's plane_cov)
@@ -1060,7 +1061,16 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
     PH(0, 6);
     float n = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
     pabcd[0] = nv[0] / n, pabcd[1] = nv[1] / n, pabcd[2] = nv[2] / n;
+    // (float)(1.0 / (double)n), common_lib.h:180 (`1.0 / n` with n a float promoted to double, stored to float): ONE division of
+    // float-representable operands in double, rounded to float - which is the correctly rounded float quotient (double rounding
+    // is innocuous for a single +, -, x, / or sqrt when the wide format has >= 2 p + 2 = 50 bits: Figueroa 1995). The float
+    // division is a third of the f64 one's instructions on this wave's chain; -DKS_PD_F64 builds the literal form (same bits:
+    // tests/test_gpu_parity.py compares either against the oracle's).
+#ifdef KS_PD_F64
     pabcd[3] = (float)(1.0 / (double)n);
+#else
+    pabcd[3] = 1.0f / n;
+#endif
     bool plane_ok = true;
 #pragma unroll
     for (int k = 0; k < 5; k++) {  // the QR overwrote A: the five points come back from this lane's LDS slots
@@ -1103,6 +1113,12 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #ifndef KS_SPLIT
 #define KS_SPLIT 1
 #endif
+#ifndef KS_PRIO_C
+#define KS_PRIO_C 0
+#endif
+#ifndef KS_PRIO_H
+#define KS_PRIO_H 0
+#endif
 constexpr int ROLE_RETIRE = 0, ROLE_CONTROL = 1, ROLE_HELPER = 2;
 // PIPE2: the level-2 walk is the pipelined one (nl_search; not in the device loop's k_search<true, .>, whose extra reuse branch
 // makes the register allocator spill with it)
@@ -1141,7 +1157,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       // (KS_SPLIT: helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses
       // its world point below and is nobody's to store later)
       if (!KS_SPLIT || a.part.world > 1) STATE_ST(a.world4[i] = w;)
-      S.nb[lane_] = nb;
+      S.nb[lane_] = sqrt(nb);  // (sqrt(p_body.norm()), :599: formed here, off phase C's chain)
       S.q[lane_] = q;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
         mine = false;
@@ -1320,8 +1336,19 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
     }
   }
   }  // (somebody walks)
-  if (!cwave) return (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) ? ROLE_HELPER : ROLE_RETIRE;
+  if (!cwave) {
+    if (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) {
+      if (KS_PRIO_H) __builtin_amdgcn_s_setprio(KS_PRIO_H);
+      return ROLE_HELPER;
+    }
+    return ROLE_RETIRE;
+  }
   // ---- phase C (control wave) ----
+  // From here to its tile this wave is ONE dependent chain of ~3 000 instructions, and its workgroup leaves when the chain ends.
+  // A SIMD's issue slots go to the waves by priority, then age (MI355X_MICROARCH: "two waves per SIMD"): the search waves of
+  // the six other workgroups on this CU, which mostly wait for memory, take slots from it whenever their candidates arrive.
+  // Raised priority hands the chain those slots first (KS_PRIO_C; the helper wave KS_PRIO_H).
+  if (KS_PRIO_C) __builtin_amdgcn_s_setprio(KS_PRIO_C);
   int lane = lane_;
   asm volatile("" : "+v"(lane));  // the query index is formed again from here on: kept across the list walk it is the one
   const int ic = qidx(lane);       // value the register allocator spills (8 B of scratch per lane for a 32-bit add)

@@ -227,6 +227,11 @@ __global__ void k_vg_init(u32 *mm) { mm[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0
 
 }  // namespace
 
+// (map_update.hip: the map array's cell order) sorts (k1, v1) by the low `bits` bits of the key, stable; scratch from `sc`
+int radix_sort_pairs_u32(Ctx *c, ArenaScope &sc, u32 *&k1, u32 *&k2, u32 *&v1, u32 *&v2, int n, int bits) {
+  return radix_sort_pairs(c, sc, k1, k2, v1, v2, n, bits);
+}
+
 // Device core. d_pts: [n][12] in HBM. On return *d_out (arena memory of the CALLER's scope: `sc`) holds *out_n points,
 // or *passthrough is set when PCL's "leaf size too small" branch applies (output = input).
 int voxel_downsample_dev(Ctx *c, ArenaScope &sc, const float *d_pts, int n, float leaf, int normal_mode, float **d_out,

@@ -502,11 +502,11 @@ def test_tile_shard_forgets_cached_probes_of_an_earlier_scan(capi, scenes):
     leaves the search at once and probes nothing - so nothing overwrote its points' cached probes, and entries of an EARLIER scan,
     against another map, passed for this scan's as soon as the points crossed into an owned tile of the same cell key between two
     search passes of one update. Staged here: scan A on map A fills the cache; the map is rebuilt (every list moves); the same
-    points, installed again, first land a whole number of tiles AND of 8-cell patches away (36 m: same grouping order, tiles of the
+    points, installed again, first land a whole number of tiles AND of 8-cell patches away (72 m: same grouping order, tiles of the
     other shard - every workgroup leaves early), then back where scan A had them: same cell keys as the stale entries. The second
     search pass must find what an unpartitioned engine on map B finds."""
-    sc = scenes.make_scene(seed=315, N=6000, Nmap=150000, L=3)
-    world, tile = 2, 12.0
+    sc = scenes.make_scene(seed=315, N=20000, Nmap=150000, L=3)
+    world, tile = 2, 24.0
     one = capi.Engine(sc["params"])
     one.map_build(sc["map"])
     one.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
@@ -516,7 +516,7 @@ def test_tile_shard_forgets_cached_probes_of_an_earlier_scan(capi, scenes):
     inner = (np.abs(w / tile - np.round(w / tile)) > 1.0 / tile).all(1)  # a metre away from every tile face
     keys, cnt = np.unique(t[inner], axis=0, return_counts=True)
     pick = inner & (t == keys[np.argmax(cnt)]).all(1)
-    assert pick.sum() >= 200
+    assert pick.sum() >= 150, pick.sum()
     scan = sc["scan"][pick]
     r0 = int(capi.part_owner(w[pick][:1], world, tile)[0])
     assert (capi.part_owner(w[pick], world, tile) == r0).all()
@@ -524,7 +524,7 @@ def test_tile_shard_forgets_cached_probes_of_an_earlier_scan(capi, scenes):
     for k in (1, -1, 2, -2, 3, -3, 4, -4):
         for ax in (0, 1):
             d = np.zeros(3)
-            d[ax] = 36.0 * k
+            d[ax] = 72.0 * k  # (3 tiles = 64 level-1 cells)
             if (capi.part_owner((w[pick] + d).astype(np.float32), world, tile) != r0).all():
                 shift = d
                 break
