@@ -673,15 +673,18 @@ def roofline_block(eng, state, args, n_points):
             committed["refused"] = ("taken from build %s, this library is %s" % (tjd.get("build_id"), build_id)) if not same_build \
                 else "its kernel time %.4f ms differs from this run's %.4f ms by more than 15 %%" % (rp_ms or float("nan"), dom_ms)
     rk = {k: float(np.mean(v)) for k, v in per_reuse.items()}
-    reuse_dom = "k_reuse" if "k_reuse" in rk else next(iter(rk), None)
+    reuse_dom = next((k for k in ("k_reuse_rows", "k_reuse") if k in rk), next(iter(rk), None))
     reuse = None
     if reuse_dom:
         r_ach = ALG_BYTES_REUSE_PASS * n_points / (rk[reuse_dom] * 1e-3) / 1e9
+        pass_ms = float(sum(rk.values()))
         reuse = {"kernel": reuse_dom, "kernel_ms": rk[reuse_dom], "alg_bytes_per_launch": ALG_BYTES_REUSE_PASS * n_points,
                  "achieved": r_ach, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS, "frac_of_achievable": r_ach / HBM_ACHIEVABLE_GBS,
-                 "kernel_event_ms": rk, "pass_kernels_ms": float(sum(rk.values())),
-                 "note": "malio_measure(converge = 0): the reuse pass' point-phase kernel; 36 B/point are its contract "
-                         "(query 16 + cached plane 16 + normal_y 4)"}
+                 "kernel_event_ms": rk, "pass_kernels_ms": pass_ms,
+                 "frac_pass": ALG_BYTES_REUSE_PASS * n_points / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "malio_measure(converge = 0): k_reuse_rows (round 6: point phase AND rows, thread = point over all waves) + "
+                         "k_final_reduce<4>; 36 B/point are the pass' contract (query 16 + cached plane 16 + normal_y 4); "
+                         "frac = the dominant kernel alone, frac_pass = all kernels of the pass (event intervals)"}
     return {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": frac,
             "frac_source": "HIP events on the engine's stream around each launch, this run, this binary (build %s)" % build_id,

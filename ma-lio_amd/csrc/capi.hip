@@ -1319,7 +1319,7 @@ int malio_measure(malio_handle_t h, const malio_state_t *s, int converge, malio_
   int rc;
   const double *res = c->h_res;
   bool need_stage2 = true;
-  if (!want_rows && converge && fuse_eligible(c, converge)) {  // (search passes: a speculating reuse pass gains nothing here)
+  if (!want_rows && fuse_eligible(c, converge)) {  // (round 6: reuse passes too - k_reuse_rows, the streaming form - not only search passes)
     // k_pass -> k_final_reduce: the rows are formed inside the point-phase kernel, weighted with the extrema of the
     // previous pass of this scan; the host checks the guess. A miss (rare: an extreme point changed sides) costs the two
     // kernels below.

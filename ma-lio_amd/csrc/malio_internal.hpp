@@ -331,7 +331,9 @@ struct Arena {
     hipError_t e = hipMalloc(&q, bytes);
     if (e == hipSuccess) extra.push_back(q);
 #ifdef MALIO_POISON
-    if (e == hipSuccess) (void)hipMemset(q, 0xFF, bytes);
+    // (hipMemset on device memory may return before it has run, on the NULL stream - which the handle's non-blocking streams do
+    // not wait for: without the synchronisation the poison lands on top of what the next kernels write)
+    if (e == hipSuccess) (void)hipMemset(q, 0xFF, bytes), (void)hipDeviceSynchronize();
 #endif
     *out = q;
     return e;
@@ -365,7 +367,7 @@ struct ArenaScope {  // allocations made through a scope die with it
         a.release_all();
         if (hipMalloc((void **)&a.base, need) == hipSuccess) a.cap = need;
 #ifdef MALIO_POISON
-        if (a.cap) (void)hipMemset(a.base, 0xFF, a.cap);
+        if (a.cap) (void)hipMemset(a.base, 0xFF, a.cap), (void)hipDeviceSynchronize();
 #endif
       }
       a.want = 0;

@@ -1113,6 +1113,9 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #ifndef KS_SPLIT
 #define KS_SPLIT 1
 #endif
+#ifndef KS_REUSE_ROWS
+#define KS_REUSE_ROWS 1  // reuse passes that may speculate run as k_reuse_rows -> k_final_reduce<4> (0: k_pass' reuse form, rounds 3-5)
+#endif
 #ifndef KS_PRIO_C
 #define KS_PRIO_C 0
 #endif
@@ -2255,6 +2258,129 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   PH_EXIT();
 }
 
+
+// ---- the REUSE pass shaped for streaming (round 6): k_reuse_rows -> k_final_reduce<4> ------------------------------------------
+// A reuse pass (ekfom_data.converge == false, laserMapping.cpp:583-595) keeps neighbours and plane: 36 bytes per point in, a few
+// out, no search - a streaming job. As k_reuse -> k_rows_reduce -> k_final_reduce it was three launches (26.8 us for 3.6 MB at
+// BASELINE config 2), as k_pass' reuse form one wave of every 64-point workgroup. Here: thread = point over ALL four waves of a
+// 256-point workgroup of ONE LiDAR (k_rows_reduce's blocks) - world point, cached plane, gates, trace (reuse_point), the extrema
+// to the atomic slots - and, speculating on the previous pass' extrema like k_pass (section 3.1 of DESIGN.md), the a5/a7 row
+// straight from the registers, staged as [u | hs | 1/r] (k_pass' 15-double record: 30 KB), one MFMA tile per wave, the four
+// tiles added (T0 + T1) + (T2 + T3): THE SAME workgroup partial, bit for bit, k_rows_reduce forms from the per-point state
+// (same expressions on the same operands: point_row; same 16 dependent MFMAs; same tree) - so a wrong guess is repaired by
+// k_rows_reduce + k_final_reduce<4> exactly as after k_pass, and the summation tree never notices which kernel ran.
+// k_final_reduce<4> folds the extrema slots (FoldArgs) and carries the gate. Used by malio_measure, the host-driven loop and
+// malio_measure_node for every reuse pass that may speculate; the enqueued-ahead chain keeps k_pass<true, .> (a unit does not
+// know in advance which kind of pass it will be).
+struct ReuseRowsArgs {
+  int seg_block0[MALIO_MAX_LIDAR + 1];  // first 256-point workgroup of each LiDAR segment
+  int seg_start[MALIO_MAX_LIDAR + 1];
+  int L;
+  PassConst pc;
+  WeightConst wc;
+  double guess[4];   // [max_u, -min_u, max_R, -min_R] the rows are weighted with
+  double *partials;  // [NSUM][pstride], entry-major: k_rows_reduce's
+  int pstride;
+};
+__global__ void __launch_bounds__(BLK) k_reuse_rows(Pass1Args a, ReuseRowsArgs f) {
+  __shared__ double U[BLK][15];
+  __shared__ double DW[BLK / 64][16][16];
+  __shared__ int wcnt[BLK / 64];
+  POISON_LDS(U);
+  POISON_LDS(DW);
+  POISON_SYNC();
+  const PassDyn dy = pass_dyn<false>(a);
+  int lid = 0;
+#pragma unroll
+  for (int l = 1; l < MALIO_MAX_LIDAR; l++)
+    if (l < f.L && (int)blockIdx.x >= f.seg_block0[l]) lid = l;
+  const int i = f.seg_start[lid] + ((int)blockIdx.x - f.seg_block0[lid]) * BLK + (int)threadIdx.x;
+  const bool in = i < f.seg_start[lid + 1];
+  bool selected;
+  double ucov, tr;
+  float4 pl, q;
+  float pd2;
+  reuse_point(a, a.qc, dy.commit_prev, in ? i : a.N, selected, ucov, tr, pl, pd2, q);  // (a.N: not a point - nothing read, nothing stored)
+  wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);  // a4: the TRUE extrema of this pass
+  if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
+  double u[12], hs = 0, r = 1;
+#pragma unroll
+  for (int k = 0; k < 12; k++) u[k] = 0;
+  if (selected) {
+    RowIn rin;
+    rin.q = q, rin.pl = pl, rin.ucov = ucov, rin.trace = tr, rin.pd2 = pd2;
+    point_row(f.wc, a.extrinsic_est_en, f.pc, f.guess, rin, lid, u, hs, r);
+  }
+  double rc = r;
+  if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  double *mine = U[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < 12; k++) mine[k] = u[k];
+  mine[12] = hs;
+#ifndef ROWS_DIVIDE
+  mine[13] = selected ? 1.0 / rc : 0.0;
+#else
+  mine[13] = selected ? rc : 0.0;
+#endif
+  const unsigned long long bal = __ballot(selected);
+  if (lane == 0) wcnt[wave] = __popcll(bal);
+  __builtin_amdgcn_wave_barrier();  // (a wave reads only the 64 records it wrote)
+  {
+    // the tile of this wave's 64 points: k_pass' operand forms (x * 1.0 == x, selects instead of branches), k_rows_reduce's bits
+    const int prow = wave * 64 + (lane >> 4), col = lane & 15;
+    const int ca = col < 12 ? col : (col < 15 ? col - 12 : 0), cb = col < 12 ? col : 12;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#ifndef ROWS_DIVIDE
+    const double wsel = col < 12 ? 0.0 : 1.0;
+#endif
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      double xa[8], wa[8], ya[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const double *up = U[prow + 4 * (8 * half + g)];
+        xa[g] = up[ca], wa[g] = up[13], ya[g] = up[cb];
+      }
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const double x = col < 15 ? xa[g] : 0.0, y = col <= 12 ? ya[g] : 0.0;
+#ifndef ROWS_DIVIDE
+        const double av = x * (col < 12 ? wa[g] : wsel);
+#else
+        const double av = col < 12 ? (wa[g] != 0.0 ? x / wa[g] : 0.0) : x;
+#endif
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) DW[wave][(lane >> 4) + 4 * rg][col] = acc[rg];
+  }
+  __syncthreads();
+  const int e = (int)threadIdx.x;
+  if (e < NSUM) {
+    double v;
+    if (e == NSUM - 1) {
+      v = (double)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
+    } else {
+      int ra, cb;
+      if (e < 78) {
+        int rem = e;
+        ra = 0;
+        while (rem >= 12 - ra) rem -= 12 - ra, ra++;
+        cb = ra + rem;
+      } else if (e < 90) {
+        ra = e - 78, cb = 12;
+      } else {
+        const int m6[6][2] = {{0, 0}, {1, 1}, {2, 2}, {0, 1}, {0, 2}, {1, 2}};
+        ra = 12 + m6[e - 90][0], cb = m6[e - 90][1];
+      }
+      v = (DW[0][ra][cb] + DW[1][ra][cb]) + (DW[2][ra][cb] + DW[3][ra][cb]);
+    }
+    f.partials[(size_t)e * f.pstride + blockIdx.x] = v;
+  }
+}
+
 // ---- batched Nearest_Search -----------------------------------------------------------------------
 constexpr int NL2_G = 16;  // lanes per query on the level-2 lists (~180 candidates), batched API
 
@@ -2567,6 +2693,7 @@ int measure_alloc(Ctx *c) {
         {c->d_ucov, sizeof(double) * K}, {c->d_trace, sizeof(double) * K}, {c->d_sel, K}, {c->d_nfound, K}, {c->d_world4, sizeof(float4) * K},
         {c->d_ny, sizeof(float) * K}, {c->d_cert, sizeof(float4) * K}, {c->d_pcache, sizeof(uint4) * K}, {c->d_kept, K}};
       for (auto &x : arr) MALIO_HIP(hipMemset(x.p, 0xFF, x.b));
+      MALIO_HIP(hipDeviceSynchronize());  // (hipMemset may still be queued on the NULL stream, which this handle's stream does not wait for)
     }
 #endif
   }
@@ -3161,6 +3288,39 @@ int pass_fused(Ctx *c, const malio_state_t *s, int converge, const GateArgs *gat
   c->last_M = -1;
   c->last_pass_search = converge != 0;
   if (converge) a.skip = search_skip_begin(c);
+  if (!converge && KS_REUSE_ROWS) {  // the streaming form (k_reuse_rows): k_rows_reduce's workgroups, partials and final reduction
+    Pass2Args p2;
+    const int nb = fill_pass2_static(c, p2);
+    bool fits = true;
+    for (int l = 0; l < c->prm.lid_num; l++)  // (k_final_reduce<4>: 64 rounds of 256 partials per LiDAR segment; longer ones take k_pass)
+      if ((c->seg_start[l + 1] - c->seg_start[l] + BLK - 1) / BLK > 64 * 256) fits = false;
+    if (fits) {
+      ReuseRowsArgs f;
+      for (int l = 0; l <= MALIO_MAX_LIDAR; l++) f.seg_block0[l] = p2.seg_block0[l], f.seg_start[l] = p2.seg_start[l];
+      f.L = c->prm.lid_num, f.wc = p2.wc;
+      fill_pass_const(c, s, c->pc);
+      f.pc = c->pc;
+      memcpy(f.guess, c->mm_guess, sizeof(f.guess));
+      if (c->fuse_debug_bad_guess) f.guess[0] += 1.0;
+      memcpy(c->fuse_guess_used, f.guess, sizeof(f.guess));
+      f.partials = c->d_partials, f.pstride = (int)c->cap_partials;
+      hipLaunchKernelGGL(k_reuse_rows, dim3(nb), dim3(BLK), 0, c->stream, a, f);
+      prof_mark(c, "k_reuse_rows");
+      SegBlocks sb;
+      for (int l = 0; l <= MALIO_MAX_LIDAR; l++) sb.b[l] = p2.seg_block0[l];
+      const int ns = sums_len(c);
+      double *out_row = row ? row : c->d_res;
+      FoldArgs fold;
+      fold.mmslots = c->d_mmslots + (size_t)c->mm_parity * MM_SLOTS * 5, fold.mm_out = out_row + ns, fold.extrinsic_est_en = c->prm.extrinsic_est_en;
+      hipLaunchKernelGGL(k_final_reduce<4>, dim3((c->prm.lid_num * NSUM * 64 + BLK - 1) / BLK), dim3(BLK), 0, c->stream,
+                         (const double *)c->d_partials, (int)c->cap_partials, sb, c->prm.lid_num, out_row, (const DevLoop *)nullptr,
+                         gate ? *gate : GateArgs{}, fold);
+      prof_mark(c, "k_final_reduce");
+      MALIO_HIP(hipGetLastError());
+      c->fuse_passes++;
+      return MALIO_OK;
+    }
+  }
   FuseArgs f;
   SegBlocks sb;
   const int nwg = fill_fuse_static(c, f, sb);

@@ -89,3 +89,29 @@ def assert_P_close(P, Q, rel=2e-3, HtH=None, P0=None):
         bound = np.maximum(bound, 64 * 2.3e-16 * (np.abs(Q[:, :C]) @ np.abs(HtH) @ np.abs(P0[:C, :])))
     bad = np.abs(P - Q) > bound
     assert not bad.any(), (int(bad.sum()), float((np.abs(P - Q) / bound).max()))
+
+
+def exact_ties(gs, os_, limit=8, at_search_state=True):
+    """Queries whose Nearest_Points differ between two searches ONLY by an exact tie of float distances. ikdtree.Nearest_Search
+    (ikd_Tree.cpp:426-461,1073-1255) orders two map points at the same float d2 by whatever its traversal and its heap leave
+    (tools/tie_census.py: in 1.2 M queries of BASELINE config 5 five such pairs, four in ascending map index, one descending); the
+    engine orders them by (d2, slot in its map array), and the slots are kept in cell order since round 6. Such a query - about
+    four in a million - has the same five DISTANCES either way (or the same four and an equally distant fifth) and is compared on
+    those; everything derived from the order of its five points (the plane's last bits, hence its gates) is left out of the
+    per-point comparisons. Returns the boolean mask; fails when two searches differ in any other way, or more often than `limit`.
+    at_search_state = False: gs / os_ were read after a REUSE pass (the neighbours are the last search pass', the world points
+    are not): the distances cannot be formed, only the count is checked (the search pass before it was compared in full)."""
+    w = gs["world"][:, None, :].astype(np.float32)
+
+    def d2(n):
+        d = w - n[:, :, :3]
+        return (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]  # calc_dist, ikd_Tree.cpp:1697
+    differ = (gs["nearest"][:, :, :3] != os_["nearest"][:, :, :3]).any(axis=(1, 2))
+    if not differ.any():
+        return differ
+    assert np.array_equal(gs["world"], os_["world"]) and np.array_equal(gs["nearest_cnt"], os_["nearest_cnt"])
+    if at_search_state:
+        dg, do = d2(gs["nearest"][differ]), d2(os_["nearest"][differ])
+        assert np.array_equal(dg, do), "neighbours differ by more than an exact tie of distances"
+    assert differ.sum() <= limit, int(differ.sum())
+    return differ
