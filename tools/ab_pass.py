@@ -31,6 +31,13 @@ if os.environ.get("REUSE") == "1":
     t = time.perf_counter()
     for _ in range(300): fr()
     extra += " reuse_pass %.2f us" % ((time.perf_counter() - t) / 300 * 1e6)
+    e.set_profiling(True)
+    racc = {}
+    for _ in range(30):
+        fr()
+        for n, ms in e.last_kernel_times(): racc.setdefault(n, []).append(ms * 1000)
+    e.set_profiling(False)
+    extra += " %s" % {n: round(float(np.median(v)), 1) for n, v in racc.items()}
 if os.environ.get("UPD") == "1":
     e.set_option("probe_cache", 1)
     upd, res = e.update_iterated_fn(sc["state0"], sc["P0"])
