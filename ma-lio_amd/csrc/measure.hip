@@ -11,6 +11,7 @@
 // (neighbour sets, accept flags) are reproducible against the CPU restatement.
 #include "malio_internal.hpp"
 #include "../host/manifold.hpp"
+#include "quad_fit.hpp"
 
 namespace malio {
 
@@ -1113,6 +1114,12 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #ifndef KS_SPLIT
 #define KS_SPLIT 1
 #endif
+// KS_QUAD (round 6): phase C - plane fit, gates, unit_cov - by the four lanes of every query on ALL four waves (quad_fit.hpp)
+// instead of one lane per query on the control wave; what the helper wave did beside the fit and did not need the neighbours
+// for (traces, point_this, 1 / R_i) it now does beside phase A, when it used to wait. 0: phase C of rounds 1-5.
+#ifndef KS_QUAD
+#define KS_QUAD 1
+#endif
 #ifndef KS_REUSE_ROWS
 #define KS_REUSE_ROWS 1  // reuse passes that may speculate run as k_reuse_rows -> k_final_reduce<4> (0: k_pass' reuse form, rounds 3-5)
 #endif
@@ -1125,9 +1132,19 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 constexpr int ROLE_RETIRE = 0, ROLE_CONTROL = 1, ROLE_HELPER = 2;
 // PIPE2: the level-2 walk is the pipelined one (nl_search; not in the device loop's k_search<true, .>, whose extra reuse branch
 // makes the register allocator spill with it)
-template <bool DEV, bool SKIP, bool PIPE2>
+// pre_a(lane, i, in_range) (KS_QUAD): called by the HELPER wave during phase A, lane = query - the plane-independent work that
+// needs nothing from the search. cp_of(ucov) (KS_QUAD, k_pass): the plane weight c_i under the guessed extrema, or null.
+struct NoPreA {
+  __device__ __forceinline__ void operator()(int, int, bool) const {}
+};
+struct NoCp {
+  static constexpr bool enabled = false;
+  __device__ __forceinline__ double operator()(double) const { return 0.0; }
+};
+template <bool DEV, bool SKIP, bool PIPE2, class PreA = NoPreA, class CpOf = NoCp>
 __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, const NlView &nl2, const QuatConst &qc,
-                                         const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po) {
+                                         const PassDyn &dy, SearchLds &S, int q0, int qend, PointOut &po, PreA pre_a = PreA(),
+                                         CpOf cp_of = CpOf(), double *cp_out = nullptr) {
   auto qidx = [&](int l) { return q0 + l; };
   const int lane_ = (int)(threadIdx.x & 63);
   const bool cwave = (int)(threadIdx.x >> 6) == 0;
@@ -1227,6 +1244,9 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       if (i < qend) a.kept[i] = keep ? 1 : 0;
     }
   }
+#if KS_QUAD
+  if ((int)(threadIdx.x >> 6) == 1) pre_a(lane_, i, i < qend);  // (the helper wave: it waited here until round 6)
+#endif
   // bit 0: a point of this workgroup is served here; bit 1: one of them has to walk the lists (only the control wave knows;
   // __syncthreads_or would reduce !!predicate, not the bits)
   int flags = 3;
@@ -1339,6 +1359,54 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
     }
   }
   }  // (somebody walks)
+#if KS_QUAD
+  // ---- phase C' (all four waves, the four lanes of a query together): a3 + gates + plane_cov ----
+  {
+    int tq = (int)threadIdx.x;
+    asm volatile("" : "+v"(tq));  // (query and lane are formed again: shared with phase B's they stay live across the list walk, which has no register for them)
+    const int ql = tq / 4, sub = tq % 4;
+    const int iq = qidx(ql);
+    const float4 wq = S.w[ql];
+    const int nfq = S.nf[ql];
+    const bool fit = iq < qend && wq.x < 1e9f && nfq == 5;  // (the four lanes agree) gate `size < 5 || d2[4] > 5` (:587)
+    bool selected = false;
+    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pd2v = 0.f;
+    double ucov = 0.0;
+    if (fit) {
+      // neighbour 0 in all four lanes (one address: one request), neighbour sub + 1 in each
+      const u32 o0 = S.og[0][ql], om = S.og[sub + 1][ql];
+#ifdef ATTR_NO_GATHER
+      const float4 m0 = make_float4(wq.x, wq.y, wq.z, 0.001f), mm = make_float4(wq.x + 0.3f * (float)(sub & 1), wq.y + 0.3f * (float)(sub >> 1), wq.z + 0.01f * (float)sub, 0.001f);
+#else
+      const float4 m0 = a.map_in[o0], mm = a.map_in[om];
+#endif
+      const float row0[3] = {m0.x, m0.y, m0.z}, mine[3] = {mm.x, mm.y, mm.z};
+      float pabcd[4];
+      const bool plane_ok = quad::esti_plane_quad<float>(row0, mine, a.plane_th, pabcd);
+      ucov = quad::unit_cov_quad<float, double>(a.cov_threshold, m0.w, mm.w);
+      pl = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
+      float pd2;
+      if (plane_ok && residual_gate(pabcd, wq.x, wq.y, wq.z, S.nb[ql], pd2)) selected = true, pd2v = pd2;
+    }
+    if (sub == 0) {
+      S.selc[ql] = selected ? 1 : 0, S.plc[ql] = pl, S.pd2c[ql] = pd2v, S.ucv[ql] = ucov;
+      if (CpOf::enabled) cp_out[ql] = cp_of(ucov);
+    }
+  }
+  __syncthreads();
+  {
+    // (wave and lane are formed again: kept across the list walk they are what the register allocator spills)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv >= 2) return ROLE_RETIRE;
+    if (wv == 1) return ROLE_HELPER;
+    po.selected = S.selc[ln] != 0, po.pl = S.plc[ln], po.pd2 = S.pd2c[ln], po.q = S.q[ln];
+  }
+  PH(0, 8);
+  return ROLE_CONTROL;
+#endif
   if (!cwave) {
     if (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) {
       if (KS_PRIO_H) __builtin_amdgcn_s_setprio(KS_PRIO_H);
@@ -1473,8 +1541,30 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     return;
   }
   PointOut po;
+#if KS_QUAD
+  // (phase A's shadow, helper wave, lane = query: the trace under both clamp rules - it needs the scan point, not the search)
+  auto pre_a = [&](int lane, int i, bool in) {
+    double trS = 0.0, trR = 0.0;
+    if (in) {
+      const float4 q = a.scan[i];
+      const int packed = __float_as_int(q.w);
+      trace_both(a, q, packed & 0xFF, packed >> 8, trS, trR);
+    }
+    S.trS[lane] = trS, S.trR[lane] = trR;
+  };
+  const int role = search_wg<DEV, SKIP, (KS_PIPE != 0) && !DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po, pre_a);
+  if (role == ROLE_RETIRE || po.skipped) return;
+  if (role == ROLE_HELPER) {  // (phase C' left flag, plane, residual and unit_cov in LDS; its barrier is behind us)
+    const int lane = (int)(threadIdx.x & 63), i = (int)blockIdx.x * SQ + lane;
+    helper_post<SKIP>(a, dy.mm_cur, S, lane, i, i < a.N && S.w[lane].x < 1e9f, S.nf[lane]);
+  }
+  PH(0, 9);
+  PH_EXIT();
+  return;
+#else
   const int role = search_wg<DEV, SKIP, (KS_PIPE != 0) && !DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po);
   if (role == ROLE_RETIRE || po.skipped) return;
+#endif
 #if KS_SPLIT
   {
     const int lane = (int)(threadIdx.x & 63), i = (int)blockIdx.x * SQ + lane;
@@ -1960,6 +2050,13 @@ __device__ __forceinline__ int tile_entry(int ra, int cb) {  // (row, col) of th
   return a == 0 ? (cb == 1 ? 93 : 94) : 95;
 }
 
+// (KS_QUAD) the plane weight c_i under the guessed extrema, formed by phase C' where unit_cov appears
+struct CpGuess {
+  static constexpr bool enabled = true;
+  const WeightConst *wc;
+  const double *mm;
+  __device__ __forceinline__ double operator()(double ucov) const { return row_plane_weight(*wc, mm, ucov); }
+};
 template <bool DEV, bool SKIP>
 __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_WPE, KS_WPE)))
 k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restrict__ dl) {
@@ -2086,8 +2183,38 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   const int lane = (int)(threadIdx.x & 63);
   PointOut po;
   int role = ROLE_CONTROL;
+#if KS_QUAD
+  double mm[4];  // the guessed extrema the rows are weighted with
+#pragma unroll
+  for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
+#endif
   if (converge) {
+#if KS_QUAD
+    // (phase A's shadow, helper wave, lane = query: both traces, point_this and 1 / R_i - the row's factors that need the scan
+    // point and the guess, not the search)
+    auto pre_a = [&](int ln, int i, bool in) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      double trS = 0.0, trR = 0.0;
+      if (in) {
+        q = a.scan[i];
+        const int packed = __float_as_int(q.w);
+        trace_both(a, q, packed & 0xFF, packed >> 8, trS, trR);
+      }
+      S.trS[ln] = trS, S.trR[ln] = trR;
+      const D3 X = row_point_imu(pc, lid, D3{(double)q.x, (double)q.y, (double)q.z});
+      RP.X[0][ln] = X.x, RP.X[1][ln] = X.y, RP.X[2][ln] = X.z;
+      double rc = row_point_noise(f.wc, a.extrinsic_est_en, mm, trS);
+      if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
+#ifndef ROWS_DIVIDE
+      RP.rw[ln] = 1.0 / rc;
+#else
+      RP.rw[ln] = rc;
+#endif
+    };
+    role = search_wg<DEV, SKIP, KS_PIPE != 0>(a, nl1, nl2, qc, dy, S, q0, qend, po, pre_a, CpGuess{&f.wc, mm}, RP.cp);
+#else
     role = search_wg<DEV, SKIP, KS_PIPE != 0>(a, nl1, nl2, qc, dy, S, q0, qend, po);
+#endif
     if (role == ROLE_RETIRE) return;  // (the search waves retire; with KS_SPLIT the second wave stays as the helper)
     if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
       for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
@@ -2117,10 +2244,19 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   }
   PH(2, 0);
   // ---- a5 / a7 with the guessed extrema ----
+#if !KS_QUAD
   double mm[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
+#endif
 #if KS_SPLIT
+#if KS_QUAD
+  if (converge && role == ROLE_HELPER) {  // (phase C' left flag, plane, residual, unit_cov and c_i in LDS; its barrier is behind us)
+    const int i = q0 + lane;
+    helper_post<SKIP>(a, dy.mm_cur, S, lane, i, i < qend && S.w[lane].x < 1e9f, S.nf[lane]);  // per-point state; a4: the TRUE extrema
+    return;
+  }
+#endif
   if (role == ROLE_HELPER) {  // (see helper_unit_cov_trace)
     const int i = q0 + lane;
     bool served;
@@ -2173,9 +2309,11 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
     PHH(3, 4);
     return;
   }
-  S.selc[lane] = po.selected ? 1 : 0, S.plc[lane] = po.pl, S.pd2c[lane] = po.pd2;
-  PH(2, 6);
-  __syncthreads();
+  if (!(KS_QUAD && converge)) {  // (a search pass under KS_QUAD: phase C' has handed everything over already)
+    S.selc[lane] = po.selected ? 1 : 0, S.plc[lane] = po.pl, S.pd2c[lane] = po.pd2;
+    PH(2, 6);
+    __syncthreads();
+  }
   PH(2, 1);
   double u[12], hs = 0;
 #pragma unroll
@@ -2296,11 +2434,45 @@ __global__ void __launch_bounds__(BLK) k_reuse_rows(Pass1Args a, ReuseRowsArgs f
     if (l < f.L && (int)blockIdx.x >= f.seg_block0[l]) lid = l;
   const int i = f.seg_start[lid] + ((int)blockIdx.x - f.seg_block0[lid]) * BLK + (int)threadIdx.x;
   const bool in = i < f.seg_start[lid + 1];
-  bool selected;
-  double ucov, tr;
-  float4 pl, q;
-  float pd2;
-  reuse_point(a, a.qc, dy.commit_prev, in ? i : a.N, selected, ucov, tr, pl, pd2, q);  // (a.N: not a point - nothing read, nothing stored)
+  // reuse_point's arithmetic and stores with ALL of the point's loads in one round trip (behind its flags they were four
+  // dependent ones: this kernel is as long as its chain of trips, 14.6 us at BASELINE config 2 AND at config 1's tenth of the
+  // points), and the trace under both clamp rules as soon as the scan point is there (trace_both: the table entry's load does
+  // not wait for the gate) - the flag picks one, bit for bit trace_for's.
+  bool selected = false;
+  double ucov = 0.0, tr = 0.0;
+  float4 pl = make_float4(0.f, 0.f, 0.f, 0.f), q = pl;
+  float pd2 = 0.f;
+  {
+    unsigned char nfo = NF_NOTMINE, sel_old = 0;
+    double ucov_st = 0.0, trace_old = 0.0;
+    float4 pl_st = pl;
+    if (in) {
+      q = a.scan[i], nfo = a.nfound[i], sel_old = a.sel[i], pl_st = a.plane[i], ucov_st = a.ucov[i];
+      if (dy.commit_prev) trace_old = a.trace[i];
+    }
+    if (in && nfo != NF_NOTMINE) {  // (a partitioned handle keeps serving the points of its last search pass)
+      const int packed = __float_as_int(q.w);
+      const int lid_p = packed & 0xFF;
+      double trS, trR;
+      trace_both(a, q, lid_p, packed >> 8, trS, trR);
+      float wx, wy, wz;
+      double nb;
+      world_point(a.qc, q, lid_p, wx, wy, wz, nb);
+      a.world[i] = wx, a.world[a.N + i] = wy, a.world[2 * a.N + i] = wz;
+      if (dy.commit_prev && !(sel_old && !a.extrinsic_est_en)) a.ny[i] = (float)trace_old;  // commit_normal_y
+      if (sel_old) {
+        pl = pl_st, ucov = ucov_st;
+        const float pabcd[4] = {pl.x, pl.y, pl.z, pl.w};
+        float p2;
+        if (residual_gate(pabcd, wx, wy, wz, sqrt(nb), p2)) selected = true, a.pd2[i] = p2, pd2 = p2;
+      }
+      a.sel[i] = selected ? 1 : 0;
+      tr = selected ? trS : trR;
+      a.trace[i] = tr;
+    } else {
+      q = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   wave_minmax_publish(a, dy.mm_cur, selected, ucov, tr);  // a4: the TRUE extrema of this pass
   if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
   double u[12], hs = 0, r = 1;

@@ -101,12 +101,12 @@ def exact_ties(gs, os_, limit=8, at_search_state=True):
     per-point comparisons. Returns the boolean mask; fails when two searches differ in any other way, or more often than `limit`.
     at_search_state = False: gs / os_ were read after a REUSE pass (the neighbours are the last search pass', the world points
     are not): the distances cannot be formed, only the count is checked (the search pass before it was compared in full)."""
-    w = gs["world"][:, None, :].astype(np.float32)
+    differ = (gs["nearest"][:, :, :3] != os_["nearest"][:, :, :3]).any(axis=(1, 2))
+    w = gs["world"][differ][:, None, :].astype(np.float32)
 
     def d2(n):
         d = w - n[:, :, :3]
         return (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]  # calc_dist, ikd_Tree.cpp:1697
-    differ = (gs["nearest"][:, :, :3] != os_["nearest"][:, :, :3]).any(axis=(1, 2))
     if not differ.any():
         return differ
     assert np.array_equal(gs["world"], os_["world"]) and np.array_equal(gs["nearest_cnt"], os_["nearest_cnt"])
