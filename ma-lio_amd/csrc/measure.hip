@@ -278,6 +278,50 @@ __device__ __forceinline__ void merge_group(Top5 &t, u32 &ev, u64 refill = TOP5_
   t = out;
 }
 
+// The same merge for the search's groups of FOUR lanes, as a sorting network on the f64 pipe (round 6; KS_MERGE_NET). The pass
+// is bound by VALU issue about as much as by its L1 queue (profiles/round6/r06e_quad_phase_c.txt: +1 900 wave-instructions per
+// workgroup cost +4 us), and the five rounds of min-reduction above are ~200 issue slots per lane - as many as a batch's eight
+// insertions. Here: a lane and its neighbour (quad_perm [1, 0, 3, 2], then [2, 3, 0, 1]: DPP moves, no LDS crossbar) hold two
+// ascending lists A, B; min(A[i], B[4 - i]), i = 0 .. 4, are the five smallest of the ten (the lower half of a bitonic merge),
+// and a nine-comparator network puts them in order: 2 x (10 moves + 5 + 18 min / max) ~ 90 slots. Keys are distinct positive
+// finite doubles (top5_insert) but for the empty-slot keys, which are equal VALUES: the result is the same list in every lane,
+// and the same list as merge_group's.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ void merge_pair_net(double k[5]) {
+  double b[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) b[i] = dpp_quad_f64<CTRL>(k[i]);
+  double c[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = f64_min_raw(k[i], b[4 - i]);
+  auto cx = [&](int i, int j) {
+    const double lo = f64_min_raw(c[i], c[j]), hi = f64_max_raw(c[i], c[j]);
+    c[i] = lo, c[j] = hi;
+  };
+  cx(0, 1), cx(3, 4), cx(2, 4), cx(2, 3), cx(1, 4), cx(0, 3), cx(0, 2), cx(1, 3), cx(1, 2);
+#pragma unroll
+  for (int i = 0; i < 5; i++) k[i] = c[i];
+}
+__device__ __forceinline__ void merge_quad_net(Top5 &t) {
+  double k[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) k[i] = __longlong_as_double((long long)t.k[i]);
+  merge_pair_net<0xB1>(k);  // quad_perm [1, 0, 3, 2]
+  merge_pair_net<0x4E>(k);  // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int i = 0; i < 5; i++) t.k[i] = (u64)__double_as_longlong(k[i]);
+}
+#ifndef KS_MERGE_NET
+#define KS_MERGE_NET 1
+#endif
+
 // Eigen ColPivHouseholderQR<Matrix<float,5,3>>::solve(b = -1) restated with static register indexing
 // (common_lib.h:174). Same operation order as the CPU restatement; no runtime-indexed arrays.
 __device__ __forceinline__ void qr_solve_5x3(float A[5][3], float x[3]) {
@@ -811,7 +855,8 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
       __builtin_amdgcn_sched_barrier(0);
       offer_round(b, n);
     }
-    if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+    if (KS_MERGE_NET && G == 4 && !CERT) merge_quad_net(t);
+    else if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
   } else {
   // The short lists of level 1 (~44 entries: two batches) keep the two-batch walk: pipelined rounds were measured 0.6-1 us
   // SLOWER there (a round's insertions, ~1 us for the SIMD's seven waves, do not cover a ~2 us round trip; rounds of 2 / 3 / 4
@@ -824,7 +869,8 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
   bool again = EARLY && cut;  // (the G lanes of a query agree on everything that steers this loop)
   while (true) {
     for (; j < end; j += NB * G) batch(j);
-    if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
+    if (KS_MERGE_NET && G == 4 && !CERT) merge_quad_net(t);
+    else if (G > 1) merge_group<G, CERT>(t, ev, top5_key(sentinel, INVALID));
     if (!(EARLY && again)) break;
     again = false;
 #pragma unroll
@@ -1114,11 +1160,18 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #ifndef KS_SPLIT
 #define KS_SPLIT 1
 #endif
-// KS_QUAD (round 6): phase C - plane fit, gates, unit_cov - by the four lanes of every query on ALL four waves (quad_fit.hpp)
-// instead of one lane per query on the control wave; what the helper wave did beside the fit and did not need the neighbours
-// for (traces, point_this, 1 / R_i) it now does beside phase A, when it used to wait. 0: phase C of rounds 1-5.
+// KS_QUAD (round 6, built exactly, measured, NOT the default): phase C - plane fit, gates, unit_cov - by the four lanes of every
+// query on ALL four waves (quad_fit.hpp: ~470 instructions per lane instead of ~1 000) instead of one lane per query on the
+// control wave; what the helper wave did beside the fit without needing the neighbours (traces, point_this, 1 / R_i) done beside
+// phase A, when it used to wait. Bit-identical (the whole GPU suite passes on it; tests/test_quad_fit.py pins the lane-parallel
+// fit to the oracle on the host) - and SLOWER wherever the GPU is full: k_pass 27.0 -> 31.0 us at BASELINE config 2, 36.0 -> 39.5
+// at config 5, 23.3 -> 24.8 at config 3, even at config 1 (profiles/round6/r06e_quad_phase_c.txt). One lane per query is the
+// form that spends the fewest WAVE-instructions on a fit; four lanes replicate row 0, the norms, the pivots and every scalar of
+// the step, and what the chain of one workgroup gains (~560 instructions) the six other workgroups of the CU pay for in issue
+// slots (+1 900 wave-instructions per workgroup on SIMDs that are busy half the time): the pass is bound by VALU issue about as
+// much as by its L1 queue. 0 (default): phase C of rounds 1-5.
 #ifndef KS_QUAD
-#define KS_QUAD 1
+#define KS_QUAD 0
 #endif
 #ifndef KS_REUSE_ROWS
 #define KS_REUSE_ROWS 1  // reuse passes that may speculate run as k_reuse_rows -> k_final_reduce<4> (0: k_pass' reuse form, rounds 3-5)
