@@ -44,7 +44,7 @@ VALU_PEAK_TLANEINSTR = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: one VALU instruction
 # One launch per pass from the second pass of a scan on (k_pass: a1-a10 with the extrema speculated); the
 # first pass of a scan - and every pass under MALIO_FUSE=0 - is k_search -> k_rows_reduce -> k_final_reduce.
 DOMINANT_KERNELS = ("k_pass", "k_search")
-PROFILE_ROUND, PROFILE_TAG = "round5", "r05"  # the committed rocprofv3 / PMC summaries the roofline block cites
+PROFILE_ROUND, PROFILE_TAG = "round6", "r06"  # the committed rocprofv3 / PMC summaries the roofline block cites
 
 
 class _quiet_stdout:

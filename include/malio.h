@@ -208,7 +208,13 @@ int malio_decode_ouster(malio_handle_t h, const unsigned char *records, int n_re
  * index counts all points, :202) that lies outside the blind sphere (x*x + y*y + z*z in float > blind * blind, :204) is
  * pushed; *maximum_time = the largest curvature pushed, or -9999 (:188,206-207; offsets may be negative: some drivers stamp
  * relative to the END of the sweep). n_points == 0: the handler returns before it touches maximum_time (:157-158) -
- * *out_n = 0 and *maximum_time is left as the caller had it. */
+ * *out_n = 0 and *maximum_time is left as the caller had it.
+ * CALLER'S SIDE of the contract (what pcl::fromROSMsg checks and this entry point cannot, having no field table): a field
+ * whose PointField::datatype is not FLOAT32 (7) - a FLOAT64 or UINT32 `time`, say - is NOT mapped by fromROSMsg and reads
+ * 0 in the reference: pass its offset as -1 (absent), never the offset of a field of another type (the bytes would be
+ * reinterpreted). The message must be little-endian (is_bigendian == 0: fromROSMsg byte-swaps otherwise, this does not) and
+ * its points contiguous (row_step == width * point_step; data[] = height * row_step bytes): hand a padded message over row
+ * by row, or repack it. */
 typedef struct malio_pc2_layout {
   int point_step;                                 /* bytes per point (sensor_msgs::PointCloud2::point_step) */
   int off_x, off_y, off_z, off_intensity, off_time; /* byte offset of each FLOAT32 field inside a point; < 0: absent */
@@ -437,7 +443,9 @@ int malio_get_option(malio_handle_t h, int option, double *value);
  * points that walked the lists, 1 when the pass was allowed to skip at all}. */
 int malio_debug_skip_stats(malio_handle_t h, int *out4);
 /* The level-1 neighbour lists as the next search would find them: out4 = {lists, lists flagged as ordered (MALIO_OPT_NL_SORTED),
- * flagged lists that are NOT in order (always 0), live entries}. Builds stale lists first. */
+ * flagged lists that are NOT in order (always 0), live entries}. Builds stale lists first. lists - flagged = the lists a walk reads
+ * whole: those above 256 entries, and - after a batch whose work list overflowed (4 M items) or could not be allocated - the
+ * ones that batch appended to, until the next rebuild puts them in order again (results are the same either way). */
 int malio_debug_list_order(malio_handle_t h, long long *out4);
 
 /* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */

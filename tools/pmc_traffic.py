@@ -7,7 +7,7 @@ Correction per MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64
 import ast, csv, json, os, re, sys
 d, tag = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else "k_pass"
-rnd = sys.argv[4] if len(sys.argv) > 4 else "round5"
+rnd = sys.argv[4] if len(sys.argv) > 4 else "round6"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as ge; ge.load_package()
 from malio_amd import capi

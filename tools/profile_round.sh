@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof_stdout.txt 2> $OUT/rocprof_stderr.txt
 bash $ROOT/tools/pmc_run.sh $TAG/pmc > $OUT/pmc_run_stdout.txt 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/pmc > $OUT/${TAG}_pmc_summary.txt 2>&1
-python $ROOT/tools/pmc_traffic.py $OUT $TAG k_pass round5 > $OUT/pmc_traffic_stdout.txt 2>&1
+python $ROOT/tools/pmc_traffic.py $OUT $TAG k_pass round6 > $OUT/pmc_traffic_stdout.txt 2>&1
 # the three-kernel pass on the same box, for comparison (MALIO_FUSE=0)
 MALIO_FUSE=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ${TAG}_nofuse -- python $ROOT/tools/run_passes.py > /dev/null 2>&1
 python $ROOT/tools/pass_timeline.py $OUT/${TAG}_nofuse_kernel_trace.csv > $OUT/${TAG}_pass_timeline_three_kernel.txt 2>&1
