@@ -1,7 +1,9 @@
-"""debug: test_search_skip_is_exact[5]'s first oracle comparison, with the differing queries printed. CO=0/1: map_cell_order"""
+"""Developer aid: one search pass of BASELINE config CFG (default 5) at an iterate a centimetre from the prior, engine against
+oracle (reference ikd-Tree inside); prints every query whose Nearest_Points differ, with both sides distances - how round 6 found
+that the two sides order exact ties of float distances differently (tests/conftest.py::exact_ties). CO=1,0: MALIO_OPT_MAP_CELL_ORDER."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge; ge.load_package()
 from malio_amd import capi, scenes
