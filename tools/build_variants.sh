@@ -8,7 +8,7 @@ SRC=$1; shift
 make -j8 libmalio_hip.so > /dev/null
 mkdir -p variants build/variants
 find variants -name "*.so" ! -name poison.so -delete
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result -Ibuild"
 [ "$SRC" = csrc/measure.hip ] && FLAGS="$FLAGS -fno-slp-vectorize"  # (as the Makefile builds it)
 OBJS=$(ls build/csrc/*.o build/host/*.o | grep -v "build/${SRC}.o")
 for spec in "$@"; do
