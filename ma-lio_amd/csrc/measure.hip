@@ -822,9 +822,6 @@ __device__ __forceinline__ bool nl_walk(const NlView &nl, float wx, float wy, fl
 #pragma unroll
       for (int u = 0; u < R; u++) {
         offer(m[u], e + (u32)(u * G));
-#ifdef KS_PIPE_SEQ
-        __builtin_amdgcn_sched_barrier(0);  // (one insertion after the other: interleaved they need more registers than the kernel has)
-#endif
       }
     };
     const float4 *pa = lst + sub;  // this lane's entry of round a (the other entries of the round: immediates)
@@ -1176,12 +1173,6 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
 #ifndef KS_REUSE_ROWS
 #define KS_REUSE_ROWS 1  // reuse passes that may speculate run as k_reuse_rows -> k_final_reduce<4> (0: k_pass' reuse form, rounds 3-5)
 #endif
-#ifndef KS_PRIO_C
-#define KS_PRIO_C 0
-#endif
-#ifndef KS_PRIO_H
-#define KS_PRIO_H 0
-#endif
 constexpr int ROLE_RETIRE = 0, ROLE_CONTROL = 1, ROLE_HELPER = 2;
 // PIPE2: the level-2 walk is the pipelined one (nl_search; not in the device loop's k_search<true, .>, whose extra reuse branch
 // makes the register allocator spill with it)
@@ -1461,18 +1452,13 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
   return ROLE_CONTROL;
 #endif
   if (!cwave) {
-    if (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) {
-      if (KS_PRIO_H) __builtin_amdgcn_s_setprio(KS_PRIO_H);
-      return ROLE_HELPER;
-    }
+    if (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) return ROLE_HELPER;
     return ROLE_RETIRE;
   }
   // ---- phase C (control wave) ----
   // From here to its tile this wave is ONE dependent chain of ~3 000 instructions, and its workgroup leaves when the chain ends.
-  // A SIMD's issue slots go to the waves by priority, then age (MI355X_MICROARCH: "two waves per SIMD"): the search waves of
-  // the six other workgroups on this CU, which mostly wait for memory, take slots from it whenever their candidates arrive.
-  // Raised priority hands the chain those slots first (KS_PRIO_C; the helper wave KS_PRIO_H).
-  if (KS_PRIO_C) __builtin_amdgcn_s_setprio(KS_PRIO_C);
+  // (Raised wave priority for it - s_setprio 1 .. 3, the helper wave likewise - was measured in round 6 and changes nothing:
+  // profiles/round6/r06b_wave_priority.txt. The chain's length is its instructions, not the slots it loses.)
   int lane = lane_;
   asm volatile("" : "+v"(lane));  // the query index is formed again from here on: kept across the list walk it is the one
   const int ic = qidx(lane);       // value the register allocator spills (8 B of scratch per lane for a 32-bit add)
@@ -2168,65 +2154,24 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
       rem -= m * nact, base_t += m;
     }
   } else {
-#ifndef KS_XCD_MODE
-#define KS_XCD_MODE 1
-#endif
-#if KS_XCD_MODE == 2
-    // Workgroup -> tile, XCD-aware. Consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own. Two
-    // things want the tiles an XCD forms chosen with care:
-    //  - a tile's 97 sums are 97 eight-byte stores into 97 different lines of the entry-major tile array; with tile == id
-    //    the 16 tiles that share a 128-byte line came from all 8 XCDs and every L2 wrote its pieces back as partial lines
-    //    at the end of the kernel (WRITE_SIZE 5.1 MB for 1.2 MB of tiles, 2.0 us of k_pass: profiles/round5/r05b);
-    //  - the scan is grouped by LiDAR, then by map column: tile k of n in LiDAR A's segment and tile k' = k n'/n in LiDAR
-    //    B's cover the same part of the map and walk the same cells' lists - on different XCDs each L2 fetched its own
-    //    copy: 44.9 MB of distinct list bytes per pass summed over the XCDs against 29.6 MB in the whole scan
-    //    (tools/cell_share.py, profiles/round5/r05i).
-    // So XCD x forms the x-th EIGHTH OF EVERY LiDAR SEGMENT (same share of every LiDAR's work for every XCD - one
-    // contiguous eighth of the whole scan per XCD was measured first and costs 1.9 us: the LiDARs' workgroups are not
-    // equally heavy): lines of the tile array are completed inside one L2, a cell's list is fetched once for the queries of
-    // all LiDARs. The ids of XCD x are x, x + 8, ...: its r-th id takes position P = (ids of lower XCDs) + r of the tiles
-    // ordered by (eighth, LiDAR, index); the eighths' sizes and the XCDs' id counts differ by at most a few tiles, which
-    // then run next door. A tile keeps its position in scan order (the summation tree's leaf); only who forms it changes.
+    // Workgroup -> tile, XCD-aware. Consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own, and a
+    // tile's 97 sums are 97 eight-byte stores into 97 different lines of the entry-major tile array: with tile == id the 16 tiles
+    // that share a 128-byte line came from all 8 XCDs and every L2 wrote its pieces back as partial lines at the end of the
+    // kernel (WRITE_SIZE 5.1 MB for 1.2 MB of tiles, 2.0 us of k_pass: profiles/round5/r05b). Inside every block of 128 ids XCD x
+    // forms the 16 CONSECUTIVE tiles [16 x, 16 x + 16): -1.0 us. (Measured and not used, profiles/round5/r05d, r05i, r05q, r05s: one
+    // contiguous eighth of the scan per XCD, the x-th eighth of every LiDAR segment per XCD - a third fewer fetched bytes, not a
+    // microsecond -, tiles dealt to the CUs by weight, a rotated sub-block per 128-block.)
     {
-      const int nt = (int)gridDim.x, xb = (int)blockIdx.x & 7, q8 = nt >> 3, rem = nt & 7;
-      int pos = xb * q8 + min(xb, rem) + ((int)blockIdx.x >> 3);  // a bijection of [0, nt)
-      bool found = false;
-      for (int x = 0; x < 8 && !found; x++) {
-#pragma unroll
-        for (int l = 0; l < MALIO_MAX_LIDAR; l++) {
-          const int n = l < f.L ? f.seg_blk0[l + 1] - f.seg_blk0[l] : 0;
-          const int lo = (int)(((long long)x * n) >> 3), cnt = (int)(((long long)(x + 1) * n) >> 3) - lo;
-          if (!found) {
-            if (pos < cnt) tile = f.seg_blk0[l] + lo + pos, found = true;
-            else pos -= cnt;
-          }
-        }
-      }
-    }
-#elif KS_XCD_MODE == 1
-    {  // (measured on the way: inside every block of 128 ids XCD x forms the 16 CONSECUTIVE tiles [16 x, 16 x + 16): the write side only, -1.0 us)
       const int b = (int)blockIdx.x, full = (int)gridDim.x & ~127;
       if (b < full) tile = (b & ~127) + ((b & 7) << 4) + ((b & 127) >> 3);
-#ifndef KS_NO_REVERSE
-      // ... and in REVERSE scan order: the launch hands out ~1 600 workgroups over ~1 us, lowest id first, and the workgroups
+      // ... in REVERSE scan order: the launch hands out ~1 600 workgroups over ~1 us, lowest id first, and the workgroups
       // that finish last are those of the sparser LiDARs at the END of the scan (fewer queries share a cell: more distinct
-      // lines to fetch per workgroup, profiles/round5/r05h) - they now enter first.
-#ifndef KS_NO_TAIL_LIGHT
-      // The ids past the last whole block of 128 are handed out LAST and land as a SEVENTH workgroup on CUs that hold six (1 564
-      // workgroups over 256 CUs at BASELINE config 2): these were the kernel's last workgroups to leave - by 2 us, whatever the
-      // rest gained (profiles/round5/r05p_*). They take the scan's FIRST tiles (the densest LiDAR: the lightest), everything
-      // else moves up.
-      // (Dealing the tiles to the CUs by weight - the dispatcher is round-robin: workgroup b runs on XCD (b & 7), CU slot
-      // ((b >> 3) & 31) - so that every CU fetches the same number of lists, the CUs with a workgroup more the lightest ones:
-      // loads 254 .. 266 per CU instead of 246 .. 301, and the same 28 us: what is left of the tail is not systematic,
-      // profiles/round5/r05q_placement.txt.)
+      // lines to fetch per workgroup, profiles/round5/r05h) - they enter first. The ids past the last whole block of 128 are handed
+      // out LAST and land as a SEVENTH workgroup on CUs that hold six (1 564 workgroups over 256 CUs at BASELINE config 2): these
+      // were the kernel's last workgroups to leave - by 2 us, whatever the rest gained (profiles/round5/r05p_*). They take the
+      // scan's FIRST tiles (the densest LiDAR: the lightest), everything else moves up.
       tile = b < full ? (int)gridDim.x - 1 - tile : b - full;
-#else
-      if (b < full) tile = full - 1 - tile;
-#endif
-#endif
     }
-#endif
 #pragma unroll
     for (int l = 1; l < MALIO_MAX_LIDAR; l++)
       if (l < f.L && tile >= f.seg_blk0[l]) lid = l;
@@ -3061,9 +3006,6 @@ __global__ void __launch_bounds__(BLK) k_sort_count(UploadRec *in, int n, QuatCo
     const u32 th = tile_hash(tx, ty, tz);
     const u32 other = part_tile_owner(part, tx, ty, tz) == (u32)part.rank ? 0u : 1u;
     b = (u32)lid * SORT_NBK + (other << 11) + (((th >> 8) & 31u) << 6) + (((cy & 7u) << 3) | (cx & 7u));
-#ifdef KS_PART_CLASS_ORDER  // A/B: the order of round 3 (64 classes ascending, owned and foreign interleaved)
-    b = (u32)lid * SORT_NBK + ((th & 63u) << 6) + (((cy & 7u) << 3) | (cx & 7u));
-#endif
   }
   keys[i] = cell;
   bkt[i] = b;
