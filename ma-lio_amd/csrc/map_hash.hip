@@ -640,8 +640,12 @@ __device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, u32 old,
 __global__ void __launch_bounds__(BLK) k_nl_sort(NlDev nl, const u32 *__restrict__ work, const u32 *__restrict__ nwork) {
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * BLK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLK) >> 6;
-  if (work) {  // a batch's work list: one list per wave and round
-    const u32 nitems = min(*nwork, nl.work_cap);
+  // a batch's work list: one list per wave and round - unless the batch touched more lists than the list holds (k_nl_place
+  // counted them all, stored what fitted): then every list of the directory is put in order, as after a build (0.5 ms at a
+  // million points; a batch of more than ~150 k new points - round-5 advisor: such lists used to stay unflagged, walked whole,
+  // until the next rebuild)
+  if (work && *nwork <= nl.work_cap) {
+    const u32 nitems = *nwork;
     for (u32 item = wave; item < nitems; item += nwaves) {
       const uint4 w0 = ((const uint4 *)work)[2 * (size_t)item], w1 = ((const uint4 *)work)[2 * (size_t)item + 1];
       nl_sort_list(nl, w0.x, w0.y, (u64)w1.x | ((u64)w1.y << 32), w0.w, w0.z, lane);
@@ -1067,7 +1071,7 @@ void nl_append(Ctx *c, hipStream_t st, NList &nl_a, NList &nl_b, const float4 *d
                      og_base, m, nl_dev(nl_a), nl_dev(nl_b));
   // the lists of the sorted level this batch appended to, in order again (one wave per list; the work list's length is on the
   // device: a grid that covers a typical batch in one round, the rest by striding)
-  if (nl_a.sorted && nl_a.work) {
+  if (nl_a.sorted) {  // (no work list - its allocation failed -: the kernel sweeps the directory)
     const NlDev a = nl_dev(nl_a);
     const long long lists = std::min<long long>((long long)m * 27, (long long)nl_a.tmask + 1);
     // (grid: a typical batch - 1 600 new points, ~8 k lists - in two rounds of one list per wave)
