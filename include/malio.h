@@ -444,8 +444,8 @@ int malio_get_option(malio_handle_t h, int option, double *value);
 int malio_debug_skip_stats(malio_handle_t h, int *out4);
 /* The level-1 neighbour lists as the next search would find them: out4 = {lists, lists flagged as ordered (MALIO_OPT_NL_SORTED),
  * flagged lists that are NOT in order (always 0), live entries}. Builds stale lists first. lists - flagged = the lists a walk reads
- * whole: those above 256 entries, and - after a batch whose work list overflowed (4 M items) or could not be allocated - the
- * ones that batch appended to, until the next rebuild puts them in order again (results are the same either way). */
+ * whole: those above 256 entries (results are the same either way). A batch that touches more lists than its work list holds
+ * (4 M items), or whose work list could not be allocated, has the whole directory put in order instead of its own lists. */
 int malio_debug_list_order(malio_handle_t h, long long *out4);
 
 /* ---- pinned host buffers (optional) ------------------------------------------------------------------------ */

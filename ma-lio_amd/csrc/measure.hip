@@ -5,6 +5,8 @@
 //   k_reuse          the same for a REUSE pass (neighbours and plane kept)
 //   k_rows_reduce    a5/a7/a10: Jacobian row, FIC weights, per-workgroup 16x16 f64 MFMA outer-product accumulation
 //   k_final_reduce   deterministic fixed-order sum of the workgroup partials
+//   k_pass           a search (or, in the enqueued-ahead update, reuse) pass WITH its rows in one kernel, speculating on the
+//                    previous pass' extrema (rounds 3-5); k_reuse_rows: the reuse pass as one streaming kernel (round 6)
 // plus the map_incremental selection (k_far_nearest, k_mapinc_classify) and the batched Nearest_Search (k_nearest).
 // Compiled with -ffp-contract=off: the float stages (distances, QR plane fit, gates) and the double
 // world transform follow the reference's operation order without FMA contraction, so discrete outcomes
@@ -31,7 +33,7 @@ __device__ long long g_phase[4][16];
 // 1.5 k workgroups would serialise for tens of microseconds and distort what they measure)
 __device__ long long g_span[14][8192];  // 12: HW_ID, 13: XCC_ID of the workgroup's first wave
 //  // entry, exit, end of level-1 search, pending level-2 queries; 4-7: each wave's own end of the level-1 search, 8-11: ... of its directory probe
-// the helper wave's stamps (KS_SPLIT): its lane 0 is thread 64
+// the helper wave's stamps: its lane 0 is thread 64
 #define PHH(kid, k)                                                                     \
   do {                                                                                  \
     if (threadIdx.x == 64 && blockIdx.x == gridDim.x / 2) g_phase[kid][k] = wall_clock64(); \
@@ -584,7 +586,7 @@ __device__ __forceinline__ double trace_for(const Pass1Args &a, const float4 q, 
   return point_trace(a.unc[off + k], q.x, q.y, q.z);
 }
 
-// The same under BOTH clamp rules, before the accept flag exists (KS_SPLIT: a helper wave evaluates the trace while the
+// The same under BOTH clamp rules, before the accept flag exists (a helper wave evaluates the trace while the
 // control wave fits the plane; the flag then picks one). trS == trace_for(.., true), trR == trace_for(.., false), bit for bit:
 // the two rules name different table entries only for the last index of a table.
 __device__ __forceinline__ void trace_both(const Pass1Args &a, const float4 q, int lid, int tidx, double &trS, double &trR) {
@@ -924,23 +926,16 @@ __device__ __forceinline__ bool nl_search(const NlView &nl, float wx, float wy, 
 // within 3e-7 relative of the true ones; sqrtf is correctly rounded)
 __device__ __forceinline__ float cert_radius(float lb2) { return sqrtf(lb2) * 0.99999f; }
 
-// a3 + gates + a6/a8 of ONE query whose neighbours are known (phase C of the search phases): writes the
-// per-point state, returns the accept flag, unit_cov and trace for the extrema.
-// cert_r >= 0: the neighbours come from a list walk at w - its certificate (w, radius free of outsiders) is stored for the
-// later search passes of this scan; < 0: the neighbours were kept under the stored certificate, which stays.
-// q: the scan point (phase A read it; it comes back from LDS, not from HBM). nbp: this lane's five LDS slots for the
-// neighbours' coordinates - the plane fit overwrites its copy, the inlier test afterwards reads them from there instead of
-// gathering them a second time. The lazy normal_y commit of the previous pass happened in phase A (search_wg).
-// (What phase A left in LDS - world point, |p'|, scan point - is read where it is used: held in registers across the
-// plane fit it is what the register allocator spills.)
-// SPLIT (KS_SPLIT, the control wave of a workgroup whose second wave stays as its helper): plane, gates and their per-point
-// state only - unit_cov, the trace, their stores and the extrema are the helper's (helper_pre / helper_post): ucov and tr
-// come back untouched.
+// a3 + gates of ONE query whose neighbours are known (phase C of the search phases, control wave): plane, accept flag and
+// residual go back to the caller, which hands them to the helper wave through LDS - unit_cov, the trace, the per-point state's
+// stores and the extrema are the helper's (helper_unit_cov_trace / helper_post). q: the scan point (phase A read it; it comes
+// back from LDS, not from HBM). The five neighbours' coordinates are kept in LDS across the fit (S.nbp: the plane fit overwrites
+// its copy, the inlier test afterwards reads them from there instead of gathering them a second time). What phase A left in
+// LDS - world point, |p'|, scan point - is read where it is used: held in registers across the plane fit it is what the
+// register allocator spills.
 struct SearchLds;
-template <bool SPLIT>
-__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
-                                            float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
-                                            float &pd2_out, float4 &q_out);
+__device__ __forceinline__ void point_phase(const Pass1Args &a, SearchLds &S, int lane, const u32 og[5], int nf, bool &selected,
+                                            float4 &pl_out, float &pd2_out, float4 &q_out);
 // REUSE pass of one point (ekfom_data.converge == false, laserMapping.cpp:583-595): neighbours, plane and flag are kept; the
 // residual and the range gate are re-evaluated at the new state.
 __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst &qc, int commit_prev, int i, bool &selected,
@@ -973,7 +968,7 @@ __device__ __forceinline__ void reuse_point(const Pass1Args &a, const QuatConst 
   tr = trace_for(a, q, lid, tidx, selected);
   a.trace[i] = tr;
 }
-// The same for the control wave of k_pass under KS_SPLIT: loads and arithmetic only. The world point, the flag and the
+// The same for the control wave of k_pass: loads and arithmetic only. The world point, the flag and the
 // residual go back to the caller, which hands them to the helper wave through LDS; the helper stores them with the rest of
 // the per-point state (helper_post), forms the trace and folds the previous pass' normal_y.
 __device__ __forceinline__ void reuse_point_ctrl(const Pass1Args &a, const QuatConst &qc, int i, bool &selected, float4 &pl_out,
@@ -1045,7 +1040,7 @@ struct SearchLds {
   float4 (*nbp)[SQ];       // phase C: [5][SQ] - the five neighbours' map points, kept across the plane fit (point_phase); the
                            // kernel's own LDS (k_pass: the storage of its row staging U, which is written after the fit)
   double nb[SQ];  // sqrt(|p'|) of phase A, consumed by the range gate in phase C
-  // KS_SPLIT: what the helper wave and the control wave hand each other across their one barrier
+  // what the helper wave and the control wave hand each other across their one barrier
   double trS[SQ], trR[SQ];  // helper -> itself: the trace under the accepted / rejected point's clamp rule (trace_both)
   double ucv[SQ];           // helper -> itself: unit_cov of the five neighbours (esti_plane's plane_cov)
   unsigned char selc[SQ];   // control -> helper: the accept flag
@@ -1058,28 +1053,17 @@ struct RowPre {
   double cp[SQ];    // plane weight c_i (:651-656)
   double rw[SQ];    // 1 / R_i after the FIC and the clamp of esekfom.hpp:624-626 (ROWS_DIVIDE: R_i itself)
 };
-template <bool SPLIT>
-__device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds &S, int lane, const u32 og[5], int nf,
-                                            float cert_r, bool &selected, double &ucov, double &tr, float4 &pl_out,
-                                            float &pd2_out, float4 &q_out) {
-  selected = false, ucov = 0.0, tr = 0.0;
+__device__ __forceinline__ void point_phase(const Pass1Args &a, SearchLds &S, int lane, const u32 og[5], int nf, bool &selected,
+                                            float4 &pl_out, float &pd2_out, float4 &q_out) {
+  selected = false;
   pl_out = make_float4(0.f, 0.f, 0.f, 0.f), pd2_out = 0.f;
   float4 (*const nbp)[SQ] = S.nbp;
-  // SPLIT: the control wave issues NO global store before its tile - on gfx9 a wave's stores and loads share one in-order
-  // counter (vmcnt), so a store in front of the neighbour gather makes the gather's wait a wait for the store's round trip
-  // too. The helper wave stores the per-point state after the barrier (helper_post), from LDS.
-  if (!SPLIT) {
-    if (cert_r >= 0.f) {
-      const float4 w = S.w[lane];
-      STATE_ST(a.cert[i] = make_float4(w.x, w.y, w.z, cert_r);)
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) STATE_ST(a.nbr[(size_t)k * a.N + i] = og[k];)
-    STATE_ST(a.nfound[i] = (unsigned char)nf;)  // (feats_down_world of a search pass is world4: malio_scan_get reads it from there)
-  }
+  // The control wave issues NO global store before its tile - on gfx9 a wave's stores and loads share one in-order counter
+  // (vmcnt), so a store in front of the neighbour gather makes the gather's wait a wait for the store's round trip too. The
+  // helper wave stores the per-point state after the barrier (helper_post), from LDS; unit_cov and the trace are its as well.
   if (nf == 5) {  // gate `size < 5 || d2[4] > 5` (:587): only d2 <= 5 candidates were kept
     // ---- esti_plane<float> (common_lib.h:144-190) ----
-    float A[5][3], W[5];
+    float A[5][3];
     {
       float4 m[5];
 #ifdef ATTR_NO_GATHER
@@ -1093,12 +1077,11 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
       asm volatile("" : "+v"(m[0].w), "+v"(m[1].w), "+v"(m[2].w), "+v"(m[3].w), "+v"(m[4].w));
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        A[k][0] = m[k].x, A[k][1] = m[k].y, A[k][2] = m[k].z, W[k] = m[k].w;
+        A[k][0] = m[k].x, A[k][1] = m[k].y, A[k][2] = m[k].z;
         nbp[k][lane] = m[k];
       }
     }
     PH(0, 4);
-    if (!SPLIT) ucov = plane_unit_cov(a.cov_threshold, W);
     float nv[3], pabcd[4];
     PH(0, 5);
     qr_solve_5x3(A, nv);
@@ -1122,41 +1105,27 @@ __device__ __forceinline__ void point_phase(const Pass1Args &a, int i, SearchLds
       if (fabsf(pabcd[0] * m.x + pabcd[1] * m.y + pabcd[2] * m.z + pabcd[3]) > a.plane_th) plane_ok = false;
     }
     pl_out = make_float4(pabcd[0], pabcd[1], pabcd[2], pabcd[3]);
-    if (!SPLIT) {
-      STATE_ST(a.plane[i] = pl_out;)
-      STATE_ST(a.ucov[i] = ucov;)
-    }
     if (plane_ok) {
       float pd2;
       const float4 w = S.w[lane];
       if (residual_gate(pabcd, w.x, w.y, w.z, S.nb[lane], pd2)) {
         selected = true;
-        if (!SPLIT) STATE_ST(a.pd2[i] = pd2;)
         pd2_out = pd2;
       }
     }
   }
-  if (!SPLIT) STATE_ST(a.sel[i] = selected ? 1 : 0;)
   PH(0, 7);
-  const float4 q = S.q[lane];
-  q_out = q;
-  if (SPLIT) return;
-  const int packed = __float_as_int(q.w);
-  tr = trace_for(a, q, packed & 0xFF, packed >> 8, selected);
-  STATE_ST(a.trace[i] = tr;)
+  q_out = S.q[lane];
 }
 
 
 // Phases A .. C for the queries [q0, q0 + 64) n [0, qend) of this workgroup. Returns ROLE_CONTROL in the control wave (with
-// its lane's PointOut filled), ROLE_RETIRE in the search waves once they have nothing left to do - and, with KS_SPLIT,
+// its lane's PointOut filled), ROLE_RETIRE in the search waves once they have nothing left to do - and
 // ROLE_HELPER in the second wave: it stays to take the plane-independent work off the control wave's chain (helper_pre /
 // helper_post below; the caller runs them).
 // SKIP: the kernels of a handle with MALIO_OPT_SEARCH_SKIP on - every list walk leaves its certificate, a search pass that is
 // not the first of its scan (dy.skip, decided per pass) keeps cached neighbours where the certificate allows (phase A').
 // SKIP = false is the search of rounds 1-3 with no trace of any of it.
-#ifndef KS_SPLIT
-#define KS_SPLIT 1
-#endif
 // KS_QUAD (round 6, built exactly, measured, NOT the default): phase C - plane fit, gates, unit_cov - by the four lanes of every
 // query on ALL four waves (quad_fit.hpp: ~470 instructions per lane instead of ~1 000) instead of one lane per query on the
 // control wave; what the helper wave did beside the fit without needing the neighbours (traces, point_this, 1 / R_i) done beside
@@ -1218,9 +1187,9 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
       if (KS_PCACHE && (dy.skip & 2)) pcv = a.pcache[i];
       double nb;
       world_point(qc, q, __float_as_int(q.w) & 0xFF, w.x, w.y, w.z, nb);
-      // (KS_SPLIT: helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses
-      // its world point below and is nobody's to store later)
-      if (!KS_SPLIT || a.part.world > 1) STATE_ST(a.world4[i] = w;)
+      // (helper_post stores it, see point_phase - except on a tile shard, where a point of another shard loses its world
+      // point below and is nobody's to store later)
+      if (a.part.world > 1) STATE_ST(a.world4[i] = w;)
       S.nb[lane_] = sqrt(nb);  // (sqrt(p_body.norm()), :599: formed here, off phase C's chain)
       S.q[lane_] = q;
       if (!part_owns(a.part, w.x, w.y, w.z)) {  // another shard serves this point (same bits there: same decision)
@@ -1452,7 +1421,7 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
   return ROLE_CONTROL;
 #endif
   if (!cwave) {
-    if (KS_SPLIT && (int)(threadIdx.x >> 6) == 1) return ROLE_HELPER;
+    if ((int)(threadIdx.x >> 6) == 1) return ROLE_HELPER;
     return ROLE_RETIRE;
   }
   // ---- phase C (control wave) ----
@@ -1471,12 +1440,12 @@ __device__ __forceinline__ int search_wg(const Pass1Args &a, const NlView &nl1, 
   const float4 wq = S.w[lane];
   const bool served = ic < qend && wq.x < 1e9f;  // == mine: a point of another shard sits at 3e9
   if (served)
-    point_phase<KS_SPLIT != 0>(a, ic, S, lane, og, nf, !SKIP || S.keep[lane] ? -1.f : S.cr[lane], po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
+    point_phase(a, S, lane, og, nf, po.selected, po.pl, po.pd2, po.q);
   PH(0, 8);
   return ROLE_CONTROL;
 }
 
-// ---- KS_SPLIT: the helper wave ---------------------------------------------------------------------------------------------
+// ---- the helper wave (round 5) ---------------------------------------------------------------------------------------------
 // The control wave's phase C is one dependent chain (gather -> QR -> gates -> ... -> row -> 16 MFMAs), 9.5 us of a 21 us
 // workgroup at BASELINE config 2, and three waves used to retire beside it. Everything on that chain that does not need the
 // PLANE is now the second wave's, lane = query as well:
@@ -1604,7 +1573,6 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
   const int role = search_wg<DEV, SKIP, (KS_PIPE != 0) && !DEV>(a, nl1, nl2, qc, dy, S, (int)blockIdx.x * SQ, a.N, po);
   if (role == ROLE_RETIRE || po.skipped) return;
 #endif
-#if KS_SPLIT
   {
     const int lane = (int)(threadIdx.x & 63), i = (int)blockIdx.x * SQ + lane;
     if (role == ROLE_HELPER) {  // (see helper_unit_cov_trace)
@@ -1622,9 +1590,6 @@ __global__ void __launch_bounds__(KS_BLK) __attribute__((amdgpu_waves_per_eu(KS_
     S.selc[lane] = po.selected ? 1 : 0, S.plc[lane] = po.pl, S.pd2c[lane] = po.pd2;
     __syncthreads();
   }
-#else
-  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4 over this wave's 64 queries
-#endif
   PH(0, 9);
   PH_EXIT();
 }
@@ -2103,10 +2068,8 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   // the 64 rows of the control wave for the MFMA operands: u[12], hs, 1/r (a_p = [u/r | u0..2 | 0], b_p = [u | hs | 0 0 0]
   // are formed when they are read: 7.7 KB instead of the two 17-double records of k_rows_reduce)
   __shared__ double U[SQ][15];
-#if KS_SPLIT
   __shared__ RowPre RP;
   POISON_LDS(RP);
-#endif
   POISON_LDS(S);
   POISON_LDS(U);
   POISON_SYNC();
@@ -2213,14 +2176,14 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
 #else
     role = search_wg<DEV, SKIP, KS_PIPE != 0>(a, nl1, nl2, qc, dy, S, q0, qend, po);
 #endif
-    if (role == ROLE_RETIRE) return;  // (the search waves retire; with KS_SPLIT the second wave stays as the helper)
+    if (role == ROLE_RETIRE) return;  // (the search waves retire; the second wave stays as the helper)
     if (po.skipped) {  // a workgroup of another shard's tiles: its leaf of the summation tree is a zero tile, nothing else
       for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
       return;
     }
   } else {  // REUSE pass: the control wave (and its helper), lane = point
     if (blockIdx.x == 0 && threadIdx.x < MM_SLOTS) mm_reset_slot(dy.mm_next, threadIdx.x);
-    if (threadIdx.x >= (KS_SPLIT ? 128 : 64)) return;
+    if (threadIdx.x >= 128) return;
     role = threadIdx.x >= 64 ? ROLE_HELPER : ROLE_CONTROL;
     const int i = q0 + lane;
     po.selected = false, po.ucov = 0.0, po.tr = 0.0, po.pd2 = 0.f;
@@ -2230,15 +2193,11 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
         for (int e = lane; e < NSUM; e += 64) f.tiles[(size_t)e * f.tstride + tile] = 0.0;
       return;  // (both waves see the same ballot)
     }
-#if KS_SPLIT
     if (role == ROLE_CONTROL) {
       float4 wld = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < qend) reuse_point_ctrl(a, qc, i, po.selected, po.pl, po.pd2, po.q, wld);
       S.w[lane] = wld;
     }
-#else
-    if (i < qend) reuse_point(a, qc, dy.commit_prev, i, po.selected, po.ucov, po.tr, po.pl, po.pd2, po.q);
-#endif
   }
   PH(2, 0);
   // ---- a5 / a7 with the guessed extrema ----
@@ -2247,7 +2206,6 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
 #pragma unroll
   for (int k = 0; k < 4; k++) mm[k] = DEV ? dl->mm_guess[k] : f.guess[k];
 #endif
-#if KS_SPLIT
 #if KS_QUAD
   if (converge && role == ROLE_HELPER) {  // (phase C' left flag, plane, residual, unit_cov and c_i in LDS; its barrier is behind us)
     const int i = q0 + lane;
@@ -2323,29 +2281,6 @@ k_pass(Pass1Args a, NlView nl1, NlView nl2, FuseArgs f, const DevLoop *__restric
   for (int k = 0; k < 12; k++) U[lane][k] = u[k];
   U[lane][12] = hs;
   U[lane][13] = po.selected ? RP.rw[lane] : 0.0;
-#else
-  wave_minmax_publish(a, dy.mm_cur, po.selected, po.ucov, po.tr);  // a4: the TRUE extrema of this pass
-  PH(2, 1);
-  double u[12], hs = 0, r = 1;
-#pragma unroll
-  for (int k = 0; k < 12; k++) u[k] = 0;
-  if (po.selected) {
-    RowIn rin;
-    rin.q = po.q, rin.pl = po.pl, rin.ucov = po.ucov, rin.trace = po.tr, rin.pd2 = po.pd2;
-    point_row(f.wc, a.extrinsic_est_en, pc, mm, rin, lid, u, hs, r);
-  }
-  double rc = r;
-  if (rc < 0.0001) rc = 0.001;  // esekfom.hpp:624-626
-  PH(2, 2);
-#pragma unroll
-  for (int k = 0; k < 12; k++) U[lane][k] = u[k];
-  U[lane][12] = hs;
-#ifndef ROWS_DIVIDE
-  U[lane][13] = po.selected ? 1.0 / rc : 0.0;
-#else
-  U[lane][13] = po.selected ? rc : 0.0;
-#endif
-#endif
   const unsigned long long bal = __ballot(po.selected);
   __builtin_amdgcn_wave_barrier();  // one wave: its LDS stores above precede its loads below (waitcnt by the compiler)
   PH(2, 3);
