@@ -434,3 +434,71 @@ def test_gpu_ordered_lists_on_a_dense_and_on_a_tiny_map(capi, scenes):
         assert res[0][0] == res[1][0]
         for k in (1, 2, 3):
             np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+@pytest.mark.gpu
+def test_gpu_cell_ordered_map_array_keeps_insertion_order_and_results(capi, scenes):
+    """MALIO_OPT_MAP_CELL_ORDER (round 6, default on): a (re)build sorts the map array by level-1 cell, appends go behind it,
+    d_map_ord remembers every slot's rank in INSERTION order. What must not change: malio_map_get hands the map out in insertion
+    order - through a build, in-place appends, box deletions, and the rebuild that sweeps a fifth of the map's tombstones out and
+    sorts again (ranks re-ranked, appended slots folded in) -, and a search finds the same neighbours whether the option is on or
+    off and whether the map was handed over in raster or in shuffled order (exact ties aside: conftest.exact_ties)."""
+    from conftest import exact_ties
+    sc = scenes.make_scene(seed=641, N=8000, Nmap=120000, L=3)
+    rng = np.random.default_rng(5)
+    shuf = sc["map"][rng.permutation(sc["Nmap"])]
+    ref = None
+    for mp in (sc["map"], shuf):
+        for co in (1, 0):
+            e = capi.Engine(sc["params"])
+            e.set_option("map_cell_order", co)
+            e.map_build(mp)
+            np.testing.assert_array_equal(e.map_get(), mp)  # insertion order, bit for bit, whatever the slots' order
+            e.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+            m = e.measure(sc["state0"], True)
+            g = e.scan_get()
+            if ref is None:
+                ref = (m, g)
+                continue
+            ok = ~exact_ties(g, ref[1])
+            assert m["M"] == ref[0]["M"] and np.array_equal(g["selected"][ok], ref[1]["selected"][ok])
+            assert np.array_equal(g["normvec"][ok], ref[1]["normvec"][ok]) and np.array_equal(g["res_last"][ok], ref[1]["res_last"][ok])
+            assert np.abs(m["HtRinvH"] - ref[0]["HtRinvH"]).max() <= 1e-11 * np.abs(ref[0]["HtRinvH"]).max()
+    # a history of mutations on the shuffled map, cell order on: the expected map is kept on the host in insertion order
+    e = capi.Engine(sc["params"])
+    e.map_build(shuf)
+    want = shuf.copy()
+    key = lambda p: p[:, [0, 1, 2, 5]]
+    for rnd in range(3):
+        new = shuf[rng.integers(0, len(shuf), 1500)].copy()
+        new[:, :3] += np.float32(300.0) + rng.normal(0, 5.0, (1500, 3)).astype(np.float32)  # empty space: all of them are kept, in order
+        assert e.map_add(new, False) == 0
+        want = np.concatenate([want, new])
+        c = want[rng.integers(0, len(want)), :3]
+        box = np.concatenate([c - 3.0, c + 3.0]).astype(np.float32)[None]
+        inside = ((want[:, :3] >= box[0, :3]) & (want[:, :3] < box[0, 3:])).all(1)
+        assert e.map_delete_boxes(box) == int(inside.sum())
+        want = want[~inside]
+        np.testing.assert_array_equal(key(e.map_get()), key(want))
+    before = e.debug_counters()["rebuilds"]
+    zc = np.median(want[:, 2])
+    big = np.array([[-1e5, -1e5, -1e5, 1e5, 1e5, zc]], np.float32)  # half the map dies: the next search compacts, re-ranks and sorts again
+    inside = ((want[:, :3] >= big[0, :3]) & (want[:, :3] < big[0, 3:])).all(1)
+    assert e.map_delete_boxes(big) == int(inside.sum()) and inside.mean() > 0.25
+    want = want[~inside]
+    e.nearest_search(want[:100], 5)
+    assert e.debug_counters()["rebuilds"] > before
+    np.testing.assert_array_equal(key(e.map_get()), key(want))
+    more = want[rng.integers(0, len(want), 500)].copy()
+    more[:, :3] += np.float32(-300.0)
+    assert e.map_add(more, False) == 0
+    want = np.concatenate([want, more])
+    np.testing.assert_array_equal(key(e.map_get()), key(want))
+    fresh = capi.Engine(sc["params"])
+    fresh.map_build(want)
+    q = want[rng.integers(0, len(want), 3000)].copy()
+    q[:, :3] += rng.normal(0, 0.3, (3000, 3)).astype(np.float32)
+    _, d2a, ca = e.nearest_search(q, 5)
+    _, d2b, cb = fresh.nearest_search(q, 5)
+    np.testing.assert_array_equal(d2a, d2b)
+    np.testing.assert_array_equal(ca, cb)
