@@ -3,7 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include "malio_internal.hpp"
-#include "../build/build_id.h"  // MALIO_BUILD_ID (written by the Makefile)
+#include "build_id.h"  // MALIO_BUILD_ID (written by the Makefile)
 #include "../host/manifold.hpp"
 
 using namespace malio;

@@ -560,41 +560,68 @@ __device__ __forceinline__ void nl_sort_body(float4 *lst, u32 n, float cx, float
     if (idx < n) lst[rank[k]] = e[k];
   }
 }
-// A list that WAS in order (its first n0 entries) and got a few entries appended: the tail's entries are ranked among all, the
-// prefix entries move up by the number of tail entries that sort before them - a compare and a ballot per tail entry instead of a
-// compare per pair (a scan's batch touches ~20 k lists with one to three new entries each: 31 -> ~10 us for the kernel, which
-// sits between a scan's map update and the next scan's first search). false: a tombstone in the prefix (its key is +inf wherever
-// it stands: the prefix is not in order by key) - the caller sorts from scratch.
+// A list that WAS in order (its first n0 entries) and got entries appended: the tail's entries are ranked among all, the live
+// prefix entries keep their order and move up by the number of tail entries that sort before them - a compare and a ballot per
+// tail entry instead of a compare per pair (a scan's batch touches ~20 k lists with a few new entries each; the kernel sits
+// between a scan's map update and the next scan's first search). Tombstones in the prefix (round 6: the voxel filter of every
+// batch replaces map points - dead entries sit in exactly the lists the batch appends to, and sorting those from scratch was
+// 15 of the kernel's 26 us): their key is +inf wherever they stand, the LIVE prefix entries are still in order among
+// themselves; a dead entry's place is behind every live one, among the dead by position - two ballots, no loop.
 template <int K>
-__device__ __forceinline__ bool nl_merge_body(float4 *lst, u32 n0, u32 n, float cx, float cy, float cz, int lane) {
+__device__ __forceinline__ void nl_merge_body(float4 *lst, u32 n0, u32 n, float cx, float cy, float cz, int lane) {
   float4 e[K];
   float key[K];
   u32 rank[K];
-  bool tomb = false;
+  unsigned long long livem[K], deadm[K];  // (wave-uniform) the entries of slot k with a finite / a non-finite key
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const u32 idx = (u32)lane + 64u * k;
-    key[k] = INFINITY, rank[k] = idx;  // a prefix entry keeps its place among the prefix entries
+    key[k] = INFINITY, rank[k] = idx;
     if (idx < n) {
       e[k] = lst[idx];
       key[k] = nl_centre_d2(e[k], cx, cy, cz);
-      tomb |= idx < n0 && !(key[k] < INFINITY);
+    }
+    livem[k] = __ballot(idx < n && key[k] < INFINITY);
+    deadm[k] = __ballot(idx < n && !(key[k] < INFINITY));
+  }
+  u32 nlive = 0;
+#pragma unroll
+  for (int k = 0; k < K; k++) nlive += (u32)__popcll(livem[k]);
+  // prefix entries: a live one starts at its place among the live prefix entries, a dead one (prefix or tail: the order under
+  // (key, position) puts every +inf key behind the finite ones, by position) gets its final place right away
+  {
+    u32 live_before = 0, dead_before = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const u32 idx = (u32)lane + 64u * k;
+      // (live entries of the PREFIX only: the tail's live entries are ranked by the loop below)
+      const unsigned long long pm = 64u * k + 64u <= n0 ? ~0ull : (64u * k >= n0 ? 0ull : (1ull << (n0 - 64u * k)) - 1ull);
+      if (idx < n) {
+        if (key[k] < INFINITY) {
+          if (idx < n0) rank[k] = live_before + (u32)__popcll(livem[k] & pm & below);
+        } else {
+          rank[k] = nlive + dead_before + (u32)__popcll(deadm[k] & below);
+        }
+      }
+      live_before += (u32)__popcll(livem[k] & pm);
+      dead_before += (u32)__popcll(deadm[k]);
     }
   }
-  if (__ballot(tomb)) return false;
-  for (u32 t = n0; t < n; t++) {  // (wave-uniform; at most NL_MERGE_MAX rounds)
+  for (u32 t = n0; t < n; t++) {  // (wave-uniform)
     const int tl = (int)(t & 63u);
     float kt = 0.f;
 #pragma unroll
     for (int k = 0; k < K; k++)
       if ((t >> 6) == (u32)k) kt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(key[k]), tl));
+    if (!(kt < INFINITY)) continue;  // (a dead tail entry has its place already and sorts before nobody alive)
     u32 before = 0;  // entries that sort before entry t: its final position
 #pragma unroll
     for (int k = 0; k < K; k++) {
       const u32 idx = (u32)lane + 64u * k;
       const bool live = idx < n;
       before += (u32)__popcll(__ballot(live && (key[k] < kt || (key[k] == kt && idx < t))));
-      if (live && idx < n0 && kt < key[k]) rank[k] += 1;  // (a tie leaves the older entry in front)
+      if (live && idx < n0 && kt < key[k] && key[k] < INFINITY) rank[k] += 1;  // (a tie leaves the older entry in front)
     }
 #pragma unroll
     for (int k = 0; k < K; k++)
@@ -605,9 +632,9 @@ __device__ __forceinline__ bool nl_merge_body(float4 *lst, u32 n0, u32 n, float 
     const u32 idx = (u32)lane + 64u * k;
     if (idx < n && rank[k] != idx) lst[rank[k]] = e[k];
   }
-  return true;
 }
-constexpr u32 NL_MERGE_MAX = 8;  // more new entries than that: sorted from scratch
+// (the merge costs ~8 K instructions per tail entry, the sort from scratch ~4 K per entry of the list: a tail up to the prefix's
+// length is merged)
 // (slot: the list's directory slot, old: its count word before the batch's appends - 0: unknown -, key / start / n: the cell and
 // the list as they are now; every lane of the wave calls with the same values)
 __device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, u32 old, u64 ckey, u32 cstart, u32 n, int lane) {
@@ -624,13 +651,11 @@ __device__ __forceinline__ void nl_sort_list(const NlDev &nl, u32 slot, u32 old,
   float4 *lst = nl.pts + (size_t)cstart;
   static_assert(NL_SORT_MAX == 256, "the dispatch below covers 64 / 128 / 256 entries");
   const u32 n0 = old & NL_COUNT;
-  bool done = false;
-  if ((old & NL_SORTED) && n0 >= 1 && n0 < n && n - n0 <= NL_MERGE_MAX) {
-    if (n <= 64) done = nl_merge_body<1>(lst, n0, n, cx, cy, cz, lane);
-    else if (n <= 128) done = nl_merge_body<2>(lst, n0, n, cx, cy, cz, lane);
-    else done = nl_merge_body<4>(lst, n0, n, cx, cy, cz, lane);
-  }
-  if (!done) {
+  if ((old & NL_SORTED) && n0 >= 1 && n0 < n && n - n0 <= n0) {
+    if (n <= 64) nl_merge_body<1>(lst, n0, n, cx, cy, cz, lane);
+    else if (n <= 128) nl_merge_body<2>(lst, n0, n, cx, cy, cz, lane);
+    else nl_merge_body<4>(lst, n0, n, cx, cy, cz, lane);
+  } else {
     if (n <= 64) nl_sort_body<1>(lst, n, cx, cy, cz, lane);
     else if (n <= 128) nl_sort_body<2>(lst, n, cx, cy, cz, lane);
     else nl_sort_body<4>(lst, n, cx, cy, cz, lane);
@@ -958,7 +983,7 @@ __global__ void __launch_bounds__(BLK) k_nl_tombstone(const float4 *__restrict__
                                                       int ndel, NlDev nl_a, NlDev nl_b) {
   const NlDev nl = blockIdx.y ? nl_b : nl_a;
   // 16 lanes per (deleted point, one of its 27 lists) on level 1 (~45 entries), a whole wave on level 2 (180..900
-  // entries: 4 round trips instead of 14; the kernel is as long as its longest walk)
+  // entries: 4 round trips instead of 14; the kernel is as long as its longest walk; 8 loads in flight: no shorter, round 6)
   const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
   const int lg = blockIdx.y ? 6 : 4;
   const u32 lanes = 1u << lg;

@@ -317,6 +317,54 @@ def test_gpu_in_place_list_updates_equal_a_full_rebuild(orc, capi, scenes):
 
 
 @pytest.mark.gpu
+def test_gpu_appends_to_lists_that_hold_tombstones_keep_them_in_order(orc, capi, scenes):
+    """A batch appends to lists whose earlier entries died (every voxel-filtered batch does: the points it replaces sit in
+    the lists it appends to). k_nl_sort merges the new entries into the live ones - which are still in order among
+    themselves - and moves the dead behind them (round 6; rounds 5 sorted such lists from scratch). Tails of every length
+    up to the prefix's, dead entries in prefix and tail, lists of one, two and four entries per lane."""
+    sc = scenes.make_scene(cfg=1)
+    eng = capi.Engine(sc["params"])
+    eng.set_option("early_min_queries", 0)   # (walks that rely on the order, at this size too)
+    rng = np.random.default_rng(5)
+    c = sc["map"][rng.integers(0, sc["map"].shape[0]), :3].astype(np.float32)
+    dense = np.repeat(sc["map"][:1], 6000, axis=0).copy()
+    dense[:, :3] = (c + rng.uniform(-6, 6, size=(6000, 3))).astype(np.float32)   # +3.5 points per m^3: lists of 100 - 250 entries
+    m0 = np.concatenate([sc["map"], dense])
+    eng.map_build(m0)
+    port = orc.VoxMap(float(sc["params"]["filter_size_map"]))
+    port.build(m0)
+    q = np.concatenate([dense[:1500], sc["map"][:1500]]).astype(np.float32).copy()
+    q[:, :3] += rng.normal(0, 0.2, size=(3000, 3)).astype(np.float32)
+    before = eng.debug_counters()
+    for r in range(6):
+        # holes in dense and thin places, then new points in and around the holes (some of them die in the next round)
+        for centre, half in ((c + rng.uniform(-4, 4, 3).astype(np.float32), 0.5 + 0.2 * r),
+                             (sc["map"][rng.integers(0, sc["map"].shape[0]), :3].astype(np.float32), 1.5)):
+            box = np.concatenate([centre - half, centre + half]).astype(np.float32)[None]
+            assert eng.map_delete_boxes(box) == port.delete_boxes(box)
+            k = (5, 40, 400, 1500, 12, 90)[r]
+            new = np.repeat(sc["map"][:1], k, axis=0).copy()
+            new[:, :3] = (centre + rng.uniform(-2 * half, 2 * half, size=(k, 3))).astype(np.float32)
+            assert eng.map_add(new, False) == port.add(new, False)
+        lo = eng.list_order()
+        assert lo["broken"] == 0 and lo["ordered"] >= 0.99 * lo["lists"], lo
+        _, d2_inc, cnt_inc = eng.nearest_search(q, 5)
+        fresh = capi.Engine(sc["params"])
+        fresh.set_option("early_min_queries", 0)
+        fresh.map_build(port.flatten())
+        _, d2_new, cnt_new = fresh.nearest_search(q, 5)
+        np.testing.assert_array_equal(d2_inc, d2_new)
+        np.testing.assert_array_equal(cnt_inc, cnt_new)
+        eng.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        fresh.scan_set(sc["scan"], sc["tables"], sc["temporal_comp"])
+        a, b = eng.measure(sc["state0"], True), fresh.measure(sc["state0"], True)
+        assert a["M"] == b["M"]
+        np.testing.assert_array_equal(eng.scan_get()["res_last"], fresh.scan_get()["res_last"])
+    after = eng.debug_counters()
+    assert after["rebuilds"] == before["rebuilds"] and after["tombstones"] > 0, (before, after)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,early", [(1, None), (1, 0), (3, None), (5, None)], ids=["cfg1", "cfg1-cut", "cfg3", "cfg5"])
 def test_gpu_ordered_lists_give_the_same_neighbours_as_unordered_ones(capi, scenes, cfg, early):
     """MALIO_OPT_NL_SORTED (default on): the level-1 lists in order of distance from the cell centre let a walk end after
